@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own modules.
+
+Runs only in the build container, where /root/reference is mounted.  It imports the reference's
+`models/*`, `models/loss.py` and `utils/diff_augment.py` unmodified, drives them with a restatement of
+`Trainer.step` (trainers/dcgan_amp.py:162-325 minus DDP / torch.cuda.amp, which need a GPU -- SURVEY.md §0.5),
+captures every random draw by replaying torch's global generator, and stores inputs + expected outputs as
+.npz.  The vectors are DATA; no reference source travels.  The oracle (oracle/dusty_oracle.py) and the HIP path
+are then both checked against these files without the reference present.
+
+usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("DUSTY_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+import models  # noqa: E402  (reference package)
+from models.loss import GANLoss  # noqa: E402
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# utils/__init__.py imports cv2/omegaconf/kornia/numba (absent here): load the two files we need by path.
+diff_augment = _load(os.path.join(REF, "utils", "diff_augment.py"), "ref_diff_augment")
+
+
+def _load_lidar():
+    """utils/lidar.py does `from . import render` (kornia/numba, visualisation only).  Give the import an empty
+    placeholder so the file loads; only Coordinate.invert_depth (pure arithmetic, :31-36) is used."""
+    pkg = types.ModuleType("ref_utils")
+    pkg.__path__ = [os.path.join(REF, "utils")]
+    sys.modules["ref_utils"] = pkg
+    sys.modules["ref_utils.render"] = types.ModuleType("ref_utils.render")
+    spec = importlib.util.spec_from_file_location("ref_utils.lidar", os.path.join(REF, "utils", "lidar.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_utils.lidar"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_cfg(arch, in_ch, ch_base, ch_max, shape, ring):
+    heads = {"none": {"depth": 1}, "dusty1": {"depth": 1, "confidence": 1}, "dusty2": {"depth": 1, "confidence": 2}}
+    gen = Cfg(arch=f"{arch}/dcgan_eqlr", in_ch=in_ch, out_ch=heads[arch], ch_base=ch_base, ch_max=ch_max,
+              drop_const=-1, shape=shape, tau=1)
+    dis = Cfg(arch="dcgan_eqlr", in_ch=1, ch_base=ch_base, ch_max=ch_max, shape=shape)
+    return Cfg(model=Cfg(gen=gen, dis=dis, ring=ring))
+
+
+# ---------------------------------------------------------------- randomness capture
+def capture_gumbel(arch, B, H, W):
+    """Replay GumbelSigmoid.logistic_noise's draws (models/dusty.py:30-36) in module call order
+    (dusty1: pixel; dusty2: pixel then image, models/dusty.py:116-118)."""
+    eps = 1e-10
+    out = {}
+    shapes = {"none": [], "dusty1": [("pixel", (B, 1, H, W))],
+              "dusty2": [("pixel", (B, 1, H, W)), ("image", (B, 1, 1, 1))]}[arch]
+    for name, shp in shapes:
+        u1 = torch.rand(*shp)
+        u2 = torch.rand_like(u1)
+        out[name] = -torch.log(torch.log(u1 + eps) / torch.log(u2 + eps) + eps)
+    return out
+
+
+def capture_aug(B, H, W, policy):
+    """Replay the draws of one DiffAugment.forward (utils/diff_augment.py:27-28,36-38,46-48,59-60,77,86-87,99)."""
+    rp = {}
+    for p in policy:
+        if p in ("brightness", "saturation", "contrast"):
+            f = torch.empty((B, 1, 1, 1))
+            f.bernoulli_(p=1.0)
+            f.uniform_(-1, 1)
+            rp[{"brightness": "u_b", "saturation": "u_s", "contrast": "u_c"}[p]] = f.flatten().clone()
+        elif p == "translation":
+            sh, sw = int(H * (1 / 8) / 2 + 0.5), int(W * (1 / 8) / 2 + 0.5)
+            rp["t_h"] = torch.randint(-sh, sh + 1, size=[B, 1, 1]).flatten()
+            rp["t_w"] = torch.randint(-sw, sw + 1, size=[B, 1, 1]).flatten()
+            torch.empty(B).bernoulli_(p=1.0)
+        elif p == "cutout":
+            ch, cw = int(H * 0.5 + 0.5), int(W * 0.5 + 0.5)
+            rp["o_x"] = torch.randint(0, H + (1 - ch % 2), size=[B, 1, 1]).flatten()
+            rp["o_y"] = torch.randint(0, W + (1 - cw % 2), size=[B, 1, 1]).flatten()
+            torch.empty(B).bernoulli_(p=1.0)
+    return rp
+
+
+def run_and_capture(fn, capture):
+    """Run fn() on the global generator, then rewind and replay `capture()` to learn what it drew."""
+    s0 = torch.get_rng_state()
+    out = fn()
+    s1 = torch.get_rng_state()
+    torch.set_rng_state(s0)
+    cap = capture()
+    assert torch.equal(torch.get_rng_state(), s1), "replayed draws do not match the reference's RNG consumption"
+    return out, cap
+
+
+def ema_inplace(ema_model, new_model, decay):  # trainers/dcgan_amp.py:30-35
+    ep, npar = dict(ema_model.named_parameters()), dict(new_model.named_parameters())
+    with torch.no_grad():
+        for k in ep:
+            ep[k].copy_(decay * ep[k] + (1.0 - decay) * npar[k])
+
+
+def sd_np(module, prefix):
+    return {f"{prefix}/{k}": v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def make_step_golden(name, arch, ring, seed, in_ch=8, ch_base=4, ch_max=16, shape=(32, 64), B=2, steps=2,
+                     gan_mode="nsgan", gp=1.0):
+    torch.manual_seed(seed)
+    cfg = make_cfg(arch, in_ch, ch_base, ch_max, list(shape), ring)
+    G = models.define_G(cfg)
+    D = models.define_D(cfg)
+    G_ema = models.define_G(cfg)
+    G_ema.eval()
+    ema_inplace(G_ema, G, 0.0)
+    A = diff_augment.DiffAugment(policy=None)
+    crit = GANLoss(gan_mode)
+    lr, b1, b2 = 0.002, 0.0, 0.99
+    optG = torch.optim.Adam(G.parameters(), lr=lr, betas=(b1, b2))
+    optD = torch.optim.Adam(D.parameters(), lr=lr, betas=(b1, b2))
+    decay = 0.5 ** (B / (10 * 1000))
+    H, W = shape
+    lidar = _load_lidar()
+
+    data = {"meta/arch": np.array(arch), "meta/ring": np.array(ring), "meta/shape": np.array(shape),
+            "meta/in_ch": np.array(in_ch), "meta/ch_base": np.array(ch_base), "meta/ch_max": np.array(ch_max),
+            "meta/B": np.array(B), "meta/steps": np.array(steps), "meta/gan_mode": np.array(gan_mode),
+            "meta/gp": np.array(gp), "meta/lr": np.array(lr), "meta/beta1": np.array(b1), "meta/beta2": np.array(b2),
+            "meta/ema_decay": np.array(decay), "meta/torch": np.array(torch.__version__)}
+    data.update(sd_np(G, "init/G"))
+    data.update(sd_np(D, "init/D"))
+
+    for it in range(steps):
+        pre = f"s{it}"
+        # synthetic "dataset" batch (polar depth in [0,1] + validity mask), then fetch_reals (:154-160)
+        pol = torch.rand(B, 1, H, W)
+        mask_b = torch.rand(B, 1, H, W) > 0.15
+        pol = pol * mask_b
+        inv = lidar.Coordinate.invert_depth(Cfg(min_depth=0.9, max_depth=120.0,
+                                                denormalize_minmax=lidar.Coordinate.denormalize_minmax,
+                                                normalize_minmax=lidar.Coordinate.normalize_minmax), pol)
+        inv = inv * 2.0 - 1.0  # sigmoid_to_tanh utils/__init__.py:70-73
+        m = mask_b.float()
+        x_real = m * inv + (1 - m) * (-1.0)
+        data[f"{pre}/pol"], data[f"{pre}/mask"], data[f"{pre}/x_real"] = pol.numpy(), mask_b.numpy(), x_real.numpy()
+
+        G.train()
+        for p in D.parameters():
+            p.requires_grad = True
+        optD.zero_grad(set_to_none=True)
+        z = torch.randn(B, in_ch)
+        data[f"{pre}/z"] = z.numpy()
+        synth, noise = run_and_capture(lambda: G(latent=z), lambda: capture_gumbel(arch, B, H, W))
+        for k, v in noise.items():
+            data[f"{pre}/noise/{k}"] = v.numpy()
+        x_real_aug, rp0 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
+        x_real_aug = x_real_aug.detach().requires_grad_()
+        x_fake_aug, rp1 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
+        x_fake_aug = x_fake_aug.detach()
+        y_real, y_fake = D(x_real_aug), D(x_fake_aug)
+        sc = {"loss/D/output/real": y_real.mean().item(), "loss/D/output/fake": y_fake.mean().item()}
+        loss_gan = crit(y_real, y_fake, "D")
+        loss_D = 1.0 * loss_gan
+        sc["loss/D/adversarial"] = loss_gan.item()
+        if gp > 0:
+            (grads,) = torch.autograd.grad(outputs=y_real.sum(), inputs=[x_real_aug], create_graph=True,
+                                           only_inputs=True)
+            r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
+            sc["loss/D/gradient_penalty"] = r1.item()
+            loss_D = loss_D + (gp / 2) * r1 + 0.0 * y_real.squeeze()[0]
+            data[f"{pre}/r1_grads"] = grads.detach().numpy()
+        loss_D.backward()
+        for k, p in D.named_parameters():
+            data[f"{pre}/grad_D/{k}"] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy()
+        optD.step()
+        for k, v in synth.items():
+            data[f"{pre}/synth/{k}"] = v.detach().numpy()
+        data[f"{pre}/x_real_aug"], data[f"{pre}/x_fake_aug"] = x_real_aug.detach().numpy(), x_fake_aug.numpy()
+        data[f"{pre}/y_real"], data[f"{pre}/y_fake"] = y_real.detach().numpy(), y_fake.detach().numpy()
+
+        for p in D.parameters():
+            p.requires_grad = False
+        optG.zero_grad(set_to_none=True)
+        x_real_aug2, rp2 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
+        x_fake_aug2, rp3 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
+        y_real2, y_fake2 = D(x_real_aug2.detach()), D(x_fake_aug2)
+        loss_gan_g = crit(y_real2, y_fake2, "G")
+        sc["loss/G/adversarial"] = loss_gan_g.item()
+        (1.0 * loss_gan_g).backward()
+        for k, p in G.named_parameters():
+            data[f"{pre}/grad_G/{k}"] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy()
+        optG.step()
+        ema_inplace(G_ema, G, decay)
+        data[f"{pre}/y_fake2"] = y_fake2.detach().numpy()
+        for j, rp in enumerate((rp0, rp1, rp2, rp3)):
+            for k, v in rp.items():
+                data[f"{pre}/aug{j}/{k}"] = v.numpy()
+        for k, v in sc.items():
+            data[f"{pre}/scalar/{k}"] = np.array(v, dtype=np.float64)
+        data.update(sd_np(G, f"{pre}/after/G"))
+        data.update(sd_np(D, f"{pre}/after/D"))
+        data.update(sd_np(G_ema, f"{pre}/after/G_ema"))
+
+    # final Adam second-moment state (exp_avg_sq) keyed like the parameters
+    for opt, mod, tag in ((optG, G, "G"), (optD, D, "D")):
+        for (k, p) in mod.named_parameters():
+            st = opt.state[p]
+            data[f"final/optim_{tag}/{k}/exp_avg"] = st["exp_avg"].numpy().copy()
+            data[f"final/optim_{tag}/{k}/exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+    path = os.path.join(HERE, f"step_{name}.npz")
+    np.savez_compressed(path, **data)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def make_ops_golden():
+    """Per-op vectors: Pad, BlurVH, Up/Down/Proj/Head modules (fwd + input/weight grads), each rand_* augment,
+    GumbelSigmoid fwd/bwd, every GANLoss metric, invert_depth."""
+    import models.ops.common as ops
+    from models.gans import dcgan_eqlr as net
+    from models import dusty
+
+    torch.manual_seed(7)
+    d = {"meta/torch": np.array(torch.__version__)}
+    x = torch.randn(2, 3, 6, 8)
+    for ring in (True, False):
+        pad = ops.Pad(padding=1, horizontal="circular" if ring else "reflect", vertical="reflect")
+        d[f"pad/ring{int(ring)}/x"], d[f"pad/ring{int(ring)}/y"] = x.numpy(), pad(x).numpy()
+        xb = torch.randn(2, 1, 8, 16)
+        d[f"blurvh/ring{int(ring)}/x"], d[f"blurvh/ring{int(ring)}/y"] = xb.numpy(), ops.BlurVH(ring)(xb).numpy()
+
+    def module_case(tag, mod, xin):
+        xin = xin.clone().requires_grad_()
+        y = mod(xin)
+        gy = torch.randn_like(y)
+        grads = torch.autograd.grad(y, [xin] + list(mod.parameters()), gy)
+        d[f"{tag}/x"], d[f"{tag}/y"], d[f"{tag}/gy"], d[f"{tag}/gx"] = xin.detach().numpy(), y.detach().numpy(), gy.numpy(), grads[0].numpy()
+        for (k, p), g in zip(mod.named_parameters(), grads[1:]):
+            d[f"{tag}/param/{k}"], d[f"{tag}/grad/{k}"] = p.detach().numpy(), g.numpy()
+
+    for ring in (True, False):
+        r = f"ring{int(ring)}"
+        up = net.Up(6, 4, ring)
+        up[2].bias.data.normal_()
+        module_case(f"up/{r}", up, torch.randn(2, 6, 4, 8))
+        dn = net.Down(4, 6, ring)
+        dn[2].bias.data.normal_()
+        module_case(f"down/{r}", dn, torch.randn(2, 4, 8, 16))
+    pj = net.Proj(5, 6, (2, 4))
+    pj[1].bias.data.normal_()
+    module_case("proj", pj, torch.randn(3, 5))
+    hd = net.Head(4, {"depth": 1, "confidence": 2}, True)
+    for h in hd.heads.values():
+        h[1].module.bias.data.normal_()
+    xh = torch.randn(2, 4, 4, 8)
+    yh = hd(xh)
+    d["head/x"] = xh.numpy()
+    for k, v in yh.items():
+        d[f"head/y/{k}"] = v.detach().numpy()
+    for k, v in hd.state_dict().items():
+        d[f"head/param/{k}"] = v.numpy()
+
+    # augment functions one by one (p=1)
+    xa = torch.randn(3, 1, 16, 32)
+    d["aug/x"] = xa.numpy()
+    for fname, policy in (("brightness", ["brightness"]), ("saturation", ["saturation"]), ("contrast", ["contrast"]),
+                          ("translation", ["translation"]), ("cutout", ["cutout"])):
+        y, rp = run_and_capture(lambda: diff_augment.AUGMENT_FNS[fname](xa, p=1.0),
+                                lambda: capture_aug(3, 16, 32, policy))
+        d[f"aug/{fname}/y"] = y.numpy()
+        for k, v in rp.items():
+            d[f"aug/{fname}/{k}"] = v.numpy()
+
+    # GumbelSigmoid fwd/bwd with captured noise
+    gs = dusty.GumbelSigmoid(tau=1.0, hard=True, pixelwise=True)
+    lg = torch.randn(2, 1, 8, 16, requires_grad=True)
+    ym, noise = run_and_capture(lambda: gs(lg), lambda: capture_gumbel("dusty1", 2, 8, 16))
+    gy = torch.randn_like(ym)
+    (glg,) = torch.autograd.grad(ym, lg, gy)
+    d["gumbel/logits"], d["gumbel/noise"], d["gumbel/y"], d["gumbel/gy"], d["gumbel/glogits"] = (
+        lg.detach().numpy(), noise["pixel"].numpy(), ym.detach().numpy(), gy.numpy(), glg.numpy())
+
+    # GANLoss, all metrics
+    pr, pf = torch.randn(5, 1, 1, 1), torch.randn(5, 1, 1, 1)
+    d["ganloss/pred_real"], d["ganloss/pred_fake"] = pr.numpy(), pf.numpy()
+    for metric in ("nsgan", "wgan", "lsgan", "hinge", "ragan", "rahinge", "ralsgan"):
+        c = GANLoss(metric)
+        d[f"ganloss/{metric}/D"] = np.array(c(pr, pf, "D").item())
+        d[f"ganloss/{metric}/G"] = np.array(c(pr, pf, "G").item())
+
+    lidar = _load_lidar()
+    pol = torch.rand(2, 1, 4, 8)
+    inv = lidar.Coordinate.invert_depth(Cfg(min_depth=0.9, max_depth=120.0,
+                                            denormalize_minmax=lidar.Coordinate.denormalize_minmax,
+                                            normalize_minmax=lidar.Coordinate.normalize_minmax), pol)
+    d["invert_depth/pol"], d["invert_depth/inv"] = pol.numpy(), inv.numpy()
+    path = os.path.join(HERE, "ops.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    make_ops_golden()
+    make_step_golden("none_ring", "none", True, seed=11)
+    make_step_golden("dusty1_ring", "dusty1", True, seed=12)
+    make_step_golden("dusty2_ring", "dusty2", True, seed=13)
+    make_step_golden("dusty2_noring", "dusty2", False, seed=14)
+    make_step_golden("dusty2_nogp", "dusty2", True, seed=15, gp=0.0)
+    # a mid-size case closer to the production channel plan (still CPU-seconds)
+    make_step_golden("dusty2_mid", "dusty2", True, seed=16, in_ch=32, ch_base=16, ch_max=64, shape=(64, 128), B=3,
+                     steps=1)
