@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the dusty-gan training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one `Trainer.step` (D update + G update + EMA, reference trainers/dcgan_amp.py:162-325) on synthetic
+64x1024 range images resident in HBM, 32 images per GPU (weak scaling).  Prints ONE JSON line on rank 0:
+metric = G+D training throughput in images/s (whole job), with steps/s beside it, a `roofline` object for the
+dominant kernel (HIP-event timed) and a `cpu_baseline` object (the CPU oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--arch", choices=["none", "dusty1", "dusty2"], default=None,
+                    help="default: BASELINE configs[1] (dcgan_eqlr baseline) at N=1, configs[3] (dusty2) at N>1")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--shape", type=int, nargs=2, default=[64, 1024])
+    ap.add_argument("--gp", type=float, default=1.0, help="R1 weight (solver.loss.gp); 0 disables R1")
+    ap.add_argument("--no-augment", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the bounded CPU-oracle sample")
+    return ap.parse_args()
+
+
+def make_trainer(args, rank, local_rank, world):
+    from dusty_gan_amd.trainers.dcgan_amp import Trainer
+    from dusty_gan_amd.utils.config import load_config
+    arch = args.arch or ("none" if world == 1 else "dusty2")
+    model = {"none": "dcgan_eqlr", "dusty1": "dusty1_dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
+    ov = [f"model={model}", "dataset=synthetic", f"dataset.shape=[{args.shape[0]},{args.shape[1]}]",
+          f"solver.batch_size={args.batch * world}", f"solver.loss.gp={args.gp}",
+          f"enable_amp={'true' if args.precision == 'bf16' else 'false'}"]
+    if args.no_augment:
+        ov.append("solver.augment=[]")
+    cfg = load_config(ov)
+    torch.manual_seed(1234 + rank)
+    tr = Trainer(cfg, {"gpu": local_rank, "ngpus": world, "batch_size": args.batch, "num_workers": 0})
+    return tr, arch
+
+
+def flops_per_sample(shape, arch, gp):
+    """Algorithmic FLOPs the schedule executes per sample per step (2*MAC, no border waste): SURVEY.md §8d's F_G/F_D
+    at this shape, with 3 F_G + 10 F_D passes when R1 is on (one D(real) forward and one backward-data pass fewer
+    than the reference's 12) and 3 F_G + 8 F_D without."""
+    H, W = shape
+    s = (H * W) / (64 * 1024)
+    n_out = {"none": 1, "dusty1": 2, "dusty2": 3}[arch]
+    f_g = 2 * (67108864 + 3 * 536870912 + 16777216 * n_out) * s
+    f_d = 2 * (393216 + 33554432 + 3 * 536870912 + 131072) * s
+    return 3 * f_g + (10 if gp > 0 else 8) * f_d, f_g, f_d
+
+
+def roofline_pass(tr, steps=2):
+    """Instrumented steps (HIP events on the launch stream around every conv / wgrad launch), run right after the
+    timed region on the same workload.  Returns the roofline object of the dominant kernel family."""
+    from dusty_gan_amd import engine as E
+    E.PROFILE = []
+    for i in range(steps):
+        tr.step(i)
+    torch.cuda.synchronize()
+    rec, E.PROFILE = E.PROFILE, None
+    fam = {}
+    for name, flops, nbytes, e0, e1, tag in rec:
+        ms = e0.elapsed_time(e1)
+        f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+        f["ms"] += ms
+        f["flops"] += flops
+        f["bytes"] += nbytes
+        f["n"] += 1
+    return fam
+
+
+def cpu_baseline(args, arch):
+    """The CPU oracle (oracle/dusty_oracle.py: the reference's algorithm in stock torch CPU ops, validated against the
+    reference's modules) timed on this host: one warm-up + one timed step at a reduced batch (bounded sample)."""
+    from oracle import dusty_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    H, W = args.shape
+    B = args.cpu_batch
+    gen = torch.Generator().manual_seed(0)
+    G = O.init_G(f"{arch}/dcgan_eqlr", 512, 64, 512, (H, W), gen)
+    D = O.init_D(1, 64, 512, (H, W), gen)
+    G_ema = {k: v.clone() for k, v in G.items()}
+    oG, oD = O.new_optim_state(G), O.new_optim_state(D)
+    policy = () if args.no_augment else ("brightness", "saturation", "contrast", "translation", "cutout")
+    cfg = O.StepConfig(arch=arch, w_gp=args.gp, policy=policy)
+    times = []
+    for it in range(2):
+        x = torch.rand(B, 1, H, W, generator=gen) * 2 - 1
+        rand = {"z": torch.randn(B, 512, generator=gen),
+                "noise": {"pixel": O.logistic_noise(torch.rand(B, 1, H, W, generator=gen), torch.rand(B, 1, H, W, generator=gen)),
+                          "image": O.logistic_noise(torch.rand(B, 1, 1, 1, generator=gen), torch.rand(B, 1, 1, 1, generator=gen))},
+                "aug": [O.draw_augment_params(B, H, W, gen) for _ in range(4)]}
+        t0 = time.perf_counter()
+        O.train_step(G, D, G_ema, oG, oD, it + 1, cfg, x, rand)
+        times.append(time.perf_counter() - t0)
+    t = times[-1]
+    return {"value": round(B / t, 3), "unit": "images/s", "steps_per_sec_at_sample_batch": round(1.0 / t, 4),
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 timed oracle step (after 1 warm-up) at batch {B} of {args.batch}, {H}x{W}, fp32, stock torch "
+                      f"CPU ops, {t:.2f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    tr, arch = make_trainer(args, rank, local_rank, world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for i in range(args.warmup):
+        last = tr.step(i)
+    if last is not None:
+        _ = list(last.values())
+    sync()
+    t0 = time.perf_counter()
+    prev = None
+    for i in range(args.steps):
+        cur = tr.step(i)
+        if prev is not None:
+            _ = list(prev.values())  # read the previous step's scalars back while this step runs (one-step delay)
+        prev = cur
+    scal = dict(prev.items())
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1e3 * dt / args.steps
+    steps_s = args.steps / dt
+    imgs = steps_s * args.batch * world
+
+    out = {"metric": "G+D train images/sec on 64x1024 LiDAR (steps/sec beside it)", "value": round(imgs, 2),
+           "unit": "images/s", "steps_per_sec": round(steps_s, 3), "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": f"{'dcgan_eqlr baseline' if arch == 'none' else arch + '_dcgan_eqlr'}, "
+                                  f"{args.shape[0]}x{args.shape[1]}, batch {args.batch}/GPU x {world}, "
+                                  f"R1 {'on' if args.gp > 0 else 'off'}, DiffAugment {'off' if args.no_augment else 'on'}, "
+                                  "Adam+EMA, random-init weights",
+                      "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+           "scalars_last_step": {k: round(v, 5) for k, v in scal.items()}}
+    fl, f_g, f_d = flops_per_sample(args.shape, arch, args.gp)
+    out["step_flops_fraction_of_mfma_peak"] = round(fl * args.batch * steps_s / 1e12 / PEAK_TFLOPS[args.precision], 4)
+
+    if rank == 0 and not args.no_roofline:
+        pass
+    if not args.no_roofline:
+        fam = roofline_pass(tr)
+        if rank == 0 and fam:
+            name = max(fam, key=lambda k: fam[k]["ms"])
+            f = fam[name]
+            tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 2),
+                               "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                               "frac": round(tf / PEAK_TFLOPS[args.precision], 4), "traffic": None,
+                               "launches": f["n"], "avg_launch_us": round(1e3 * f["ms"] / f["n"], 2)}
+            out["kernel_families"] = {
+                k: {"ms_per_step": round(v["ms"] / 2, 3), "launches_per_step": v["n"] // 2,
+                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                    "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, arch)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+"""ctypes binding of libdustygan_hip.so (the C ABI declared in include/dusty_gan_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing, importing the product path raises.
+PyTorch is used only as the owner of device memory and of the HIP stream.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libdustygan_hip.so")
+
+DG_OK, DG_EINVAL, DG_EUNSUPPORTED, DG_EHIP = 0, 1, 2, 3
+DG_F32, DG_BF16 = 0, 1
+MODE_S2, MODE_UP, MODE_GEMM = 0, 1, 2
+EPI_LINEAR, EPI_LRELU, EPI_MASK = 0, 1, 2
+POLICY_BITS = {"brightness": 1, "saturation": 2, "contrast": 4, "translation": 8, "cutout": 16}
+
+_ERR = {1: "DG_EINVAL (bad argument)", 2: "DG_EUNSUPPORTED (shape not supported by the requested kernel)",
+        3: "DG_EHIP (HIP runtime error)"}
+
+
+class DgError(RuntimeError):
+    pass
+
+
+class DgConv(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int), ("adj", C.c_int), ("ring", C.c_int),
+        ("B", C.c_int), ("Hc", C.c_int), ("Wc", C.c_int),
+        ("K", C.c_int), ("N", C.c_int),
+        ("in_", C.c_void_p), ("in_sb", C.c_long), ("in_sp", C.c_long), ("in_sk", C.c_long),
+        ("out", C.c_void_p), ("out_sb", C.c_long), ("out_sp", C.c_long), ("out_sn", C.c_long),
+        ("w", C.c_void_p), ("w_st", C.c_long), ("w_sk", C.c_long), ("w_sn", C.c_long),
+        ("scale", C.c_float), ("epi", C.c_int),
+        ("bias", C.c_void_p), ("bias_mod", C.c_int),
+        ("aux", C.c_void_p), ("dbias", C.c_void_p), ("rowscale", C.c_void_p),
+        ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("w_dtype", C.c_int),
+        ("nscale", C.c_void_p),
+    ]
+
+
+class DgWgrad(C.Structure):
+    _fields_ = [
+        ("wmode", C.c_int), ("ring", C.c_int),
+        ("B", C.c_int), ("Hc", C.c_int), ("Wc", C.c_int),
+        ("Ci", C.c_int), ("Co", C.c_int),
+        ("a", C.c_void_p), ("a_sb", C.c_long), ("a_sp", C.c_long), ("a_sc", C.c_long),
+        ("g", C.c_void_p), ("g_sb", C.c_long), ("g_sp", C.c_long), ("g_sc", C.c_long),
+        ("dw", C.c_void_p), ("scale", C.c_float), ("rowscale", C.c_void_p),
+        ("a_dtype", C.c_int), ("g_dtype", C.c_int),
+    ]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
+
+# name -> argtypes (all return int except dg_version); mirrors include/dusty_gan_hip.h one to one
+PROTOTYPES = {
+    "dg_conv": [C.POINTER(DgConv), _I, _P],
+    "dg_conv_mfma_supported": [C.POINTER(DgConv)],
+    "dg_wgrad": [C.POINTER(DgWgrad), _I, _I, _P],
+    "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
+    "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
+    "dg_final_bwd_data": [_P, _I, _P, _P, _P, _F, _I, _L, _I, _P, _P, _P],
+    "dg_batch_wsum": [_P, _I, _P, _F, _I, _L, _P, _P],
+    "dg_head_post_fwd": [_P, _P, _P, _I, _I, _F, _F, _I, _L, _P, _P, _P],
+    "dg_head_post_bwd": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _L, _F, _F, _P, _P, _P],
+    "dg_logistic_noise": [_P, _P, _F, _L, _P, _P],
+    "dg_diffaug_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_diffaug_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_nsgan_d": [_P, _P, _I, _F, _P, _P, _P, _P],
+    "dg_nsgan_g": [_P, _I, _F, _P, _P, _P],
+    "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
+    "dg_sample_sum": [_P, _I, _L, _I, _P, _P],
+    "dg_scale": [_P, _F, _L, _P, _P],
+    "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "dg_cast": [_P, _P, _I, _L, _P],
+    "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
+    "dg_philox_bits": [_U64, _U64, _U64, _L, _P, _P],
+    "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
+    "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise DgError("building libdustygan_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises DgError when the library is absent: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DgError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C dusty_gan_amd/csrc`). "
+            "There is no CPU or PyTorch fallback for the hot path.")
+    h = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(h, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    h.dg_version.restype = C.c_char_p
+    h.dg_version.argtypes = []
+    _lib = h
+    return h
+
+
+def check(rc, what=""):
+    if rc != DG_OK:
+        raise DgError(f"{what or 'libdustygan_hip call'} failed: {_ERR.get(rc, rc)}")
+
+
+def dtype_code(t):
+    import torch
+    if t == torch.float32:
+        return DG_F32
+    if t == torch.bfloat16:
+        return DG_BF16
+    raise DgError(f"unsupported dtype {t}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def policy_mask(policy):
+    m = 0
+    for p in policy or ():
+        if p not in POLICY_BITS:
+            raise KeyError(p)
+        m |= POLICY_BITS[p]
+    return m

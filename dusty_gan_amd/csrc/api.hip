@@ -1,0 +1,41 @@
+// extern "C" dispatchers of the conv-like passes (include/dusty_gan_hip.h).
+#include "common.h"
+
+int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
+int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream);
+int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
+int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream);
+
+extern "C" {
+
+const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
+
+int dg_conv(const DgConv* p, int force, void* stream) {
+  if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
+  if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
+  if (p->mode != MODE_GEMM && (p->Hc < 2 || p->Wc < 2)) return DG_EINVAL;
+  if (p->epi == EPI_MASK && !p->aux) return DG_EINVAL;
+  if (p->bias && p->bias_mod <= 0) return DG_EINVAL;
+  if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
+  if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s) : DG_EUNSUPPORTED;
+  if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s);
+  return dg_conv_direct_launch(p, s);
+}
+
+int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
+  if (!p || !p->a || !p->g || !p->dw) return DG_EINVAL;
+  if (p->B <= 0 || p->Ci <= 0 || p->Co <= 0 || p->Hc <= 0 || p->Wc <= 0) return DG_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool mfma_ok = dg_wgrad_mfma_supported(p);
+  if (force == 2) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
+  if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
+  if (!accumulate) {
+    const long n = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
+    HIP_CHECK_RET(hipMemsetAsync(p->dw, 0, sizeof(float) * n, s));
+  }
+  return dg_wgrad_direct_launch(p, s);
+}
+
+}  // extern "C"

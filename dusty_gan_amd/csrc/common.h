@@ -1,0 +1,162 @@
+// Shared definitions for the dusty-gan HIP kernels (gfx950 / MI355X only).
+//
+// Layout conventions (DESIGN.md "Data layout in HBM"):
+//   * activations: pixel-major / channel-minor ("NHWC"), element type T = float or __bf16
+//   * conv weights (engine master, fp32):   M[ky][kx][ci][co]         ("cico")
+//     shadows in T:                         S_cico[tap][ci][co], S_coci[tap][co][ci]
+//   * every conv-like op is expressed on a COARSE grid (Hc x Wc) and a FINE grid (2Hc x 2Wc):
+//       MODE_S2: out on the coarse grid, in on the fine grid  (Down forward, Up backward-data)
+//       MODE_UP: out on the fine grid,  in on the coarse grid (Up forward, Down backward-data)
+//     with boundary flavour adj=0 (the reference's Pad: reflect rows, circular/reflect columns;
+//     models/ops/common.py:9-20) or adj=1 (its adjoint: zero fill + reflect-adjoint extra taps).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+
+#include "../../include/dusty_gan_hip.h"
+
+#define MODE_S2 0
+#define MODE_UP 1
+#define MODE_GEMM 2  // plain row-major GEMM rows (Proj): no taps
+
+#define EPI_LINEAR 0
+#define EPI_LRELU 1
+#define EPI_MASK 2
+
+#define LRELU_SLOPE 0.2f
+#define SQRT2 1.4142135623730951f
+
+#define HIP_CHECK_RET(x)                  \
+  do {                                    \
+    hipError_t _e = (x);                  \
+    if (_e != hipSuccess) return DG_EHIP; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// 1-D tap enumeration shared by every conv-like kernel (host+device; unit-tested on the host).
+//
+// For output index P on an axis whose coarse size is Nc (fine size 2Nc), tap i in [0,6):
+// returns false if the tap does not exist, else the source index `src` on the INPUT axis and the
+// 4-tap kernel index k.  Derivation: SURVEY.md §2.1 (probe-verified against F.conv2d /
+// F.conv_transpose2d), boundary rules of models/ops/common.py:9-20.
+//   circ=1: circular axis (W with ring=True): the adjoint of a circular conv is circular, adj is ignored.
+//   circ=0: reflect axis (H always; W when ring=False).
+__host__ __device__ inline bool dg_tap1d(int mode, int adj, int circ, int P, int Nc, int i, int& src, int& k) {
+  const int Nf = 2 * Nc;
+  if (mode == MODE_S2) {
+    // out[P] = sum_k w[k] * in_f[2P-1+k]
+    if (i < 4) {
+      int r = 2 * P - 1 + i;
+      k = i;
+      if (circ) {
+        if (r < 0) r += Nf;
+        if (r >= Nf) r -= Nf;
+        src = r;
+        return true;
+      }
+      if (!adj) {  // reflect: -1 -> 1, Nf -> Nf-2
+        if (r < 0) r = -r;
+        if (r >= Nf) r = 2 * Nf - 2 - r;
+        src = r;
+        return true;
+      }
+      src = r;
+      return r >= 0 && r < Nf;
+    }
+    if (circ || !adj) return false;
+    // adjoint of Up's reflect padding: out_up[0] read x[1] through w[3]; out_up[Nf-1] read x[Nc-2] through w[0]
+    if (i == 4) { src = 0; k = 3; return P == 1; }
+    if (i == 5) { src = Nf - 1; k = 0; return P == Nc - 2; }
+    return false;
+  }
+  // MODE_UP: P on the fine axis. even: w[1]*x[m] + w[3]*x[m-1]; odd: w[0]*x[m+1] + w[2]*x[m]
+  const int m = P >> 1, par = P & 1;
+  if (i < 2) {
+    int r;
+    if (i == 0) { r = par ? m + 1 : m; k = par ? 0 : 1; }
+    else        { r = par ? m : m - 1; k = par ? 2 : 3; }
+    if (circ) {
+      if (r < 0) r += Nc;
+      if (r >= Nc) r -= Nc;
+      src = r;
+      return true;
+    }
+    if (!adj) {
+      if (r < 0) r = -r;
+      if (r >= Nc) r = 2 * Nc - 2 - r;
+      src = r;
+      return true;
+    }
+    src = r;
+    return r >= 0 && r < Nc;
+  }
+  if (circ || !adj) return false;
+  // adjoint of Down's reflect padding: out_down[0] read x[1] through w[0]; out_down[Nc-1] read x[Nf-2] through w[3]
+  if (i == 2) { src = 0; k = 0; return P == 1; }
+  if (i == 3) { src = Nc - 1; k = 3; return P == Nf - 2; }
+  return false;
+}
+
+// Weight-gradient index maps.  For coarse index m and kernel index k (0..3) along one axis:
+//   wmode 0 (Down): input on the fine axis at  map(2m+k-1), gradient on the coarse axis at m
+//   wmode 1 (Up):   input on the coarse axis at map(m+d_k), gradient on the fine axis at 2m+par_k
+__host__ __device__ inline void dg_wgrad1d(int wmode, int circ, int m, int Nc, int k, int& src_in, int& src_g) {
+  if (wmode == 0) {
+    const int Nf = 2 * Nc;
+    int r = 2 * m - 1 + k;
+    if (circ) { if (r < 0) r += Nf; if (r >= Nf) r -= Nf; }
+    else      { if (r < 0) r = -r;  if (r >= Nf) r = 2 * Nf - 2 - r; }
+    src_in = r;
+    src_g = m;
+  } else {
+    const int par = (k == 0 || k == 2) ? 1 : 0;
+    const int d = (k == 0) ? 1 : (k == 3 ? -1 : 0);
+    int r = m + d;
+    if (circ) { if (r < 0) r += Nc; if (r >= Nc) r -= Nc; }
+    else      { if (r < 0) r = -r;  if (r >= Nc) r = 2 * Nc - 2 - r; }
+    src_in = r;
+    src_g = 2 * m + par;
+  }
+}
+
+// Parameter blocks are part of the C ABI: include/dusty_gan_hip.h
+typedef DgConv ConvP;
+typedef DgWgrad WgradP;
+
+__device__ __forceinline__ float dg_ld(const void* p, long i, int dtype) {
+  return dtype == DG_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void dg_st(void* p, long i, int dtype, float v) {
+  if (dtype == DG_BF16) ((bf16*)p)[i] = (bf16)v;
+  else ((float*)p)[i] = v;
+}
+
+__device__ __forceinline__ float dg_epilogue(float acc, float scale, int epi, float bias, float auxv) {
+  float v = acc * scale + bias;
+  if (epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
+  else if (epi == EPI_MASK) v *= (auxv > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+  return v;
+}
+
+__device__ __forceinline__ float dg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum (blockDim.x a multiple of 64, <= 1024); result valid in thread 0.
+__device__ __forceinline__ float dg_block_sum(float v, float* red /* >= 16 floats of LDS */) {
+  v = dg_wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += red[i];
+  }
+  return r;
+}

@@ -1,0 +1,163 @@
+// Direct (VALU) conv-like kernels.
+//
+// Two jobs:
+//  1. the production kernels of the THIN layers, which are HBM-bound and have nothing for MFMA to chew on:
+//     Head (Cout<=3, models/gans/dcgan_eqlr.py:29-46), Down1 (Cin=2 after BlurVH, :90), their backward-data and
+//     weight-gradient passes;
+//  2. the general-shape path (any channel count, ring=False) used for tiny nets such as the golden-vector cases,
+//     and the on-GPU cross-check of the MFMA kernels.
+#include "common.h"
+
+// One thread computes NV consecutive output channels of one output pixel.
+template <int NV>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p) {
+  __shared__ float s_db[512];
+  const bool want_db = p.dbias != nullptr;
+  if (want_db) {
+    for (int i = threadIdx.x; i < p.bias_mod; i += blockDim.x) s_db[i] = 0.f;
+    __syncthreads();
+  }
+  const int NG = (p.N + NV - 1) / NV;
+  int Ho, Wo, Ws;
+  if (p.mode == MODE_S2) { Ho = p.Hc; Wo = p.Wc; Ws = 2 * p.Wc; }
+  else if (p.mode == MODE_UP) { Ho = 2 * p.Hc; Wo = 2 * p.Wc; Ws = p.Wc; }
+  else { Ho = 1; Wo = 1; Ws = 1; }
+  const long total = (long)p.B * Ho * Wo * NG;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) {
+    const int ng = (int)(idx % NG);
+    const long pix = idx / NG;
+    const int X = (int)(pix % Wo);
+    const int Y = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long)Wo * Ho));
+    const int n0 = ng * NV;
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    const long in_b = (long)b * p.in_sb;
+    if (p.mode == MODE_GEMM) {
+      for (int k = 0; k < p.K; ++k) {
+        const float a = dg_ld(p.in, in_b + (long)k * p.in_sk, p.in_dtype);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          if (n0 + v < p.N) acc[v] += a * dg_ld(p.w, (long)k * p.w_sk + (long)(n0 + v) * p.w_sn, p.w_dtype);
+      }
+    } else {
+      for (int i = 0; i < 6; ++i) {
+        int r, ky;
+        if (!dg_tap1d(p.mode, p.adj, 0, Y, p.Hc, i, r, ky)) continue;
+        for (int j = 0; j < 6; ++j) {
+          int c, kx;
+          if (!dg_tap1d(p.mode, p.adj, p.ring, X, p.Wc, j, c, kx)) continue;
+          const long ib = in_b + ((long)r * Ws + c) * p.in_sp;
+          const long wb = (long)(ky * 4 + kx) * p.w_st;
+          for (int k = 0; k < p.K; ++k) {
+            const float a = dg_ld(p.in, ib + (long)k * p.in_sk, p.in_dtype);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+              if (n0 + v < p.N) acc[v] += a * dg_ld(p.w, wb + (long)k * p.w_sk + (long)(n0 + v) * p.w_sn, p.w_dtype);
+          }
+        }
+      }
+    }
+    const long ob = (long)b * p.out_sb + ((long)Y * Wo + X) * p.out_sp;
+    const float rs = p.rowscale ? p.rowscale[b] : 1.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int n = n0 + v;
+      if (n < p.N) {
+        const long o = ob + (long)n * p.out_sn;
+        const float bias = p.bias ? p.bias[n % p.bias_mod] : 0.f;
+        const float auxv = p.epi == EPI_MASK ? dg_ld(p.aux, o, p.out_dtype) : 0.f;
+        const float r = dg_epilogue(acc[v], p.nscale ? p.scale * p.nscale[n] : p.scale, p.epi, bias, auxv);
+        dg_st(p.out, o, p.out_dtype, r);
+        if (want_db) atomicAdd(&s_db[n % p.bias_mod], r * rs);
+      }
+    }
+  }
+  if (want_db) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.bias_mod; i += blockDim.x) {
+      const float v = s_db[i];
+      if (v != 0.f) atomicAdd(&p.dbias[i], v);
+    }
+  }
+}
+
+// Weight gradient, direct form.  One thread owns dw[tap][ci][co] for one pixel slab (gridDim.y slabs over the
+// B*Hc coarse rows) and adds its partial sum with one fp32 atomic.
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradP p) {
+  const int ntap = p.wmode == 2 ? 1 : 16;
+  const long total = (long)ntap * p.Ci * p.Co;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int co = (int)(idx % p.Co);
+  const int ci = (int)((idx / p.Co) % p.Ci);
+  const int tap = (int)(idx / ((long)p.Co * p.Ci));
+  const int ky = tap >> 2, kx = tap & 3;
+  const long rows = (long)p.B * p.Hc;
+  const long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * per;
+  const long r1 = r0 + per < rows ? r0 + per : rows;
+  const int Wa = p.wmode == 0 ? 2 * p.Wc : p.Wc;
+  const int Wg = p.wmode == 1 ? 2 * p.Wc : p.Wc;
+  float tot = 0.f;
+  for (long row = r0; row < r1; ++row) {
+    const int b = (int)(row / p.Hc), m = (int)(row % p.Hc);
+    float acc = 0.f;
+    if (p.wmode == 2) {
+      acc = dg_ld(p.a, (long)b * p.a_sb + (long)ci * p.a_sc, p.a_dtype) *
+            dg_ld(p.g, (long)b * p.g_sb + (long)co * p.g_sc, p.g_dtype);
+    } else {
+      int ra, rg;
+      dg_wgrad1d(p.wmode, 0, m, p.Hc, ky, ra, rg);
+      const long ab = (long)b * p.a_sb + (long)ci * p.a_sc;
+      const long gb = (long)b * p.g_sb + (long)co * p.g_sc;
+      for (int x = 0; x < p.Wc; ++x) {
+        int ca, cg;
+        dg_wgrad1d(p.wmode, p.ring, x, p.Wc, kx, ca, cg);
+        acc += dg_ld(p.a, ab + ((long)ra * Wa + ca) * p.a_sp, p.a_dtype) *
+               dg_ld(p.g, gb + ((long)rg * Wg + cg) * p.g_sp, p.g_dtype);
+      }
+    }
+    tot += (p.rowscale ? p.rowscale[b] : 1.f) * acc;
+  }
+  atomicAdd(&p.dw[idx], tot * p.scale);
+}
+
+int dg_conv_direct_launch(const ConvP* p, hipStream_t stream) {
+  int Ho, Wo;
+  if (p->mode == MODE_S2) { Ho = p->Hc; Wo = p->Wc; }
+  else if (p->mode == MODE_UP) { Ho = 2 * p->Hc; Wo = 2 * p->Wc; }
+  else { Ho = 1; Wo = 1; }
+  if (p->dbias && p->bias_mod > 512) return DG_EINVAL;
+  int nv = p->N >= 8 ? 8 : (p->N >= 4 ? 4 : p->N);
+  const int NG = (p->N + nv - 1) / nv;
+  const long total = (long)p->B * Ho * Wo * NG;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (grid == 0) return DG_OK;
+  switch (nv) {
+    case 1: conv_direct_kernel<1><<<grid, 256, 0, stream>>>(*p); break;
+    case 2: conv_direct_kernel<2><<<grid, 256, 0, stream>>>(*p); break;
+    case 3: conv_direct_kernel<3><<<grid, 256, 0, stream>>>(*p); break;
+    case 4: conv_direct_kernel<4><<<grid, 256, 0, stream>>>(*p); break;
+    default: conv_direct_kernel<8><<<grid, 256, 0, stream>>>(*p); break;
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream) {
+  const int ntap = p->wmode == 2 ? 1 : 16;
+  const long total = (long)ntap * p->Ci * p->Co;
+  const long rows = (long)p->B * p->Hc;
+  // enough slabs to fill the chip, never more than the rows there are
+  long slabs = (256L * 16 * 256) / (total > 0 ? total : 1);
+  if (slabs < 1) slabs = 1;
+  if (slabs > rows) slabs = rows;
+  if (slabs > 4096) slabs = 4096;
+  dim3 grid((unsigned)((total + 255) / 256), (unsigned)slabs);
+  wgrad_direct_kernel<<<grid, 256, 0, stream>>>(*p);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}

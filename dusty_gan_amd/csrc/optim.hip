@@ -1,0 +1,215 @@
+// Optimizer / parameter-state kernels: fused Adam (+EMA, + low-precision shadow write), the transposed weight
+// shadow used by the MFMA forward kernels, and the Philox4x32-10 generator for z / Gumbel / DiffAugment draws.
+#include "common.h"
+
+// torch.optim.Adam (no weight decay / amsgrad) as configured at trainers/dcgan_amp.py:116-125, fused with
+// ema_inplace (:30-35) and with the T-typed shadow copy the conv kernels read.  All buffers are flat.
+//   g <- grad * gscale (gscale = 1/world_size after a SUM all-reduce)
+//   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
+//   ema <- d ema + (1-d) p   (only where ema != null)
+template <typename T>
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+                                float* __restrict__ v, float* __restrict__ ema, T* __restrict__ shadow, long n,
+                                float gscale, float lr_bc1, float inv_sqrt_bc2, float b1, float b2, float eps,
+                                float ema_decay) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * g;
+  const float vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+  const float pi = p[i] - lr_bc1 * (mi / denom);
+  p[i] = pi;
+  if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pi;
+  if (shadow) shadow[i] = (T)pi;
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (T)src[i];
+}
+
+// master [16][ci][co] fp32 -> shadow [16][co][ci] T, through a 32x32 LDS tile per (tap, ci-tile, co-tile)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                               int Ci, int Co) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* s = src + (long)tap * Ci * Co;
+  T* d = dst + (long)tap * Ci * Co;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    tile[r][tx] = (ci < Ci && co < Co) ? s[(long)ci * Co + co] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    if (ci < Ci && co < Co) d[(long)co * Ci + ci] = (T)tile[tx][r];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; the counter-based generator torch's device RNG also uses).  One call of
+// philox(counter=(i,0,0,0) + offset, key=seed) yields 4 x 32 random bits for element group i.
+__host__ __device__ inline void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__host__ __device__ inline void philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// raw bits: out[4*i + j] = philox(seed, counter = (offset + i, stream))[j]
+__global__ void philox_bits_kernel(uint64_t seed, uint64_t stream, uint64_t offset, long n4, uint32_t* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  uint32_t r[4];
+  philox4x32_10(seed, offset + (uint64_t)i, stream, r);
+  out[4 * i + 0] = r[0]; out[4 * i + 1] = r[1]; out[4 * i + 2] = r[2]; out[4 * i + 3] = r[3];
+}
+
+// kind 0: uniform in [0,1) with 24 bits (bits >> 8) * 2^-24
+// kind 1: standard normal by Box-Muller on pairs (u in (0,1]: 1 - uniform)
+// kind 2: uniform(lo,hi)
+// kind 3: integer in [ilo, ihi) as int32 (modulo of the 32-bit draw; range << 2^32 so the bias is < 2^-20)
+__global__ void philox_fill_kernel(uint64_t seed, uint64_t stream, uint64_t offset, int kind, float lo, float hi,
+                                   int ilo, int ihi, long n, void* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 outputs
+  if (4 * i >= n) return;
+  uint32_t r[4];
+  philox4x32_10(seed, offset + (uint64_t)i, stream, r);
+  float f[4];
+  int q[4];
+  const float s24 = 1.f / 16777216.f;
+  if (kind == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const float u1 = 1.f - (float)(r[j] >> 8) * s24;  // (0,1]
+      const float u2 = (float)(r[j + 1] >> 8) * s24;
+      const float rad = sqrtf(-2.f * logf(u1));
+      f[j] = rad * cosf(6.283185307179586f * u2);
+      f[j + 1] = rad * sinf(6.283185307179586f * u2);
+    }
+  } else if (kind == 3) {
+    const uint32_t range = (uint32_t)(ihi - ilo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = ilo + (int)(r[j] % range);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = (float)(r[j] >> 8) * s24;
+      f[j] = kind == 2 ? lo + (hi - lo) * u : u;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long o = 4 * i + j;
+    if (o < n) {
+      if (kind == 3) ((int*)out)[o] = q[j];
+      else ((float*)out)[o] = f[j];
+    }
+  }
+}
+
+// One DiffAugment parameter set per sample (utils/diff_augment.py:27-28,36-38,46-48,59-60,86-87): three
+// uniform(-1,1) draws and four integer draws, from two Philox counters per sample.
+__global__ void aug_draw_kernel(uint64_t seed, uint64_t stream, uint64_t offset, int B, int sh, int sw, int nx, int ny,
+                                float* __restrict__ uf, int* __restrict__ qi) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  uint32_t r0[4], r1[4];
+  philox4x32_10(seed, offset + 2 * (uint64_t)b, stream, r0);
+  philox4x32_10(seed, offset + 2 * (uint64_t)b + 1, stream, r1);
+  const float s24 = 1.f / 16777216.f;
+  for (int j = 0; j < 3; ++j) uf[j * B + b] = -1.f + 2.f * (float)(r0[j] >> 8) * s24;
+  qi[0 * B + b] = -sh + (int)(r1[0] % (uint32_t)(2 * sh + 1));
+  qi[1 * B + b] = -sw + (int)(r1[1] % (uint32_t)(2 * sw + 1));
+  qi[2 * B + b] = (int)(r1[2] % (uint32_t)nx);
+  qi[3 * B + b] = (int)(r1[3] % (uint32_t)ny);
+}
+
+static inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" {
+
+int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema, void* shadow, int shadow_dtype,
+                     long n, float gscale, float lr, float beta1, float beta2, float eps, int step, float ema_decay,
+                     void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (n <= 0) return DG_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float lr_bc1 = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  if (shadow && shadow_dtype == DG_BF16)
+    adam_ema_kernel<bf16><<<nblk(n), 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
+  else
+    adam_ema_kernel<float><<<nblk(n), 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_cast(const float* src, void* dst, int dtype, long n, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (dtype == DG_BF16) cast_kernel<bf16><<<nblk(n), 256, 0, s>>>(src, (bf16*)dst, n);
+  else cast_kernel<float><<<nblk(n), 256, 0, s>>>(src, (float*)dst, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_transpose_shadow(const float* master, void* dst, int dtype, int Ci, int Co, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, 16);
+  if (dtype == DG_BF16) transpose_shadow_kernel<bf16><<<grid, 256, 0, s>>>(master, (bf16*)dst, Ci, Co);
+  else transpose_shadow_kernel<float><<<grid, 256, 0, s>>>(master, (float*)dst, Ci, Co);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_philox_bits(uint64_t seed, uint64_t stream, uint64_t offset, long n4, uint32_t* out, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  philox_bits_kernel<<<nblk(n4), 256, 0, s>>>(seed, stream, offset, n4, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_philox_fill(uint64_t seed, uint64_t stream, uint64_t offset, int kind, float lo, float hi, int ilo, int ihi,
+                   long n, void* out, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (kind < 0 || kind > 3) return DG_EINVAL;
+  if (kind == 3 && ihi <= ilo) return DG_EINVAL;
+  philox_fill_kernel<<<nblk((n + 3) / 4), 256, 0, s>>>(seed, stream, offset, kind, lo, hi, ilo, ihi, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_aug_draw(uint64_t seed, uint64_t stream, uint64_t offset, int B, int H, int W, float* uf, int* qi, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const int sh = (int)(H * (1.0 / 8.0) / 2 + 0.5), sw = (int)(W * (1.0 / 8.0) / 2 + 0.5);  // diff_augment.py:58
+  const int ch = (int)(H * 0.5 + 0.5), cw = (int)(W * 0.5 + 0.5);                          // diff_augment.py:85
+  aug_draw_kernel<<<nblk(B), 256, 0, s>>>(seed, stream, offset, B, sh, sw, H + (1 - ch % 2), W + (1 - cw % 2), uf, qi);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,522 @@
+// HBM-bound kernels of the step: BlurVH, the final (4 x w0) dot, head post-processing (tanh + Gumbel point-drop),
+// DiffAugment, NSGAN losses, fetch_reals and small reductions.  Images are fp32 [B,1,H,W]; feature maps are T.
+#include "common.h"
+
+// ----------------------------------------------------------------------------------------------------------
+// BlurVH (models/ops/common.py:74-88): x [B,H,W] fp32 -> h0 [B,H,W,2] (ch0 = vertical [1,2,1]/4 with reflect rows,
+// ch1 = horizontal [1,2,1]/4 with circular / reflect columns).
+template <typename T>
+__global__ void blur_fwd_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H, int W, int ring) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W;
+  if (idx >= total) return;
+  const int xx = (int)(idx % W), y = (int)((idx / W) % H);
+  const long base = idx - (long)y * W - xx;  // b*H*W
+  const int yu = y == 0 ? 1 : y - 1, yd = y == H - 1 ? H - 2 : y + 1;
+  int xl = xx - 1, xr = xx + 1;
+  if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
+  else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
+  const float c = x[idx];
+  const float v = 0.25f * x[base + (long)yu * W + xx] + 0.5f * c + 0.25f * x[base + (long)yd * W + xx];
+  const float h = 0.25f * x[base + (long)y * W + xl] + 0.5f * c + 0.25f * x[base + (long)y * W + xr];
+  out[idx * 2 + 0] = (T)v;
+  out[idx * 2 + 1] = (T)h;
+}
+
+// Adjoint of BlurVH: d [B,H,W,2] -> dx [B,H,W] fp32.
+template <typename T>
+__global__ void blur_bwd_kernel(const T* __restrict__ d, float* __restrict__ dx, int B, int H, int W, int ring) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W;
+  if (idx >= total) return;
+  const int xx = (int)(idx % W), y = (int)((idx / W) % H);
+  const long base = idx - (long)y * W - xx;
+  auto D0 = [&](int yy, int xq) { return (float)d[(base + (long)yy * W + xq) * 2 + 0]; };
+  auto D1 = [&](int yy, int xq) { return (float)d[(base + (long)yy * W + xq) * 2 + 1]; };
+  float v = 0.5f * D0(y, xx);
+  if (y > 0) v += 0.25f * D0(y - 1, xx);
+  if (y < H - 1) v += 0.25f * D0(y + 1, xx);
+  if (y == 1) v += 0.25f * D0(0, xx);          // row 0 read x[1] as its reflected upper neighbour
+  if (y == H - 2) v += 0.25f * D0(H - 1, xx);  // row H-1 read x[H-2] as its reflected lower neighbour
+  float h = 0.5f * D1(y, xx);
+  if (ring) {
+    h += 0.25f * D1(y, xx == 0 ? W - 1 : xx - 1) + 0.25f * D1(y, xx == W - 1 ? 0 : xx + 1);
+  } else {
+    if (xx > 0) h += 0.25f * D1(y, xx - 1);
+    if (xx < W - 1) h += 0.25f * D1(y, xx + 1);
+    if (xx == 1) h += 0.25f * D1(y, 0);
+    if (xx == W - 2) h += 0.25f * D1(y, W - 1);
+  }
+  dx[idx] = v + h;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Final EqualLR(Conv2d(C,1,(h0,w0))) (models/gans/dcgan_eqlr.py:95): y[b] = scale * <d4[b], wf> + bias.
+template <typename T>
+__global__ __launch_bounds__(256) void final_fwd_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
+                                                        const float* __restrict__ bias, float scale, long n,
+                                                        float* __restrict__ y) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const T* row = d4 + (long)b * n;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) acc += (float)row[i] * wf[i];
+  const float s = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) y[b] = s * scale + (bias ? bias[0] : 0.f);
+}
+
+// dd4[b][i] = up[b] * scale * wf[i] * lrelu'(d4[b][i]) * sqrt2 ; dbias4[i % C] += rowscale[b] * dd4[b][i]
+template <typename T>
+__global__ __launch_bounds__(256) void final_bwd_data_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
+                                                             const float* __restrict__ up,
+                                                             const float* __restrict__ rowscale, float scale, int B,
+                                                             long n, int C, T* __restrict__ dd4,
+                                                             float* __restrict__ dbias) {
+  // grid.x covers n in chunks of blockDim; each thread loops over the batch so its channel (i % C) is fixed
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float w = wf[i] * scale;
+  float db = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float a = (float)d4[(long)b * n + i];
+    const float g = (up ? up[b] : 1.f) * w * (a > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+    dd4[(long)b * n + i] = (T)g;
+    db += (rowscale ? rowscale[b] : 1.f) * g;
+  }
+  if (dbias) atomicAdd(&dbias[i % C], db);
+}
+
+// out[i] += scale * sum_b coef[b] * src[b][i]   (coef null -> 1)
+template <typename T>
+__global__ void batch_wsum_kernel(const T* __restrict__ src, const float* __restrict__ coef, float scale, int B,
+                                  long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += (coef ? coef[b] : 1.f) * (float)src[(long)b * n + i];
+  out[i] += acc * scale;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Head post-processing: Generator.forward's tanh (models/gans/dcgan_eqlr.py:71) + DUSty maskout
+// (models/dusty.py:77-91, 107-127).  gout [B,1+k,H,W] planar fp32: ch0 raw depth -> tanh in place (depth_orig),
+// ch1.. confidence logits (kept).  arch: 0 none, 1 dusty1, 2 dusty2.  noise_pixel [B,H,W], noise_image [B].
+__global__ void head_post_fwd_kernel(float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                     const float* __restrict__ noise_image, int arch, int training, float inv_tau,
+                                     float drop_const, int B, long HW, float* __restrict__ mask,
+                                     float* __restrict__ depth) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * HW) return;
+  const int b = (int)(idx / HW);
+  const long p = idx - (long)b * HW;
+  const int nch = 1 + (arch == 0 ? 0 : arch);
+  float* g = gout + (long)b * nch * HW + p;
+  const float t = tanhf(g[0]);
+  g[0] = t;
+  if (arch == 0) { depth[idx] = t; return; }
+  const float sp = 1.f / (1.f + __expf(-(g[HW] + noise_pixel[idx]) * inv_tau));
+  const float mp = sp > 0.5f ? 1.f : 0.f;
+  float m = mp;
+  if (arch == 1) {
+    mask[idx] = mp;
+  } else {
+    float mi;
+    if (training) {
+      const float si = 1.f / (1.f + __expf(-(g[2 * HW] + noise_image[b]) * inv_tau));
+      mi = si > 0.5f ? 1.f : 0.f;
+    } else {
+      mi = g[2 * HW] > 0.f ? 1.f : 0.f;
+    }
+    mask[(long)b * 2 * HW + p] = mp;
+    mask[(long)b * 2 * HW + HW + p] = mi;
+    m = mp * mi;
+  }
+  depth[idx] = m * t + (1.f - m) * drop_const;
+}
+
+// Backward of the above: ddepth [B,H,W] -> draw [B,1+k,H,W] planar (gradient w.r.t. the head conv outputs).
+__global__ void head_post_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                     const float* __restrict__ noise_image, const float* __restrict__ mask,
+                                     const float* __restrict__ ddepth, int arch, float inv_tau, float drop_const,
+                                     int B, long HW, float s_depth, float s_conf, float* __restrict__ draw,
+                                     float* __restrict__ dbias) {
+  __shared__ float red[16];
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f;  // unscaled gradients w.r.t. the head outputs (= the head bias gradients)
+  if (idx < (long)B * HW) {
+  const int b = (int)(idx / HW);
+  const long p = idx - (long)b * HW;
+  const int nch = 1 + (arch == 0 ? 0 : arch);
+  const float* g = gout + (long)b * nch * HW + p;
+  float* d = draw + (long)b * nch * HW + p;
+  const float t = g[0];
+  const float dt = 1.f - t * t;
+  const float go = ddepth[idx];
+  if (arch == 0) {
+    d0 = go * dt;
+  } else {
+    const float sp = 1.f / (1.f + __expf(-(g[HW] + noise_pixel[idx]) * inv_tau));
+    const float dmask = go * (t - drop_const);
+    if (arch == 1) {
+      const float mp = mask[idx];
+      d0 = mp * go * dt;
+      d1 = dmask * sp * (1.f - sp) * inv_tau;
+    } else {
+      const float mp = mask[(long)b * 2 * HW + p], mi = mask[(long)b * 2 * HW + HW + p];
+      const float si = 1.f / (1.f + __expf(-(g[2 * HW] + noise_image[b]) * inv_tau));
+      d0 = mp * mi * go * dt;
+      d1 = dmask * mi * sp * (1.f - sp) * inv_tau;
+      d2 = dmask * mp * si * (1.f - si) * inv_tau;
+      d[2 * HW] = d2 * s_conf;
+    }
+    d[HW] = d1 * s_conf;
+  }
+  d[0] = d0 * s_depth;
+  }
+  if (dbias) {  // head biases are outside EqualLR's input scaling: their gradient is the unscaled sum
+    const float a0 = dg_block_sum(d0, red);
+    if (threadIdx.x == 0) atomicAdd(&dbias[0], a0);
+    if (arch >= 1) { const float a1 = dg_block_sum(d1, red); if (threadIdx.x == 0) atomicAdd(&dbias[1], a1); }
+    if (arch >= 2) { const float a2 = dg_block_sum(d2, red); if (threadIdx.x == 0) atomicAdd(&dbias[2], a2); }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Per-sample reductions: out[b] = sum_i f(x[b][i]) with f = identity (sq=0) or square (sq=1).  One block per
+// (sample, slab); slabs are combined with atomics (out must be zeroed by the caller).
+__global__ __launch_bounds__(256) void sample_sum_kernel(const float* __restrict__ x, long n, int sq,
+                                                         float* __restrict__ out) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const float* row = x + (long)b * n;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = row[i];
+    acc += sq ? v * v : v;
+  }
+  const float s = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(&out[b], s);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// DiffAugment (utils/diff_augment.py:114-132, p = 1) on [B,1,H,W] fp32, one fused gather pass.
+// policy bits: 1 brightness, 2 saturation (identity for one channel), 4 contrast, 8 translation, 16 cutout.
+// Per-sample parameters: u_b,u_c (the uniform(-1,1) draws; the applied factor is u*u),
+// t_h,t_w,o_x,o_y ints.  xsum[b] = sum of x[b] (needed by contrast: mean of x + brightness).
+struct AugP {
+  const float *u_b, *u_c;
+  const int *t_h, *t_w, *o_x, *o_y;
+  int policy, B, H, W, cut_h, cut_w;
+};
+
+__device__ __forceinline__ bool aug_cut(const AugP& a, int b, int y, int x) {
+  if (!(a.policy & 16)) return false;
+  const int r0 = a.o_x[b] - a.cut_h / 2, c0 = a.o_y[b] - a.cut_w / 2;
+  return y >= r0 && y < r0 + a.cut_h && x >= c0 && x < c0 + a.cut_w;
+}
+
+__global__ void diffaug_fwd_kernel(AugP a, const float* __restrict__ x, const float* __restrict__ xsum,
+                                   float* __restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long HW = (long)a.H * a.W;
+  if (idx >= (long)a.B * HW) return;
+  const int b = (int)(idx / HW);
+  const int yy = (int)((idx - (long)b * HW) / a.W), xx = (int)(idx % a.W);
+  if (aug_cut(a, b, yy, xx)) { y[idx] = 0.f; return; }
+  int sy = yy, sx = xx;
+  if (a.policy & 8) {
+    sy = yy + a.t_h[b];
+    sx = (xx + a.t_w[b]) % (a.W - 1);
+    if (sx < 0) sx += a.W - 1;
+    if (sy < 0 || sy >= a.H) { y[idx] = 0.f; return; }
+  }
+  float v = x[(long)b * HW + (long)sy * a.W + sx];
+  float br = 0.f;
+  if (a.policy & 1) { const float u = a.u_b[b]; br = 0.5f * u * u; v += br; }
+  if (a.policy & 4) {
+    const float u = a.u_c[b];
+    const float c = 1.f + 0.5f * u * u;
+    const float mean = xsum[b] / (float)HW + br;
+    v = mean + c * (v - mean);
+  }
+  y[idx] = v;
+}
+
+// Backward pass 1: gsum[b] = sum over the augmented image of the gradient that reaches x2 (pre-translation
+// image): every (y,x) not cut out and with a valid source row contributes once.
+__global__ __launch_bounds__(256) void diffaug_bwd_sum_kernel(AugP a, const float* __restrict__ gy,
+                                                              float* __restrict__ gsum) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const long HW = (long)a.H * a.W;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+    const int yy = (int)(i / a.W), xx = (int)(i % a.W);
+    if (aug_cut(a, b, yy, xx)) continue;
+    if (a.policy & 8) { const int sy = yy + a.t_h[b]; if (sy < 0 || sy >= a.H) continue; }
+    acc += gy[(long)b * HW + i];
+  }
+  const float s = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(&gsum[b], s);
+}
+
+// Backward pass 2 (gather form of the scatter): gx[b,r,c] from gy.
+__global__ void diffaug_bwd_kernel(AugP a, const float* __restrict__ gy, const float* __restrict__ gsum,
+                                   float* __restrict__ gx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long HW = (long)a.H * a.W;
+  if (idx >= (long)a.B * HW) return;
+  const int b = (int)(idx / HW);
+  const int r = (int)((idx - (long)b * HW) / a.W), c = (int)(idx % a.W);
+  float g2 = 0.f;  // gradient w.r.t. the pre-translation image at (r,c)
+  if (a.policy & 8) {
+    const int yy = r - a.t_h[b];
+    if (yy >= 0 && yy < a.H && c <= a.W - 2) {
+      int w1 = (c - a.t_w[b]) % (a.W - 1);
+      if (w1 < 0) w1 += a.W - 1;
+      if (!aug_cut(a, b, yy, w1)) g2 += gy[(long)b * HW + (long)yy * a.W + w1];
+      // columns 0 and W-1 of the output both read source column (t_w mod (W-1))
+      if (w1 == 0 && !aug_cut(a, b, yy, a.W - 1)) g2 += gy[(long)b * HW + (long)yy * a.W + a.W - 1];
+    }
+  } else {
+    if (!aug_cut(a, b, r, c)) g2 = gy[idx];
+  }
+  float g = g2;
+  if (a.policy & 4) {
+    const float u = a.u_c[b];
+    const float cc = 1.f + 0.5f * u * u;
+    g = cc * g2 + (1.f - cc) * gsum[b] / (float)HW;
+  }
+  gx[idx] = g;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// NSGAN losses (models/loss.py:39-41, 68-69) + their gradients w.r.t. the logits; one block.
+// scal[0]=mean(y_real) scal[1]=mean(y_fake) scal[2]=loss_D ; dy_* = d(w_gan*loss_D)/dy
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void nsgan_d_kernel(const float* __restrict__ y_real,
+                                                      const float* __restrict__ y_fake, int B, float w_gan,
+                                                      float* __restrict__ dy_real, float* __restrict__ dy_fake,
+                                                      float* __restrict__ scal) {
+  __shared__ float red[16];
+  float sr = 0.f, sf = 0.f, lr = 0.f, lf = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float r = y_real[i], f = y_fake[i];
+    sr += r; sf += f;
+    lr += softplus_f(-r); lf += softplus_f(f);
+    dy_real[i] = -w_gan * sigmoid_f(-r) / (float)B;
+    dy_fake[i] = w_gan * sigmoid_f(f) / (float)B;
+  }
+  const float a = dg_block_sum(sr, red), b = dg_block_sum(sf, red);
+  const float c = dg_block_sum(lr, red), d = dg_block_sum(lf, red);
+  if (threadIdx.x == 0) {
+    scal[0] = a / B; scal[1] = b / B; scal[2] = c / B + d / B;
+  }
+}
+
+// scal[0] = loss_G ; dy = d(w_gan*loss_G)/dy_fake
+__global__ __launch_bounds__(256) void nsgan_g_kernel(const float* __restrict__ y_fake, int B, float w_gan,
+                                                      float* __restrict__ dy, float* __restrict__ scal) {
+  __shared__ float red[16];
+  float l = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float f = y_fake[i];
+    l += softplus_f(-f);
+    dy[i] = -w_gan * sigmoid_f(-f) / (float)B;
+  }
+  const float s = dg_block_sum(l, red);
+  if (threadIdx.x == 0) scal[0] = s / B;
+}
+
+// fetch_reals (trainers/dcgan_amp.py:154-160; utils/lidar.py:31-36; utils/__init__.py:70-73)
+__global__ void fetch_reals_kernel(const float* __restrict__ pol, const float* __restrict__ mask, float min_d,
+                                   float max_d, float drop_const, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float depth = pol[i] * (max_d - min_d) + min_d;
+  const float disp = 1.f / depth;
+  float inv = (disp - 1.f / max_d) / (1.f / min_d - 1.f / max_d);
+  inv = inv * 2.f - 1.f;
+  const float m = mask[i];
+  out[i] = m * inv + (1.f - m) * drop_const;
+}
+
+// y = a * x
+__global__ void scale_kernel(const float* __restrict__ x, float a, long n, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i];
+}
+
+// logistic noise of GumbelSigmoid (models/dusty.py:30-36) from two uniform fields
+__global__ void logistic_noise_kernel(const float* __restrict__ u1, const float* __restrict__ u2, float eps, long n,
+                                      float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = -logf(logf(u1[i] + eps) / logf(u2[i] + eps) + eps);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+static inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" {
+
+int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const long n = (long)B * H * W;
+  if (dtype == DG_BF16) blur_fwd_kernel<bf16><<<nblk(n), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
+  else blur_fwd_kernel<float><<<nblk(n), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ring, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const long n = (long)B * H * W;
+  if (dtype == DG_BF16) blur_bwd_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
+  else blur_bwd_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
+                 void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (dtype == DG_BF16) final_fwd_kernel<bf16><<<B, 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
+  else final_fwd_kernel<float><<<B, 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_final_bwd_data(const void* d4, int dtype, const float* wf, const float* up, const float* rowscale, float scale,
+                      int B, long n, int C, void* dd4, float* dbias, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (dtype == DG_BF16)
+    final_bwd_data_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d4, wf, up, rowscale, scale, B, n, C, (bf16*)dd4, dbias);
+  else
+    final_bwd_data_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d4, wf, up, rowscale, scale, B, n, C, (float*)dd4, dbias);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_batch_wsum(const void* src, int dtype, const float* coef, float scale, int B, long n, float* out,
+                  void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (dtype == DG_BF16) batch_wsum_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)src, coef, scale, B, n, out);
+  else batch_wsum_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)src, coef, scale, B, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
+                     float tau, float drop_const, int B, long HW, float* mask, float* depth, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (arch < 0 || arch > 2) return DG_EINVAL;
+  head_post_fwd_kernel<<<nblk((long)B * HW), 256, 0, s>>>(gout, noise_pixel, noise_image, arch, training, 1.f / tau,
+                                                           drop_const, B, HW, mask, depth);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
+                     const float* ddepth, int arch, float tau, float drop_const, int B, long HW, float s_depth,
+                     float s_conf, float* draw, float* dbias,
+                     void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (arch < 0 || arch > 2) return DG_EINVAL;
+  head_post_bwd_kernel<<<nblk((long)B * HW), 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, arch,
+                                                           1.f / tau, drop_const, B, HW, s_depth, s_conf, draw, dbias);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  HIP_CHECK_RET(hipMemsetAsync(out, 0, sizeof(float) * B, s));
+  unsigned gx = nblk(n, 256 * 8);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  sample_sum_kernel<<<dim3(gx, B), 256, 0, s>>>(x, n, sq, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+static AugP make_aug(const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                     const int* o_y, int policy, int B, int H, int W) {
+  AugP a;
+  a.u_b = u_b; a.u_c = u_c; a.t_h = t_h; a.t_w = t_w; a.o_x = o_x; a.o_y = o_y;
+  a.policy = policy; a.B = B; a.H = H; a.W = W;
+  a.cut_h = (int)(H * 0.5 + 0.5);  // utils/diff_augment.py:85
+  a.cut_w = (int)(W * 0.5 + 0.5);
+  return a;
+}
+
+// xsum: [B] workspace (per-sample sum of x), y: [B,H,W]
+int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                   const int* o_x, const int* o_y, int policy, int B, int H, int W, float* xsum, float* y,
+                   void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
+  if (policy & 4) {
+    const int rc = dg_sample_sum(x, B, (long)H * W, 0, xsum, s);
+    if (rc) return rc;
+  }
+  diffaug_fwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, x, xsum, y);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                   const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
+                   void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
+  if (policy & 4) {
+    HIP_CHECK_RET(hipMemsetAsync(gsum, 0, sizeof(float) * B, s));
+    unsigned gxn = nblk((long)H * W, 256 * 8);
+    if (gxn > 64) gxn = 64;
+    diffaug_bwd_sum_kernel<<<dim3(gxn, B), 256, 0, s>>>(a, gy, gsum);
+  }
+  diffaug_bwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, gy, gsum, gx);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_nsgan_d(const float* y_real, const float* y_fake, int B, float w_gan, float* dy_real, float* dy_fake,
+               float* scal, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  nsgan_d_kernel<<<1, 256, 0, s>>>(y_real, y_fake, B, w_gan, dy_real, dy_fake, scal);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_nsgan_g(const float* y_fake, int B, float w_gan, float* dy, float* scal, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  nsgan_g_kernel<<<1, 256, 0, s>>>(y_fake, B, w_gan, dy, scal);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,
+                   float* out, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  fetch_reals_kernel<<<nblk(n), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_scale(const float* x, float a, long n, float* y, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  scale_kernel<<<nblk(n), 256, 0, s>>>(x, a, n, y);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_logistic_noise(const float* u1, const float* u2, float eps, long n, float* out, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  logistic_noise_kernel<<<nblk(n), 256, 0, s>>>(u1, u2, eps, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+}  // extern "C"

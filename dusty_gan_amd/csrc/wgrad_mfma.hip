@@ -1,0 +1,237 @@
+// Weight-gradient GEMM on the matrix cores: dW[tap][ci][co] += scale * sum_b rs[b] sum_pixels A[src_a][ci] G[src_g][co]
+// for Down (wmode 0), Up (wmode 1) and plain row-major operands (wmode 2: Proj, pixels = batch rows).
+// Autograd counterpart in the reference: the weight gradients of nn.Conv2d / nn.ConvTranspose2d inside EqualLR
+// (models/gans/dcgan_eqlr.py:9,24,80; models/ops/common.py:132-133), incl. the R1 double-backward terms.
+//
+// GEMM view: M = ci, N = co, K = pixels.  Both operands are stored pixel-major / channel-minor, i.e. the reduction
+// index is the ROW of both tiles, so the MFMA fragments (8 consecutive k per lane) are read with the gfx950
+// transposing LDS load ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32 MFMA takes one k per lane).
+//   * workgroup = 4 waves (2 x 2) on a BM x BN tile of one tap; grid.y = tap, grid.z = K split over (sample,row)
+//     units; partial sums are added with fp32 atomics whose wave-instruction writes two 128-B row segments (the
+//     full-rate shape), or stored when there is a single split and nothing to accumulate onto.
+//   * the per-sample weight (dy_b for the real batch) is applied when a sample's pixels end:
+//     tot += rs[b] * acc, so the MFMA accumulation itself stays unscaled.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define BKP 32  // coarse pixels per K chunk
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, int accumulate) {
+  constexpr int ES = sizeof(T);
+  constexpr int EPC = 16 / ES;
+  constexpr int RSA = BM * ES + 16, RSG = BN * ES + 16;  // LDS row strides (bytes)
+  constexpr int CPA = BM * ES / 16, CPG = BN * ES / 16;  // 16-B chunks per row
+  constexpr int UA = CPA / 8, UG = CPG / 8;              // chunks per thread (32 rows * CP / 256)
+  constexpr int TM = BM / 64, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BKP * (RSA + RSG)];
+  unsigned char* ldsA = lds;
+  unsigned char* ldsG = lds + BKP * RSA;
+
+  const int tid = threadIdx.x;
+  const int ct = blockIdx.x % tiles_n, mt = blockIdx.x / tiles_n;
+  const int ci0 = mt * BM, co0 = ct * BN;
+  const int tap = blockIdx.y, ky = tap >> 2, kx = tap & 3;
+  const long units = (long)p.B * p.Hc;
+  const long u0 = units * blockIdx.z / gridDim.z, u1 = units * (blockIdx.z + 1) / gridDim.z;
+  const int chunks_per_row = (p.Wc + BKP - 1) / BKP;
+  const long nchunks = (u1 - u0) * chunks_per_row;
+  const int Wa = p.wmode == 0 ? 2 * p.Wc : p.Wc;
+  const int Wg = p.wmode == 1 ? 2 * p.Wc : p.Wc;
+  const T* A = (const T*)p.a;
+  const T* G = (const T*)p.g;
+
+  uint4 ra[UA], rg[UG];
+  auto load_tiles = [&](long u, int xc) {
+    const int b = (int)(u / p.Hc), m = (int)(u % p.Hc);
+    int rowa = 0, rowg = 0;
+    if (p.wmode != 2) dg_wgrad1d(p.wmode, 0, m, p.Hc, ky, rowa, rowg);
+    const T* ab = A + (long)b * p.a_sb + ci0;
+    const T* gb = G + (long)b * p.g_sb + co0;
+#pragma unroll
+    for (int v = 0; v < UA; ++v) {
+      const int c = tid + 256 * v;
+      const int row = c / CPA, part = c % CPA;
+      const int x = xc * BKP + row;
+      int ca = x, cg = x;
+      if (p.wmode != 2 && x < p.Wc) dg_wgrad1d(p.wmode, 1, x, p.Wc, kx, ca, cg);
+      ra[v] = x < p.Wc ? *(const uint4*)(ab + ((long)rowa * Wa + ca) * p.a_sp + part * EPC) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < UG; ++v) {
+      const int c = tid + 256 * v;
+      const int row = c / CPG, part = c % CPG;
+      const int x = xc * BKP + row;
+      int ca = x, cg = x;
+      if (p.wmode != 2 && x < p.Wc) dg_wgrad1d(p.wmode, 1, x, p.Wc, kx, ca, cg);
+      rg[v] = x < p.Wc ? *(const uint4*)(gb + ((long)rowg * Wg + cg) * p.g_sp + part * EPC) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int v = 0; v < UA; ++v) {
+      const int c = tid + 256 * v;
+      *(uint4*)(ldsA + (c / CPA) * RSA + (c % CPA) * 16) = ra[v];
+    }
+#pragma unroll
+    for (int v = 0; v < UG; ++v) {
+      const int c = tid + 256 * v;
+      *(uint4*)(ldsG + (c / CPG) * RSG + (c % CPG) * 16) = rg[v];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
+
+  if (nchunks > 0) {
+    long u = u0;
+    int xc = 0;
+    load_tiles(u, xc);
+    store_tiles();
+    __syncthreads();
+    for (long s = 0; s < nchunks; ++s) {
+      const int cur_b = (int)(u / p.Hc);
+      if (++xc == chunks_per_row) { xc = 0; ++u; }
+      const bool more = s + 1 < nchunks;
+      if (more) load_tiles(u, xc);
+      if constexpr (ES == 2) {
+        // lane -> (row block q, column quad pp) inside its 16-lane group; group -> (k half, column block)
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+          bf16x8 fa[TM], fg[TN];
+          const int prow = kq * 16 + 8 * kh + q;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const unsigned char* ptr = ldsA + prow * RSA + (wm * (BM / 2) + i * 32 + 16 * cb + 4 * pp) * 2;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(ptr));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(ptr + 4 * RSA));
+            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const unsigned char* ptr = ldsG + prow * RSG + (wn * (BN / 2) + j * 32 + 16 * cb + 4 * pp) * 2;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(ptr));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(ptr + 4 * RSG));
+            fg[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll 4
+        for (int k2 = 0; k2 < BKP / 2; ++k2) {
+          float fa[TM], fg[TN];
+          const int prow = 2 * k2 + lh;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[i] = *(const float*)(ldsA + prow * RSA + (wm * (BM / 2) + i * 32 + lr) * 4);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fg[j] = *(const float*)(ldsG + prow * RSG + (wn * (BN / 2) + j * 32 + lr) * 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fg[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (p.rowscale) {
+        const int next_b = (int)(u / p.Hc);
+        if (!more || next_b != cur_b) {
+          const float rs = p.rowscale[cur_b];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              tot[i][j] += acc[i][j] * rs;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            }
+        }
+      }
+      __syncthreads();
+      if (more) {
+        store_tiles();
+        __syncthreads();
+      }
+    }
+  }
+
+  // D layout: col = lane & 31 (co), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (ci)
+  float* dw = p.dw + (long)tap * p.Ci * p.Co;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int co = co0 + wn * (BN / 2) + j * 32 + lr;
+        if (ci < p.Ci && co < p.Co) {
+          const float v = (p.rowscale ? tot[i][j][e] : acc[i][j][e]) * p.scale;
+          float* dst = dw + (long)ci * p.Co + co;
+          if (accumulate) atomicAdd(dst, v);
+          else *dst = v;
+        }
+      }
+}
+
+template <typename T, int BM, int BN>
+static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
+  const int tiles_m = (p->Ci + BM - 1) / BM, tiles_n = (p->Co + BN - 1) / BN;
+  const int ntap = p->wmode == 2 ? 1 : 16;
+  const long units = (long)p->B * p->Hc;
+  long tiles = (long)tiles_m * tiles_n * ntap;
+  long split = 1;
+  if (accumulate) {
+    split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
+    if (split > units) split = units;
+    if (split < 1) split = 1;
+  }
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ntap, (unsigned)split);
+  wgrad_mfma_kernel<T, BM, BN><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+extern "C" int dg_wgrad_mfma_supported(const WgradP* p) {
+  if (p->a_dtype != p->g_dtype) return 0;
+  if (p->a_sc != 1 || p->g_sc != 1) return 0;
+  if (p->Ci % 64 != 0 || p->Co % 64 != 0) return 0;
+  if (p->wmode != 2) {
+    if (!p->ring) return 0;
+    if (p->Wc % BKP != 0) return 0;
+  }
+  return 1;
+}
+
+// accumulate = 1: dw += (atomics, K split over workgroups); accumulate = 0: dw = (single pass, plain stores)
+int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream) {
+  if (!dg_wgrad_mfma_supported(p)) return DG_EUNSUPPORTED;
+  const bool m128 = p->Ci % 128 == 0, n128 = p->Co % 128 == 0;
+  if (p->a_dtype == DG_BF16) {
+    if (m128 && n128) return launch_cfg<bf16, 128, 128>(p, accumulate, stream);
+    if (m128) return launch_cfg<bf16, 128, 64>(p, accumulate, stream);
+    if (n128) return launch_cfg<bf16, 64, 128>(p, accumulate, stream);
+    return launch_cfg<bf16, 64, 64>(p, accumulate, stream);
+  }
+  if (m128 && n128) return launch_cfg<float, 128, 128>(p, accumulate, stream);
+  if (m128) return launch_cfg<float, 128, 64>(p, accumulate, stream);
+  if (n128) return launch_cfg<float, 64, 128>(p, accumulate, stream);
+  return launch_cfg<float, 64, 64>(p, accumulate, stream);
+}

@@ -1,0 +1,446 @@
+"""MI355X engine for the dusty-gan training hot path: parameter storage, workspaces and the explicit
+forward / backward-data / weight-gradient schedule of one `Trainer.step` (reference: trainers/dcgan_amp.py:162-325).
+
+No autograd: every pass is a kernel of libdustygan_hip.so launched on torch's current HIP stream.  torch owns the
+device memory (flat parameter stores, workspaces) and nothing else.  See DESIGN.md for the schedule and layouts.
+"""
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+
+ARCH_ID = {"none": 0, "dusty1": 1, "dusty2": 2}
+
+# bench.py sets this to a list to time every conv / wgrad launch with HIP events (kernel family, algorithmic FLOPs,
+# algorithmic bytes, start event, end event, shape tag).  None = no instrumentation (the normal path).
+PROFILE = None
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class Segment:
+    __slots__ = ("name", "off", "shape", "numel", "kind")
+
+    def __init__(self, name, off, shape, kind):
+        self.name, self.off, self.shape, self.kind = name, off, tuple(shape), kind
+        n = 1
+        for s in shape:
+            n *= s
+        self.numel = n
+
+
+class ParamStore:
+    """Flat fp32 parameter storage in ENGINE layout (+ grad / Adam state / low-precision shadow, same offsets).
+
+    Conv weights are stored [ky][kx][ci][co]; the reference-shaped nn.Parameters are strided views of `flat`
+    (see models/gans/dcgan_eqlr.py in this package), so state_dict() keeps the reference's keys and shapes.
+    """
+
+    def __init__(self, segments):
+        self.seg = OrderedDict()
+        off = 0
+        for name, shape, kind in segments:
+            s = Segment(name, off, shape, kind)
+            self.seg[name] = s
+            off = _align(off + s.numel)
+        self.n = off
+        self.flat = torch.zeros(self.n, dtype=torch.float32)
+        self.grad = None
+        self.m = None
+        self.v = None
+        self.shadow = None  # T copy of flat (same offsets)
+        self.coci = {}  # name -> transposed conv shadow [16][co][ci] in T
+        self.shadow_dtype = None
+        self._seen_version = -1
+
+    # -- views
+    def view(self, name, buf=None):
+        s = self.seg[name]
+        buf = self.flat if buf is None else buf
+        return buf[s.off:s.off + s.numel].view(s.shape)
+
+    def apply(self, fn):
+        self.flat = fn(self.flat)
+        for k in ("grad", "m", "v", "shadow"):
+            t = getattr(self, k)
+            if t is not None:
+                setattr(self, k, fn(t))
+        self.coci = {k: fn(v) for k, v in self.coci.items()}
+        self._seen_version = -1
+
+    @property
+    def device(self):
+        return self.flat.device
+
+    def ensure_train_state(self):
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.flat)
+            self.m = torch.zeros_like(self.flat)
+            self.v = torch.zeros_like(self.flat)
+
+    def refresh_shadows(self, dtype, force=False):
+        """(Re)build the T-typed copies the conv kernels read.  Cheap no-op when nothing changed."""
+        ver = self.flat._version
+        if not force and self.shadow is not None and self.shadow_dtype == dtype and ver == self._seen_version:
+            return
+        lib, st = L.lib(), L.stream_ptr()
+        if self.shadow is None or self.shadow_dtype != dtype or self.shadow.device != self.flat.device:
+            self.shadow = torch.empty(self.n, dtype=dtype, device=self.flat.device)
+            self.coci = {}
+            self.shadow_dtype = dtype
+        L.check(lib.dg_cast(L.ptr(self.flat), L.ptr(self.shadow), L.dtype_code(dtype), self.n, st), "dg_cast")
+        self.refresh_transposed()
+        self._seen_version = ver
+
+    def refresh_transposed(self):
+        lib, st = L.lib(), L.stream_ptr()
+        for name, s in self.seg.items():
+            if s.kind != "conv":
+                continue
+            _, _, ci, co = s.shape
+            if name not in self.coci:
+                self.coci[name] = torch.empty(16 * ci * co, dtype=self.shadow_dtype, device=self.flat.device)
+            L.check(lib.dg_transpose_shadow(L.ptr(self.flat) + 4 * s.off, L.ptr(self.coci[name]),
+                                            L.dtype_code(self.shadow_dtype), ci, co, st), "dg_transpose_shadow")
+
+    def sptr(self, name):
+        """device pointer of the T shadow of a segment"""
+        return L.ptr(self.shadow) + self.shadow.element_size() * self.seg[name].off
+
+    def fptr(self, name, buf=None):
+        buf = self.flat if buf is None else buf
+        return L.ptr(buf) + 4 * self.seg[name].off
+
+
+def g_segments(nz, ch, shape, nheads):
+    h0, w0 = shape[0] >> 4, shape[1] >> 4
+    segs = [("proj_w", (h0, w0, ch[3], nz), "gemm"), ("proj_b", (ch[3],), "bias")]
+    for i, (ci, co) in enumerate(((ch[3], ch[2]), (ch[2], ch[1]), (ch[1], ch[0])), start=1):
+        segs += [(f"up{i}_w", (4, 4, ci, co), "conv"), (f"up{i}_b", (co,), "bias")]
+    segs += [("head_w", (4, 4, ch[0], nheads), "conv"), ("head_b", (nheads,), "bias")]
+    return segs
+
+
+def d_segments(in_ch, ch, shape):
+    h0, w0 = shape[0] >> 4, shape[1] >> 4
+    segs = []
+    ci = 2 * in_ch
+    for i in range(4):
+        segs += [(f"d{i + 1}_w", (4, 4, ci, ch[i]), "conv"), (f"d{i + 1}_b", (ch[i],), "bias")]
+        ci = ch[i]
+    segs += [("final_w", (h0, w0, ch[3]), "vec"), ("final_b", (1,), "bias")]
+    return segs
+
+
+class NetCfg:
+    def __init__(self, shape, nz, ch, arch="none", ring=True, tau=1.0, drop_const=-1.0, dis_in_ch=1):
+        self.H, self.W = int(shape[0]), int(shape[1])
+        if self.H % 16 or self.W % 16 or self.H < 32:
+            raise ValueError(f"shape {shape}: H and W must be multiples of 16 and H >= 32 (SURVEY.md §0.2)")
+        self.nz, self.ch = int(nz), [int(c) for c in ch]
+        self.arch, self.ring, self.tau, self.drop_const = arch, bool(ring), float(tau), float(drop_const)
+        self.nheads = 1 + ARCH_ID[arch]
+        self.h0, self.w0 = self.H >> 4, self.W >> 4
+        if dis_in_ch != 1:
+            raise NotImplementedError("discriminator in_ch != 1 (the range-image path is single channel)")
+
+
+class Ops:
+    """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
+
+    def __init__(self, dtype):
+        self.lib = L.lib()
+        self.dtype = dtype
+        self.dt = L.dtype_code(dtype)
+        self.es = 2 if dtype == torch.bfloat16 else 4
+        # 0 auto (MFMA implicit GEMM where the shape allows), 1 direct VALU kernels only (cross-check runs)
+        self.force = int(os.environ.get("DUSTY_GAN_FORCE_KERNEL", "0"))
+
+    def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
+             bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
+             x_off=0, out_off=0, aux_off=0):
+        p = L.DgConv()
+        p.mode, p.adj, p.ring = mode, adj, int(ring)
+        p.B, p.Hc, p.Wc, p.K, p.N = B, Hc, Wc, K, N
+        in_dt = self.dt if in_dt is None else in_dt
+        out_dt = self.dt if out_dt is None else out_dt
+        ies = 2 if in_dt == L.DG_BF16 else 4
+        oes = 2 if out_dt == L.DG_BF16 else 4
+        p.in_ = L.ptr(x) + ies * x_off
+        p.in_sb, p.in_sp, p.in_sk = x_strides
+        p.out = L.ptr(out) + oes * out_off
+        p.out_sb, p.out_sp, p.out_sn = out_strides
+        p.w = w_ptr
+        p.w_st, p.w_sn, p.w_sk = N * K, K, 1
+        p.scale, p.epi = scale, epi
+        p.bias, p.bias_mod = bias, bias_mod
+        p.aux = None if aux is None else L.ptr(aux) + oes * aux_off
+        p.dbias, p.rowscale = dbias, L.ptr(rowscale)
+        p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, self.dt
+        p.nscale = L.ptr(nscale)
+        if PROFILE is None:
+            L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
+            return
+        # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
+        mfma = self.force != 1 and not nscale and bool(self.lib.dg_conv_mfma_supported(C.byref(p)))
+        taps = 1 if mode == L.MODE_GEMM else (16 if mode == L.MODE_S2 else 4)
+        npix = B if mode == L.MODE_GEMM else (B * Hc * Wc if mode == L.MODE_S2 else B * 4 * Hc * Wc)
+        flops = 2.0 * npix * N * K * taps
+        nbytes = npix * (N * oes + K * ies * (1 if mode != L.MODE_S2 else 4)) + taps * N * K * self.es
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
+        e1.record()
+        PROFILE.append(("conv_mfma_kernel" if mfma else "conv_direct_kernel", flops, nbytes, e0, e1,
+                        f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
+
+    def wgrad(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale=None,
+              accumulate=1, a_dt=None, g_dt=None, a_off=0, g_off=0):
+        p = L.DgWgrad()
+        p.wmode, p.ring = wmode, int(ring)
+        p.B, p.Hc, p.Wc, p.Ci, p.Co = B, Hc, Wc, Ci, Co
+        a_dt = self.dt if a_dt is None else a_dt
+        g_dt = self.dt if g_dt is None else g_dt
+        p.a = L.ptr(a) + (2 if a_dt == L.DG_BF16 else 4) * a_off
+        p.a_sb, p.a_sp, p.a_sc = a_strides
+        p.g = L.ptr(g) + (2 if g_dt == L.DG_BF16 else 4) * g_off
+        p.g_sb, p.g_sp, p.g_sc = g_strides
+        p.dw, p.scale, p.rowscale = dw_ptr, scale, L.ptr(rowscale)
+        p.a_dtype, p.g_dtype = a_dt, g_dt
+        if PROFILE is None:
+            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
+            return
+        mfma = self.force != 1 and bool(self.lib.dg_wgrad_mfma_supported(C.byref(p)))
+        taps = 1 if wmode == 2 else 16
+        flops = 2.0 * B * Hc * Wc * Ci * Co * taps
+        nbytes = B * Hc * Wc * (Ci + Co) * self.es * (1 if wmode == 2 else 4) + taps * Ci * Co * 4
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
+        e1.record()
+        PROFILE.append(("wgrad_mfma_kernel" if mfma else "wgrad_direct_kernel", flops, nbytes, e0, e1,
+                        f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
+
+
+class GEngine:
+    """Generator forward / backward on one ParamStore (models/gans/dcgan_eqlr.py:49-72 + models/dusty.py)."""
+
+    def __init__(self, cfg: NetCfg, dtype):
+        self.cfg, self.dtype = cfg, dtype
+        self.ops = Ops(dtype)
+        self.ws_B = 0
+
+    def alloc(self, B, device):
+        if self.ws_B == B and self.a[0].device == device:
+            return
+        c = self.cfg
+        T = self.dtype
+        hw = [(c.h0 << i, c.w0 << i) for i in range(5)]  # grids of a0..a3 and the image
+        chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
+        self.grid = hw
+        self.a = [torch.empty(B * hw[i][0] * hw[i][1] * chs[i], dtype=T, device=device) for i in range(4)]
+        self.dp = [torch.empty_like(t) for t in self.a]  # gradients w.r.t. the pre-activations of a0..a3
+        HW = c.H * c.W
+        self.gout = torch.empty(B, c.nheads, c.H, c.W, dtype=torch.float32, device=device)
+        self.draw = torch.empty_like(self.gout)
+        self.mask = torch.empty(B, max(c.nheads - 1, 1), c.H, c.W, dtype=torch.float32, device=device)
+        self.depth = torch.empty(B, 1, c.H, c.W, dtype=torch.float32, device=device)
+        self.zT = torch.empty(B * c.nz, dtype=T, device=device)
+        self.noise_pixel = None
+        self.noise_image = None
+        k = c.nheads - 1
+        s_depth = 1.0 / math.sqrt(1 * 16)
+        s_conf = 1.0 / math.sqrt(k * 16) if k else 0.0
+        self.head_scales = (s_depth, s_conf)
+        self.nscale = torch.tensor([s_depth] + [s_conf] * k, dtype=torch.float32, device=device)
+        self.HW = HW
+        self.ws_B = B
+
+    def forward(self, st: ParamStore, z, noise=None, training=True):
+        """z [B,nz] fp32; noise: dict(pixel [B,1,H,W], image [B,1,1,1]) logistic noise (dusty archs).
+        Returns the reference's output dict (views of engine workspaces)."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        B = z.shape[0]
+        self.alloc(B, z.device)
+        st.refresh_shadows(self.dtype)
+        sp = L.stream_ptr()
+        chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
+        z = z.contiguous().float()
+        L.check(lib.dg_cast(L.ptr(z), L.ptr(self.zT), o.dt, B * c.nz, sp), "dg_cast")
+        # Proj (dcgan_eqlr.py:6-16): GEMM [B,nz] x [N',nz]^T, N' = h0*w0*C3 in (y,x,c) order
+        Np = c.h0 * c.w0 * chs[0]
+        o.conv(L.MODE_GEMM, 0, 1, B, 1, 1, c.nz, Np, self.zT, (c.nz, 0, 1), self.a[0], (Np, 0, 1), st.sptr("proj_w"),
+               1.0 / math.sqrt(Np), L.EPI_LRELU, bias=st.fptr("proj_b"), bias_mod=chs[0])
+        # Up x3 (dcgan_eqlr.py:19-26)
+        for i in (1, 2, 3):
+            hc, wc = self.grid[i - 1]
+            ci, co = chs[i - 1], chs[i]
+            o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.a[i],
+                   (4 * hc * wc * co, co, 1), L.ptr(st.coci[f"up{i}_w"]), 1.0 / math.sqrt(co * 16), L.EPI_LRELU,
+                   bias=st.fptr(f"up{i}_b"), bias_mod=co)
+        # Head (dcgan_eqlr.py:29-46), all heads in one pass, planar fp32 output
+        hc, wc = self.grid[3]
+        o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.gout,
+               (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR,
+               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale)
+        arch = ARCH_ID[c.arch]
+        if arch:
+            if noise is None or "pixel" not in noise:
+                raise ValueError("dusty generator needs logistic noise (engine.sample_noise or injected)")
+            self.noise_pixel = noise["pixel"].contiguous().float()
+            self.noise_image = noise["image"].contiguous().float() if (arch == 2 and training) else None
+            if arch == 2 and training and self.noise_image is None:
+                raise ValueError("dusty2 in training mode needs image-level noise")
+        L.check(lib.dg_head_post_fwd(L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
+                                     L.ptr(self.noise_image) if arch == 2 and training else None, arch,
+                                     int(training), c.tau, c.drop_const, B, self.HW, L.ptr(self.mask),
+                                     L.ptr(self.depth), sp), "dg_head_post_fwd")
+        out = OrderedDict()
+        out["depth"] = self.depth
+        if arch:
+            out["confidence"] = self.gout[:, 1:]
+            out["depth_orig"] = self.gout[:, 0:1]
+            out["mask"] = self.mask
+        return out
+
+    def backward(self, st: ParamStore, ddepth, accumulate_proj=False):
+        """ddepth [B,1,H,W] fp32 = dLoss/d(output depth).  Accumulates every G parameter gradient into st.grad
+        (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309)."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        B = ddepth.shape[0]
+        sp = L.stream_ptr()
+        chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
+        arch = ARCH_ID[c.arch]
+        s_depth, s_conf = self.head_scales
+        L.check(lib.dg_head_post_bwd(L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
+                                     L.ptr(self.noise_image) if arch == 2 else None,
+                                     L.ptr(self.mask) if arch else None, L.ptr(ddepth), arch, c.tau, c.drop_const, B,
+                                     self.HW, s_depth, s_conf, L.ptr(self.draw), st.fptr("head_b", st.grad), sp),
+                "dg_head_post_bwd")
+        hc, wc = self.grid[3]
+        pl = (c.nheads * self.HW, 1, self.HW)
+        # head weight gradient and backward-data (gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad)
+        o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw, pl,
+                st.fptr("head_w", st.grad), 1.0, g_dt=L.DG_F32)
+        o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw, pl, self.dp[3],
+               (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
+               dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], in_dt=L.DG_F32)
+        for i in (3, 2, 1):
+            hc, wc = self.grid[i - 1]
+            ci, co = chs[i - 1], chs[i]
+            s = 1.0 / math.sqrt(co * 16)
+            o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
+                    (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), s)
+            prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
+            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, self.dp[i], (4 * hc * wc * co, co, 1), self.dp[i - 1],
+                   (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
+                   dbias=st.fptr(prev_b, st.grad), bias_mod=ci)
+        Np = c.h0 * c.w0 * chs[0]
+        # Proj weight gradient: dW[n'][k] = s * sum_b dp0[b][n'] z[b][k]  (overwrite: nothing else writes it)
+        o.wgrad(2, 1, 1, 1, B, Np, c.nz, self.dp[0], (0, Np, 1), self.zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
+                1.0 / math.sqrt(Np), accumulate=int(accumulate_proj))
+
+
+class DEngine:
+    """Discriminator passes (models/gans/dcgan_eqlr.py:85-96): forward, the shared backward-data chain, the R1
+    tangent pass and the weight gradients."""
+
+    def __init__(self, cfg: NetCfg, dtype):
+        self.cfg, self.dtype = cfg, dtype
+        self.ops = Ops(dtype)
+        self.ws_B = 0
+
+    def alloc(self, nb, device):
+        """Workspaces for `nb` images (the D phase uses 3B slots: real | fake | R1 tangent)."""
+        if self.ws_B >= nb and self.h[0].device == device:
+            return
+        c, T = self.cfg, self.dtype
+        self.grid = [(c.H >> i, c.W >> i) for i in range(5)]  # h0 (image) .. d4
+        self.chs = [2, c.ch[0], c.ch[1], c.ch[2], c.ch[3]]
+        self.per = [self.grid[i][0] * self.grid[i][1] * self.chs[i] for i in range(5)]
+        self.h = [torch.empty(nb * self.per[i], dtype=T, device=device) for i in range(5)]
+        self.e = [torch.empty(nb * self.per[i], dtype=T, device=device) for i in range(5)]
+        self.y = torch.empty(nb, dtype=torch.float32, device=device)
+        self.ws_B = nb
+
+    def forward(self, st, x, slot, tangent_of=None):
+        """x [n,1,H,W] fp32 written to batch slots [slot, slot+n).  tangent_of = slot of the saved activations whose
+        lrelu masks gate the R1 tangent pass (then no bias, no activation: the Jacobian-vector product)."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        n = x.shape[0]
+        sp = L.stream_ptr()
+        st.refresh_shadows(self.dtype)
+        es = o.es
+        L.check(lib.dg_blur_fwd(L.ptr(x), L.ptr(self.h[0]) + es * slot * self.per[0], o.dt, n, c.H, c.W, int(c.ring),
+                                sp), "dg_blur_fwd")
+        for i in range(1, 5):
+            hc, wc = self.grid[i]
+            ci, co = self.chs[i - 1], self.chs[i]
+            tang = tangent_of is not None
+            o.conv(L.MODE_S2, 0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.h[i],
+                   (self.per[i], co, 1), L.ptr(st.coci[f"d{i}_w"]), 1.0 / math.sqrt(ci * 16),
+                   L.EPI_MASK if tang else L.EPI_LRELU, bias=None if tang else st.fptr(f"d{i}_b"), bias_mod=co,
+                   aux=self.h[i] if tang else None, x_off=slot * self.per[i - 1], out_off=slot * self.per[i],
+                   aux_off=(tangent_of or 0) * self.per[i])
+        if tangent_of is None:
+            nf = self.per[4]
+            L.check(lib.dg_final_fwd(L.ptr(self.h[4]) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
+                                     1.0 / math.sqrt(nf), n, nf, L.ptr(self.y) + 4 * slot, sp), "dg_final_fwd")
+        return self.y[slot:slot + n]
+
+    def _bwd_layer(self, st, i, slot, n, rowscale, want_dbias):
+        """e[i-1] = lrelu'(h[i-1]) * sqrt2 * s_i * conv_i^T(e[i])  (no mask for i == 1: BlurVH has no activation)"""
+        c, o = self.cfg, self.ops
+        hc, wc = self.grid[i]
+        ci, co = self.chs[i - 1], self.chs[i]
+        first = i == 1
+        o.conv(L.MODE_UP, 1, c.ring, n, hc, wc, co, ci, self.e[i], (self.per[i], co, 1), self.e[i - 1],
+               (self.per[i - 1], ci, 1), st.sptr(f"d{i}_w"), 1.0 / math.sqrt(ci * 16),
+               L.EPI_LINEAR if first else L.EPI_MASK, aux=None if first else self.h[i - 1],
+               dbias=(st.fptr(f"d{i - 1}_b", st.grad) if (want_dbias and not first) else None), bias_mod=ci,
+               rowscale=rowscale, x_off=slot * self.per[i], out_off=slot * self.per[i - 1],
+               aux_off=slot * self.per[i - 1])
+
+    def backward_data(self, st, slot, n, up, rowscale, want_dbias):
+        """Backward-data chain over batch slots [slot, slot+n): e4 = up*s_f*wf*mask4, then e3, e2, e1 (each the
+        gradient w.r.t. a layer's pre-activation).  up: per-sample upstream gradient or None (= 1, the R1 chain);
+        rowscale: per-sample weight of the bias-gradient sums (dLoss/dy_real for the shared real chain)."""
+        o, lib = self.ops, L.lib()
+        nf = self.per[4]
+        L.check(lib.dg_final_bwd_data(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), L.ptr(up),
+                                      L.ptr(rowscale), 1.0 / math.sqrt(nf), n, nf, self.chs[4],
+                                      L.ptr(self.e[4]) + o.es * slot * nf,
+                                      st.fptr("d4_b", st.grad) if want_dbias else None, L.stream_ptr()),
+                "dg_final_bwd_data")
+        for i in (4, 3, 2):
+            self._bwd_layer(st, i, slot, n, rowscale, want_dbias)
+
+    def backward_input(self, st, slot, n, dx):
+        """Continue a chain from e1 to the image: Down1 backward-data + BlurVH adjoint -> dx [n,1,H,W] fp32."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        self._bwd_layer(st, 1, slot, n, None, False)
+        L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
+                                int(c.ring), L.stream_ptr()), "dg_blur_bwd")
+
+    def wgrad(self, st, a_slot, g_slot, n, rowscale):
+        """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot+b]) for the four Down layers."""
+        c, o = self.cfg, self.ops
+        for i in range(1, 5):
+            hc, wc = self.grid[i]
+            ci, co = self.chs[i - 1], self.chs[i]
+            o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
+                    (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
+                    a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i])
+
+    def final_wgrad(self, st, slot, n, coef):
+        """dwf += s_f * sum_b coef[b] * h4[slot+b]"""
+        o, lib = self.ops, L.lib()
+        nf = self.per[4]
+        L.check(lib.dg_batch_wsum(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n, nf,
+                                  st.fptr("final_w", st.grad), L.stream_ptr()), "dg_batch_wsum")

@@ -1,0 +1,452 @@
+"""Trainer for the DCGAN-eqlr / DUSty training hot path on MI355X -- reference: trainers/dcgan_amp.py.
+
+Drop-in surface: Trainer(cfg, local_cfg) with .device, .start_iteration, .loader, .fetch_reals,
+.A, .step(i) -> dict[str,float], .generate, .save_models; plus optimize_D()/optimize_G() which `step` is made of.
+
+What differs underneath:
+  * no autograd / DDP / GradScaler: one explicit schedule of HIP kernels per phase, fp32 master parameters in flat
+    engine-layout buffers, bf16 (enable_amp) or fp32 activations, one RCCL all-reduce per network per step;
+  * the discriminator is piecewise linear, so the R1 backward-data chain d(sum y_real)/dx is reused (scaled per
+    sample by dLoss/dy_real) as the real batch's ordinary backward pass, and the R1 double backward is a
+    forward-mode tangent pass through the saved leaky-relu masks (SURVEY.md §7 "hard parts");
+  * the G-phase D(real) forward of the reference (:259) is dead code for non-relativistic losses and is not run;
+  * scalars are gathered with ONE packed all-reduce and read back lazily.
+"""
+import os.path as osp
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib as L
+from ..models import define_D, define_G
+from ..models.loss import GANLoss
+from ..utils import cycle, sigmoid_to_tanh, tanh_to_sigmoid  # noqa: F401  (re-exported like the reference)
+from ..utils.context_manager import gradient_accumulation
+from ..utils.diff_augment import DiffAugment
+from ..utils.lidar import LiDAR
+from ..utils.rng import Philox
+from ..utils.synthetic import SyntheticLiDAR
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class LazyScalars(dict):
+    """dict[str,float] whose values are read back from the device on first access (one D2H copy per step instead
+    of the reference's 5-7 blocking `.item()` calls, trainers/dcgan_amp.py:319-323)."""
+
+    def __init__(self, keys, dev_tensor):
+        super().__init__()
+        self._keys, self._dev, self._done = list(keys), dev_tensor, False
+
+    def _resolve(self):
+        if not self._done:
+            vals = self._dev.tolist()
+            for k, v in zip(self._keys, vals):
+                dict.__setitem__(self, k, v)
+            self._done = True
+            self._dev = None
+
+    def __getitem__(self, k):
+        self._resolve()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def keys(self):
+        self._resolve()
+        return dict.keys(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._resolve()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __contains__(self, k):
+        return k in self._keys
+
+    def __repr__(self):
+        self._resolve()
+        return dict.__repr__(self)
+
+
+class FlatAdam:
+    """Adam state on a flat ParamStore, exported/imported in torch.optim.Adam's state_dict format so checkpoints
+    interchange with the reference (trainers/dcgan_amp.py:116-125, 138-141, 403-404)."""
+
+    def __init__(self, net, lr, betas, eps=1e-8):
+        self.net, self.lr, self.betas, self.eps = net, float(lr), (float(betas[0]), float(betas[1])), eps
+        self.step_count = 0
+
+    @property
+    def store(self):
+        return self.net.store
+
+    def _param_views(self, buf):
+        """views of `buf` (grad/m/v) shaped like the module's parameters, in named_parameters() order"""
+        st = self.store
+        pairs = self.net.backbone._bind_pairs() if hasattr(self.net, "backbone") else self.net._bind_pairs()
+        by_param = {id(p): mk for p, mk in pairs}
+        views = []
+        saved = st.flat
+        for _, p in self.net.named_parameters():
+            st.flat = buf
+            try:
+                views.append(by_param[id(p)](st))
+            finally:
+                st.flat = saved
+        return views
+
+    def state_dict(self):
+        st = self.store
+        state = {}
+        if self.step_count > 0:
+            ms, vs = self._param_views(st.m), self._param_views(st.v)
+            for i, (m, v) in enumerate(zip(ms, vs)):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().cpu().contiguous(),
+                            "exp_avg_sq": v.detach().cpu().contiguous()}
+        n = len(list(self.net.parameters()))
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(n))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        st = self.store
+        st.ensure_train_state()
+        ms, vs = self._param_views(st.m), self._param_views(st.v)
+        steps = []
+        with torch.no_grad():
+            for i, s in sd["state"].items():
+                ms[int(i)].copy_(s["exp_avg"])
+                vs[int(i)].copy_(s["exp_avg_sq"])
+                steps.append(int(float(s["step"])))
+        self.step_count = max(steps) if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+
+    def zero_grad(self, set_to_none=True):
+        self.store.grad.zero_()
+
+    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32):
+        st = self.store
+        self.step_count += 1
+        L.check(L.lib().dg_adam_ema_step(L.ptr(st.flat), L.ptr(st.grad), L.ptr(st.m), L.ptr(st.v),
+                                         L.ptr(ema_store.flat) if ema_store is not None else None, L.ptr(st.shadow),
+                                         L.dtype_code(shadow_dtype), st.n, gscale, self.lr, self.betas[0],
+                                         self.betas[1], self.eps, self.step_count, ema_decay, L.stream_ptr()),
+                "dg_adam_ema_step")
+        st.refresh_transposed()
+        if ema_store is not None:
+            ema_store._seen_version = -1  # its shadows are rebuilt lazily when G_ema is used
+
+
+def _store(net):
+    return net.store
+
+
+def _backbone(G):
+    return G.backbone if hasattr(G, "backbone") else G
+
+
+class Trainer:
+    def __init__(self, cfg, local_cfg, loader=None):
+        self.cfg = cfg
+        self.local_cfg = local_cfg
+        gpu = local_cfg["gpu"] if isinstance(local_cfg, dict) else local_cfg.gpu
+        self.device = torch.device("cuda", int(gpu)) if not isinstance(gpu, torch.device) else gpu
+        if not torch.cuda.is_available():
+            raise RuntimeError("dusty_gan_amd.Trainer needs an MI355X (no CPU path; see oracle/ for the CPU checker)")
+        torch.cuda.set_device(self.device)
+        L.lib()  # fail loudly now if the HIP library is missing
+        self.local_batch = int(local_cfg["batch_size"] if isinstance(local_cfg, dict) else local_cfg.batch_size)
+
+        # setup models (reference :45-51)
+        self.cfg.model.gen.shape = self.cfg.dataset.shape
+        self.cfg.model.dis.shape = self.cfg.dataset.shape
+        self.G = define_G(self.cfg)
+        self.D = define_D(self.cfg)
+        self.G_ema = define_G(self.cfg)
+        self.G_ema.eval()
+        self.dtype = _backbone(self.G).compute_dtype
+        self.A = DiffAugment(policy=list(self.cfg.solver.augment) if self.cfg.solver.augment is not None else None)
+        H, W = self.cfg.dataset.shape
+        self.H, self.W = int(H), int(W)
+        self.lidar = LiDAR(num_ring=H, num_points=W, min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth,
+                           angle_file=osp.join(cfg.dataset.root, "angles.pt") if cfg.dataset.get("root") else None)
+
+        self.G.to(self.device)
+        self.D.to(self.device)
+        self.G_ema.to(self.device)
+        for net in (self.G, self.D):
+            net.store.ensure_train_state()
+
+        # DDP construction broadcasts rank 0's parameters (reference :68-69)
+        self.world = _world()
+        if self.world > 1:
+            dist.broadcast(self.G.store.flat, src=0)
+            dist.broadcast(self.D.store.flat, src=0)
+            self.G.store._seen_version = -1
+            self.D.store._seen_version = -1
+        self.G_ema.store.flat.copy_(self.G.store.flat)  # ema_inplace(G_ema, G, 0.0) (:51)
+        self.G_ema.store._seen_version = -1
+
+        self.ema_decay = 0.5 ** (self.cfg.solver.batch_size / (self.cfg.solver.smoothing_kimg * 1000))
+
+        # data: the hot path is fed from a device-resident pool for `dataset.name == synthetic`; file datasets are
+        # the "next" row of SURVEY.md §8f -- any iterator of {"depth","mask"} batches can be passed as `loader`.
+        if loader is not None:
+            self.loader = loader
+        elif str(self.cfg.dataset.name) == "synthetic":
+            self.dataset = SyntheticLiDAR(self.local_batch, self.H, self.W, self.device, seed=1234 + _rank(),
+                                          pool=int(self.cfg.dataset.get("pool", 4)),
+                                          min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth)
+            self.loader = cycle(self.dataset)
+        else:
+            raise NotImplementedError(
+                f"dataset '{self.cfg.dataset.name}': the file-based KITTI/MPO input path is outside this round's "
+                "scope (SURVEY.md §8f row 1); pass dataset=synthetic or give Trainer(..., loader=<iterator>)")
+
+        # losses (reference :104-113)
+        self.loss_weight = dict(self.cfg.solver.loss)
+        self.criterion = {"gan": GANLoss(self.cfg.solver.gan_mode)}
+        if self.criterion["gan"].metric != "nsgan":
+            raise NotImplementedError("only gan_mode=nsgan has fused loss kernels (SURVEY.md §8f row 4)")
+        if self.loss_weight.get("gp", 0) > 0.0:
+            self.criterion["gp"] = True
+        if self.loss_weight.get("pl", 0) > 0.0:
+            raise NotImplementedError("path-length regularisation (loss.pl > 0) is outside the hot path scope")
+
+        # optimizers (reference :116-125)
+        betas = (float(self.cfg.solver.lr.beta1), float(self.cfg.solver.lr.beta2))
+        self.optim_G = FlatAdam(self.G, self.cfg.solver.lr.alpha.gen, betas)
+        self.optim_D = FlatAdam(self.D, self.cfg.solver.lr.alpha.dis, betas)
+        self.enable_amp = bool(cfg.enable_amp)
+
+        # resume (reference :134-144)
+        self.start_iteration = 0
+        if self.cfg.resume is not None:
+            sd = torch.load(self.cfg.resume, map_location="cpu")
+            self.start_iteration = sd["step"] // self.cfg.solver.batch_size
+            self.G.load_state_dict(sd["G"])
+            self.D.load_state_dict(sd["D"])
+            self.G_ema.load_state_dict(sd["G_ema"])
+            self.optim_G.load_state_dict(sd["optim_G"])
+            self.optim_D.load_state_dict(sd["optim_D"])
+
+        self.n_acc = int(self.cfg.solver.num_accumulation)
+        self.rng = Philox(torch.initial_seed() + 7919 * _rank(), self.device, stream_id=1)
+        self.fixed_noise = self.sample_latents(self.local_batch)
+        self._geng = None
+        self._pending = None
+        self._dev_scal = None
+
+    # ------------------------------------------------------------------ helpers
+    def sample_latents(self, B):
+        """reference :151-152"""
+        return self.rng.normal(B * self.cfg.model.gen.in_ch).view(B, self.cfg.model.gen.in_ch)
+
+    def fetch_reals(self, raw_batch):
+        """reference :154-160"""
+        pol = raw_batch["depth"].to(self.device, non_blocking=True)
+        mask = raw_batch["mask"].to(self.device, non_blocking=True).float()
+        return self.lidar.fetch_reals(pol, mask, float(self.cfg.model.gen.drop_const))
+
+    def _g_engines(self):
+        """one generator workspace per micro-batch: the D phase's G activations are reused by the G phase (:196,256)"""
+        if self._geng is None:
+            from ..engine import GEngine
+            bb = _backbone(self.G)
+            first = bb.engine()
+            self._geng = [first] + [GEngine(first.cfg, self.dtype) for _ in range(self.n_acc - 1)]
+        return self._geng
+
+    def _sample_noise(self, B):
+        arch = _backbone(self.G).masker
+        if arch == "none":
+            return None
+        noise = {"pixel": self.rng.logistic_noise((B, 1, self.H, self.W))}
+        if arch == "dusty2":
+            noise["image"] = self.rng.logistic_noise((B, 1, 1, 1))
+        return noise
+
+    def _draw_rand(self, B):
+        return {"z": self.sample_latents(B), "noise": self._sample_noise(B),
+                "aug": [self.A.draw(B, self.H, self.W, self.device) for _ in range(4)]}
+
+    def _prep_rand(self, rand, B):
+        if rand is None:
+            return self._draw_rand(B)
+        out = {"z": torch.as_tensor(rand["z"]).to(self.device, torch.float32)}
+        nz = rand.get("noise")
+        out["noise"] = None if not nz else {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in nz.items()}
+        out["aug"] = [DiffAugment.params_to_device(rp, self.device) for rp in rand["aug"]]
+        return out
+
+    def _allreduce(self, store):
+        if self.world > 1:
+            dist.all_reduce(store.grad)  # SUM; the 1/world of DDP's averaging is folded into the Adam kernel
+
+    # ------------------------------------------------------------------ D phase (reference :171-238)
+    def optimize_D(self, reals=None, rands=None):
+        """One discriminator update over `num_accumulation` micro-batches.
+        reals: optional list of (x_real, m_real) already through fetch_reals; rands: optional list of randomness
+        bundles {"z", "noise", "aug":[4 parameter sets]} (parity tests); defaults draw from the loader / Philox."""
+        lib, sp = L.lib(), L.stream_ptr()
+        B = self.local_batch
+        Gb, D = _backbone(self.G), self.D
+        self.G.train()
+        self.optim_D.zero_grad()
+        gengs = self._g_engines()
+        deng = D.engine()
+        deng.alloc(3 * B, self.device)
+        Dst, Gst = D.store, Gb.store
+        Dst.refresh_shadows(self.dtype)
+        Gst.refresh_shadows(self.dtype)
+        gp = float(self.loss_weight.get("gp", 0.0)) if "gp" in self.criterion else 0.0
+        w_gan = float(self.loss_weight["gan"]) / self.n_acc
+        self._mb = []
+        dev = self.device
+        scal = torch.zeros(5, dtype=torch.float32, device=dev)  # real, fake, adv, gp, G adv (sums over micro-batches)
+        f32 = dict(dtype=torch.float32, device=dev)
+        for j, sync in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
+            if reals is not None:
+                x_real, m_real = reals[j]
+            else:
+                x_real, m_real = self.fetch_reals(next(self.loader))
+            rand = self._prep_rand(rands[j] if rands is not None else None, B)
+            synth = gengs[j].forward(Gst, rand["z"], rand["noise"], training=True)  # :195 (graph kept = workspaces)
+            xcat = torch.empty(2 * B, 1, self.H, self.W, **f32)
+            self.A.apply(x_real, rand["aug"][0], out=xcat[:B])  # :199
+            self.A.apply(synth["depth"], rand["aug"][1], out=xcat[B:])  # :200
+            y = deng.forward(Dst, xcat, 0)  # :203-204, real | fake in one pass
+            dy = torch.empty(2 * B, **f32)
+            sc = torch.empty(3, **f32)
+            L.check(lib.dg_nsgan_d(L.ptr(y), L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(dy) + 4 * B, L.ptr(sc), sp),
+                    "dg_nsgan_d")
+            scal[0:3] += sc
+            if gp > 0:
+                # chain upstream: 1 for the real half (that IS d sum(y_real)/dx, :218-223), dLoss/dy for the fake half;
+                # the real half's ordinary backward is the same chain weighted per sample by dLoss/dy_real.
+                up = torch.cat([torch.ones(B, **f32), dy[B:]])
+                rs = torch.cat([dy[:B], torch.ones(B, **f32)])
+                deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
+                g = torch.empty(B, 1, self.H, self.W, **f32)
+                deng.backward_input(Dst, 0, B, g)
+                ssq = torch.empty(B, **f32)
+                L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
+                scal[3] += ssq.mean()  # :229
+                # R1 double backward: tangent v = d(gp/2 * mean_b |g_b|^2)/dg = (gp/B) g, pushed forward through D
+                vg = torch.empty_like(g)
+                L.check(lib.dg_scale(L.ptr(g), gp / self.n_acc / B, g.numel(), L.ptr(vg), sp), "dg_scale")
+                deng.forward(Dst, vg, 2 * B, tangent_of=0)
+                deng.wgrad(Dst, 0, 0, 2 * B, rs)       # real (weighted by dLoss/dy_real) + fake
+                deng.wgrad(Dst, 2 * B, 0, B, None)      # tangent (x) real chain
+                deng.final_wgrad(Dst, 0, 2 * B, dy)
+                deng.final_wgrad(Dst, 2 * B, B, None)
+            else:
+                deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
+                deng.wgrad(Dst, 0, 0, 2 * B, None)
+                deng.final_wgrad(Dst, 0, 2 * B, dy)
+            Dst.view("final_b", Dst.grad).add_(dy.sum())
+            self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
+        self._allreduce(Dst)
+        self.optim_D.step(gscale=1.0 / self.world, shadow_dtype=self.dtype)  # :238
+        self._dev_scal = scal
+        return scal
+
+    # ------------------------------------------------------------------ G phase (reference :240-316)
+    def optimize_G(self):
+        lib, sp = L.lib(), L.stream_ptr()
+        B = self.local_batch
+        Gb, D = _backbone(self.G), self.D
+        Gst, Dst = Gb.store, D.store
+        self.optim_G.zero_grad()
+        deng = D.engine()
+        w_gan = float(self.loss_weight["gan"]) / self.n_acc
+        f32 = dict(dtype=torch.float32, device=self.device)
+        scal = self._dev_scal
+        for j, sync in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
+            mb = self._mb[j]
+            rand = mb["rand"]
+            # :255/:259 A(real) and D(real) feed only relativistic losses; nsgan's loss_G ignores them (loss.py:68-69)
+            x_aug = self.A.apply(mb["synth"]["depth"], rand["aug"][3])  # :256
+            y = deng.forward(Dst, x_aug, 0)  # :260, updated D
+            dy = torch.empty(B, **f32)
+            sc = torch.empty(1, **f32)
+            L.check(lib.dg_nsgan_g(L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(sc), sp), "dg_nsgan_g")
+            scal[4:5] += sc
+            deng.backward_data(Dst, 0, B, dy, None, want_dbias=False)
+            dx = torch.empty(B, 1, self.H, self.W, **f32)
+            deng.backward_input(Dst, 0, B, dx)
+            ddepth = self.A.backward(dx, rand["aug"][3])
+            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0))
+        self._allreduce(Gst)
+        # Adam + EMA fused (:312, :316)
+        self.optim_G.step(gscale=1.0 / self.world, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
+                          shadow_dtype=self.dtype)
+        self._mb = []
+        return scal
+
+    def step(self, i=0, reals=None, rands=None):
+        """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""
+        self.optimize_D(reals, rands)
+        scal = self.optimize_G()
+        scal = scal / self.n_acc
+        keys = ["loss/D/output/real", "loss/D/output/fake", "loss/D/adversarial"]
+        idx = [0, 1, 2]
+        if "gp" in self.criterion:
+            keys.append("loss/D/gradient_penalty")
+            idx.append(3)
+        keys.append("loss/G/adversarial")
+        idx.append(4)
+        out = scal[idx]
+        if self.world > 1:
+            dist.all_reduce(out)  # one packed collective instead of 5-7 (:319-323)
+            out = out / self.world
+        return LazyScalars(keys, out)
+
+    # ------------------------------------------------------------------ inference / checkpoints
+    def postprocess(self, synth):
+        """reference :327-329 adds points/normals via utils.postprocess (visualisation; out of scope): pass-through"""
+        return synth
+
+    @torch.no_grad()
+    def generate(self, ema=False):
+        """reference :331-340"""
+        net = self.G_ema if ema else self.G
+        net.eval()
+        synth = net(self.fixed_noise)
+        return self.postprocess({k: v.clone() for k, v in synth.items()})
+
+    def validation(self):
+        raise NotImplementedError("validation metrics (SWD/JSD/COV-MMD-1NNA, FPS/Chamfer kernels) are the 'next' rows "
+                                  "of SURVEY.md §8f, not part of the training hot path")
+
+    def state(self, step):
+        def sd(m):
+            return OrderedDict((k, v.detach().cpu().contiguous()) for k, v in m.state_dict().items())
+        return {"step": step, "G": sd(self.G), "D": sd(self.D), "G_ema": sd(self.G_ema),
+                "optim_G": self.optim_G.state_dict(), "optim_D": self.optim_D.state_dict(), "pl_ema": None}
+
+    def save_models(self, suffix, step, directory="models"):
+        """reference :395-409 (same keys, reference-shaped tensors)"""
+        import os
+        os.makedirs(directory, exist_ok=True)
+        path = osp.join(directory, "checkpoint_{}.pth".format(str(suffix)))
+        torch.save(self.state(step), path)
+        return path

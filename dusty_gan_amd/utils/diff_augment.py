@@ -1,0 +1,95 @@
+"""DiffAugment on [B,1,H,W] range images -- reference: utils/diff_augment.py:114-132 (p = 1.0).
+
+One fused gather kernel per call (csrc/pointwise.hip) instead of the reference's ~40 small ops, plus the hand-derived
+backward (the G phase differentiates through A(fake), trainers/dcgan_amp.py:256).  Every random draw of one call is
+an explicit parameter set `rp` so parity tests can inject the reference's draws:
+    u_b,u_s,u_c float [B] (the uniform_(-1,1) draws; the applied factor is u*u),
+    t_h,t_w,o_x,o_y int [B].
+"""
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .rng import Philox
+
+DEFAULT_POLICY = ["brightness", "saturation", "contrast", "translation", "cutout"]
+
+
+class DiffAugment(nn.Module):
+    def __init__(self, policy=None, p=1.0, seed=None):
+        super().__init__()
+        self.policy = list(DEFAULT_POLICY if policy is None else policy)
+        for k in self.policy:
+            if k not in L.POLICY_BITS:
+                raise KeyError(k)  # same failure mode as AUGMENT_FNS[p] in the reference
+        if p != 1.0:
+            raise NotImplementedError("DiffAugment probability p != 1 (the reference trainer always uses p=1)")
+        self.p = p
+        self.mask = L.policy_mask(self.policy)
+        self._seed = seed
+        self._rng = None
+
+    # ---- parameter draws
+    def rng(self, device):
+        if self._rng is None or self._rng.device != device:
+            seed = torch.initial_seed() + 101 if self._seed is None else self._seed
+            self._rng = Philox(seed, device, stream_id=5)
+        return self._rng
+
+    def draw(self, B, H, W, device):
+        r = self.rng(device)
+        uf = torch.empty(3, B, dtype=torch.float32, device=device)
+        qi = torch.empty(4, B, dtype=torch.int32, device=device)
+        L.check(L.lib().dg_aug_draw(r.seed, r.stream_id, r.offset, B, H, W, L.ptr(uf), L.ptr(qi), L.stream_ptr()),
+                "dg_aug_draw")
+        r.offset += 2 * B
+        return {"u_b": uf[0], "u_s": uf[1], "u_c": uf[2], "t_h": qi[0], "t_w": qi[1], "o_x": qi[2], "o_y": qi[3]}
+
+    @staticmethod
+    def params_to_device(rp, device):
+        """Accept CPU / int64 parameter sets (golden vectors) and put them in the kernel's dtypes."""
+        out = {}
+        for k, v in rp.items():
+            v = torch.as_tensor(v)
+            out[k] = v.to(device=device, dtype=torch.float32 if k.startswith("u_") else torch.int32).contiguous()
+        return out
+
+    def _args(self, rp, B, device):
+        z_f = torch.zeros(B, dtype=torch.float32, device=device)
+        z_i = torch.zeros(B, dtype=torch.int32, device=device)
+        g = lambda k, z: L.ptr(rp[k]) if k in rp else L.ptr(z)
+        keep = (z_f, z_i)
+        return (g("u_b", z_f), g("u_c", z_f), g("t_h", z_i), g("t_w", z_i), g("o_x", z_i), g("o_y", z_i)), keep
+
+    # ---- forward / backward
+    def apply(self, x, rp, out=None):
+        """y = A(x) with the given draws.  x [B,1,H,W] fp32 (cuda)."""
+        if not x.is_cuda:
+            raise RuntimeError("DiffAugment runs on the GPU only")
+        B, Cc, H, W = x.shape
+        if Cc != 1:
+            raise NotImplementedError("DiffAugment kernel handles single-channel range images")
+        x = x.contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        ws = torch.empty(B, dtype=torch.float32, device=x.device)
+        args, keep = self._args(rp, B, x.device)
+        L.check(L.lib().dg_diffaug_fwd(L.ptr(x), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()),
+                "dg_diffaug_fwd")
+        return out
+
+    def backward(self, gy, rp, out=None):
+        """gx = dL/dx from gy = dL/dA(x) for the same draws."""
+        B, _, H, W = gy.shape
+        gy = gy.contiguous()
+        if out is None:
+            out = torch.empty_like(gy)
+        ws = torch.empty(B, dtype=torch.float32, device=gy.device)
+        args, keep = self._args(rp, B, gy.device)
+        L.check(L.lib().dg_diffaug_bwd(L.ptr(gy), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()),
+                "dg_diffaug_bwd")
+        return out
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        return self.apply(x, self.draw(B, H, W, x.device))

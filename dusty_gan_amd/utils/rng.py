@@ -1,0 +1,41 @@
+"""Philox4x32-10 stream on the device (csrc/optim.hip).  The reference draws z, Gumbel uniforms and DiffAugment
+parameters from torch's unseeded device generator (trainers/dcgan_amp.py:151-152; models/dusty.py:33-34;
+utils/diff_augment.py:27-28,59-60,86-87); here every draw is a counter-based Philox call so a (seed, rank) pair
+reproduces a run and parity tests can inject the draws instead."""
+import torch
+
+from .. import _lib as L
+
+
+class Philox:
+    def __init__(self, seed, device, stream_id=0):
+        self.seed, self.device, self.stream_id = int(seed) & (2**64 - 1), device, int(stream_id)
+        self.offset = 0
+
+    def _fill(self, kind, n, lo=0.0, hi=1.0, ilo=0, ihi=1):
+        out = torch.empty(n, dtype=torch.int32 if kind == 3 else torch.float32, device=self.device)
+        L.check(L.lib().dg_philox_fill(self.seed, self.stream_id, self.offset, kind, lo, hi, ilo, ihi, n, L.ptr(out),
+                                       L.stream_ptr()), "dg_philox_fill")
+        self.offset += (n + 3) // 4
+        return out
+
+    def uniform(self, n, lo=0.0, hi=1.0):
+        return self._fill(2 if (lo != 0.0 or hi != 1.0) else 0, n, lo, hi)
+
+    def normal(self, n):
+        return self._fill(1, n)
+
+    def randint(self, lo, hi, n):
+        """integers in [lo, hi)"""
+        return self._fill(3, n, ilo=lo, ihi=hi)
+
+    def logistic_noise(self, shape, eps=1e-10):
+        """GumbelSigmoid.logistic_noise (reference: models/dusty.py:30-36)"""
+        n = 1
+        for s in shape:
+            n *= s
+        u1, u2 = self.uniform(n), self.uniform(n)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        L.check(L.lib().dg_logistic_noise(L.ptr(u1), L.ptr(u2), eps, n, L.ptr(out), L.stream_ptr()),
+                "dg_logistic_noise")
+        return out.view(*shape)

@@ -1,0 +1,168 @@
+/* dusty_gan_hip.h -- C ABI of libdustygan_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary of the dusty-gan training hot path.  The reference (kazuto1011/dusty-gan) has no native
+ * code on this path: every entry point below replaces a PyTorch module call (or its autograd backward) that the
+ * reference's `Trainer.step` (trainers/dcgan_amp.py:162-325) makes.  The file:line next to each declaration is the
+ * reference interface it replaces.  A maintainer binds these with ctypes; PyTorch is only the
+ * owner of device memory and streams.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; nothing is allocated inside the library,
+ *     workspaces are caller-owned; `stream` is a hipStream_t passed as void*;
+ *   - return value: DG_OK (0) or a DG_E* code; kernels are launched asynchronously on `stream`;
+ *   - images are fp32 [B,1,H,W]; feature maps are pixel-major/channel-minor ("NHWC") in `dtype` (DG_F32|DG_BF16);
+ *   - conv weights: engine master fp32 [ky][kx][ci][co] ("cico"); the reference's (Cout,Cin,4,4) / (Cin,Cout,4,4)
+ *     parameter tensors are strided VIEWS of that storage (no copy), so state_dict()/checkpoints keep the
+ *     reference's shapes.
+ */
+#ifndef DUSTY_GAN_HIP_H
+#define DUSTY_GAN_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_OK 0
+#define DG_EINVAL 1
+#define DG_EUNSUPPORTED 2
+#define DG_EHIP 3
+
+#define DG_F32 0
+#define DG_BF16 1
+
+/* conv-like op geometry: a COARSE grid Hc x Wc and a FINE grid 2Hc x 2Wc */
+#define DG_MODE_S2 0   /* out on coarse, in on fine : Down forward, Up backward-data          */
+#define DG_MODE_UP 1   /* out on fine, in on coarse : Up/Head forward, Down backward-data     */
+#define DG_MODE_GEMM 2 /* plain rows (Proj)                                                   */
+
+#define DG_EPI_LINEAR 0 /* out = scale*acc + bias                                             */
+#define DG_EPI_LRELU 1  /* FusedLeakyReLU: leaky_relu(scale*acc + bias, 0.2) * sqrt(2)        */
+#define DG_EPI_MASK 2   /* out = scale*acc * lrelu'(aux) * sqrt(2)  (backward / R1 tangent)   */
+
+/* Parameter block of dg_conv.  Strides are in ELEMENTS. */
+typedef struct DgConv {
+  int mode, adj, ring;       /* adj: 0 = the reference's Pad (reflect rows, circular|reflect cols), 1 = its adjoint */
+  int B, Hc, Wc;
+  int K, N;                  /* contraction channels, output channels */
+  const void* in;
+  long in_sb, in_sp, in_sk;  /* batch, pixel (row*W+col), channel */
+  void* out;
+  long out_sb, out_sp, out_sn;
+  const void* w;
+  long w_st, w_sk, w_sn;     /* tap (ky*4+kx), k, n */
+  float scale;               /* EqualLR runtime scale, models/ops/common.py:124-125,133 */
+  int epi;
+  const float* bias;         /* fp32 [bias_mod] or NULL; index n % bias_mod */
+  int bias_mod;
+  const void* aux;           /* DG_EPI_MASK: saved activation with out's layout/dtype */
+  float* dbias;              /* optional: dbias[n % bias_mod] += rowscale[b] * sum_pixels out */
+  const float* rowscale;     /* optional per-sample weight of the dbias sum */
+  int in_dtype, out_dtype, w_dtype;
+  const float* nscale;       /* optional per-output-channel scale (Head: one EqualLR scale per head) */
+} DgConv;
+
+/* Parameter block of dg_wgrad:  dw[tap][ci][co] += scale * sum_b rowscale[b] * sum_pixels a[..][ci] * g[..][co] */
+typedef struct DgWgrad {
+  int wmode, ring;           /* 0 = Down, 1 = Up/Head, 2 = plain rows (Proj: set B=1,Hc=1,Wc=batch) */
+  int B, Hc, Wc;
+  int Ci, Co;
+  const void* a;             /* the layer's forward input */
+  long a_sb, a_sp, a_sc;
+  const void* g;             /* gradient w.r.t. the layer's pre-activation output */
+  long g_sb, g_sp, g_sc;
+  float* dw;                 /* fp32 [tap][Ci][Co] */
+  float scale;
+  const float* rowscale;     /* optional [B] */
+  int a_dtype, g_dtype;
+} DgWgrad;
+
+/* ---- conv-like passes ------------------------------------------------------------------------------------
+ * dg_conv replaces, depending on (mode, adj, epi):
+ *   Down.forward            models/gans/dcgan_eqlr.py:75-82  (Pad :77 + EqualLR(Conv2d 4,2,0) :80 + FusedLeakyReLU :81)
+ *   Up.forward              models/gans/dcgan_eqlr.py:19-26  (Pad + EqualLR(ConvTranspose2d 4,2,3) + FusedLeakyReLU)
+ *   Head.forward            models/gans/dcgan_eqlr.py:29-46
+ *   Proj.forward            models/gans/dcgan_eqlr.py:6-16
+ *   their autograd backward-data passes (loss.backward() at trainers/dcgan_amp.py:235,309 and
+ *   torch.autograd.grad(create_graph=True) at :218-223), and the R1 tangent pass (double backward, :229-235).
+ * force: 0 = pick (MFMA implicit GEMM when the shape allows, else direct), 1 = direct VALU kernel, 2 = MFMA or error.
+ */
+int dg_conv(const DgConv* p, int force, void* stream);
+int dg_conv_mfma_supported(const DgConv* p);
+
+/* dg_wgrad replaces the weight-gradient half of the same autograd calls.  accumulate: 1 = atomically add onto dw
+ * (dw zeroed by the caller at step start: optim.zero_grad, trainers/dcgan_amp.py:177,246), 0 = overwrite. */
+int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream);
+int dg_wgrad_mfma_supported(const DgWgrad* p);
+
+/* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */
+int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* stream);
+int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ring, void* stream);
+
+/* ---- final EqualLR(Conv2d(C,1,(h0,w0)))  models/gans/dcgan_eqlr.py:95 ------------------------------------ */
+int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
+                 void* stream);
+/* dd4[b] = up[b]*scale*wf*lrelu'(d4[b])*sqrt2 ; dbias4[i%C] += rowscale[b]*dd4[b][i] */
+int dg_final_bwd_data(const void* d4, int dtype, const float* wf, const float* up, const float* rowscale, float scale,
+                      int B, long n, int C, void* dd4, float* dbias, void* stream);
+/* out[i] += scale * sum_b coef[b]*src[b][i] */
+int dg_batch_wsum(const void* src, int dtype, const float* coef, float scale, int B, long n, float* out, void* stream);
+
+/* ---- Generator tanh + DUSty maskout  models/gans/dcgan_eqlr.py:71; models/dusty.py:45-59,77-91,107-127 ---- */
+/* gout [B,1+k,H,W] planar fp32 (ch0 raw depth -> tanh in place, ch1.. logits); arch 0 none, 1 dusty1, 2 dusty2 */
+int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
+                     float tau, float drop_const, int B, long HW, float* mask, float* depth, void* stream);
+/* draw[n] = s_n * d(loss)/d(head output n) (s_depth for ch0, s_conf for the logits: the EqualLR scale of each head,
+ * pre-multiplied so the head's backward-data / weight-gradient passes run with scale 1); dbias[n] += unscaled sums */
+int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
+                     const float* ddepth, int arch, float tau, float drop_const, int B, long HW, float s_depth,
+                     float s_conf, float* draw, float* dbias, void* stream);
+/* GumbelSigmoid.logistic_noise  models/dusty.py:30-36 */
+int dg_logistic_noise(const float* u1, const float* u2, float eps, long n, float* out, void* stream);
+
+/* ---- DiffAugment.forward  utils/diff_augment.py:114-132 (p = 1) and its backward ------------------------- */
+/* policy bits: 1 brightness, 2 saturation, 4 contrast, 8 translation, 16 cutout; per-sample draws are arguments */
+int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                   const int* o_y, int policy, int B, int H, int W, float* xsum_ws, float* y, void* stream);
+int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                   const int* o_y, int policy, int B, int H, int W, float* gsum_ws, float* gx, void* stream);
+
+/* ---- GANLoss(nsgan)  models/loss.py:39-41,68-69 + gradient w.r.t. the logits ----------------------------- */
+/* scal[0]=mean(y_real) scal[1]=mean(y_fake) scal[2]=loss_D */
+int dg_nsgan_d(const float* y_real, const float* y_fake, int B, float w_gan, float* dy_real, float* dy_fake,
+               float* scal, void* stream);
+int dg_nsgan_g(const float* y_fake, int B, float w_gan, float* dy, float* scal, void* stream);
+
+/* ---- Trainer.fetch_reals  trainers/dcgan_amp.py:154-160 (utils/lidar.py:31-36, utils/__init__.py:70-73) -- */
+int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,
+                   float* out, void* stream);
+
+/* ---- small reductions / helpers --------------------------------------------------------------------------- */
+int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */
+int dg_scale(const float* x, float a, long n, float* y, void* stream);
+
+/* ---- optim.Adam.step + ema_inplace  trainers/dcgan_amp.py:116-125,238,312,316 and :30-35 ------------------ */
+int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema, void* shadow, int shadow_dtype,
+                     long n, float gscale, float lr, float beta1, float beta2, float eps, int step, float ema_decay,
+                     void* stream);
+int dg_cast(const float* src, void* dst, int dtype, long n, void* stream);
+int dg_transpose_shadow(const float* master, void* dst, int dtype, int Ci, int Co, void* stream);
+
+/* ---- Philox4x32-10 draws (the reference uses torch's device RNG: trainers/dcgan_amp.py:151-152, models/dusty.py:33-34,
+ *      utils/diff_augment.py:27-28,59-60,86-87) --------------------------------------------------------------- */
+int dg_philox_bits(uint64_t seed, uint64_t stream_id, uint64_t offset, long n4, uint32_t* out, void* stream);
+/* kind 0 uniform[0,1), 1 normal, 2 uniform(lo,hi), 3 int32 in [ilo,ihi) */
+int dg_philox_fill(uint64_t seed, uint64_t stream_id, uint64_t offset, int kind, float lo, float hi, int ilo, int ihi,
+                   long n, void* out, void* stream);
+
+/* one DiffAugment parameter set per sample: uf [3][B] = u_b,u_s,u_c in (-1,1); qi [4][B] = t_h,t_w,o_x,o_y
+ * (ranges of utils/diff_augment.py:58-60,85-87); consumes 2*B Philox counters starting at `offset` */
+int dg_aug_draw(uint64_t seed, uint64_t stream_id, uint64_t offset, int B, int H, int W, float* uf, int* qi,
+                void* stream);
+
+const char* dg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

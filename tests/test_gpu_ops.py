@@ -1,0 +1,395 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle, same seeded inputs.
+
+fp32 kernels: rel-L2 <= 1e-4 (expected ~1e-6); bf16 MFMA kernels: rel-L2 <= 2e-2 (bf16 inputs, fp32 accumulate:
+the tolerance the reference's own AMP path needs).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dusty_oracle as O
+from tests.golden_util import load, rel_l2, sub
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL32 = 1e-4
+TOLBF = 2e-2
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dusty_gan_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def nhwc(x):  # [B,C,H,W] -> flat pixel-major/channel-minor
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def from_nhwc(flat, B, C_, H, W):
+    return flat.view(B, H, W, C_).permute(0, 3, 1, 2).contiguous()
+
+
+def run_conv(L, mode, adj, ring, x, wpacked_nk, N, scale, epi, dtype, force, bias=None, aux=None, want_db=False,
+             rowscale=None):
+    """x [B,K,Hin,Win] torch cpu; wpacked_nk [16][N][K]; returns out [B,N,Ho,Wo] float cpu (+ dbias)"""
+    from dusty_gan_amd.engine import Ops
+    o = Ops(dtype)
+    o.force = force
+    B, K, Hin, Win = x.shape
+    if mode == L.MODE_S2:
+        Hc, Wc, Ho, Wo = Hin // 2, Win // 2, Hin // 2, Win // 2
+    else:
+        Hc, Wc, Ho, Wo = Hin, Win, 2 * Hin, 2 * Win
+    xd = nhwc(x).to(DEV, dtype)
+    wd = wpacked_nk.contiguous().to(DEV, dtype)
+    out = torch.empty(B * Ho * Wo * N, device=DEV, dtype=dtype)
+    auxd = None if aux is None else nhwc(aux).to(DEV, dtype)
+    biasd = None if bias is None else bias.to(DEV, torch.float32)
+    db = torch.zeros(N, device=DEV) if want_db else None
+    rs = None if rowscale is None else rowscale.to(DEV, torch.float32)
+    o.conv(mode, adj, ring, B, Hc, Wc, K, N, xd, (Hin * Win * K, K, 1), out, (Ho * Wo * N, N, 1), wd.data_ptr(), scale,
+           epi, bias=None if biasd is None else biasd.data_ptr(), bias_mod=N, aux=auxd,
+           dbias=None if db is None else db.data_ptr(), rowscale=rs)
+    torch.cuda.synchronize()
+    res = from_nhwc(out.float().cpu(), B, N, Ho, Wo)
+    return (res, db.cpu()) if want_db else res
+
+
+def pack_down(w):  # Conv2d weight (Co,Ci,4,4) -> fwd [16][n=co][k=ci], bwd [16][n=ci][k=co]
+    fwd = w.permute(2, 3, 0, 1).reshape(16, w.shape[0], w.shape[1])
+    bwd = w.permute(2, 3, 1, 0).reshape(16, w.shape[1], w.shape[0])
+    return fwd, bwd
+
+
+def pack_up(w):  # ConvTranspose2d weight (Ci,Co,4,4) -> fwd [16][co][ci], bwd [16][ci][co]
+    fwd = w.permute(2, 3, 1, 0).reshape(16, w.shape[1], w.shape[0])
+    bwd = w.permute(2, 3, 0, 1).reshape(16, w.shape[0], w.shape[1])
+    return fwd, bwd
+
+
+CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct kernel, 2 = MFMA kernel
+    (6, 4, 8, 16, 2, True, torch.float32, 1),
+    (6, 4, 8, 16, 2, False, torch.float32, 1),
+    (5, 3, 4, 6, 3, True, torch.float32, 1),
+    (64, 64, 8, 64, 2, True, torch.float32, 2),
+    (64, 128, 4, 128, 2, True, torch.float32, 2),
+    (128, 64, 8, 64, 1, True, torch.bfloat16, 2),
+    (128, 128, 4, 128, 2, True, torch.bfloat16, 2),
+]
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,B,ring,dtype,force", CASES)
+def test_down_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
+    """Down (dcgan_eqlr.py:75-82): forward, backward-data (+ bias grads, lrelu mask), weight gradient."""
+    g = torch.Generator().manual_seed(Ci * 1000 + Co + H)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    x = torch.randn(B, Ci, 2 * H, 2 * W, generator=g)
+    w = torch.randn(Co, Ci, 4, 4, generator=g)
+    b = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = O.down(xr, wr, br, ring)
+    gy = torch.randn(y.shape, generator=g)
+    fwd, bwd = pack_down(w)
+    s = 1.0 / math.sqrt(Ci * 16)
+    out = run_conv(L, L.MODE_S2, 0, ring, x, fwd, Co, s, L.EPI_LRELU, dtype, force, bias=b)
+    assert rel_l2(out, y) < tol
+    # backward: e = gy * lrelu'(y) * sqrt2 is the gradient w.r.t. the pre-activation
+    e = gy * torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)
+    if dtype == torch.bfloat16:
+        e = e.bfloat16().float()
+    gx, gw, gb = torch.autograd.grad(y, [xr, wr, br], gy)
+    assert rel_l2(e.sum(dim=[0, 2, 3]), gb) < 1e-2 if dtype == torch.bfloat16 else 1e-4
+    # backward-data into a "previous layer" with its own activation mask (aux) and bias-gradient sums
+    prev = torch.randn(x.shape, generator=g)
+    rs = torch.rand(B, generator=g) + 0.5
+    dx, db = run_conv(L, L.MODE_UP, 1, ring, e, bwd, Ci, s, L.EPI_MASK, dtype, force, aux=prev, want_db=True,
+                      rowscale=rs)
+    if dtype == torch.bfloat16:  # reference backward from the SAME rounded e
+        gx = torch.autograd.grad(y, xr, e / (torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)))[0]
+    ref_dx = gx * torch.where(prev > 0, 1.0, 0.2) * math.sqrt(2.0)
+    assert rel_l2(dx, ref_dx) < tol
+    assert rel_l2(db, (ref_dx * rs.view(B, 1, 1, 1)).sum(dim=[0, 2, 3])) < (tol if dtype == torch.float32 else 5e-2)
+    # weight gradient
+    from dusty_gan_amd.engine import Ops
+    o = Ops(dtype)
+    o.force = force
+    xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
+    dw = torch.zeros(16, Ci, Co, device=DEV)
+    o.wgrad(0, ring, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw.data_ptr(), s)
+    torch.cuda.synchronize()
+    if dtype == torch.bfloat16:
+        gw = torch.autograd.grad(O.down(xr, wr, br, ring), wr, e / (torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)))[0]
+    got = dw.cpu().view(4, 4, Ci, Co).permute(3, 2, 0, 1)
+    assert rel_l2(got, gw) < tol
+    # per-sample weights (the real-batch reuse of the R1 chain)
+    dw2 = torch.zeros(16, Ci, Co, device=DEV)
+    o.wgrad(0, ring, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw2.data_ptr(), s,
+            rowscale=rs.to(DEV))
+    torch.cuda.synchronize()
+    ew = e * rs.view(B, 1, 1, 1)
+    gw2 = torch.autograd.grad(O.down(xr, wr, br, ring), wr, ew / (torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)))[0]
+    assert rel_l2(dw2.cpu().view(4, 4, Ci, Co).permute(3, 2, 0, 1), gw2) < tol
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,B,ring,dtype,force", CASES)
+def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
+    """Up (dcgan_eqlr.py:19-26): forward, backward-data, weight gradient."""
+    g = torch.Generator().manual_seed(Ci * 77 + Co + W)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Ci, Co, 4, 4, generator=g)
+    b = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = O.up(xr, wr, br, ring)
+    fwd, bwd = pack_up(w)
+    s = 1.0 / math.sqrt(Co * 16)
+    out = run_conv(L, L.MODE_UP, 0, ring, x, fwd, Co, s, L.EPI_LRELU, dtype, force, bias=b)
+    assert rel_l2(out, y) < tol
+    gy = torch.randn(y.shape, generator=g)
+    lr = torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)
+    e = gy * lr
+    if dtype == torch.bfloat16:
+        e = e.bfloat16().float()
+    gx, gw = torch.autograd.grad(y, [xr, wr], e / lr)
+    prev = torch.randn(x.shape, generator=g)
+    dx, db = run_conv(L, L.MODE_S2, 1, ring, e, bwd, Ci, s, L.EPI_MASK, dtype, force, aux=prev, want_db=True)
+    ref_dx = gx * torch.where(prev > 0, 1.0, 0.2) * math.sqrt(2.0)
+    assert rel_l2(dx, ref_dx) < tol
+    assert rel_l2(db, ref_dx.sum(dim=[0, 2, 3])) < (tol if dtype == torch.float32 else 5e-2)
+    from dusty_gan_amd.engine import Ops
+    o = Ops(dtype)
+    o.force = force
+    xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
+    dw = torch.zeros(16, Ci, Co, device=DEV)
+    o.wgrad(1, ring, B, H, W, Ci, Co, xd, (H * W * Ci, Ci, 1), ed, (4 * H * W * Co, Co, 1), dw.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().view(4, 4, Ci, Co).permute(2, 3, 0, 1), gw) < tol
+
+
+@pytest.mark.parametrize("dtype,force,B,nz,C3", [(torch.float32, 1, 3, 5, 6), (torch.float32, 2, 5, 64, 64),
+                                                 (torch.bfloat16, 2, 32, 128, 64)])
+def test_proj_gemm_and_wgrad(L, dtype, force, B, nz, C3):
+    """Proj (dcgan_eqlr.py:6-16) as a GEMM with the (y,x,c) output order + its weight gradient."""
+    from dusty_gan_amd.engine import Ops
+    g = torch.Generator().manual_seed(5)
+    h0, w0 = 2, 4
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    z = torch.randn(B, nz, generator=g)
+    w = torch.randn(nz, C3, h0, w0, generator=g)
+    b = torch.randn(C3, generator=g)
+    if dtype == torch.bfloat16:
+        z, w = z.bfloat16().float(), w.bfloat16().float()
+    wr = w.clone().requires_grad_()
+    y = O.proj(z, wr, b)  # [B,C3,h0,w0]
+    Np = h0 * w0 * C3
+    o = Ops(dtype)
+    o.force = force
+    wm = w.permute(2, 3, 1, 0).contiguous().view(Np, nz).to(DEV, dtype)  # master [y][x][c][k]
+    zd = z.to(DEV, dtype).contiguous()
+    out = torch.empty(B * Np, device=DEV, dtype=dtype)
+    bd = b.to(DEV)
+    o.conv(L.MODE_GEMM, 0, 1, B, 1, 1, nz, Np, zd, (nz, 0, 1), out, (Np, 0, 1), wm.data_ptr(), 1.0 / math.sqrt(Np),
+           L.EPI_LRELU, bias=bd.data_ptr(), bias_mod=C3)
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(B, h0, w0, C3).permute(0, 3, 1, 2)
+    assert rel_l2(got, y) < tol
+    gy = torch.randn(y.shape, generator=g)
+    lr = torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)
+    e = gy * lr
+    if dtype == torch.bfloat16:
+        e = e.bfloat16().float()
+    (gw,) = torch.autograd.grad(y, wr, e / lr)
+    ed = e.permute(0, 2, 3, 1).contiguous().view(B, Np).to(DEV, dtype)
+    dw = torch.full((Np, nz), 7.0, device=DEV)
+    o.wgrad(2, 1, 1, 1, B, Np, nz, ed, (0, Np, 1), zd, (0, nz, 1), dw.data_ptr(), 1.0 / math.sqrt(Np), accumulate=0)
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().view(h0, w0, C3, nz).permute(3, 2, 0, 1), gw) < tol
+
+
+@pytest.mark.parametrize("ring", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_blur_and_final(L, ring, dtype):
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C3 = 3, 32, 64, 8
+    x = torch.randn(B, 1, H, W, generator=g).requires_grad_()
+    y = O.blur_vh(x, ring)
+    xd = x.detach().to(DEV)
+    out = torch.empty(B * H * W * 2, device=DEV, dtype=dtype)
+    L.check(lib.dg_blur_fwd(xd.data_ptr(), out.data_ptr(), L.dtype_code(dtype), B, H, W, int(ring), None))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert rel_l2(from_nhwc(out.float().cpu(), B, 2, H, W), y) < tol
+    gy = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    (gx,) = torch.autograd.grad(y, x, gy)
+    dx = torch.empty(B, 1, H, W, device=DEV)
+    L.check(lib.dg_blur_bwd(nhwc(gy).to(DEV, dtype).data_ptr(), L.dtype_code(dtype), dx.data_ptr(), B, H, W, int(ring),
+                            None))
+    assert rel_l2(dx.cpu(), gx) < 1e-6
+    # final dot + its backward
+    h0, w0 = 2, 4
+    d4 = torch.randn(B, C3, h0, w0, generator=g)
+    if dtype == torch.bfloat16:
+        d4 = d4.bfloat16().float()
+    d4r = d4.clone().requires_grad_()
+    wf = torch.randn(1, C3, h0, w0, generator=g).requires_grad_()
+    bf = torch.randn(1, generator=g)
+    n = h0 * w0 * C3
+    yf = F.conv2d(d4r * O.equal_lr_scale(wf), wf, bf).view(B)
+    d4d = nhwc(d4).to(DEV, dtype)
+    wfd = wf.detach().permute(0, 2, 3, 1).contiguous().view(-1).to(DEV)
+    yd = torch.empty(B, device=DEV)
+    L.check(lib.dg_final_fwd(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), bf.to(DEV).data_ptr(),
+                             1.0 / math.sqrt(n), B, n, yd.data_ptr(), None))
+    assert rel_l2(yd.cpu(), yf) < 1e-5
+    up = torch.randn(B, generator=g)
+    gd4, gwf = torch.autograd.grad(yf, [d4r, wf], up)
+    mask = torch.where(d4 > 0, 1.0, 0.2) * math.sqrt(2.0)
+    dd4 = torch.empty_like(d4d)
+    db = torch.zeros(C3, device=DEV)
+    L.check(lib.dg_final_bwd_data(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), up.to(DEV).data_ptr(), None,
+                                  1.0 / math.sqrt(n), B, n, C3, dd4.data_ptr(), db.data_ptr(), None))
+    ref = gd4 * mask
+    assert rel_l2(from_nhwc(dd4.float().cpu(), B, C3, h0, w0), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < (1e-5 if dtype == torch.float32 else 2e-2)
+    dwf = torch.zeros(n, device=DEV)
+    L.check(lib.dg_batch_wsum(d4d.data_ptr(), L.dtype_code(dtype), up.to(DEV).data_ptr(), 1.0 / math.sqrt(n), B, n,
+                              dwf.data_ptr(), None))
+    assert rel_l2(dwf.cpu().view(h0, w0, C3).permute(2, 0, 1), gwf[0]) < 1e-5
+
+
+@pytest.mark.parametrize("arch", ["none", "dusty1", "dusty2"])
+def test_head_post_fwd_bwd(L, arch):
+    """tanh + GumbelSigmoid + maskout (dcgan_eqlr.py:71; dusty.py:45-59,77-91,107-127) forward and backward."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 8, 32
+    k = {"none": 0, "dusty1": 1, "dusty2": 2}[arch]
+    raw = torch.randn(B, 1 + k, H, W, generator=g).requires_grad_()
+    noise = {"pixel": O.logistic_noise(torch.rand(B, 1, H, W, generator=g), torch.rand(B, 1, H, W, generator=g)),
+             "image": O.logistic_noise(torch.rand(B, 1, 1, 1, generator=g), torch.rand(B, 1, 1, 1, generator=g))}
+    out = {"depth": torch.tanh(raw[:, 0:1])}
+    if k:
+        out["confidence"] = raw[:, 1:]
+    out = O.maskout(out, arch, noise, 1.0, -1.0, True)
+    gd = raw.detach().clone().to(DEV)
+    mask = torch.empty(B, max(k, 1), H, W, device=DEV)
+    depth = torch.empty(B, 1, H, W, device=DEV)
+    npx, nim = noise["pixel"].to(DEV).contiguous(), noise["image"].to(DEV).contiguous().view(B)
+    L.check(lib.dg_head_post_fwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), k, 1, 1.0, -1.0, B, H * W,
+                                 mask.data_ptr(), depth.data_ptr(), None))
+    assert rel_l2(depth.cpu(), out["depth"]) < 1e-5
+    if k:
+        assert torch.equal(mask.cpu(), out["mask"].detach())
+        assert rel_l2(gd[:, 0:1].cpu(), out["depth_orig"]) < 1e-6
+    go = torch.randn(B, 1, H, W, generator=g)
+    (graw,) = torch.autograd.grad(out["depth"], raw, go)
+    draw = torch.empty(B, 1 + k, H, W, device=DEV)
+    dbias = torch.zeros(3, device=DEV)
+    s_d, s_c = 0.25, 0.125
+    L.check(lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(),
+                                 go.to(DEV).data_ptr(), k, 1.0, -1.0, B, H * W, s_d, s_c, draw.data_ptr(),
+                                 dbias.data_ptr(), None))
+    scale = torch.tensor([s_d] + [s_c] * k).view(1, -1, 1, 1)
+    assert rel_l2(draw.cpu(), graw * scale) < 1e-5
+    assert rel_l2(dbias.cpu()[:1 + k], graw.sum(dim=[0, 2, 3])) < 1e-4
+
+
+@pytest.mark.parametrize("H,W", [(16, 32), (64, 1024)])
+def test_diffaug_fwd_bwd(L, H, W):
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    g = torch.Generator().manual_seed(H)
+    B = 4
+    A = DiffAugment()
+    x = torch.randn(B, 1, H, W, generator=g).requires_grad_()
+    for trial in range(3):
+        rp = O.draw_augment_params(B, H, W, g)
+        if trial == 0:  # extreme draws: clamp-to-border cutout, maximal shifts
+            rp["o_x"][:] = torch.tensor([0, H, 0, H])[:B]
+            rp["o_y"][:] = torch.tensor([0, W, W, 0])[:B]
+            sh, sw = O.translation_shift(H, W)
+            rp["t_h"][:] = torch.tensor([-sh, sh, 0, 1])[:B]
+            rp["t_w"][:] = torch.tensor([-sw, sw, 1, 0])[:B]
+        y = O.diff_augment(x, rp)
+        rpd = DiffAugment.params_to_device(rp, DEV)
+        yd = A.apply(x.detach().to(DEV), rpd)
+        assert rel_l2(yd.cpu(), y) < 1e-5
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        gxd = A.backward(gy.to(DEV), rpd)
+        assert rel_l2(gxd.cpu(), gx) < 1e-5
+    # the module call draws its own parameters from the Philox stream and stays in range
+    rp = A.draw(B, H, W, torch.device(DEV))
+    sh, sw = O.translation_shift(H, W)
+    assert rp["u_b"].abs().max() <= 1 and rp["t_h"].abs().max() <= sh and rp["t_w"].abs().max() <= sw
+    assert rp["o_x"].min() >= 0 and rp["o_x"].max() <= H and rp["o_y"].max() <= W
+
+
+def test_losses_fetch_reals_adam(L):
+    lib = L.lib()
+    ops = load("ops")
+    pr, pf = torch.from_numpy(ops["ganloss/pred_real"]).view(-1), torch.from_numpy(ops["ganloss/pred_fake"]).view(-1)
+    B = pr.numel()
+    dy, sc = torch.empty(2 * B, device=DEV), torch.empty(3, device=DEV)
+    L.check(lib.dg_nsgan_d(pr.to(DEV).data_ptr(), pf.to(DEV).data_ptr(), B, 1.0, dy.data_ptr(), dy.data_ptr() + 4 * B,
+                           sc.data_ptr(), None))
+    assert abs(float(sc[2]) - float(ops["ganloss/nsgan/D"])) < 1e-6
+    prr, pfr = pr.clone().requires_grad_(), pf.clone().requires_grad_()
+    gr, gf = torch.autograd.grad(O.gan_loss("nsgan", prr, pfr, "D"), [prr, pfr])
+    assert rel_l2(dy[:B].cpu(), gr) < 1e-5 and rel_l2(dy[B:].cpu(), gf) < 1e-5
+    dyg, scg = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    L.check(lib.dg_nsgan_g(pf.to(DEV).data_ptr(), B, 1.0, dyg.data_ptr(), scg.data_ptr(), None))
+    assert abs(float(scg[0]) - float(ops["ganloss/nsgan/G"])) < 1e-6
+    # fetch_reals against the reference vector
+    pol = torch.from_numpy(ops["invert_depth/pol"])
+    out = torch.empty_like(pol, device=DEV)
+    L.check(lib.dg_fetch_reals(pol.to(DEV).data_ptr(), torch.ones_like(pol).to(DEV).data_ptr(), 0.9, 120.0, -1.0,
+                               pol.numel(), out.data_ptr(), None))
+    assert rel_l2((out.cpu() + 1) / 2, ops["invert_depth/inv"]) < 1e-5
+    # Adam + EMA + shadow against the oracle's restatement of torch.optim.Adam
+    g = torch.Generator().manual_seed(1)
+    n = 1000
+    p, gr_, m, v, ema = (torch.randn(n, generator=g) for _ in range(5))
+    m.zero_(); v.abs_()
+    pc, mc, vc, ec = p.clone(), m.clone(), v.clone(), ema.clone()
+    O.adam_update(pc, gr_ * 0.5, mc, vc, 3, 0.002, 0.0, 0.99)
+    ec = 0.9 * ec + 0.1 * pc
+    pd, gd, md, vd, ed = (t.to(DEV) for t in (p, gr_, m, v, ema))
+    sh = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    L.check(lib.dg_adam_ema_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), ed.data_ptr(),
+                                 sh.data_ptr(), L.DG_BF16, n, 0.5, 0.002, 0.0, 0.99, 1e-8, 3, 0.9, None))
+    assert rel_l2(pd.cpu(), pc) < 1e-6 and rel_l2(vd.cpu(), vc) < 1e-6 and rel_l2(ed.cpu(), ec) < 1e-6
+    assert torch.equal(sh.cpu(), pd.cpu().bfloat16())
+
+
+def test_philox_known_answer(L):
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors):
+    counter=0,key=0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8; counter=ff..,key=ff.. -> 408f276d 41c83b0e a20bc7c6 6d5451fd"""
+    lib = L.lib()
+    out = torch.empty(4, dtype=torch.int32, device=DEV)
+    L.check(lib.dg_philox_bits(0, 0, 0, 1, out.data_ptr(), None))
+    got = [int(v) & 0xFFFFFFFF for v in out.cpu().tolist()]
+    assert got == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    L.check(lib.dg_philox_bits(2**64 - 1, 2**64 - 1, 2**64 - 1, 1, out.data_ptr(), None))
+    got = [int(v) & 0xFFFFFFFF for v in out.cpu().tolist()]
+    assert got == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    # distribution sanity of the derived draws
+    n = 1 << 20
+    u = torch.empty(n, device=DEV)
+    L.check(lib.dg_philox_fill(123, 0, 0, 0, 0.0, 1.0, 0, 1, n, u.data_ptr(), None))
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
+    z = torch.empty(n, device=DEV)
+    L.check(lib.dg_philox_fill(123, 1, 0, 1, 0.0, 1.0, 0, 1, n, z.data_ptr(), None))
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
