@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU-oracle sample")
     return ap.parse_args()
 
 
@@ -96,7 +97,10 @@ def cpu_baseline(args, arch):
     """The CPU oracle (oracle/dusty_oracle.py: the reference's algorithm in stock torch CPU ops, validated against the
     reference's modules) timed on this host: one warm-up + one timed step at a reduced batch (bounded sample)."""
     from oracle import dusty_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch's CPU conv kernels stop scaling (and then collapse) far below this host's thread count at batch 4:
+    # measured on the GPU box (scripts/cpu_threads.py: 8/16/32/64/128 threads -> 0.85/0.73/0.86/1.27/2.83 s per
+    # batch-4 step), 16 threads are the fastest; all 256 take 133 s.
+    torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
     H, W = args.shape
     B = args.cpu_batch
     gen = torch.Generator().manual_seed(0)

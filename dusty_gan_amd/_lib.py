@@ -59,8 +59,10 @@ _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 PROTOTYPES = {
     "dg_conv": [C.POINTER(DgConv), _I, _P],
     "dg_conv_mfma_supported": [C.POINTER(DgConv)],
+    "dg_conv_kernel_choice": [C.POINTER(DgConv)],
     "dg_wgrad": [C.POINTER(DgWgrad), _I, _I, _P],
     "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
+    "dg_wgrad_kernel_choice": [C.POINTER(DgWgrad)],
     "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],

@@ -3,13 +3,18 @@
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream);
+int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
+int dg_conv_thin_supported(const ConvP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream);
+int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
+int dg_wgrad_thin_supported(const WgradP* p);
 
 extern "C" {
 
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
+// force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error
 int dg_conv(const DgConv* p, int force, void* stream) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
   if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
@@ -19,9 +24,18 @@ int dg_conv(const DgConv* p, int force, void* stream) {
   if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
+  const bool thin_ok = dg_conv_thin_supported(p);
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s) : DG_EUNSUPPORTED;
+  if (force == 3) return thin_ok ? dg_conv_thin_launch(p, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s);
+  if (force == 0 && thin_ok) return dg_conv_thin_launch(p, s);
   return dg_conv_direct_launch(p, s);
+}
+
+int dg_conv_kernel_choice(const DgConv* p) {  // 2 = MFMA, 3 = thin, 1 = direct (what force == 0 would pick)
+  if (!p->nscale && dg_conv_mfma_supported(p)) return 2;
+  if (dg_conv_thin_supported(p)) return 3;
+  return 1;
 }
 
 int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
@@ -29,13 +43,22 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   if (p->B <= 0 || p->Ci <= 0 || p->Co <= 0 || p->Hc <= 0 || p->Wc <= 0) return DG_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
+  const bool thin_ok = dg_wgrad_thin_supported(p);
   if (force == 2) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
   if (!accumulate) {
     const long n = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
     HIP_CHECK_RET(hipMemsetAsync(p->dw, 0, sizeof(float) * n, s));
   }
+  if (force == 3) return thin_ok ? dg_wgrad_thin_launch(p, s) : DG_EUNSUPPORTED;
+  if (force == 0 && thin_ok) return dg_wgrad_thin_launch(p, s);
   return dg_wgrad_direct_launch(p, s);
+}
+
+int dg_wgrad_kernel_choice(const DgWgrad* p) {
+  if (dg_wgrad_mfma_supported(p)) return 2;
+  if (dg_wgrad_thin_supported(p)) return 3;
+  return 1;
 }
 
 }  // extern "C"

@@ -105,9 +105,11 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradP p) {
   for (long row = r0; row < r1; ++row) {
     const int b = (int)(row / p.Hc), m = (int)(row % p.Hc);
     float acc = 0.f;
-    if (p.wmode == 2) {
-      acc = dg_ld(p.a, (long)b * p.a_sb + (long)ci * p.a_sc, p.a_dtype) *
-            dg_ld(p.g, (long)b * p.g_sb + (long)co * p.g_sc, p.g_dtype);
+    if (p.wmode == 2) {  // plain rows: "pixels" are the Wc rows of both operands, no taps
+      const long ab = (long)b * p.a_sb + (long)ci * p.a_sc;
+      const long gb = (long)b * p.g_sb + (long)co * p.g_sc;
+      for (int x = 0; x < p.Wc; ++x)
+        acc += dg_ld(p.a, ab + (long)x * p.a_sp, p.a_dtype) * dg_ld(p.g, gb + (long)x * p.g_sp, p.g_dtype);
     } else {
       int ra, rg;
       dg_wgrad1d(p.wmode, 0, m, p.Hc, ky, ra, rg);

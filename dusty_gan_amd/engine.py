@@ -164,7 +164,7 @@ class Ops:
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
-             x_off=0, out_off=0, aux_off=0):
+             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None):
         p = L.DgConv()
         p.mode, p.adj, p.ring = mode, adj, int(ring)
         p.B, p.Hc, p.Wc, p.K, p.N = B, Hc, Wc, K, N
@@ -177,18 +177,21 @@ class Ops:
         p.out = L.ptr(out) + oes * out_off
         p.out_sb, p.out_sp, p.out_sn = out_strides
         p.w = w_ptr
-        p.w_st, p.w_sn, p.w_sk = N * K, K, 1
+        if w_strides is None:
+            p.w_st, p.w_sn, p.w_sk = N * K, K, 1  # shadow in T, [tap][n][k]
+        else:
+            p.w_st, p.w_sk, p.w_sn = w_strides  # e.g. the fp32 master [tap][ci][co] read in place
         p.scale, p.epi = scale, epi
         p.bias, p.bias_mod = bias, bias_mod
         p.aux = None if aux is None else L.ptr(aux) + oes * aux_off
         p.dbias, p.rowscale = dbias, L.ptr(rowscale)
-        p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, self.dt
+        p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, (self.dt if w_dt is None else w_dt)
         p.nscale = L.ptr(nscale)
         if PROFILE is None:
             L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
-        mfma = self.force != 1 and not nscale and bool(self.lib.dg_conv_mfma_supported(C.byref(p)))
+        choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
         taps = 1 if mode == L.MODE_GEMM else (16 if mode == L.MODE_S2 else 4)
         npix = B if mode == L.MODE_GEMM else (B * Hc * Wc if mode == L.MODE_S2 else B * 4 * Hc * Wc)
         flops = 2.0 * npix * N * K * taps
@@ -197,7 +200,7 @@ class Ops:
         e0.record()
         L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
         e1.record()
-        PROFILE.append(("conv_mfma_kernel" if mfma else "conv_direct_kernel", flops, nbytes, e0, e1,
+        PROFILE.append(({2: "conv_mfma_kernel", 3: "conv_thin_kernel"}.get(choice, "conv_direct_kernel"), flops, nbytes, e0, e1,
                         f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
 
     def wgrad(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale=None,
@@ -216,7 +219,7 @@ class Ops:
         if PROFILE is None:
             L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
             return
-        mfma = self.force != 1 and bool(self.lib.dg_wgrad_mfma_supported(C.byref(p)))
+        choice = self.lib.dg_wgrad_kernel_choice(C.byref(p)) if self.force == 0 else self.force
         taps = 1 if wmode == 2 else 16
         flops = 2.0 * B * Hc * Wc * Ci * Co * taps
         nbytes = B * Hc * Wc * (Ci + Co) * self.es * (1 if wmode == 2 else 4) + taps * Ci * Co * 4
@@ -224,7 +227,7 @@ class Ops:
         e0.record()
         L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
         e1.record()
-        PROFILE.append(("wgrad_mfma_kernel" if mfma else "wgrad_direct_kernel", flops, nbytes, e0, e1,
+        PROFILE.append(({2: "wgrad_mfma_kernel", 3: "wgrad_thin_kernel"}.get(choice, "wgrad_direct_kernel"), flops, nbytes, e0, e1,
                         f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
 
 
@@ -287,8 +290,9 @@ class GEngine:
         # Head (dcgan_eqlr.py:29-46), all heads in one pass, planar fp32 output
         hc, wc = self.grid[3]
         o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.gout,
-               (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR,
-               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale)
+               (c.nheads * self.HW, 1, self.HW), st.fptr("head_w"), 1.0, L.EPI_LINEAR,
+               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale,
+               w_strides=(chs[3] * c.nheads, c.nheads, 1), w_dt=L.DG_F32)
         arch = ARCH_ID[c.arch]
         if arch:
             if noise is None or "pixel" not in noise:
@@ -401,11 +405,13 @@ class DEngine:
         ci, co = self.chs[i - 1], self.chs[i]
         first = i == 1
         o.conv(L.MODE_UP, 1, c.ring, n, hc, wc, co, ci, self.e[i], (self.per[i], co, 1), self.e[i - 1],
-               (self.per[i - 1], ci, 1), st.sptr(f"d{i}_w"), 1.0 / math.sqrt(ci * 16),
-               L.EPI_LINEAR if first else L.EPI_MASK, aux=None if first else self.h[i - 1],
+               (self.per[i - 1], ci, 1), st.fptr(f"d{i}_w") if first else st.sptr(f"d{i}_w"),
+               1.0 / math.sqrt(ci * 16), L.EPI_LINEAR if first else L.EPI_MASK,
+               aux=None if first else self.h[i - 1],
                dbias=(st.fptr(f"d{i - 1}_b", st.grad) if (want_dbias and not first) else None), bias_mod=ci,
                rowscale=rowscale, x_off=slot * self.per[i], out_off=slot * self.per[i - 1],
-               aux_off=slot * self.per[i - 1])
+               aux_off=slot * self.per[i - 1], w_strides=(ci * co, 1, co) if first else None,
+               w_dt=L.DG_F32 if first else None)
 
     def backward_data(self, st, slot, n, up, rowscale, want_dbias):
         """Backward-data chain over batch slots [slot, slot+n): e4 = up*s_f*wf*mask4, then e3, e2, e1 (each the

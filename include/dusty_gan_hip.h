@@ -85,15 +85,18 @@ typedef struct DgWgrad {
  *   Proj.forward            models/gans/dcgan_eqlr.py:6-16
  *   their autograd backward-data passes (loss.backward() at trainers/dcgan_amp.py:235,309 and
  *   torch.autograd.grad(create_graph=True) at :218-223), and the R1 tangent pass (double backward, :229-235).
- * force: 0 = pick (MFMA implicit GEMM when the shape allows, else direct), 1 = direct VALU kernel, 2 = MFMA or error.
+ * force: 0 = pick (MFMA implicit GEMM when the shape allows, else the thin LDS/VALU kernel for <=4-channel sides,
+ * else the general direct kernel), 1 = direct, 2 = MFMA or error, 3 = thin or error.
  */
 int dg_conv(const DgConv* p, int force, void* stream);
 int dg_conv_mfma_supported(const DgConv* p);
+int dg_conv_kernel_choice(const DgConv* p);   /* what force == 0 launches: 2 MFMA, 3 thin, 1 direct */
 
 /* dg_wgrad replaces the weight-gradient half of the same autograd calls.  accumulate: 1 = atomically add onto dw
  * (dw zeroed by the caller at step start: optim.zero_grad, trainers/dcgan_amp.py:177,246), 0 = overwrite. */
 int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream);
 int dg_wgrad_mfma_supported(const DgWgrad* p);
+int dg_wgrad_kernel_choice(const DgWgrad* p);
 
 /* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* stream);

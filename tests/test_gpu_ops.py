@@ -106,7 +106,7 @@ def test_down_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     e = gy * torch.where(y > 0, 1.0, 0.2) * math.sqrt(2.0)
     if dtype == torch.bfloat16:
         e = e.bfloat16().float()
-    gx, gw, gb = torch.autograd.grad(y, [xr, wr, br], gy)
+    gx, gw, gb = torch.autograd.grad(y, [xr, wr, br], gy, retain_graph=True)
     assert rel_l2(e.sum(dim=[0, 2, 3]), gb) < 1e-2 if dtype == torch.bfloat16 else 1e-4
     # backward-data into a "previous layer" with its own activation mask (aux) and bias-gradient sums
     prev = torch.randn(x.shape, generator=g)
@@ -235,8 +235,8 @@ def test_blur_and_final(L, ring, dtype):
         gy = gy.bfloat16().float()
     (gx,) = torch.autograd.grad(y, x, gy)
     dx = torch.empty(B, 1, H, W, device=DEV)
-    L.check(lib.dg_blur_bwd(nhwc(gy).to(DEV, dtype).data_ptr(), L.dtype_code(dtype), dx.data_ptr(), B, H, W, int(ring),
-                            None))
+    gyd = nhwc(gy).to(DEV, dtype)  # keep every device operand referenced until the kernel has run
+    L.check(lib.dg_blur_bwd(gyd.data_ptr(), L.dtype_code(dtype), dx.data_ptr(), B, H, W, int(ring), None))
     assert rel_l2(dx.cpu(), gx) < 1e-6
     # final dot + its backward
     h0, w0 = 2, 4
@@ -251,21 +251,23 @@ def test_blur_and_final(L, ring, dtype):
     d4d = nhwc(d4).to(DEV, dtype)
     wfd = wf.detach().permute(0, 2, 3, 1).contiguous().view(-1).to(DEV)
     yd = torch.empty(B, device=DEV)
-    L.check(lib.dg_final_fwd(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), bf.to(DEV).data_ptr(),
+    bfd = bf.to(DEV)
+    L.check(lib.dg_final_fwd(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), bfd.data_ptr(),
                              1.0 / math.sqrt(n), B, n, yd.data_ptr(), None))
     assert rel_l2(yd.cpu(), yf) < 1e-5
     up = torch.randn(B, generator=g)
+    upd = up.to(DEV)
     gd4, gwf = torch.autograd.grad(yf, [d4r, wf], up)
     mask = torch.where(d4 > 0, 1.0, 0.2) * math.sqrt(2.0)
     dd4 = torch.empty_like(d4d)
     db = torch.zeros(C3, device=DEV)
-    L.check(lib.dg_final_bwd_data(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), up.to(DEV).data_ptr(), None,
+    L.check(lib.dg_final_bwd_data(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), upd.data_ptr(), None,
                                   1.0 / math.sqrt(n), B, n, C3, dd4.data_ptr(), db.data_ptr(), None))
     ref = gd4 * mask
     assert rel_l2(from_nhwc(dd4.float().cpu(), B, C3, h0, w0), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
     assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < (1e-5 if dtype == torch.float32 else 2e-2)
     dwf = torch.zeros(n, device=DEV)
-    L.check(lib.dg_batch_wsum(d4d.data_ptr(), L.dtype_code(dtype), up.to(DEV).data_ptr(), 1.0 / math.sqrt(n), B, n,
+    L.check(lib.dg_batch_wsum(d4d.data_ptr(), L.dtype_code(dtype), upd.data_ptr(), 1.0 / math.sqrt(n), B, n,
                               dwf.data_ptr(), None))
     assert rel_l2(dwf.cpu().view(h0, w0, C3).permute(2, 0, 1), gwf[0]) < 1e-5
 
@@ -297,10 +299,11 @@ def test_head_post_fwd_bwd(L, arch):
     go = torch.randn(B, 1, H, W, generator=g)
     (graw,) = torch.autograd.grad(out["depth"], raw, go)
     draw = torch.empty(B, 1 + k, H, W, device=DEV)
+    god = go.to(DEV)
     dbias = torch.zeros(3, device=DEV)
     s_d, s_c = 0.25, 0.125
     L.check(lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(),
-                                 go.to(DEV).data_ptr(), k, 1.0, -1.0, B, H * W, s_d, s_c, draw.data_ptr(),
+                                 god.data_ptr(), k, 1.0, -1.0, B, H * W, s_d, s_c, draw.data_ptr(),
                                  dbias.data_ptr(), None))
     scale = torch.tensor([s_d] + [s_c] * k).view(1, -1, 1, 1)
     assert rel_l2(draw.cpu(), graw * scale) < 1e-5
@@ -343,19 +346,21 @@ def test_losses_fetch_reals_adam(L):
     pr, pf = torch.from_numpy(ops["ganloss/pred_real"]).view(-1), torch.from_numpy(ops["ganloss/pred_fake"]).view(-1)
     B = pr.numel()
     dy, sc = torch.empty(2 * B, device=DEV), torch.empty(3, device=DEV)
-    L.check(lib.dg_nsgan_d(pr.to(DEV).data_ptr(), pf.to(DEV).data_ptr(), B, 1.0, dy.data_ptr(), dy.data_ptr() + 4 * B,
+    prd, pfd = pr.to(DEV), pf.to(DEV)
+    L.check(lib.dg_nsgan_d(prd.data_ptr(), pfd.data_ptr(), B, 1.0, dy.data_ptr(), dy.data_ptr() + 4 * B,
                            sc.data_ptr(), None))
     assert abs(float(sc[2]) - float(ops["ganloss/nsgan/D"])) < 1e-6
     prr, pfr = pr.clone().requires_grad_(), pf.clone().requires_grad_()
     gr, gf = torch.autograd.grad(O.gan_loss("nsgan", prr, pfr, "D"), [prr, pfr])
     assert rel_l2(dy[:B].cpu(), gr) < 1e-5 and rel_l2(dy[B:].cpu(), gf) < 1e-5
     dyg, scg = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
-    L.check(lib.dg_nsgan_g(pf.to(DEV).data_ptr(), B, 1.0, dyg.data_ptr(), scg.data_ptr(), None))
+    L.check(lib.dg_nsgan_g(pfd.data_ptr(), B, 1.0, dyg.data_ptr(), scg.data_ptr(), None))
     assert abs(float(scg[0]) - float(ops["ganloss/nsgan/G"])) < 1e-6
     # fetch_reals against the reference vector
     pol = torch.from_numpy(ops["invert_depth/pol"])
     out = torch.empty_like(pol, device=DEV)
-    L.check(lib.dg_fetch_reals(pol.to(DEV).data_ptr(), torch.ones_like(pol).to(DEV).data_ptr(), 0.9, 120.0, -1.0,
+    pold, oned = pol.to(DEV), torch.ones_like(pol).to(DEV)
+    L.check(lib.dg_fetch_reals(pold.data_ptr(), oned.data_ptr(), 0.9, 120.0, -1.0,
                                pol.numel(), out.data_ptr(), None))
     assert rel_l2((out.cpu() + 1) / 2, ops["invert_depth/inv"]) < 1e-5
     # Adam + EMA + shadow against the oracle's restatement of torch.optim.Adam

@@ -1,0 +1,131 @@
+"""GPU parity of the thin (<= 4-channel side) LDS/VALU kernels of csrc/conv_thin.hip against the CPU oracle:
+Down1 forward / backward-data / weight gradient (Cin = 2) and Head forward / backward-data / weight gradient
+(Cout = 1..3), in fp32 and bf16 feature-map storage, forced through the thin path (force = 3)."""
+import math
+
+import pytest
+import torch
+
+from oracle import dusty_oracle as O
+from tests.golden_util import rel_l2
+from tests.test_gpu_ops import DEV, from_nhwc, nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dusty_gan_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Hc,Wc,B", [(4, 64, 3), (16, 128, 2)])
+def test_down1_thin(L, dtype, Hc, Wc, B):
+    from dusty_gan_amd.engine import Ops
+    g = torch.Generator().manual_seed(Hc + Wc)
+    Ci, Co = 2, 64
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    x = torch.randn(B, Ci, 2 * Hc, 2 * Wc, generator=g)
+    w = torch.randn(Co, Ci, 4, 4, generator=g)
+    b = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    wq = w.bfloat16().float() if dtype == torch.bfloat16 else w  # forward reads the T shadow
+    y = O.down(xr, wq.clone().requires_grad_(), br, True)
+    s = 1.0 / math.sqrt(Ci * 16)
+    o = Ops(dtype)
+    o.force = 3
+    xd = nhwc(x).to(DEV, dtype)
+    master = w.permute(2, 3, 1, 0).contiguous().to(DEV)  # [ky][kx][ci][co] fp32
+    coci = w.permute(2, 3, 0, 1).contiguous().to(DEV, dtype)  # [tap][co][ci] shadow
+    out = torch.empty(B * Hc * Wc * Co, device=DEV, dtype=dtype)
+    bd = b.to(DEV)
+    o.conv(L.MODE_S2, 0, True, B, Hc, Wc, Ci, Co, xd, (4 * Hc * Wc * Ci, Ci, 1), out, (Hc * Wc * Co, Co, 1),
+           coci.data_ptr(), s, L.EPI_LRELU, bias=bd.data_ptr(), bias_mod=Co)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nhwc(out.float().cpu(), B, Co, Hc, Wc), y) < tol
+    # backward-data (MODE_UP adjoint, N = 2) straight from the fp32 master weights
+    y32 = O.down(xr, wr, br, True)
+    gy = torch.randn(y32.shape, generator=g)
+    lr = torch.where(y32 > 0, 1.0, 0.2) * math.sqrt(2.0)
+    e = gy * lr
+    if dtype == torch.bfloat16:
+        e = e.bfloat16().float()
+    gx, gw = torch.autograd.grad(y32, [xr, wr], e / lr)
+    ed = nhwc(e).to(DEV, dtype)
+    dx = torch.empty(B * 4 * Hc * Wc * Ci, device=DEV, dtype=dtype)
+    o.conv(L.MODE_UP, 1, True, B, Hc, Wc, Co, Ci, ed, (Hc * Wc * Co, Co, 1), dx, (4 * Hc * Wc * Ci, Ci, 1),
+           master.data_ptr(), s, L.EPI_LINEAR, w_strides=(Ci * Co, 1, Co), w_dt=L.DG_F32)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nhwc(dx.float().cpu(), B, Ci, 2 * Hc, 2 * Wc), gx) < (1e-4 if dtype == torch.float32 else 1e-2)
+    # weight gradient with per-sample weights
+    rs = torch.rand(B, generator=g) + 0.5
+    dw = torch.zeros(16, Ci, Co, device=DEV)
+    rsd = rs.to(DEV)
+    o.wgrad(0, True, B, Hc, Wc, Ci, Co, xd, (4 * Hc * Wc * Ci, Ci, 1), ed, (Hc * Wc * Co, Co, 1), dw.data_ptr(), s,
+            rowscale=rsd)
+    torch.cuda.synchronize()
+    (gw2,) = torch.autograd.grad(O.down(xr, wr, br, True), wr, (e * rs.view(B, 1, 1, 1)) / lr)
+    assert rel_l2(dw.cpu().view(4, 4, Ci, Co).permute(3, 2, 0, 1), gw2) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nh", [1, 2, 3])
+def test_head_thin(L, dtype, nh):
+    from dusty_gan_amd.engine import Ops
+    g = torch.Generator().manual_seed(nh)
+    B, Hc, Wc, C0 = 2, 8, 64, 64
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    x = torch.randn(B, C0, Hc, Wc, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    ws = [torch.randn(C0, 1, 4, 4, generator=g)] + ([torch.randn(C0, nh - 1, 4, 4, generator=g)] if nh > 1 else [])
+    bs = [torch.randn(1, generator=g)] + ([torch.randn(nh - 1, generator=g)] if nh > 1 else [])
+    xr = x.clone().requires_grad_()
+    wr = [w.clone().requires_grad_() for w in ws]
+    ys = [O.head(xr, w, b, True) for w, b in zip(wr, bs)]
+    y = torch.cat(ys, dim=1)  # [B,nh,2Hc,2Wc]
+    master = torch.cat(ws, dim=1).permute(2, 3, 0, 1).contiguous().to(DEV)  # [ky][kx][ci][co]
+    bias = torch.cat(bs).to(DEV)
+    scales = [1.0 / math.sqrt(16)] + [1.0 / math.sqrt(max(nh - 1, 1) * 16)] * (nh - 1)
+    nscale = torch.tensor(scales, device=DEV)
+    o = Ops(dtype)
+    o.force = 3
+    xd = nhwc(x).to(DEV, dtype)
+    HW = 4 * Hc * Wc
+    out = torch.empty(B, nh, 2 * Hc, 2 * Wc, device=DEV)
+    o.conv(L.MODE_UP, 0, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), out, (nh * HW, 1, HW), master.data_ptr(),
+           1.0, L.EPI_LINEAR, bias=bias.data_ptr(), bias_mod=nh, out_dt=L.DG_F32, nscale=nscale,
+           w_strides=(C0 * nh, nh, 1), w_dt=L.DG_F32)
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), y) < tol
+    # backward: draw = s_n * dL/dy (planar fp32) -> gradient w.r.t. the previous pre-activation, masked, + bias sums
+    gy = torch.randn(y.shape, generator=g)
+    grads = torch.autograd.grad(y, [xr] + wr, gy)
+    gx, gws = grads[0], grads[1:]
+    draw = (gy * torch.tensor(scales).view(1, nh, 1, 1)).to(DEV).contiguous()
+    prev = torch.randn(x.shape, generator=g)
+    prevd = nhwc(prev).to(DEV, dtype)
+    shadow = master.to(dtype)  # cico shadow [tap][ci][co]: n = ci, k = co
+    dp = torch.empty(B * Hc * Wc * C0, device=DEV, dtype=dtype)
+    db = torch.zeros(C0, device=DEV)
+    o.conv(L.MODE_S2, 1, True, B, Hc, Wc, nh, C0, draw, (nh * HW, 1, HW), dp, (Hc * Wc * C0, C0, 1), shadow.data_ptr(),
+           1.0, L.EPI_MASK, aux=prevd, dbias=db.data_ptr(), bias_mod=C0, in_dt=L.DG_F32)
+    torch.cuda.synchronize()
+    if dtype == torch.bfloat16:  # the kernel reads bf16-rounded weights
+        wq = [w.bfloat16().float().requires_grad_() for w in ws]
+        yq = torch.cat([O.head(xr, w, b, True) for w, b in zip(wq, bs)], dim=1)
+        (gx,) = torch.autograd.grad(yq, xr, gy)
+    ref = gx * torch.where(prev > 0, 1.0, 0.2) * math.sqrt(2.0)
+    assert rel_l2(from_nhwc(dp.float().cpu(), B, C0, Hc, Wc), ref) < tol
+    assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < (1e-4 if dtype == torch.float32 else 2e-2)
+    # weight gradient (scale 1: draw is pre-scaled)
+    dw = torch.zeros(16, C0, nh, device=DEV)
+    o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw, (nh * HW, 1, HW), dw.data_ptr(), 1.0,
+            g_dt=L.DG_F32)
+    torch.cuda.synchronize()
+    got = dw.cpu().view(4, 4, C0, nh).permute(2, 3, 0, 1)
+    assert rel_l2(got, torch.cat(list(gws), dim=1)) < tol
