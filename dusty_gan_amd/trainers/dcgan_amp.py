@@ -23,6 +23,7 @@ from ..models import define_D, define_G
 from ..models.loss import GANLoss
 from ..utils import cycle, sigmoid_to_tanh, tanh_to_sigmoid  # noqa: F401  (re-exported like the reference)
 from ..utils.context_manager import gradient_accumulation
+from ..utils import dist as D_
 from ..utils.diff_augment import DiffAugment
 from ..utils.lidar import LiDAR
 from ..utils.rng import Philox
@@ -198,8 +199,7 @@ class Trainer:
         # DDP construction broadcasts rank 0's parameters (reference :68-69)
         self.world = _world()
         if self.world > 1:
-            dist.broadcast(self.G.store.flat, src=0)
-            dist.broadcast(self.D.store.flat, src=0)
+            D_.broadcast_params([self.G.store.flat, self.D.store.flat], src=0)
             self.G.store._seen_version = -1
             self.D.store._seen_version = -1
         self.G_ema.store.flat.copy_(self.G.store.flat)  # ema_inplace(G_ema, G, 0.0) (:51)
@@ -298,8 +298,9 @@ class Trainer:
         return out
 
     def _allreduce(self, store):
-        if self.world > 1:
-            dist.all_reduce(store.grad)  # SUM; the 1/world of DDP's averaging is folded into the Adam kernel
+        """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
+        _, gscale = D_.allreduce_grads(store.grad)
+        return gscale
 
     # ------------------------------------------------------------------ D phase (reference :171-238)
     def optimize_D(self, reals=None, rands=None):
@@ -364,8 +365,8 @@ class Trainer:
                 deng.final_wgrad(Dst, 0, 2 * B, dy)
             Dst.view("final_b", Dst.grad).add_(dy.sum())
             self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
-        self._allreduce(Dst)
-        self.optim_D.step(gscale=1.0 / self.world, shadow_dtype=self.dtype)  # :238
+        gscale = self._allreduce(Dst)
+        self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype)  # :238
         self._dev_scal = scal
         return scal
 
@@ -395,9 +396,9 @@ class Trainer:
             deng.backward_input(Dst, 0, B, dx)
             ddepth = self.A.backward(dx, rand["aug"][3])
             mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0))
-        self._allreduce(Gst)
+        gscale = self._allreduce(Gst)
         # Adam + EMA fused (:312, :316)
-        self.optim_G.step(gscale=1.0 / self.world, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
+        self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
                           shadow_dtype=self.dtype)
         self._mb = []
         return scal
@@ -414,10 +415,7 @@ class Trainer:
             idx.append(3)
         keys.append("loss/G/adversarial")
         idx.append(4)
-        out = scal[idx]
-        if self.world > 1:
-            dist.all_reduce(out)  # one packed collective instead of 5-7 (:319-323)
-            out = out / self.world
+        out = D_.mean_scalars(scal[idx])  # one packed collective instead of 5-7 (:319-323)
         return LazyScalars(keys, out)
 
     # ------------------------------------------------------------------ inference / checkpoints

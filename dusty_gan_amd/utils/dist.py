@@ -1,0 +1,55 @@
+"""Data-parallel exchange for the training step: one process per GPU, torch.distributed over RCCL ("nccl" backend on
+ROCm) / xGMI.  Replaces what DistributedDataParallel does for the reference (trainers/dcgan_amp.py:68-69, SURVEY.md
+§2.3): a parameter broadcast at construction and a gradient average per network per step.
+
+The flat ParamStore makes each exchange ONE collective on ONE contiguous fp32 buffer (no bucketing, no per-parameter
+hooks); the 1/world_size of DDP's averaging is folded into the Adam kernel (`gscale`), so the collective is a plain
+SUM.  With num_accumulation > 1 the exchange happens once, after the last micro-batch (the reference's
+DDP.no_sync() schedule, utils/context_manager.py:21-35).  The path shards by sample only: there is no other
+collective on the data path.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def local_batch(global_batch, ngpus, num_accumulation):
+    """per-GPU per-micro-batch size, with the reference's divisibility asserts (train.py:54-57)"""
+    assert global_batch % ngpus == 0
+    b = global_batch // ngpus
+    assert b % num_accumulation == 0
+    return b // num_accumulation
+
+
+def broadcast_params(flats, src=0):
+    """DDP's constructor broadcast: every rank starts from rank `src`'s parameters."""
+    if world_size() > 1:
+        for t in flats:
+            dist.broadcast(t, src=src)
+
+
+def allreduce_grads(flat_grad, async_op=False):
+    """SUM all-reduce of one network's flat gradient buffer; returns (work handle or None, gscale) where gscale is the
+    factor the optimizer applies to turn the sum into DDP's average."""
+    w = world_size()
+    if w == 1:
+        return None, 1.0
+    work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+    return (work if async_op else None), 1.0 / w
+
+
+def mean_scalars(t):
+    """one packed collective for the logged scalars (the reference does one all_reduce + .item() per key,
+    trainers/dcgan_amp.py:319-323)"""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t / w
+    return t

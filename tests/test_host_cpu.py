@@ -1,0 +1,159 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/dusty_gan_hip.h declares,
+the ctypes structs match the header, the config tree loads, the model mirrors keep the reference's state_dict
+layout, and the host-side helpers behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load, sub
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from dusty_gan_amd import _lib
+    _lib.build()  # hipcc cross-compiles gfx950 without a GPU; a no-op when up to date
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    h = open(os.path.join(ROOT, "include", "dusty_gan_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(dg_\w+)\s*\(", h, flags=re.M))
+    assert len(declared) >= 25
+    lib = built.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported by libdustygan_hip.so"
+    # every binding the Python side uses is declared in the header
+    assert set(built.PROTOTYPES) <= declared
+    assert lib.dg_version().decode().startswith("dusty_gan_hip")
+
+
+def test_ctypes_structs_match_header(built):
+    h = open(os.path.join(ROOT, "include", "dusty_gan_hip.h")).read()
+    for cname, cls in (("DgConv", built.DgConv), ("DgWgrad", built.DgWgrad)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), h, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = [n.strip().lstrip("*").strip() for n in decl.split(",")]
+            names[0] = names[0].split()[-1].lstrip("*")
+            fields += names
+        mine = [f[0].rstrip("_") for f in cls._fields_]
+        assert mine == fields, (cname, mine, fields)
+
+
+def test_error_codes_without_gpu(built):
+    """argument validation happens before any launch, so it can be exercised on the CPU"""
+    lib = built.lib()
+    p = built.DgConv()
+    assert lib.dg_conv(C.byref(p), 0, None) == built.DG_EINVAL
+    w = built.DgWgrad()
+    assert lib.dg_wgrad(C.byref(w), 1, 0, None) == built.DG_EINVAL
+    with pytest.raises(built.DgError):
+        built.check(built.DG_EUNSUPPORTED, "x")
+    assert built.policy_mask(["brightness", "cutout"]) == 17
+    with pytest.raises(KeyError):
+        built.policy_mask(["nope"])
+
+
+def test_config_tree_and_overrides():
+    from dusty_gan_amd.utils.config import load_config
+    cfg = load_config([])
+    assert cfg.model.gen.arch == "dusty1/dcgan_eqlr" and cfg.dataset.shape == [64, 256]
+    assert cfg.solver.batch_size == 32 and cfg.solver.loss.gp == 1 and cfg.solver.lr.beta1 == 0.0
+    assert cfg.solver.augment == ["brightness", "saturation", "contrast", "translation", "cutout"]
+    cfg = load_config(["model=dusty2_dcgan_eqlr", "dataset.shape=[64,1024]", "solver.loss.gp=0", "enable_amp=false"])
+    assert cfg.model.gen.out_ch == {"depth": 1, "confidence": 2} and cfg.dataset.shape == [64, 1024]
+    assert cfg.solver.loss.gp == 0 and cfg.enable_amp is False
+    with pytest.raises(FileNotFoundError):
+        load_config(["solver=nsgan"])  # the reference's broken default
+
+
+@pytest.mark.parametrize("case", ["none_ring", "dusty1_ring", "dusty2_noring"])
+def test_state_dict_layout_matches_reference(case):
+    """keys, shapes and values round-trip through the strided views of the flat engine-layout store"""
+    from dusty_gan_amd.models import define_D, define_G
+    from dusty_gan_amd.utils.config import load_config
+    g = load("step_" + case)
+    arch = str(g["meta/arch"])
+    model = {"none": "dcgan_eqlr", "dusty1": "dusty1_dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
+    cfg = load_config([f"model={model}", "dataset.shape=[32,64]", "model.gen.in_ch=8", "model.gen.ch_base=4",
+                       "model.gen.ch_max=16", "model.dis.ch_base=4", "model.dis.ch_max=16",
+                       f"model.ring={str(bool(g['meta/ring'])).lower()}", "enable_amp=false"])
+    cfg.model.gen.shape = cfg.dataset.shape
+    cfg.model.dis.shape = cfg.dataset.shape
+    G, D = define_G(cfg), define_D(cfg)
+    refG, refD = sub(g, "init/G"), sub(g, "init/D")
+    assert list(G.state_dict().keys()) == list(refG.keys())
+    assert list(D.state_dict().keys()) == list(refD.keys())
+    G.load_state_dict(refG)
+    D.load_state_dict(refD)
+    for k, v in G.state_dict().items():
+        assert v.shape == refG[k].shape and torch.equal(v, refG[k]), k
+    for k, v in D.state_dict().items():
+        assert v.shape == refD[k].shape and torch.allclose(v, refD[k]), k
+    # engine layout underneath: conv weights are [ky][kx][ci][co]
+    st = D.store
+    w = refD["2.1.module.weight"]  # Conv2d (Co,Ci,4,4)
+    assert torch.equal(st.view("d2_w"), w.permute(2, 3, 1, 0))
+    # parameter count equals the reference's (probe numbers of SURVEY.md §8a at full size are checked on the GPU box)
+    assert sum(p.numel() for p in G.parameters()) == sum(v.numel() for k, v in refG.items() if k != "drop_const")
+    # no CPU execution path
+    with pytest.raises(RuntimeError):
+        D(torch.zeros(1, 1, 32, 64))
+    with pytest.raises(NotImplementedError):
+        cfg.model.gen.arch = "dusty3/dcgan_eqlr"
+        define_G(cfg)
+    with pytest.raises(NotImplementedError):
+        cfg.model.dis.arch = "stylegan"
+        define_D(cfg)
+
+
+def test_full_size_parameter_counts():
+    """SURVEY.md §8a probe: G 69 863 361 / 69 864 386 / 69 865 411 (none/dusty1/dusty2), D 2 886 593 at 64x1024"""
+    from dusty_gan_amd.models.gans.dcgan_eqlr import Discriminator, Generator
+    for heads, n in (({"depth": 1}, 69863361), ({"depth": 1, "confidence": 1}, 69864386),
+                     ({"depth": 1, "confidence": 2}, 69865411)):
+        G = Generator(512, heads, 64, 512, (64, 1024), True)
+        assert sum(p.numel() for p in G.parameters()) == n
+    D = Discriminator(1, 64, 512, (64, 1024), True)
+    assert sum(p.numel() for p in D.parameters()) == 2886593
+
+
+def test_lazy_scalars_and_flat_adam_format():
+    from dusty_gan_amd.models.gans.dcgan_eqlr import Discriminator
+    from dusty_gan_amd.trainers.dcgan_amp import FlatAdam, LazyScalars
+    s = LazyScalars(["a", "b"], torch.tensor([1.5, 2.5]))
+    assert len(s) == 2 and "a" in s and s["b"] == 2.5 and dict(s.items()) == {"a": 1.5, "b": 2.5}
+    D = Discriminator(1, 4, 16, (32, 64), True)
+    D.store.ensure_train_state()
+    opt = FlatAdam(D, 0.002, (0.0, 0.99))
+    D.store.v.uniform_()
+    opt.step_count = 3
+    sd = opt.state_dict()
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in D.parameters()], lr=0.002, betas=(0.0, 0.99))
+    assert sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
+    assert sd["state"][0]["exp_avg_sq"].shape == tuple(next(iter(D.parameters())).shape)
+    opt2 = FlatAdam(Discriminator(1, 4, 16, (32, 64), True), 0.1, (0.5, 0.5))
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 3 and opt2.lr == 0.002
+    for a, b in zip(opt2._param_views(opt2.store.v), opt._param_views(D.store.v)):  # (alignment gaps are not state)
+        assert torch.equal(a, b)
+
+
+def test_philox_oracle_known_answers():
+    """Random123 kat_vectors for philox4x32-10 pin oracle/philox.py (which in turn pins the HIP generator on the GPU)"""
+    from oracle.philox import bits, philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    assert list(bits(0, 0, 0, 1)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
