@@ -83,13 +83,22 @@ def roofline_pass(tr, steps=2):
     torch.cuda.synchronize()
     rec, E.PROFILE = E.PROFILE, None
     fam = {}
+    detail = {}
     for name, flops, nbytes, e0, e1, tag in rec:
         ms = e0.elapsed_time(e1)
+        d = detail.setdefault((name, tag), [0.0, 0.0, 0])
+        d[0] += ms
+        d[1] += flops
+        d[2] += 1
         f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
         f["ms"] += ms
         f["flops"] += flops
         f["bytes"] += nbytes
         f["n"] += 1
+    if os.environ.get("DUSTY_BENCH_DETAIL"):
+        for (name, tag), (ms, fl, n) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
+            print(f"  {name:20s} {tag:40s} n={n:3d} avg {1e3 * ms / n:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s",
+                  file=sys.stderr)
     return fam
 
 

@@ -9,40 +9,60 @@
 //   * one workgroup = 256 threads = 4 waves (2 x 2), tile BM x BN with BM,BN in {64,128}
 //   * an M-tile lies inside ONE output row (and one column parity in MODE_UP) so the tap list - including the
 //     reflect-adjoint extra taps - is workgroup-uniform (scalar control flow, no per-lane predication)
-//   * K step = 128 bytes of channels (64 bf16 / 32 f32) per tap; tiles are staged global -> registers -> LDS with
-//     the next tile's loads in flight during the MFMAs; LDS rows are padded to 144 B (conflict-free ds_read_b128)
+//   * K step = 128 bytes of channels (64 bf16 / 32 f32) per tap
+//   * PIPE_DMA (default): tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no
+//     ds_write), two LDS buffers, ONE barrier per K step, the next tile's DMA in flight during the MFMAs.  LDS rows
+//     are 128 B unpadded; bank conflicts are removed by an XOR swizzle applied on the per-lane SOURCE address
+//     (lane -> chunk ^ ((row >> 1) & 7)) and undone on the fragment reads (conflict-free for every ds_read_b128
+//     16-lane group).  Measured before the change: with every global load removed the register-staged kernel
+//     only went 394 -> 444 TFLOP/s, i.e. it was bound by ds_write_b128 (79 B/clk/CU) + two barriers per step.
+//   * PIPE_REG: the register-staged pipeline (global -> VGPR -> ds_write, rows padded to 144 B), kept for A/B runs
+//     (DG_CONV_PIPE=reg).
 //   * bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact fp32, the parity mode)
 //   * blockIdx is remapped so each XCD (private L2) walks a contiguous range of M-tiles across all their N-tiles
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-#define RS 144  // LDS row stride in bytes (128 B of K + 16 B pad)
+#define LDS_READ128(dst, addr, imm) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 
-__device__ __forceinline__ void mma_tile(const bf16*, const uint4& a, const uint4& b, f32x16& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, acc, 0, 0, 0);
+__device__ __forceinline__ void mma_tile(const bf16*, const i32x4& a, const i32x4& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
-__device__ __forceinline__ void mma_tile(const float*, const uint4& a, const uint4& b, f32x16& acc) {
-  const f32x4 fa = *(const f32x4*)&a, fb = *(const f32x4*)&b;
+__device__ __forceinline__ void mma_tile(const float*, const i32x4& a, const i32x4& b, f32x16& acc) {
+  const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int tiles_n, int tiles_x) {
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+  // one wave instruction: lane l's 16 bytes land at lds_dst + 16*l (lds_dst is wave-uniform)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int SB, int NS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n, int tiles_x, int dbg) {
+  // SB = bytes of K per row per pipeline stage (64 or 128), NS = LDS stages (prefetch distance NS-1)
   constexpr int ES = sizeof(T);
-  constexpr int BK = 128 / ES;   // channels per K step
-  constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
+  constexpr int BK = SB / ES;          // channels per K step
+  constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AU = BM / 32, BU = BN / 32;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * RS + 512];
-  unsigned char* ldsA = lds;
-  unsigned char* ldsB = lds + BM * RS;
-  int* s_tap = (int*)(lds + (BM + BN) * RS);  // [0] = ntaps, then {src_row, col_offset, weight_tap} x ntaps
+  constexpr int RPI = 1024 / SB;       // tile rows moved by one DMA wave-instruction (1 KiB)
+  constexpr int CPR = SB / 16;         // 16-byte chunks per row
+  constexpr int KS = SB / 32;          // MFMA k-steps (16 bf16 / 8 f32) per stage
+  constexpr int STAGE = (BM + BN) * SB;
+  constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;  // DMA instructions per wave per tile (A, B)
+  constexpr int IPT = IA + IB;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   // ---- XCD-aware, bijective block remap (blocks id and id+8 share an XCD)
   const int nwg = gridDim.x, id = blockIdx.x;
@@ -68,78 +88,92 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int tiles_n, in
   }
 
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    int nt_ = 0;
-    if (p.mode == MODE_GEMM) {
-      s_tap[1] = 0; s_tap[2] = 0; s_tap[3] = 0; nt_ = 1;
-    } else {
-      for (int i = 0; i < 6; ++i) {
-        int r, ky;
-        if (!dg_tap1d(p.mode, p.adj, 0, Y, p.Hc, i, r, ky)) continue;
-        const int nw = p.mode == MODE_S2 ? 4 : 2;
-        for (int j = 0; j < nw; ++j) {
-          int coff, kx;
-          if (p.mode == MODE_S2) { coff = j - 1; kx = j; }
-          else if (px == 0) { coff = j == 0 ? 0 : -1; kx = j == 0 ? 1 : 3; }
-          else { coff = j == 0 ? 1 : 0; kx = j == 0 ? 0 : 2; }
-          s_tap[1 + 3 * nt_ + 0] = r;
-          s_tap[1 + 3 * nt_ + 1] = coff;
-          s_tap[1 + 3 * nt_ + 2] = ky * 4 + kx;
-          ++nt_;
-        }
-      }
+  // ---- tap enumeration is scalar code on the ISSUE side only (no LDS table: a compiler-visible ds_read inside the
+  //      loop would make hipcc drain the LDS-DMA queue with vmcnt(0) before it)
+  const int nW = p.mode == MODE_S2 ? 4 : (p.mode == MODE_UP ? 2 : 1);
+  int nH = 1;
+  if (p.mode != MODE_GEMM) {
+    nH = 0;
+    for (int i = 0; i < 6; ++i) {
+      int r, ky;
+      nH += dg_tap1d(p.mode, p.adj, 0, Y, p.Hc, i, r, ky) ? 1 : 0;
     }
-    s_tap[0] = nt_;
   }
-  __syncthreads();
-  const int ntaps = s_tap[0];
   const int KC = p.K / BK;
-  const int nsteps = ntaps * KC;
+  const int nsteps = nH * nW * KC;
 
-  const int part = tid & 7, rbase = tid >> 3;
   const T* in = (const T*)p.in;
   const T* w = (const T*)p.w;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lrow = lane / CPR, pos = lane % CPR;
 
-  uint4 ra[AU], rb[BU];
-  auto load_tiles = [&](int tq, int kc) {
-    const int r = s_tap[1 + 3 * tq + 0], coff = s_tap[1 + 3 * tq + 1], wt = s_tap[1 + 3 * tq + 2];
-    const long koff = (long)kc * BK + part * EPC;
+  // row swizzle: chunk position of global chunk g in tile row `row` is g ^ swz(row)
+  auto swz = [](int row) { return SB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+  // issue-side iterator over (H tap, W tap, k chunk)
+  int it_i = -1, it_j = 0, it_kc = 0, it_r = 0, it_ky = 0;
+  auto next_htap = [&]() {
+    if (p.mode == MODE_GEMM) { it_i = 0; return; }
+    for (++it_i; it_i < 6; ++it_i)
+      if (dg_tap1d(p.mode, p.adj, 0, Y, p.Hc, it_i, it_r, it_ky)) break;
+  };
+  next_htap();
+  auto advance = [&]() {
+    if (++it_kc == KC) {
+      it_kc = 0;
+      if (++it_j == nW) { it_j = 0; next_htap(); }
+    }
+  };
+
+  // ---------------- DMA of one K-step tile into stage `st`: wave `wave` moves row groups wave, wave+4, ...
+  auto issue_dma = [&](int st) {
+    int coff = 0, kx = 0;
+    if (p.mode == MODE_S2) { coff = it_j - 1; kx = it_j; }
+    else if (p.mode == MODE_UP) {
+      if (px == 0) { coff = it_j == 0 ? 0 : -1; kx = it_j == 0 ? 1 : 3; }
+      else { coff = it_j == 0 ? 1 : 0; kx = it_j == 0 ? 0 : 2; }
+    }
+    const int wt = p.mode == MODE_GEMM ? 0 : it_ky * 4 + kx;
+    unsigned char* base = lds + st * STAGE;
+    const long k0 = (long)it_kc * BK;
 #pragma unroll
-    for (int u = 0; u < AU; ++u) {
-      const int row = rbase + 32 * u;
+    for (int u = 0; u < IA; ++u) {
+      const int grp = wave + 4 * u;
+      const int row = grp * RPI + lrow;
+      const long koff = k0 + (pos ^ swz(row)) * EPC;
       const T* src;
-      bool ok = true;
       if (p.mode == MODE_GEMM) {
-        const int br = n0 + row;
-        ok = br < p.B;
-        src = in + (long)(ok ? br : 0) * p.in_sb + koff;
+        int br = n0 + row;
+        if (br >= p.B) br = p.B - 1;  // rows past the batch: duplicate data, dropped in the epilogue
+        src = in + (long)br * p.in_sb + koff;
       } else {
         int c = cmul * (n0 + row) + coff;
         if (c < 0) c += Ws; else if (c >= Ws) c -= Ws;
-        src = in + (long)b * p.in_sb + ((long)r * Ws + c) * p.in_sp + koff;
+        src = in + (long)b * p.in_sb + ((long)it_r * Ws + c) * p.in_sp + koff;
       }
-      ra[u] = ok ? *(const uint4*)src : make_uint4(0, 0, 0, 0);
+      dma16(src, base + grp * 1024);
     }
 #pragma unroll
-    for (int u = 0; u < BU; ++u) {
-      const int n = nb0 + rbase + 32 * u;
-      const bool ok = n < p.N;
-      const T* src = w + (long)wt * p.w_st + (long)(ok ? n : 0) * p.w_sn + koff;
-      rb[u] = ok ? *(const uint4*)src : make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < IB; ++u) {
+      const int grp = wave + 4 * u;
+      const int row = grp * RPI + lrow;
+      int n = nb0 + row;
+      if (n >= p.N) n = p.N - 1;
+      dma16(w + (long)wt * p.w_st + (long)n * p.w_sn + k0 + (pos ^ swz(row)) * EPC, base + BM * SB + grp * 1024);
     }
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int u = 0; u < AU; ++u) *(uint4*)(ldsA + (rbase + 32 * u) * RS + part * 16) = ra[u];
-#pragma unroll
-    for (int u = 0; u < BU; ++u) *(uint4*)(ldsB + (rbase + 32 * u) * RS + part * 16) = rb[u];
   };
 
-  const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
-  const unsigned char* fa = ldsA + (wm * (BM / 2) + lr) * RS + lh * 16;
-  const unsigned char* fb = ldsB + (wn * (BN / 2) + lr) * RS + lh * 16;
+  const int sw = swz(lr);  // tile-row bases of the fragments are multiples of 32, so swz(row) == swz(lr)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  unsigned fragA[KS], fragB[KS];  // LDS byte addresses (stage 0) of this lane's A / B fragment per MFMA k-step
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int off = ((2 * ks + lh) ^ sw) * 16;
+    fragA[ks] = lds0 + (wm * (BM / 2) + lr) * SB + off;
+    fragB[ks] = lds0 + (BM + wn * (BN / 2) + lr) * SB + off;
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -149,77 +183,157 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int tiles_n, in
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  int tq = 0, kc = 0;
-  load_tiles(0, 0);
-  store_tiles();
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    if (++kc == KC) { kc = 0; ++tq; }
-    const bool more = s + 1 < nsteps;
-    if (more) load_tiles(tq, kc);
+  // Fragment reads are inline asm: a compiler-visible LDS load after an LDS-DMA makes hipcc emit s_waitcnt vmcnt(0)
+  // (it cannot prove the DMA writes another stage), which would serialise DMA and MFMA.  The reads of k-step ks+1
+  // are issued before the MFMAs of k-step ks; counted lgkmcnt + sched_barrier keep the MFMAs behind their operands.
+  i32x4 fa[2][TM], fb[2][TN];
+  auto read_frags = [&](int set, unsigned a_addr, unsigned b_addr) {
+    LDS_READ128(fa[set][0], a_addr, 0);
+    if constexpr (TM == 2) LDS_READ128(fa[set][1], a_addr, 32 * SB);
+    LDS_READ128(fb[set][0], b_addr, 0);
+    if constexpr (TN == 2) LDS_READ128(fb[set][1], b_addr, 32 * SB);
+  };
+  auto compute = [&](unsigned st_off) {
+    read_frags(0, fragA[0] + st_off, fragB[0] + st_off);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      uint4 a[TM], bb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const uint4*)(fa + i * 32 * RS + ks * 32);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bb[j] = *(const uint4*)(fb + j * 32 * RS + ks * 32);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        read_frags((ks + 1) & 1, fragA[ks + 1] + st_off, fragB[ks + 1] + st_off);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma_tile((const T*)nullptr, a[i], bb[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j)
+          mma_tile((const T*)nullptr, fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    if (more) {
-      store_tiles();
-      __syncthreads();
-    }
-  }
+  };
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float* s_db = (float*)lds;  // BN floats, LDS is free now
-  const bool want_db = p.dbias != nullptr;
-  if (want_db) {
-    if (tid < BN) s_db[tid] = 0.f;
-    __syncthreads();
+  // ---- NS-stage ring, prefetch distance D = NS-1, ONE raw barrier per K step, counted vmcnt (never a drain in
+  //      steady state).  Tile s lives in stage s % NS.  At the top of step s: wait until tile s has landed
+  //      (at most D-1 younger tiles still in flight), barrier (everyone's share landed AND everyone finished
+  //      reading stage (s-1) % NS), then refill that stage with tile s+D, then compute tile s.
+  constexpr int D = NS - 1;
+  int issued = 0;
+  for (; issued < D && issued < nsteps; ++issued) {
+    issue_dma(issued % NS);
+    advance();
   }
+  for (int s = 0; s < nsteps; ++s) {
+    const int younger = issued - 1 - s;  // tiles issued after tile s (0 .. D-1), uniform
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (issued < nsteps) {
+      if (!(dbg & 1)) issue_dma(issued % NS);
+      advance();
+      ++issued;
+    }
+    if (!(dbg & 2)) compute((unsigned)((s % NS) * STAGE));
+  }
+  __syncthreads();
+
+  if (dbg & 4) return;
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5),
+  //      i.e. a lane owns ONE channel of 16 pixels: storing from there is 2-byte scattered traffic (measured: 35 %
+  //      of the kernel).  Instead each half of the tile (BM/2 pixel rows) is transposed through LDS and written
+  //      as 16-byte chunks, whole channel rows per pixel; the leaky-relu mask source (aux) is read the same way and
+  //      the bias-gradient column sums are folded with two shuffles + one LDS atomic per 16 lanes.
+  constexpr int ORS = BN * ES + 16;            // LDS row stride of the staged output tile (bytes)
+  constexpr int OCH = BN * ES / 16;            // 16-byte chunks per output row
+  constexpr bool ONEPASS = BM * ORS + BN * 4 <= NS * STAGE;  // whole tile staged at once when LDS allows
+  constexpr int PASSES = ONEPASS ? 1 : 2;
+  constexpr int PROWS = BM / PASSES;           // tile rows per pass
+  constexpr int CPT = PROWS * OCH / 256;       // 16-byte chunks per thread per pass
+  static_assert(PROWS * ORS + BN * 4 <= NS * STAGE, "epilogue staging does not fit the pipeline's LDS");
+  unsigned char* s_out = lds;
+  float* s_db = (float*)(lds + PROWS * ORS);
+  const bool want_db = p.dbias != nullptr;
+  if (tid < BN) s_db[tid] = 0.f;
   T* out = (T*)p.out;
-  const T* aux = (const T*)p.aux;
+  float csum[EPC];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = nb0 + wn * (BN / 2) + j * 32 + lr;
-    const bool nok = n < p.N;
-    const float bias = (p.bias && nok) ? p.bias[n % p.bias_mod] : 0.f;
-    float colsum = 0.f;
+  for (int e = 0; e < EPC; ++e) csum[e] = 0.f;
+  const int part = tid % OCH;                  // this thread's 16-byte column chunk (fixed: 256 % OCH == 0)
+  const bool nok = nb0 + part * EPC < p.N;
+  auto out_off = [&](int trow, bool& ok) -> long {  // element offset of (tile row, this thread's chunk)
+    ok = nok;
+    if (p.mode == MODE_GEMM) {
+      const int br = n0 + trow;
+      ok = ok && br < p.B;
+      return (long)br * p.out_sb + nb0 + part * EPC;
+    }
+    const int X = p.mode == MODE_S2 ? n0 + trow : 2 * (n0 + trow) + px;
+    return (long)b * p.out_sb + ((long)Y * Wo + X) * p.out_sp + nb0 + part * EPC;
+  };
+  for (int pass = 0; pass < PASSES; ++pass) {
+    // leaky-relu mask source of this pass: issue the loads now, they land while the tile is being staged
+    uint4 araw[CPT];
+    if (p.epi == EPI_MASK) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int u = 0; u < CPT; ++u) {
+        bool ok;
+        const long o = out_off(pass * PROWS + (tid + 256 * u) / OCH, ok);
+        araw[u] = ok ? *(const uint4*)((const T*)p.aux + o) : make_uint4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();                           // previous pass fully written out / main loop done
+    if (ONEPASS || wm == pass) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        long o;
-        bool ok = nok;
-        if (p.mode == MODE_GEMM) {
-          const int br = n0 + row;
-          ok = ok && br < p.B;
-          o = (long)br * p.out_sb + (long)n * p.out_sn;
-        } else {
-          const int X = p.mode == MODE_S2 ? n0 + row : 2 * (n0 + row) + px;
-          o = (long)b * p.out_sb + ((long)Y * Wo + X) * p.out_sp + (long)n * p.out_sn;
-        }
-        if (ok) {
-          const float auxv = p.epi == EPI_MASK ? (float)aux[o] : 0.f;
-          const float v = dg_epilogue(acc[i][j][e], p.scale, p.epi, bias, auxv);
-          out[o] = (T)v;
-          colsum += v;
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * (BN / 2) + j * 32 + lr;
+        const int n = nb0 + col;
+        const float bias = (p.bias && n < p.N) ? p.bias[n % p.bias_mod] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (ONEPASS ? wm * (BM / 2) : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v = acc[i][j][e] * p.scale + bias;
+            if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
+            *(T*)(s_out + row * ORS + col * ES) = (T)v;
+          }
         }
       }
     }
-    if (want_db) {
-      colsum += __shfl_xor(colsum, 32, 64);
-      if (lh == 0 && nok) atomicAdd(&s_db[wn * (BN / 2) + j * 32 + lr], colsum);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int row = (tid + 256 * u) / OCH;   // (tid + 256 u) % OCH == part
+      bool ok;
+      const long o = out_off(pass * PROWS + row, ok);
+      if (!ok) continue;
+      uint4 raw = *(const uint4*)(s_out + row * ORS + part * 16);
+      T* v = (T*)&raw;
+      if (p.epi == EPI_MASK) {
+        const T* av = (const T*)&araw[u];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float f = (float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+          v[e] = (T)f;
+        }
+      }
+      if (want_db) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) csum[e] += (float)v[e];
+      }
+      *(uint4*)(out + o) = raw;
     }
   }
   if (want_db) {
+    // threads with equal `part` inside a wave are OCH lanes apart (OCH = 8 or 16 for bf16, 16 or 32 for f32)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float v = csum[e];
+      for (int d = OCH; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+      if (lane < OCH) atomicAdd(&s_db[part * EPC + e], v);
+    }
     __syncthreads();
     if (tid < BN && nb0 + tid < p.N) {
       const float rs = p.rowscale ? p.rowscale[b] : 1.f;
@@ -238,18 +352,24 @@ static int launch_cfg(const ConvP* p, hipStream_t stream) {
   else tiles_m = (p->B + BM - 1) / BM;
   const long nwg = tiles_m * tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) return DG_EINVAL;
-  conv_mfma_kernel<T, BM, BN><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x);
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+  static int var = -1;  // DG_CONV_VAR: 0 = 64-byte stages x 3, 1 = 64 x 4, 2 = 128 x 2
+  if (var < 0) { const char* e = getenv("DG_CONV_VAR"); var = e ? atoi(e) : 2; }
+  if (var == 1) conv_mfma_kernel<T, BM, BN, 64, 4><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, dbg);
+  else if (var == 2) conv_mfma_kernel<T, BM, BN, 128, 2><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, dbg);
+  else conv_mfma_kernel<T, BM, BN, 64, 3><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, dbg);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
 
-// Shapes this kernel takes; everything else goes to the direct kernel (dg_conv in api.hip decides).
+// Shapes this kernel takes; everything else goes to the thin / direct kernels (dg_conv in api.hip decides).
 extern "C" int dg_conv_mfma_supported(const ConvP* p) {
   const int es = p->in_dtype == DG_BF16 ? 2 : 4;
-  const int BK = 128 / es;
+  const int BK = 128 / es;  // K must be a multiple of the largest stage (128 B of channels)
   if (p->in_dtype != p->out_dtype || p->in_dtype != p->w_dtype) return 0;
   if (p->K % BK != 0 || p->N % 64 != 0) return 0;
-  if (p->in_sk != 1 || p->w_sk != 1) return 0;
+  if (p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1) return 0;
   if (p->mode == MODE_GEMM) return p->dbias == nullptr;
   if (!p->ring) return 0;
   if (p->Wc % 64 != 0) return 0;

@@ -1,0 +1,94 @@
+"""Micro-benchmark of the MFMA conv / wgrad kernels on the layer shapes of the 64x1024 step (random data, HIP events,
+interleaved rounds in one process).  usage: python scripts/bench_conv.py [bf16|fp32] [B]"""
+import math
+import os
+import sys
+
+sys.path.insert(0, ".")
+import torch
+
+from dusty_gan_amd import _lib as L
+from dusty_gan_amd.engine import Ops
+
+dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+dev = "cuda"
+o = Ops(dtype)
+o.force = 2
+torch.manual_seed(0)
+
+# (name, mode, adj, Hc, Wc, K, N, batch multiplier)
+CONV = [
+    ("down2 fwd", L.MODE_S2, 0, 16, 256, 64, 128, 2), ("down3 fwd", L.MODE_S2, 0, 8, 128, 128, 256, 2),
+    ("down4 fwd", L.MODE_S2, 0, 4, 64, 256, 512, 2),
+    ("down4 bwd", L.MODE_UP, 1, 4, 64, 512, 256, 2), ("down3 bwd", L.MODE_UP, 1, 8, 128, 256, 128, 2),
+    ("down2 bwd", L.MODE_UP, 1, 16, 256, 128, 64, 2),
+    ("up1 fwd", L.MODE_UP, 0, 4, 64, 512, 256, 1), ("up2 fwd", L.MODE_UP, 0, 8, 128, 256, 128, 1),
+    ("up3 fwd", L.MODE_UP, 0, 16, 256, 128, 64, 1),
+    ("up3 bwd", L.MODE_S2, 1, 16, 256, 64, 128, 1), ("up2 bwd", L.MODE_S2, 1, 8, 128, 128, 256, 1),
+    ("up1 bwd", L.MODE_S2, 1, 4, 64, 256, 512, 1),
+]
+WGRAD = [("down2 wg", 0, 16, 256, 64, 128, 2), ("down3 wg", 0, 8, 128, 128, 256, 2), ("down4 wg", 0, 4, 64, 256, 512, 2),
+         ("up3 wg", 1, 16, 256, 128, 64, 1), ("up2 wg", 1, 8, 128, 256, 128, 1), ("up1 wg", 1, 4, 64, 512, 256, 1)]
+
+
+def timeit(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+tot_ms, tot_fl = 0.0, 0.0
+for name, mode, adj, Hc, Wc, K, N, bm in CONV:
+    n = B * bm
+    if mode == L.MODE_S2:
+        hin, win, ho, wo, taps = 2 * Hc, 2 * Wc, Hc, Wc, 16
+    else:
+        hin, win, ho, wo, taps = Hc, Wc, 2 * Hc, 2 * Wc, 4
+    x = torch.randn(n * hin * win * K, device=dev).to(dtype)
+    w = torch.randn(16 * N * K, device=dev).to(dtype)
+    out = torch.empty(n * ho * wo * N, device=dev, dtype=dtype)
+    aux = torch.randn(n * ho * wo * N, device=dev).to(dtype)
+    bias = torch.randn(N, device=dev)
+    db = torch.zeros(N, device=dev)
+    epi = L.EPI_MASK if adj else L.EPI_LRELU
+
+    def run():
+        o.conv(mode, adj, True, n, Hc, Wc, K, N, x, (hin * win * K, K, 1), out, (ho * wo * N, N, 1), w.data_ptr(),
+               0.01, epi, bias=None if adj else bias.data_ptr(), bias_mod=N, aux=aux if adj else None,
+               dbias=db.data_ptr() if adj else None)
+    ms = timeit(run)
+    fl = 2.0 * n * ho * wo * N * K * taps
+    tot_ms += ms
+    tot_fl += fl
+    print(f"{name:10s} B{n:3d} {Hc:2d}x{Wc:3d} K{K:3d} N{N:3d}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TFLOP/s")
+print(f"conv total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+
+o.force = 2
+tot_ms, tot_fl = 0.0, 0.0
+for name, wmode, Hc, Wc, Ci, Co, bm in WGRAD:
+    n = B * bm
+    wa = 2 * Wc if wmode == 0 else Wc
+    ha = 2 * Hc if wmode == 0 else Hc
+    wg = 2 * Wc if wmode == 1 else Wc
+    hg = 2 * Hc if wmode == 1 else Hc
+    a = torch.randn(n * ha * wa * Ci, device=dev).to(dtype)
+    g = torch.randn(n * hg * wg * Co, device=dev).to(dtype)
+    dw = torch.zeros(16 * Ci * Co, device=dev)
+    rs = torch.rand(n, device=dev)
+
+    def run():
+        o.wgrad(wmode, True, n, Hc, Wc, Ci, Co, a, (ha * wa * Ci, Ci, 1), g, (hg * wg * Co, Co, 1), dw.data_ptr(), 0.01,
+                rowscale=rs)
+    ms = timeit(run)
+    fl = 2.0 * n * Hc * Wc * Ci * Co * 16
+    tot_ms += ms
+    tot_fl += fl
+    print(f"{name:10s} B{n:3d} {Hc:2d}x{Wc:3d} Ci{Ci:3d} Co{Co:3d}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TFLOP/s")
+print(f"wgrad total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
