@@ -96,81 +96,97 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// thin_smalln: block = (b, coarse row m, 64 coarse columns) -> the 2 x 128 fine outputs of that patch; each of the
-// 4 waves owns one output parity (py,px), so its tap weights are wave-uniform (scalar loads).
+// thin_smalln: block = (b, coarse row m), looping over 64-column tiles -> the 2 x 128 fine outputs of each tile.
+// Each of the 4 waves owns one output parity (py,px): its tap weights are wave-uniform (LDS broadcast reads in the
+// bf16 build, where v_dot2c_f32_bf16 does 2 MACs per VALU instruction with no converts; plain loads + v_fmac in the
+// fp32 build).  Input rows m-1, m, m+1 of the tile are staged in LDS once.
+// Weights: the T shadow laid out [tap][n][k] (k contiguous).
 #define SN_PX 64
-template <typename T, int NMAX>
-__global__ __launch_bounds__(256) void thin_smalln_kernel(ConvP p, int tiles_x) {
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+template <typename T, int N>
+__global__ __launch_bounds__(256) void thin_smalln_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // s_in[3 rows][66 cols][K] in T, row stride padded by 16 B
+  constexpr int ES = sizeof(T);
   const int K = p.K;
-  const int rowb = K * (int)sizeof(T) + 16;
-  T* s_in = (T*)smem;
+  const int rowb = K * ES + 16;                  // padded LDS pixel stride
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  const int xt = bid % tiles_x; bid /= tiles_x;
-  const int m = bid % p.Hc, b = bid / p.Hc;
-  const int n0 = xt * SN_PX;
-  // stage rows m-1, m, m+1 (those that exist), columns n0-1 .. n0+64 (circular)
-  const int cpr = K * (int)sizeof(T) / 16;  // 16-B chunks per pixel
+  const int m = blockIdx.x % p.Hc, b = blockIdx.x / p.Hc;
+  const int cpr = K * ES / 16;                   // 16-B chunks per pixel
   const T* in = (const T*)p.in;
-  for (int i = tid; i < 3 * (SN_PX + 2) * cpr; i += 256) {
-    const int ch = i % cpr, c = (i / cpr) % (SN_PX + 2), rr = i / (cpr * (SN_PX + 2));
-    const int r = m - 1 + rr;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r >= 0 && r < p.Hc) {
-      int col = n0 - 1 + c;
-      if (col < 0) col += p.Wc; else if (col >= p.Wc) col -= p.Wc;
-      v = *(const uint4*)(in + (long)b * p.in_sb + ((long)r * p.Wc + col) * p.in_sp + ch * (16 / (int)sizeof(T)));
-    }
-    *(uint4*)(smem + ((rr * (SN_PX + 2) + c) * rowb) + ch * 16) = v;
-  }
-  __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int py = wave >> 1, px = wave & 1;
   const int Y = 2 * m + py;
-  float acc[NMAX];
-#pragma unroll
-  for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
-  const float* __restrict__ w = (const float*)p.w;  // fp32 master weights [tap][k][n], uniform indices
+  // this wave's taps (wave-uniform): up to 3 row taps (2 regular + 1 reflect-adjoint extra) x 2 column taps
+  int trow[3], tky[3], nrow = 0;
   for (int i = 0; i < 4; ++i) {
     int r, ky;
-    if (!dg_tap1d(MODE_UP, p.adj, 0, Y, p.Hc, i, r, ky)) continue;
-    const int rr = r - (m - 1);
+    if (nrow < 3 && dg_tap1d(MODE_UP, p.adj, 0, Y, p.Hc, i, r, ky)) { trow[nrow] = r - (m - 1); tky[nrow] = ky; ++nrow; }
+  }
+  const int dcol[2] = {px == 0 ? 0 : 1, px == 0 ? -1 : 0};
+  const int kxs[2] = {px == 0 ? 1 : 0, px == 0 ? 3 : 2};
+  // bf16: the whole [16][N][K] weight block lives in LDS behind the input strip (wave-uniform reads broadcast)
+  unsigned char* s_w = smem + 3 * (SN_PX + 2) * rowb;
+  if constexpr (ES == 2) {
+    for (int i = tid; i < 16 * N * K / 8; i += 256) {
+      const int k8 = i % (K / 8), j = (i / (K / 8)) % N, t = i / (K / 8 * N);
+      *(uint4*)(s_w + ((t * N + j) * K + k8 * 8) * 2) =
+          *(const uint4*)((const T*)p.w + (long)t * p.w_st + (long)j * p.w_sn + k8 * 8);
+    }
+  }
+  for (int n0 = 0; n0 < p.Wc; n0 += SN_PX) {
+    __syncthreads();
+    for (int i = tid; i < 3 * (SN_PX + 2) * cpr; i += 256) {
+      const int ch = i % cpr, c = (i / cpr) % (SN_PX + 2), rr = i / (cpr * (SN_PX + 2));
+      const int r = m - 1 + rr;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r >= 0 && r < p.Hc) {
+        int col = n0 - 1 + c;
+        if (col < 0) col += p.Wc; else if (col >= p.Wc) col -= p.Wc;
+        v = *(const uint4*)(in + (long)b * p.in_sb + ((long)r * p.Wc + col) * p.in_sp + ch * (16 / ES));
+      }
+      *(uint4*)(smem + ((rr * (SN_PX + 2) + c) * rowb) + ch * 16) = v;
+    }
+    __syncthreads();
+    float acc[N];
 #pragma unroll
-    for (int jx = 0; jx < 2; ++jx) {
-      const int d = px == 0 ? (jx == 0 ? 0 : -1) : (jx == 0 ? 1 : 0);
-      const int kx = px == 0 ? (jx == 0 ? 1 : 3) : (jx == 0 ? 0 : 2);
-      const unsigned char* src = smem + ((rr * (SN_PX + 2) + lane + 1 + d) * rowb);
-      const float* wt = w + (long)(ky * 4 + kx) * p.w_st;
-      for (int k8 = 0; k8 < K; k8 += 16 / (int)sizeof(T)) {
-        const uint4 raw = *(const uint4*)(src + k8 * sizeof(T));
-        float a[16 / sizeof(T)];
-        if (sizeof(T) == 2) {
-          const bf16* h = (const bf16*)&raw;
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    for (int ti = 0; ti < nrow; ++ti) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = (float)h[e];
-        } else {
-          const float* h = (const float*)&raw;
+      for (int jx = 0; jx < 2; ++jx) {
+        const unsigned char* src = smem + ((trow[ti] * (SN_PX + 2) + lane + 1 + dcol[jx]) * rowb);
+        const T* wt = (const T*)p.w + (long)(tky[ti] * 4 + kxs[jx]) * p.w_st;  // [n][k] of this tap, uniform
+        for (int k0 = 0; k0 < K; k0 += 16 / ES) {
+          const uint4 raw = *(const uint4*)(src + k0 * ES);
+          if constexpr (ES == 2) {
+            const unsigned a4[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] = h[e];
-        }
+            for (int j = 0; j < N; ++j) {
+              const uint4 wr = *(const uint4*)(s_w + (((tky[ti] * 4 + kxs[jx]) * N + j) * K + k0) * 2);
+              const unsigned wq[4] = {wr.x, wr.y, wr.z, wr.w};
 #pragma unroll
-        for (int e = 0; e < (int)(16 / sizeof(T)); ++e) {
-          const float* wk = wt + (long)(k8 + e) * p.w_sk;
+              for (int q = 0; q < 4; ++q)
+                acc[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a4[q]),
+                                                         __builtin_bit_cast(bf16x2, wq[q]), acc[j], false);
+            }
+          } else {
+            const float a4[4] = {__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y),
+                                 __builtin_bit_cast(float, raw.z), __builtin_bit_cast(float, raw.w)};
 #pragma unroll
-          for (int j = 0; j < NMAX; ++j)
-            if (j < p.N) acc[j] += a[e] * wk[j * p.w_sn];
+            for (int j = 0; j < N; ++j) {
+              const float* wq = (const float*)(wt + (long)j * p.w_sn + k0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[j] += a4[q] * wq[q];
+            }
+          }
         }
       }
     }
-  }
-  const int X = 2 * (n0 + lane) + px;
-  const long o = (long)b * p.out_sb + ((long)Y * (2 * p.Wc) + X) * p.out_sp;
+    const int X = 2 * (n0 + lane) + px;
+    const long o = (long)b * p.out_sb + ((long)Y * (2 * p.Wc) + X) * p.out_sp;
 #pragma unroll
-  for (int j = 0; j < NMAX; ++j) {
-    if (j < p.N) {
+    for (int j = 0; j < N; ++j) {
       const float sc = p.nscale ? p.scale * p.nscale[j] : p.scale;
       const float v = acc[j] * sc + (p.bias ? p.bias[j % p.bias_mod] : 0.f);
       dg_st(p.out, o + (long)j * p.out_sn, p.out_dtype, v);
@@ -307,14 +323,105 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_kernel(WgradP p, int ci_bas
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// thin_wgrad_down_mfma (bf16, Ci == 2, Co == 64): Down1's weight gradient on the matrix cores.
+//   dW[(ky,kx,ci) = 32][co = 64] = sum_pixels A[pixel][(ky,kx,ci)] * G[pixel][co]
+// GEMM view: M = 32 (one MFMA tile), N = 64 (two tiles), K = coarse pixels.  A block owns ROWS_PB consecutive
+// coarse rows of one sample; the 4 input rows a coarse row touches are staged in LDS as (ci0,ci1) dwords and each
+// wave walks a quarter of the row in 16-pixel K steps: the A fragment (8 consecutive pixels of one (tap,ci)) is
+// gathered from the staged rows, the G fragment comes from a wave-private [16][64] LDS tile through the
+// transposing read ds_read_b64_tr_b16.  Waves are reduced through LDS, then one fp32 atomic per element per block.
+typedef __attribute__((ext_vector_type(8))) __bf16 tw_bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 tw_bf16x4;
+typedef __attribute__((ext_vector_type(16))) float tw_f32x16;
+#define WG_ROWS_PB 4
+
+__global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Wf = 2 * p.Wc, ncol = Wf + 2;
+  unsigned* s_a = (unsigned*)smem;                                   // [4 ky][ncol] dwords = (ci0, ci1)
+  unsigned char* s_g = smem + (size_t)4 * ncol * 4;                  // [4 waves][16 px][144 B]
+  float* s_red = (float*)(s_g + 4 * 16 * 144);                       // [4 waves][32][64] fp32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long units = (long)p.B * p.Hc;
+  const long u0 = (long)blockIdx.x * WG_ROWS_PB;
+  const bf16* A = (const bf16*)p.a;
+  const bf16* G = (const bf16*)p.g;
+  // lane roles
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m_ky = lr >> 3, m_kx = (lr >> 1) & 3, m_ci = lr & 1;     // A row of this lane: m = (ky*4+kx)*2+ci
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3; // transposing-read roles (see wgrad_mfma.hip)
+  unsigned char* my_g = s_g + wave * 16 * 144;
+  tw_f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int seg = p.Wc / 4;                                          // pixels per wave per row
+  for (long u = u0; u < u0 + WG_ROWS_PB && u < units; ++u) {
+    const int b = (int)(u / p.Hc), Y = (int)(u % p.Hc);
+    __syncthreads();
+    for (int i = tid; i < 4 * ncol; i += 256) {
+      const int col = i % ncol, kk = i / ncol;
+      int ra, rg;
+      dg_wgrad1d(0, 0, Y, p.Hc, kk, ra, rg);
+      int cc = col - 1;
+      if (cc < 0) cc += Wf; else if (cc >= Wf) cc -= Wf;
+      s_a[i] = *(const unsigned*)(A + (long)b * p.a_sb + ((long)ra * Wf + cc) * p.a_sp);
+    }
+    __syncthreads();
+    const bf16* s_a16 = (const bf16*)s_a;
+    const bf16* grow = G + (long)b * p.g_sb + (long)Y * p.Wc * p.g_sp;
+    for (int xb = wave * seg; xb < (wave + 1) * seg; xb += 16) {
+      // stage G[xb .. xb+15][0..63] (128 B per pixel) into this wave's tile: 2 x (64 lanes x 16 B)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int c = lane + 64 * v, row = c >> 3, part = c & 7;
+        *(uint4*)(my_g + row * 144 + part * 16) = *(const uint4*)(grow + (long)(xb + row) * p.g_sp + part * 8);
+      }
+      // A fragment: pixels xb + 8 lh + j, j = 0..7, of this lane's (ky,kx,ci)
+      tw_bf16x8 fa;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        fa[j] = s_a16[((long)m_ky * ncol + 2 * (xb + 8 * lh + j) + m_kx) * 2 + m_ci];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const unsigned char* ptr = my_g + (8 * kh + q) * 144 + (jt * 32 + 16 * cb + 4 * pp) * 2;
+        const tw_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tw_bf16x4 __attribute__((address_space(3)))*)(ptr));
+        const tw_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tw_bf16x4 __attribute__((address_space(3)))*)(ptr + 4 * 144));
+        const tw_bf16x8 fg = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fg, acc[jt], 0, 0, 0);
+      }
+    }
+  }
+  // reduce the 4 waves, then one atomic per element.  D layout: col = lane & 31 (co), row = (e&3)+8(e>>2)+4 lh (m)
+  const int b0 = (int)(u0 / p.Hc);
+  const float sc = p.scale * (p.rowscale ? p.rowscale[b0] : 1.f);
+  __syncthreads();
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int mrow = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      s_red[(wave * 32 + mrow) * 64 + jt * 32 + lr] = acc[jt][e];
+    }
+  __syncthreads();
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const float v = s_red[i] + s_red[2048 + i] + s_red[4096 + i] + s_red[6144 + i];
+    atomicAdd(&p.dw[i], v * sc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 int dg_conv_thin_supported(const ConvP* p) {
   if (!p->ring || p->mode == MODE_GEMM) return 0;
   if (p->mode == MODE_S2)  // small K -> wide N
     return p->K <= 4 && p->N % 64 == 0 && p->Wc % SK_PX == 0 && !p->nscale && (!p->dbias || p->bias_mod >= p->N);
-  // MODE_UP: wide K -> small N; fp32 master weights expected ([tap][k][n] strides given), no mask / bias-grad epilogue
-  if (p->N > 4 || p->Wc % SN_PX != 0 || p->in_sk != 1) return 0;
+  // MODE_UP: wide K -> small N; weights = the T shadow [tap][n][k]; no mask / bias-grad epilogue
+  if (p->N > 3 || p->Wc % SN_PX != 0 || p->in_sk != 1 || p->w_sk != 1) return 0;
   const int es = p->in_dtype == DG_BF16 ? 2 : 4;
-  if ((p->K * es) % 16 != 0 || p->w_dtype != DG_F32) return 0;
+  if ((p->K * es) % 16 != 0 || p->w_dtype != p->in_dtype) return 0;
   if (p->epi != EPI_LINEAR || p->dbias) return 0;
   return 1;
 }
@@ -329,13 +436,19 @@ int dg_conv_thin_launch(const ConvP* p, hipStream_t s) {
       else thin_smallk_kernel<4><<<grid, 256, 0, s>>>(*p, tiles_x, nb);
     }
   } else {
-    const int tiles_x = p->Wc / SN_PX;
-    const unsigned grid = (unsigned)((long)p->B * p->Hc * tiles_x);
+    const unsigned grid = (unsigned)((long)p->B * p->Hc);
     const int es = p->in_dtype == DG_BF16 ? 2 : 4;
-    const size_t lds = (size_t)3 * (SN_PX + 2) * (p->K * es + 16);
+    const size_t lds = (size_t)3 * (SN_PX + 2) * (p->K * es + 16) + (es == 2 ? (size_t)16 * p->N * p->K * 2 : 0);
     if (lds > 64 * 1024) return DG_EUNSUPPORTED;
-    if (p->in_dtype == DG_BF16) thin_smalln_kernel<bf16, 4><<<grid, 256, lds, s>>>(*p, tiles_x);
-    else thin_smalln_kernel<float, 4><<<grid, 256, lds, s>>>(*p, tiles_x);
+    if (p->in_dtype == DG_BF16) {
+      if (p->N == 1) thin_smalln_kernel<bf16, 1><<<grid, 256, lds, s>>>(*p);
+      else if (p->N == 2) thin_smalln_kernel<bf16, 2><<<grid, 256, lds, s>>>(*p);
+      else thin_smalln_kernel<bf16, 3><<<grid, 256, lds, s>>>(*p);
+    } else {
+      if (p->N == 1) thin_smalln_kernel<float, 1><<<grid, 256, lds, s>>>(*p);
+      else if (p->N == 2) thin_smalln_kernel<float, 2><<<grid, 256, lds, s>>>(*p);
+      else thin_smalln_kernel<float, 3><<<grid, 256, lds, s>>>(*p);
+    }
   }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
@@ -354,6 +467,15 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (!dg_wgrad_thin_supported(p)) return DG_EUNSUPPORTED;
   const long units = (long)p->B * p->Hc;
   unsigned grid = units < 1024 ? (unsigned)units : 1024u;
+  if (p->wmode == 0 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 2 && p->Co == 64 && p->a_sc == 1 &&
+      p->g_sc == 1 && p->a_sp == 2 && p->g_sp == 64 && p->Wc % 64 == 0 && p->Hc % WG_ROWS_PB == 0) {
+    const size_t lds = (size_t)4 * (2 * p->Wc + 2) * 4 + 4 * 16 * 144 + 4 * 32 * 64 * 4;
+    if (lds <= 64 * 1024) {
+      thin_wgrad_down_mfma_kernel<<<(unsigned)(units / WG_ROWS_PB), 256, lds, s>>>(*p);
+      HIP_CHECK_RET(hipGetLastError());
+      return DG_OK;
+    }
+  }
   if (p->wmode == 0) {
     for (int cb = 0; cb < p->Co; cb += 64) {
       if (p->Ci <= 2) thin_wgrad_down_kernel<2><<<grid, 256, (size_t)4 * (2 * p->Wc + 2) * 2 * sizeof(float), s>>>(*p, cb);

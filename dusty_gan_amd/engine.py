@@ -290,9 +290,8 @@ class GEngine:
         # Head (dcgan_eqlr.py:29-46), all heads in one pass, planar fp32 output
         hc, wc = self.grid[3]
         o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.gout,
-               (c.nheads * self.HW, 1, self.HW), st.fptr("head_w"), 1.0, L.EPI_LINEAR,
-               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale,
-               w_strides=(chs[3] * c.nheads, c.nheads, 1), w_dt=L.DG_F32)
+               (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR,
+               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale)
         arch = ARCH_ID[c.arch]
         if arch:
             if noise is None or "pixel" not in noise:
@@ -405,13 +404,12 @@ class DEngine:
         ci, co = self.chs[i - 1], self.chs[i]
         first = i == 1
         o.conv(L.MODE_UP, 1, c.ring, n, hc, wc, co, ci, self.e[i], (self.per[i], co, 1), self.e[i - 1],
-               (self.per[i - 1], ci, 1), st.fptr(f"d{i}_w") if first else st.sptr(f"d{i}_w"),
+               (self.per[i - 1], ci, 1), st.sptr(f"d{i}_w"),
                1.0 / math.sqrt(ci * 16), L.EPI_LINEAR if first else L.EPI_MASK,
                aux=None if first else self.h[i - 1],
                dbias=(st.fptr(f"d{i - 1}_b", st.grad) if (want_dbias and not first) else None), bias_mod=ci,
                rowscale=rowscale, x_off=slot * self.per[i], out_off=slot * self.per[i - 1],
-               aux_off=slot * self.per[i - 1], w_strides=(ci * co, 1, co) if first else None,
-               w_dt=L.DG_F32 if first else None)
+               aux_off=slot * self.per[i - 1])
 
     def backward_data(self, st, slot, n, up, rowscale, want_dbias):
         """Backward-data chain over batch slots [slot, slot+n): e4 = up*s_f*wf*mask4, then e3, e2, e1 (each the

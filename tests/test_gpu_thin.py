@@ -57,9 +57,16 @@ def test_down1_thin(L, dtype, Hc, Wc, B):
     gx, gw = torch.autograd.grad(y32, [xr, wr], e / lr)
     ed = nhwc(e).to(DEV, dtype)
     dx = torch.empty(B * 4 * Hc * Wc * Ci, device=DEV, dtype=dtype)
+    cico = master.to(dtype)  # backward-data reads the T shadow [tap][n = ci][k = co]
     o.conv(L.MODE_UP, 1, True, B, Hc, Wc, Co, Ci, ed, (Hc * Wc * Co, Co, 1), dx, (4 * Hc * Wc * Ci, Ci, 1),
-           master.data_ptr(), s, L.EPI_LINEAR, w_strides=(Ci * Co, 1, Co), w_dt=L.DG_F32)
+           cico.data_ptr(), s, L.EPI_LINEAR)
     torch.cuda.synchronize()
+    if dtype == torch.bfloat16:
+        # the kernel applies the LINEAR adjoint to e with the bf16 shadow weights; differentiate the linear part
+        # only (going through O.down would re-derive the leaky-relu slopes from the bf16-weight forward, which flips
+        # a few of them relative to `lr`)
+        y_lin = torch.nn.functional.conv2d(O.pad_ring(xr, True) * s, wq, None, 2, 0)
+        (gx,) = torch.autograd.grad(y_lin, xr, e)
     assert rel_l2(from_nhwc(dx.float().cpu(), B, Ci, 2 * Hc, 2 * Wc), gx) < (1e-4 if dtype == torch.float32 else 1e-2)
     # weight gradient with per-sample weights
     rs = torch.rand(B, generator=g) + 0.5
@@ -88,6 +95,7 @@ def test_head_thin(L, dtype, nh):
     wr = [w.clone().requires_grad_() for w in ws]
     ys = [O.head(xr, w, b, True) for w, b in zip(wr, bs)]
     y = torch.cat(ys, dim=1)  # [B,nh,2Hc,2Wc]
+    y_graph = y
     master = torch.cat(ws, dim=1).permute(2, 3, 0, 1).contiguous().to(DEV)  # [ky][kx][ci][co]
     bias = torch.cat(bs).to(DEV)
     scales = [1.0 / math.sqrt(16)] + [1.0 / math.sqrt(max(nh - 1, 1) * 16)] * (nh - 1)
@@ -97,14 +105,16 @@ def test_head_thin(L, dtype, nh):
     xd = nhwc(x).to(DEV, dtype)
     HW = 4 * Hc * Wc
     out = torch.empty(B, nh, 2 * Hc, 2 * Wc, device=DEV)
-    o.conv(L.MODE_UP, 0, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), out, (nh * HW, 1, HW), master.data_ptr(),
-           1.0, L.EPI_LINEAR, bias=bias.data_ptr(), bias_mod=nh, out_dt=L.DG_F32, nscale=nscale,
-           w_strides=(C0 * nh, nh, 1), w_dt=L.DG_F32)
+    coci = torch.cat(ws, dim=1).permute(2, 3, 1, 0).contiguous().to(DEV, dtype)  # forward shadow [tap][n = co][k = ci]
+    o.conv(L.MODE_UP, 0, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), out, (nh * HW, 1, HW), coci.data_ptr(),
+           1.0, L.EPI_LINEAR, bias=bias.data_ptr(), bias_mod=nh, out_dt=L.DG_F32, nscale=nscale)
     torch.cuda.synchronize()
+    if dtype == torch.bfloat16:
+        y = torch.cat([O.head(x, w.bfloat16().float(), b, True) for w, b in zip(ws, bs)], dim=1)
     assert rel_l2(out.cpu(), y) < tol
     # backward: draw = s_n * dL/dy (planar fp32) -> gradient w.r.t. the previous pre-activation, masked, + bias sums
     gy = torch.randn(y.shape, generator=g)
-    grads = torch.autograd.grad(y, [xr] + wr, gy)
+    grads = torch.autograd.grad(y_graph, [xr] + wr, gy)
     gx, gws = grads[0], grads[1:]
     draw = (gy * torch.tensor(scales).view(1, nh, 1, 1)).to(DEV).contiguous()
     prev = torch.randn(x.shape, generator=g)
