@@ -9,23 +9,28 @@
 //   * workgroup = 4 waves (2 x 2) on a BM x BN tile of one tap; grid.y = tap, grid.z = K split over (sample,row)
 //     units; partial sums are added with fp32 atomics whose wave-instruction writes two 128-B row segments (the
 //     full-rate shape), or stored when there is a single split and nothing to accumulate onto.
-//   * the per-sample weight (dy_b for the real batch) is applied when a sample's pixels end:
-//     tot += rs[b] * acc, so the MFMA accumulation itself stays unscaled.
+//   * the per-sample weight (dy_b for the real batch) costs no second accumulator set: the running sum is
+//     kept divided by the current sample's weight and rescaled by rs_old / rs_new when the sample changes.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#define BKP 32  // coarse pixels per K chunk
+// coarse pixels per K chunk: 64 (bf16) / 32 (fp32)
+#define BKP_OF(es) ((es) == 2 ? 64 : 32)
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, int accumulate) {
   constexpr int ES = sizeof(T);
   constexpr int EPC = 16 / ES;
-  constexpr int RSA = BM * ES + 16, RSG = BN * ES + 16;  // LDS row strides (bytes)
+  constexpr int BKP = BKP_OF(ES);
+  // LDS row strides (bytes).  bf16: +64 B so that the 4 rows x 2 column blocks x 4 column quads a 32-lane half
+  // touches in one ds_read_b64_tr_b16 fall on distinct bank pairs (row stride = 16 dwords mod 64); the +16 B
+  // padding of the first version cost 8-10 % of the wave cycles in SQ_LDS_BANK_CONFLICT.
+  constexpr int RSA = BM * ES + (ES == 2 ? 64 : 16), RSG = BN * ES + (ES == 2 ? 64 : 16);
   constexpr int CPA = BM * ES / 16, CPG = BN * ES / 16;  // 16-B chunks per row
-  constexpr int UA = CPA / 8, UG = CPG / 8;              // chunks per thread (32 rows * CP / 256)
+  constexpr int UA = BKP * CPA / 256, UG = BKP * CPG / 256;  // chunks per thread
   constexpr int TM = BM / 64, TN = BN / 64;
   __shared__ __attribute__((aligned(16))) unsigned char lds[BKP * (RSA + RSG)];
   unsigned char* ldsA = lds;
@@ -87,14 +92,19 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
-  f32x16 acc[TM][TN], tot[TM][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  float cur_rs = 1.f;
+  if (p.rowscale && nchunks > 0) {
+    cur_rs = p.rowscale[(int)(u0 / p.Hc)];
+    if (fabsf(cur_rs) < 1e-30f) cur_rs = cur_rs < 0.f ? -1e-30f : 1e-30f;
+  }
   if (nchunks > 0) {
     long u = u0;
     int xc = 0;
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
         const int g16 = lane >> 4, i16 = lane & 15;
         const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3;
 #pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
+        for (int kq = 0; kq < BKP / 16; ++kq) {
           bf16x8 fa[TM], fg[TN];
           const int prow = kq * 16 + 8 * kh + q;
 #pragma unroll
@@ -150,18 +160,20 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fg[j], acc[i][j], 0, 0, 0);
         }
       }
-      if (p.rowscale) {
+      if (p.rowscale && more) {
+        // Per-sample weights without a second accumulator set: the running sum is kept DIVIDED by the current
+        // sample's weight, so MFMAs add unscaled products; on a sample change it is rescaled by rs_old / rs_new
+        // (fp32 multiply: same relative error as summing rs_b * acc_b), and multiplied by the last weight at the end.
         const int next_b = (int)(u / p.Hc);
-        if (!more || next_b != cur_b) {
-          const float rs = p.rowscale[cur_b];
+        if (next_b != cur_b) {
+          float rn = p.rowscale[next_b];
+          if (fabsf(rn) < 1e-30f) rn = rn < 0.f ? -1e-30f : 1e-30f;
+          const float ratio = cur_rs / rn;
+          cur_rs = rn;
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              tot[i][j] += acc[i][j] * rs;
-#pragma unroll
-              for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            }
+            for (int j = 0; j < TN; ++j) acc[i][j] *= ratio;
         }
       }
       __syncthreads();
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
         const int ci = ci0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int co = co0 + wn * (BN / 2) + j * 32 + lr;
         if (ci < p.Ci && co < p.Co) {
-          const float v = (p.rowscale ? tot[i][j][e] : acc[i][j][e]) * p.scale;
+          const float v = acc[i][j][e] * (p.scale * cur_rs);
           float* dst = dw + (long)ci * p.Co + co;
           if (accumulate) atomicAdd(dst, v);
           else *dst = v;
@@ -215,7 +227,7 @@ extern "C" int dg_wgrad_mfma_supported(const WgradP* p) {
   if (p->Ci % 64 != 0 || p->Co % 64 != 0) return 0;
   if (p->wmode != 2) {
     if (!p->ring) return 0;
-    if (p->Wc % BKP != 0) return 0;
+    if (p->Wc % BKP_OF(p->a_dtype == DG_BF16 ? 2 : 4) != 0) return 0;
   }
   return 1;
 }
