@@ -8,22 +8,40 @@
 //   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
 //   ema <- d ema + (1-d) p   (only where ema != null)
 template <typename T>
-__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
-                                float* __restrict__ v, float* __restrict__ ema, T* __restrict__ shadow, long n,
-                                float gscale, float lr_bc1, float inv_sqrt_bc2, float b1, float b2, float eps,
-                                float ema_decay) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float g = grad[i] * gscale;
-  const float mi = b1 * m[i] + (1.f - b1) * g;
-  const float vi = b2 * v[i] + (1.f - b2) * g * g;
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-  const float pi = p[i] - lr_bc1 * (mi / denom);
-  p[i] = pi;
-  if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pi;
-  if (shadow) shadow[i] = (T)pi;
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ grad,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ ema, T* __restrict__ shadow, long n4,
+                                                       float gscale, float lr_bc1, float inv_sqrt_bc2, float b1,
+                                                       float b2, float eps, float ema_decay) {
+  // 16 bytes per lane per stream, grid-stride.  m == nullptr (beta1 == 0: exp_avg IS the scaled gradient) drops two
+  // of the nine fp32 streams; the exported optimizer state rebuilds exp_avg from the gradient buffer.
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 g4 = ((const float4*)grad)[i];
+    const float4 v4 = ((const float4*)v)[i];
+    float4 p4 = ((const float4*)p)[i];
+    float4 m4 = m ? ((const float4*)m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 e4 = ema ? ((const float4*)ema)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float gg[4] = {g4.x * gscale, g4.y * gscale, g4.z * gscale, g4.w * gscale};
+    float pv[4] = {p4.x, p4.y, p4.z, p4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float mi = b1 * mv[k] + (1.f - b1) * gg[k];
+      const float vi = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+      mv[k] = mi;
+      vv[k] = vi;
+      pv[k] = pv[k] - lr_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+      ev[k] = ema_decay * ev[k] + (1.f - ema_decay) * pv[k];
+    }
+    ((float4*)p)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    ((float4*)v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (m) ((float4*)m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    if (ema) ((float4*)ema)[i] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    if (shadow) {
+      T* sd = shadow + 4 * i;
+      sd[0] = (T)pv[0]; sd[1] = (T)pv[1]; sd[2] = (T)pv[2]; sd[3] = (T)pv[3];
+    }
+  }
 }
 
 template <typename T>
@@ -157,14 +175,18 @@ int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema
                      void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (n <= 0) return DG_OK;
+  if (n % 4 != 0) return DG_EINVAL;  // flat stores are padded to 64 elements
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float lr_bc1 = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const long n4 = n / 4;
+  unsigned grid = nblk(n4);
+  if (grid > 256 * 16) grid = 256 * 16;
   if (shadow && shadow_dtype == DG_BF16)
-    adam_ema_kernel<bf16><<<nblk(n), 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
+    adam_ema_kernel<bf16><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n4, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
   else
-    adam_ema_kernel<float><<<nblk(n), 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
+    adam_ema_kernel<float><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n4, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -56,13 +56,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void final_fwd_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
                                                         const float* __restrict__ bias, float scale, long n,
                                                         float* __restrict__ y) {
+  // grid = (slabs, B): each block reduces one slab of one sample and adds it to y[b] (zeroed by the launcher);
+  // slab 0 also adds the bias.  One block per sample left 7/8 of the chip idle (0.18 ms per call at B = 64).
   __shared__ float red[16];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   const T* row = d4 + (long)b * n;
   float acc = 0.f;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) acc += (float)row[i] * wf[i];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    acc += (float)row[i] * wf[i];
   const float s = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) y[b] = s * scale + (bias ? bias[0] : 0.f);
+  if (threadIdx.x == 0) atomicAdd(&y[b], s * scale + ((bias && blockIdx.x == 0) ? bias[0] : 0.f));
 }
 
 // dd4[b][i] = up[b] * scale * wf[i] * lrelu'(d4[b][i]) * sqrt2 ; dbias4[i % C] += rowscale[b] * dd4[b][i]
@@ -382,8 +385,12 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
                  void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  if (dtype == DG_BF16) final_fwd_kernel<bf16><<<B, 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
-  else final_fwd_kernel<float><<<B, 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
+  HIP_CHECK_RET(hipMemsetAsync(y, 0, sizeof(float) * B, s));
+  unsigned slabs = nblk(n, 256 * 16);
+  if (slabs > 32) slabs = 32;
+  if (slabs < 1) slabs = 1;
+  if (dtype == DG_BF16) final_fwd_kernel<bf16><<<dim3(slabs, B), 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
+  else final_fwd_kernel<float><<<dim3(slabs, B), 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -116,6 +116,8 @@ class FlatAdam:
         st = self.store
         state = {}
         if self.step_count > 0:
+            if self.betas[0] == 0.0 and getattr(self, "_last_gscale", None) is not None:
+                st.m.copy_(st.grad * self._last_gscale)  # exp_avg of torch.optim.Adam at beta1 = 0
             ms, vs = self._param_views(st.m), self._param_views(st.v)
             for i, (m, v) in enumerate(zip(ms, vs)):
                 state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().cpu().contiguous(),
@@ -140,13 +142,29 @@ class FlatAdam:
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
 
-    def zero_grad(self, set_to_none=True):
-        self.store.grad.zero_()
+    def zero_grad(self, set_to_none=True, skip=()):
+        """zero the flat gradient buffer; `skip` names segments the backward pass OVERWRITES (Proj's 268 MB weight
+        gradient is written with plain stores when there is a single micro-batch), which need no memset"""
+        st = self.store
+        if not skip:
+            st.grad.zero_()
+            return
+        cuts = sorted((st.seg[k].off, st.seg[k].off + st.seg[k].numel) for k in skip)
+        pos = 0
+        for a, b in cuts:
+            if a > pos:
+                st.grad[pos:a].zero_()
+            pos = b
+        if pos < st.n:
+            st.grad[pos:].zero_()
 
     def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32):
         st = self.store
         self.step_count += 1
-        L.check(L.lib().dg_adam_ema_step(L.ptr(st.flat), L.ptr(st.grad), L.ptr(st.m), L.ptr(st.v),
+        self._last_gscale = gscale
+        # beta1 == 0 (the reference's solver): exp_avg == scaled gradient, so the kernel neither reads nor writes it
+        m_ptr = None if self.betas[0] == 0.0 else L.ptr(st.m)
+        L.check(L.lib().dg_adam_ema_step(L.ptr(st.flat), L.ptr(st.grad), m_ptr, L.ptr(st.v),
                                          L.ptr(ema_store.flat) if ema_store is not None else None, L.ptr(st.shadow),
                                          L.dtype_code(shadow_dtype), st.n, gscale, self.lr, self.betas[0],
                                          self.betas[1], self.eps, self.step_count, ema_decay, L.stream_ptr()),
@@ -376,7 +394,7 @@ class Trainer:
         B = self.local_batch
         Gb, D = _backbone(self.G), self.D
         Gst, Dst = Gb.store, D.store
-        self.optim_G.zero_grad()
+        self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
         deng = D.engine()
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         f32 = dict(dtype=torch.float32, device=self.device)
