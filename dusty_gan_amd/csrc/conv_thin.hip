@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+int dg_conv_s2_mfma_supported(const ConvP* p);
+int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s);
+
 int dg_conv_thin_supported(const ConvP* p) {
   if (!p->ring || p->mode == MODE_GEMM) return 0;
   if (p->mode == MODE_S2)  // small K -> wide N
@@ -428,6 +431,7 @@ int dg_conv_thin_supported(const ConvP* p) {
 
 int dg_conv_thin_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_thin_supported(p)) return DG_EUNSUPPORTED;
+  if (dg_conv_s2_mfma_supported(p)) return dg_conv_s2_mfma_launch(p, s);
   if (p->mode == MODE_S2) {
     const int tiles_x = p->Wc / SK_PX;
     const unsigned grid = (unsigned)((long)p->B * p->Hc * tiles_x);
@@ -485,6 +489,181 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
     for (int cb = 0; cb < p->Ci; cb += 64)
       thin_wgrad_up_kernel<4><<<grid, 256, (size_t)2 * 2 * p->Wc * 4 * sizeof(float), s>>>(*p, cb);
   }
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// thin_s2_mfma (bf16): MODE_S2 with a CP-channel input (CP = 2: Down1 forward / R1 tangent, Head backward-data with
+// <= 2 heads; CP = 4: Head backward-data with 3 heads, channels zero-padded) -> 64 output channels, on the matrix
+// cores with NO LDS staging of the operands: in pixel-major / channel-minor memory the 4 kx taps x CP channels of
+// one kernel row of one output pixel are 16 (CP=2) or 32 (CP=4) CONTIGUOUS bytes, i.e. exactly the 8 consecutive k
+// an MFMA lane needs, so every A fragment is one 16-byte global load.  K = 4 ky x 4 kx x CP.
+//   CP = 2: 2 MFMA k-steps, lane half h <-> ky = 2 s + h, j <-> (kx = j >> 1, c = j & 1)
+//   CP = 4: 4 MFMA k-steps, step s <-> ky, lane half h <-> kx in {2h, 2h+1}, j <-> (kx = 2h + (j >> 2), c = j & 3)
+// One wave = one 32-pixel x 64-channel tile at a time (grid-stride), weights live in 16 / 32 VGPRs for the whole
+// kernel, the result tile is transposed through a wave-private 4.5 KB LDS patch and written as whole 128-byte rows.
+template <int CP>
+__global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x, long ntiles) {
+  constexpr int NS = CP == 2 ? 2 : 4;            // MFMA k-steps per kernel (without adjoint extras)
+  __shared__ __attribute__((aligned(16))) unsigned char s_t[4][32 * 144];
+  __shared__ float s_db[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int Wf = 2 * p.Wc, Hf = 2 * p.Hc;
+  const bf16* in = (const bf16*)p.in;
+  const bf16* w = (const bf16*)p.w;              // [tap][n][k = c] with strides w_st, w_sn, 1 ; k < p.K real channels
+  if (tid < 64) s_db[tid] = 0.f;
+  __syncthreads();
+
+  // B fragments: element j of step s for output channel n = jt*32 + lr
+  auto wval = [&](int ky, int kx, int c, int n) -> bf16 {
+    return c < p.K ? w[(long)(ky * 4 + kx) * p.w_st + (long)n * p.w_sn + c] : (bf16)0.f;
+  };
+  tw_bf16x8 fb[NS][2], fbx[2];                   // fbx: ky = 3 placed in lane half 0 (reflect-adjoint extra tap)
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int n = jt * 32 + lr;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ky = CP == 2 ? 2 * s + lh : s;
+        const int kx = CP == 2 ? (j >> 1) : 2 * lh + (j >> 2);
+        const int c = CP == 2 ? (j & 1) : (j & 3);
+        fb[s][jt][j] = wval(ky, kx, c, n);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fbx[jt][j] = CP == 2 ? wval(3, j >> 1, j & 1, n) : (bf16)0.f;
+  }
+
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+  const long gw = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  unsigned char* my = s_t[wave];
+  for (long t = gw; t < ntiles; t += nw) {
+    const int xt = (int)(t % tiles_x);
+    const int Y = (int)((t / tiles_x) % p.Hc), b = (int)(t / ((long)tiles_x * p.Hc));
+    const int X = xt * 32 + lr;                  // this lane's output pixel (as A-fragment row)
+    const bf16* img = in + (long)b * p.in_sb;
+    // one 16-byte window of input row r starting at fine column c0 (circular): 4 (CP=2) or 2 (CP=4) pixels
+    auto window = [&](int r, int c0) -> uint4 {
+      constexpr int NPX = 8 / CP;
+      if (c0 >= 0 && c0 + NPX <= Wf) return *(const uint4*)(img + ((long)r * Wf + c0) * CP);
+      unsigned d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {              // dword q = pixel q (CP=2) or half pixel (CP=4)
+        int cc = c0 + (CP == 2 ? q : (q >> 1));
+        if (cc < 0) cc += Wf; else if (cc >= Wf) cc -= Wf;
+        d[q] = *(const unsigned*)(img + ((long)r * Wf + cc) * CP + (CP == 2 ? 0 : (q & 1) * 2));
+      }
+      return make_uint4(d[0], d[1], d[2], d[3]);
+    };
+    tw_f32x16 acc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int ky = CP == 2 ? 2 * s + lh : s;
+      int r = 2 * Y - 1 + ky;
+      bool ok = true;
+      if (!p.adj) { if (r < 0) r = -r; if (r >= Hf) r = 2 * Hf - 2 - r; }
+      else ok = r >= 0 && r < Hf;
+      const int c0 = 2 * X - 1 + (CP == 2 ? 0 : 2 * lh);
+      uint4 a = make_uint4(0, 0, 0, 0);
+      if (ok) a = window(r, c0);
+      const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[s][jt], acc[jt], 0, 0, 0);
+    }
+    if (p.adj && CP == 2 && (Y == 1 || Y == p.Hc - 2)) {
+      // reflect-adjoint extras (common.h dg_tap1d, MODE_S2/adj): row 0 through ky = 3 into Y == 1,
+      // row Hf-1 through ky = 0 into Y == Hc-2; the tap sits in lane half 0, half 1 multiplies zeros
+      const int c0 = 2 * X - 1;
+      if (Y == 1) {
+        uint4 a = make_uint4(0, 0, 0, 0);
+        if (lh == 0) a = window(0, c0);
+        const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbx[jt], acc[jt], 0, 0, 0);
+      }
+      if (Y == p.Hc - 2) {
+        uint4 a = make_uint4(0, 0, 0, 0);
+        if (lh == 0) a = window(Hf - 1, c0);
+        const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][jt], acc[jt], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: D[row = pixel][col = channel]; transpose through the wave's LDS patch
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const int n = jt * 32 + lr;
+      const float bias = p.bias ? p.bias[n % p.bias_mod] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v = acc[jt][e] * p.scale + bias;
+        if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
+        *(bf16*)(my + row * 144 + n * 2) = (bf16)v;
+      }
+    }
+    const long obase = (long)b * p.out_sb + ((long)Y * p.Wc + xt * 32) * p.out_sp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u, row = c >> 3, part = c & 7;   // part == lane & 7 for every u
+      const long o = obase + (long)row * p.out_sp + part * 8;
+      uint4 raw = *(const uint4*)(my + row * 144 + part * 16);
+      bf16* v = (bf16*)&raw;
+      if (p.epi == EPI_MASK) {
+        const uint4 araw = *(const uint4*)((const bf16*)p.aux + o);
+        const bf16* av = (const bf16*)&araw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2));
+      }
+      if (p.dbias) {
+        const float rs = p.rowscale ? p.rowscale[b] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += rs * (float)v[e];
+      }
+      *(uint4*)((bf16*)p.out + o) = raw;
+    }
+  }
+  if (p.dbias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = csum[e];
+      for (int d = 8; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+      if (lane < 8) atomicAdd(&s_db[lane * 8 + e], v);
+    }
+    __syncthreads();
+    if (tid < 64) atomicAdd(&p.dbias[tid % p.bias_mod], s_db[tid]);
+  }
+}
+
+int dg_conv_s2_mfma_supported(const ConvP* p) {
+  if (p->mode != MODE_S2 || !p->ring || p->nscale) return 0;
+  if (p->in_dtype != DG_BF16 || p->out_dtype != DG_BF16 || p->w_dtype != DG_BF16) return 0;
+  if (p->N != 64 || p->K > 4 || p->Wc % 32 != 0 || p->Hc < 4) return 0;
+  const int cp = p->in_sp;  // padded channel count of the input tensor
+  if ((cp != 2 && cp != 4) || p->K > cp || p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1 || p->out_sp != 64) return 0;
+  if (cp == 4 && p->adj) return 0;  // (3-head backward-data stays on the VALU kernel)
+  if (p->dbias && p->bias_mod != 64) return 0;
+  return 1;
+}
+
+int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
+  if (!dg_conv_s2_mfma_supported(p)) return DG_EUNSUPPORTED;
+  const int tiles_x = p->Wc / 32;
+  const long ntiles = (long)p->B * p->Hc * tiles_x;
+  long blocks = (ntiles + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (p->in_sp == 2) thin_s2_mfma_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
+  else thin_s2_mfma_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
