@@ -142,7 +142,7 @@ __global__ void head_post_bwd_kernel(const float* __restrict__ gout, const float
                                      const float* __restrict__ noise_image, const float* __restrict__ mask,
                                      const float* __restrict__ ddepth, int arch, float inv_tau, float drop_const,
                                      int B, long HW, float s_depth, float s_conf, float* __restrict__ draw,
-                                     float* __restrict__ dbias) {
+                                     float* __restrict__ dbias, bf16* __restrict__ draw_pm, int cp) {
   __shared__ float red[16];
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float d0 = 0.f, d1 = 0.f, d2 = 0.f;  // unscaled gradients w.r.t. the head outputs (= the head bias gradients)
@@ -175,6 +175,14 @@ __global__ void head_post_bwd_kernel(const float* __restrict__ gout, const float
     d[HW] = d1 * s_conf;
   }
   d[0] = d0 * s_depth;
+  if (draw_pm) {  // second copy, pixel-major / channel-minor bf16 [B,H,W,cp], channels zero-padded: the operand layout
+                  // of the MFMA backward-data kernel (thin_s2_mfma)
+    bf16* q = draw_pm + idx * cp;
+    q[0] = (bf16)(d0 * s_depth);
+    if (cp > 1) q[1] = (bf16)(arch >= 1 ? d1 * s_conf : 0.f);
+    if (cp > 2) q[2] = (bf16)(arch >= 2 ? d2 * s_conf : 0.f);
+    if (cp > 3) q[3] = (bf16)0.f;
+  }
   }
   if (dbias) {  // head biases are outside EqualLR's input scaling: their gradient is the unscaled sum
     const float a0 = dg_block_sum(d0, red);
@@ -427,12 +435,12 @@ int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_i
 
 int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
                      const float* ddepth, int arch, float tau, float drop_const, int B, long HW, float s_depth,
-                     float s_conf, float* draw, float* dbias,
+                     float s_conf, float* draw, float* dbias, void* draw_pm, int cp,
                      void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (arch < 0 || arch > 2) return DG_EINVAL;
   head_post_bwd_kernel<<<nblk((long)B * HW), 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, arch,
-                                                           1.f / tau, drop_const, B, HW, s_depth, s_conf, draw, dbias);
+                                                           1.f / tau, drop_const, B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, cp);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

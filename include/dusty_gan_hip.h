@@ -119,7 +119,8 @@ int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_i
  * pre-multiplied so the head's backward-data / weight-gradient passes run with scale 1); dbias[n] += unscaled sums */
 int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
                      const float* ddepth, int arch, float tau, float drop_const, int B, long HW, float s_depth,
-                     float s_conf, float* draw, float* dbias, void* stream);
+                     float s_conf, float* draw, float* dbias, void* draw_pm /* optional bf16 [B,H,W,cp] copy */, int cp,
+                     void* stream);
 /* GumbelSigmoid.logistic_noise  models/dusty.py:30-36 */
 int dg_logistic_noise(const float* u1, const float* u2, float eps, long n, float* out, void* stream);
 

@@ -300,14 +300,17 @@ def test_head_post_fwd_bwd(L, arch):
     (graw,) = torch.autograd.grad(out["depth"], raw, go)
     draw = torch.empty(B, 1 + k, H, W, device=DEV)
     god = go.to(DEV)
+    draw_pm = torch.empty(B, H, W, 4, device=DEV, dtype=torch.bfloat16)
     dbias = torch.zeros(3, device=DEV)
     s_d, s_c = 0.25, 0.125
     L.check(lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(),
                                  god.data_ptr(), k, 1.0, -1.0, B, H * W, s_d, s_c, draw.data_ptr(),
-                                 dbias.data_ptr(), None))
+                                 dbias.data_ptr(), draw_pm.data_ptr(), 4, None))
     scale = torch.tensor([s_d] + [s_c] * k).view(1, -1, 1, 1)
     assert rel_l2(draw.cpu(), graw * scale) < 1e-5
     assert rel_l2(dbias.cpu()[:1 + k], graw.sum(dim=[0, 2, 3])) < 1e-4
+    pm = draw_pm.float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(pm[:, :1 + k], graw * scale) < 1e-2 and float(pm[:, 1 + k:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("H,W", [(16, 32), (64, 1024)])

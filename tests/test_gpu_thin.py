@@ -139,3 +139,36 @@ def test_head_thin(L, dtype, nh):
     torch.cuda.synchronize()
     got = dw.cpu().view(4, 4, C0, nh).permute(2, 3, 0, 1)
     assert rel_l2(got, torch.cat(list(gws), dim=1)) < tol
+
+
+@pytest.mark.parametrize("nh", [1, 2])
+def test_head_bwd_data_pixel_major_mfma(L, nh):
+    """Head backward-data through the direct-fragment MFMA kernel (thin_s2_mfma, adjoint boundary incl. the
+    reflect-adjoint extra taps at rows 1 and H-2) from the pixel-major bf16 copy of the head gradient."""
+    from dusty_gan_amd.engine import Ops
+    g = torch.Generator().manual_seed(40 + nh)
+    B, Hc, Wc, C0 = 2, 8, 64, 64
+    dtype = torch.bfloat16
+    x = torch.randn(B, C0, Hc, Wc, generator=g).requires_grad_()
+    ws = [torch.randn(C0, 1, 4, 4, generator=g).bfloat16().float()] + \
+         ([torch.randn(C0, nh - 1, 4, 4, generator=g).bfloat16().float()] if nh > 1 else [])
+    y = torch.cat([O.head(x, w, None, True) * math.sqrt(w.shape[1] * 16) for w in ws], dim=1)  # unscaled linear map
+    gy = torch.randn(y.shape, generator=g).bfloat16().float()
+    (gx,) = torch.autograd.grad(y, x, gy)
+    prev = torch.randn(x.shape, generator=g)
+    ref = gx * torch.where(prev > 0, 1.0, 0.2) * math.sqrt(2.0)
+    o = Ops(dtype)
+    o.force = 3
+    HW = 4 * Hc * Wc
+    draw_pm = torch.zeros(B, 2 * Hc, 2 * Wc, 2)
+    draw_pm[..., :nh] = gy.permute(0, 2, 3, 1)
+    draw_pm = draw_pm.to(DEV, dtype).contiguous()
+    shadow = torch.cat(ws, dim=1).permute(2, 3, 0, 1).contiguous().to(DEV, dtype)  # [tap][n = ci][k = co]
+    prevd = nhwc(prev).to(DEV, dtype)
+    dp = torch.empty(B * Hc * Wc * C0, device=DEV, dtype=dtype)
+    db = torch.zeros(C0, device=DEV)
+    o.conv(L.MODE_S2, 1, True, B, Hc, Wc, nh, C0, draw_pm, (HW * 2, 2, 1), dp, (Hc * Wc * C0, C0, 1),
+           shadow.data_ptr(), 1.0, L.EPI_MASK, aux=prevd, dbias=db.data_ptr(), bias_mod=C0)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nhwc(dp.float().cpu(), B, C0, Hc, Wc), ref) < 1e-2
+    assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < 2e-2
