@@ -314,7 +314,15 @@ class GEngine:
             out["mask"] = self.mask
         return out
 
-    def backward(self, st: ParamStore, ddepth, accumulate_proj=False):
+    def proj_wgrad(self, st: ParamStore, dp0, zT, nb, accumulate=False):
+        """Proj weight gradient dW[n'][k] = s * sum_b dp0[b][n'] z[b][k] over `nb` samples (the local batch, or the
+        all-gathered global batch in data-parallel runs: utils/dist.py).  Plain stores unless accumulating."""
+        c = self.cfg
+        Np = c.h0 * c.w0 * c.ch[3]
+        self.ops.wgrad(2, 1, 1, 1, nb, Np, c.nz, dp0, (0, Np, 1), zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
+                       1.0 / math.sqrt(Np), accumulate=int(accumulate))
+
+    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False):
         """ddepth [B,1,H,W] fp32 = dLoss/d(output depth).  Accumulates every G parameter gradient into st.grad
         (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309)."""
         c, o, lib = self.cfg, self.ops, L.lib()
@@ -352,10 +360,8 @@ class GEngine:
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, self.dp[i], (4 * hc * wc * co, co, 1), self.dp[i - 1],
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
                    dbias=st.fptr(prev_b, st.grad), bias_mod=ci)
-        Np = c.h0 * c.w0 * chs[0]
-        # Proj weight gradient: dW[n'][k] = s * sum_b dp0[b][n'] z[b][k]  (overwrite: nothing else writes it)
-        o.wgrad(2, 1, 1, 1, B, Np, c.nz, self.dp[0], (0, Np, 1), self.zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
-                1.0 / math.sqrt(Np), accumulate=int(accumulate_proj))
+        if not skip_proj:
+            self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
 
 
 class DEngine:

@@ -395,6 +395,7 @@ class Trainer:
         Gb, D = _backbone(self.G), self.D
         Gst, Dst = Gb.store, D.store
         self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
+        gather_proj = self.world > 1 and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
         deng = D.engine()
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -413,8 +414,20 @@ class Trainer:
             dx = torch.empty(B, 1, self.H, self.W, **f32)
             deng.backward_input(Dst, 0, B, dx)
             ddepth = self.A.backward(dx, rand["aug"][3])
-            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0))
-        gscale = self._allreduce(Gst)
+            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj)
+        if gather_proj:
+            # Proj.weight is 96 % of G's gradient bytes (268 MB fp32) and the last tensor backward produces.  It is a
+            # plain linear layer, so instead of all-reducing its gradient every rank gathers the tiny operands
+            # (z [B,nz] and dL/da0 [B,h0*w0*C], 8.4 MB per rank in bf16) and forms the GLOBAL-batch gradient locally:
+            # same sum, 3.5x less xGMI traffic, and the 268 MB never cross a link.
+            geng = self._mb[0]["geng"]
+            zg = D_.all_gather_cat(geng.zT)
+            dg = D_.all_gather_cat(geng.dp[0])
+            geng.proj_wgrad(Gst, dg, zg, self.world * B)
+            tail = Gst.seg["proj_b"].off
+            _, gscale = D_.allreduce_grads(Gst.grad[tail:])
+        else:
+            gscale = self._allreduce(Gst)
         # Adam + EMA fused (:312, :316)
         self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
                           shadow_dtype=self.dtype)

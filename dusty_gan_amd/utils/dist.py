@@ -53,3 +53,17 @@ def mean_scalars(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t = t / w
     return t
+
+
+def all_gather_cat(t):
+    """concatenation over ranks of a flat device tensor (any dtype: moved as raw bytes so every backend takes it)"""
+    w = world_size()
+    if w == 1:
+        return t
+    raw = t.contiguous().view(torch.uint8)
+    out = torch.empty(w * raw.numel(), dtype=torch.uint8, device=t.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, raw)
+    else:
+        dist.all_gather(list(out.view(w, -1).unbind(0)), raw)
+    return out.view(t.dtype)

@@ -1,0 +1,87 @@
+"""The data-parallel path of the Trainer on REAL kernels: two ranks share the one GPU of the test box (gloo moves the
+CUDA buffers through the host, RCCL refuses two ranks on one device) and must reproduce the single-process
+full-batch step: identical parameter broadcast, gradient averaging (one all-reduce per network), packed scalar
+reduce.  The 8-GPU RCCL run uses exactly this code with backend "nccl"."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import dusty_oracle as O
+from tests.golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+ARCH, SHAPE, NZ, CB, CM, B = "dusty2", (32, 64), 8, 4, 16, 4
+
+
+def make_rand():
+    gen = torch.Generator().manual_seed(77)
+    H, W = SHAPE
+    x = torch.rand(B, 1, H, W, generator=gen) * 2 - 1
+    rand = {"z": torch.randn(B, NZ, generator=gen),
+            "noise": {"pixel": O.logistic_noise(torch.rand(B, 1, H, W, generator=gen), torch.rand(B, 1, H, W, generator=gen)),
+                      "image": O.logistic_noise(torch.rand(B, 1, 1, 1, generator=gen), torch.rand(B, 1, 1, 1, generator=gen))},
+            "aug": [O.draw_augment_params(B, H, W, gen) for _ in range(4)]}
+    return x, rand
+
+
+def shard(x, rand, s):
+    return x[s].contiguous(), {"z": rand["z"][s], "noise": {k: v[s] for k, v in rand["noise"].items()},
+                               "aug": [{k: v[s] for k, v in rp.items()} for rp in rand["aug"]]}
+
+
+def run_steps(tr, x, rand, steps=2):
+    out = []
+    for i in range(steps):
+        xd = x.to("cuda")
+        s = tr.step(i, reals=[(xd, torch.ones_like(xd))], rands=[rand])
+        out.append(dict(s.items()))
+    return out
+
+
+def worker(rank, world, init_file, out_dir, sdG, sdD):
+    from tests.test_gpu_step import make_trainer
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # ranks build DIFFERENT nets; the constructor's broadcast must fix that
+    tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
+    if rank == 0:
+        tr.G.load_state_dict(sdG)
+        tr.D.load_state_dict(sdD)
+    from dusty_gan_amd.utils import dist as DD
+    DD.broadcast_params([tr.G.store.flat, tr.D.store.flat], src=0)
+    tr.G.refresh() if hasattr(tr.G, "refresh") else tr.G.backbone.refresh()
+    tr.D.refresh()
+    tr.G_ema.store.flat.copy_(tr.G.store.flat)
+    x, rand = make_rand()
+    lb = B // world
+    xs, rs = shard(x, rand, slice(rank * lb, (rank + 1) * lb))
+    scal = run_steps(tr, xs, rs)
+    torch.save({"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": scal},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_process():
+    from tests.test_gpu_step import make_trainer
+    torch.manual_seed(5)
+    ref = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B)
+    sdG = {k: v.detach().cpu().clone() for k, v in ref.G.state_dict().items()}
+    sdD = {k: v.detach().cpu().clone() for k, v in ref.D.state_dict().items()}
+    x, rand = make_rand()
+    scal_ref = run_steps(ref, x, rand)
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(worker, args=(2, os.path.join(td, "init"), td, sdG, sdD), nprocs=2, join=True)
+        outs = [torch.load(os.path.join(td, f"r{r}.pt")) for r in range(2)]
+    for o in outs:
+        assert rel_l2(o["D"], ref.D.store.flat.cpu()) < 1e-4
+        assert rel_l2(o["G"], ref.G.store.flat.cpu()) < 1e-4
+        assert rel_l2(o["E"], ref.G_ema.store.flat.cpu()) < 1e-4
+        for s_got, s_ref in zip(o["scal"], scal_ref):
+            for k, v in s_ref.items():
+                assert abs(s_got[k] - v) < 1e-4 * max(1.0, abs(v)), k
+    assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
