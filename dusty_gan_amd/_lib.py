@@ -84,6 +84,10 @@ PROTOTYPES = {
     "dg_philox_bits": [_U64, _U64, _U64, _L, _P, _P],
     "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
+    "dg_counter_add": [_P, _U64, _P],
+    "dg_philox_fill_dev": [_U64, _U64, _P, _I, _F, _F, _I, _I, _L, _P, _P],
+    "dg_aug_draw_dev": [_U64, _U64, _P, _I, _I, _I, _P, _P, _P],
+    "dg_adam_ema_step_dev": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _P, _F, _P],
 }
 
 _lib = None

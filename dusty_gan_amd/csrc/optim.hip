@@ -12,7 +12,13 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        float* __restrict__ ema, T* __restrict__ shadow, long n4,
                                                        float gscale, float lr_bc1, float inv_sqrt_bc2, float b1,
-                                                       float b2, float eps, float ema_decay) {
+                                                       float b2, float eps, float ema_decay,
+                                                       const unsigned long long* __restrict__ stepp, float lr) {
+  if (stepp) {  // step count in device memory (graph replay): bias corrections computed here
+    const float t = (float)(*stepp + 1ull);
+    lr_bc1 = lr / (1.f - (b1 > 0.f ? powf(b1, t) : 0.f));
+    inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, t));
+  }
   // 16 bytes per lane per stream, grid-stride.  m == nullptr (beta1 == 0: exp_avg IS the scaled gradient) drops two
   // of the nine fp32 streams; the exported optimizer state rebuilds exp_avg from the gradient buffer.
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -166,6 +172,53 @@ __global__ void aug_draw_kernel(uint64_t seed, uint64_t stream, uint64_t offset,
   qi[3 * B + b] = (int)(r1[3] % (uint32_t)ny);
 }
 
+// ---- device-resident counters: the same draws with the Philox offset / Adam step count read from device memory, so
+//      a whole training step can be captured once in a hipGraph and replayed (a host-side offset would be frozen in
+//      the captured kernel arguments).  dg_counter_add advances a counter after its consumers (stream order).
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
+}
+__global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
+                                       int kind, float lo, float hi, int ilo, int ihi, long n, void* __restrict__ out) {
+  const uint64_t offset = *offp;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * i >= n) return;
+  uint32_t r[4];
+  philox4x32_10(seed, offset + (uint64_t)i, stream, r);
+  const float s24 = 1.f / 16777216.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long o = 4 * i + j;
+    if (o >= n) break;
+    if (kind == 3) {
+      ((int*)out)[o] = ilo + (int)(r[j] % (uint32_t)(ihi - ilo));
+    } else if (kind == 1) {
+      const int a = j & ~1;
+      const float u1 = 1.f - (float)(r[a] >> 8) * s24, u2 = (float)(r[a + 1] >> 8) * s24;
+      const float rad = sqrtf(-2.f * logf(u1));
+      ((float*)out)[o] = (j & 1) ? rad * sinf(6.283185307179586f * u2) : rad * cosf(6.283185307179586f * u2);
+    } else {
+      const float u = (float)(r[j] >> 8) * s24;
+      ((float*)out)[o] = kind == 2 ? lo + (hi - lo) * u : u;
+    }
+  }
+}
+__global__ void aug_draw_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp, int B,
+                                    int sh, int sw, int nx, int ny, float* __restrict__ uf, int* __restrict__ qi) {
+  const uint64_t offset = *offp;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  uint32_t r0[4], r1[4];
+  philox4x32_10(seed, offset + 2 * (uint64_t)b, stream, r0);
+  philox4x32_10(seed, offset + 2 * (uint64_t)b + 1, stream, r1);
+  const float s24 = 1.f / 16777216.f;
+  for (int j = 0; j < 3; ++j) uf[j * B + b] = -1.f + 2.f * (float)(r0[j] >> 8) * s24;
+  qi[0 * B + b] = -sh + (int)(r1[0] % (uint32_t)(2 * sh + 1));
+  qi[1 * B + b] = -sw + (int)(r1[1] % (uint32_t)(2 * sw + 1));
+  qi[2 * B + b] = (int)(r1[2] % (uint32_t)nx);
+  qi[3 * B + b] = (int)(r1[3] % (uint32_t)ny);
+}
+
 static inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 extern "C" {
@@ -184,9 +237,9 @@ int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema
   unsigned grid = nblk(n4);
   if (grid > 256 * 16) grid = 256 * 16;
   if (shadow && shadow_dtype == DG_BF16)
-    adam_ema_kernel<bf16><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n4, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
+    adam_ema_kernel<bf16><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n4, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay, nullptr, lr);
   else
-    adam_ema_kernel<float><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n4, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay);
+    adam_ema_kernel<float><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n4, gscale, lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, ema_decay, nullptr, lr);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -230,6 +283,49 @@ int dg_aug_draw(uint64_t seed, uint64_t stream, uint64_t offset, int B, int H, i
   const int sh = (int)(H * (1.0 / 8.0) / 2 + 0.5), sw = (int)(W * (1.0 / 8.0) / 2 + 0.5);  // diff_augment.py:58
   const int ch = (int)(H * 0.5 + 0.5), cw = (int)(W * 0.5 + 0.5);                          // diff_augment.py:85
   aug_draw_kernel<<<nblk(B), 256, 0, s>>>(seed, stream, offset, B, sh, sw, H + (1 - ch % 2), W + (1 - cw % 2), uf, qi);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* s_) {
+  counter_add_kernel<<<1, 64, 0, (hipStream_t)s_>>>(counter, delta);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_philox_fill_dev(uint64_t seed, uint64_t stream, const unsigned long long* offset_dev, int kind, float lo,
+                       float hi, int ilo, int ihi, long n, void* out, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (kind < 0 || kind > 3) return DG_EINVAL;
+  if (kind == 3 && ihi <= ilo) return DG_EINVAL;
+  philox_fill_dev_kernel<<<nblk((n + 3) / 4), 256, 0, s>>>(seed, stream, offset_dev, kind, lo, hi, ilo, ihi, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_aug_draw_dev(uint64_t seed, uint64_t stream, const unsigned long long* offset_dev, int B, int H, int W,
+                    float* uf, int* qi, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const int sh = (int)(H * (1.0 / 8.0) / 2 + 0.5), sw = (int)(W * (1.0 / 8.0) / 2 + 0.5);
+  const int ch = (int)(H * 0.5 + 0.5), cw = (int)(W * 0.5 + 0.5);
+  aug_draw_dev_kernel<<<nblk(B), 256, 0, s>>>(seed, stream, offset_dev, B, sh, sw, H + (1 - ch % 2), W + (1 - cw % 2), uf, qi);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_adam_ema_step_dev(float* p, const float* grad, float* m, float* v, float* ema, void* shadow, int shadow_dtype,
+                         long n, float gscale, float lr, float beta1, float beta2, float eps,
+                         const unsigned long long* step_dev, float ema_decay, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (n <= 0) return DG_OK;
+  if (n % 4 != 0 || !step_dev) return DG_EINVAL;
+  const long n4 = n / 4;
+  unsigned grid = nblk(n4);
+  if (grid > 256 * 16) grid = 256 * 16;
+  if (shadow && shadow_dtype == DG_BF16)
+    adam_ema_kernel<bf16><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n4, gscale, 0.f, 0.f, beta1, beta2, eps, ema_decay, step_dev, lr);
+  else
+    adam_ema_kernel<float><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n4, gscale, 0.f, 0.f, beta1, beta2, eps, ema_decay, step_dev, lr);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -91,7 +91,8 @@ class FlatAdam:
 
     def __init__(self, net, lr, betas, eps=1e-8):
         self.net, self.lr, self.betas, self.eps = net, float(lr), (float(betas[0]), float(betas[1])), eps
-        self.step_count = 0
+        self.step_count = 0      # host mirror (checkpoints); the kernels read the device counter
+        self._step_dev = None
 
     @property
     def store(self):
@@ -139,6 +140,7 @@ class FlatAdam:
                 vs[int(i)].copy_(s["exp_avg_sq"])
                 steps.append(int(float(s["step"])))
         self.step_count = max(steps) if steps else 0
+        self._step_dev = None  # rebuilt from step_count on the next step
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
 
@@ -160,15 +162,20 @@ class FlatAdam:
 
     def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32):
         st = self.store
+        if self._step_dev is None or self._step_dev.device != st.flat.device:
+            self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=st.flat.device)
         self.step_count += 1
         self._last_gscale = gscale
         # beta1 == 0 (the reference's solver): exp_avg == scaled gradient, so the kernel neither reads nor writes it
         m_ptr = None if self.betas[0] == 0.0 else L.ptr(st.m)
-        L.check(L.lib().dg_adam_ema_step(L.ptr(st.flat), L.ptr(st.grad), m_ptr, L.ptr(st.v),
+        lib = L.lib()
+        # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
+        L.check(lib.dg_adam_ema_step_dev(L.ptr(st.flat), L.ptr(st.grad), m_ptr, L.ptr(st.v),
                                          L.ptr(ema_store.flat) if ema_store is not None else None, L.ptr(st.shadow),
                                          L.dtype_code(shadow_dtype), st.n, gscale, self.lr, self.betas[0],
-                                         self.betas[1], self.eps, self.step_count, ema_decay, L.stream_ptr()),
-                "dg_adam_ema_step")
+                                         self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
+                "dg_adam_ema_step_dev")
+        L.check(lib.dg_counter_add(L.ptr(self._step_dev), 1, L.stream_ptr()), "dg_counter_add")
         st.refresh_transposed()
         if ema_store is not None:
             ema_store._seen_version = -1  # its shadows are rebuilt lazily when G_ema is used
@@ -272,6 +279,10 @@ class Trainer:
         self._geng = None
         self._pending = None
         self._dev_scal = None
+        # hipGraph replay of the step (single GPU, synthetic device-resident data); DUSTY_GAN_GRAPH=0 disables it
+        import os
+        self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
+        self._graph, self._eager_steps = None, 0
 
     # ------------------------------------------------------------------ helpers
     def sample_latents(self, B):
@@ -434,11 +445,7 @@ class Trainer:
         self._mb = []
         return scal
 
-    def step(self, i=0, reals=None, rands=None):
-        """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""
-        self.optimize_D(reals, rands)
-        scal = self.optimize_G()
-        scal = scal / self.n_acc
+    def _scalar_keys(self):
         keys = ["loss/D/output/real", "loss/D/output/fake", "loss/D/adversarial"]
         idx = [0, 1, 2]
         if "gp" in self.criterion:
@@ -446,8 +453,56 @@ class Trainer:
             idx.append(3)
         keys.append("loss/G/adversarial")
         idx.append(4)
-        out = D_.mean_scalars(scal[idx])  # one packed collective instead of 5-7 (:319-323)
-        return LazyScalars(keys, out)
+        return keys, idx
+
+    def _step_eager(self, reals=None, rands=None):
+        """the launch sequence of one iteration; returns the device tensor of (locally averaged) scalars"""
+        self.optimize_D(reals, rands)
+        scal = self.optimize_G()
+        scal = scal / self.n_acc
+        # (slices, not a Python index list: that would be a host-to-device copy, illegal during graph capture)
+        return scal if "gp" in self.criterion else torch.cat((scal[:3], scal[4:5]))
+
+    def _graph_eligible(self, reals, rands):
+        from .. import engine as E
+        return (self.world == 1 and reals is None and rands is None and self.use_graph and E.PROFILE is None
+                and isinstance(getattr(self, "dataset", None), SyntheticLiDAR))
+
+    def _step_graph(self):
+        """hipGraph replay of the whole iteration (single-GPU, device-resident data): the ~180 kernel launches of a
+        step cost ~5 ms of Python/ctypes time when issued one by one, more than the kernels themselves; captured once
+        they replay from one host call.  Everything that changes between steps lives in device memory (Philox
+        counters, Adam step counts, the input batch in a static buffer), so replays draw fresh randomness."""
+        batch = next(self.loader)
+        if self._graph is None:
+            if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
+                self._eager_steps += 1
+                return self._step_eager(reals=[self.fetch_reals(batch)] if self.n_acc == 1 else None)
+            self._g_pol = batch["depth"].to(self.device).clone()
+            self._g_mask = batch["mask"].to(self.device).clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._g_out = self._step_eager(reals=[self.fetch_reals({"depth": self._g_pol, "mask": self._g_mask})])
+            self._graph = g
+            # the capture did not execute anything, but the host mirrors of the Adam step counts advanced once
+            self.optim_D.step_count -= 1
+            self.optim_G.step_count -= 1
+        self._g_pol.copy_(batch["depth"], non_blocking=True)
+        self._g_mask.copy_(batch["mask"], non_blocking=True)
+        self._graph.replay()
+        self.optim_D.step_count += 1
+        self.optim_G.step_count += 1
+        return self._g_out.clone()
+
+    def step(self, i=0, reals=None, rands=None):
+        """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""
+        if self._graph_eligible(reals, rands) and self.n_acc == 1:
+            out = self._step_graph()
+        else:
+            out = self._step_eager(reals, rands)
+        out = D_.mean_scalars(out)  # one packed collective instead of 5-7 (:319-323)
+        return LazyScalars(self._scalar_keys()[0], out)
 
     # ------------------------------------------------------------------ inference / checkpoints
     def postprocess(self, synth):

@@ -40,9 +40,9 @@ class DiffAugment(nn.Module):
         r = self.rng(device)
         uf = torch.empty(3, B, dtype=torch.float32, device=device)
         qi = torch.empty(4, B, dtype=torch.int32, device=device)
-        L.check(L.lib().dg_aug_draw(r.seed, r.stream_id, r.offset, B, H, W, L.ptr(uf), L.ptr(qi), L.stream_ptr()),
-                "dg_aug_draw")
-        r.offset += 2 * B
+        L.check(L.lib().dg_aug_draw_dev(r.seed, r.stream_id, L.ptr(r.ctr), B, H, W, L.ptr(uf), L.ptr(qi),
+                                        L.stream_ptr()), "dg_aug_draw_dev")
+        r.advance(2 * B)
         return {"u_b": uf[0], "u_s": uf[1], "u_c": uf[2], "t_h": qi[0], "t_w": qi[1], "o_x": qi[2], "o_y": qi[3]}
 
     @staticmethod

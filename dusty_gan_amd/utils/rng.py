@@ -8,15 +8,26 @@ from .. import _lib as L
 
 
 class Philox:
+    """The counter (Philox offset) lives in DEVICE memory and is advanced by a tiny kernel after each draw, so a
+    training step captured in a hipGraph replays with fresh draws (a host-side offset would be frozen in the
+    captured kernel arguments)."""
+
     def __init__(self, seed, device, stream_id=0):
         self.seed, self.device, self.stream_id = int(seed) & (2**64 - 1), device, int(stream_id)
-        self.offset = 0
+        self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
+
+    @property
+    def offset(self):
+        return int(self.ctr.item())
+
+    def advance(self, n):
+        L.check(L.lib().dg_counter_add(L.ptr(self.ctr), int(n), L.stream_ptr()), "dg_counter_add")
 
     def _fill(self, kind, n, lo=0.0, hi=1.0, ilo=0, ihi=1):
         out = torch.empty(n, dtype=torch.int32 if kind == 3 else torch.float32, device=self.device)
-        L.check(L.lib().dg_philox_fill(self.seed, self.stream_id, self.offset, kind, lo, hi, ilo, ihi, n, L.ptr(out),
-                                       L.stream_ptr()), "dg_philox_fill")
-        self.offset += (n + 3) // 4
+        L.check(L.lib().dg_philox_fill_dev(self.seed, self.stream_id, L.ptr(self.ctr), kind, lo, hi, ilo, ihi, n,
+                                           L.ptr(out), L.stream_ptr()), "dg_philox_fill_dev")
+        self.advance((n + 3) // 4)
         return out
 
     def uniform(self, n, lo=0.0, hi=1.0):

@@ -164,6 +164,18 @@ int dg_philox_fill(uint64_t seed, uint64_t stream_id, uint64_t offset, int kind,
 int dg_aug_draw(uint64_t seed, uint64_t stream_id, uint64_t offset, int B, int H, int W, float* uf, int* qi,
                 void* stream);
 
+/* ---- device-resident counters (hipGraph-friendly variants): Philox offset / Adam step count read from device memory;
+ *      dg_counter_add advances a counter after its consumers.  A step captured once replays with fresh draws. */
+int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* stream);
+int dg_philox_fill_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int kind, float lo,
+                       float hi, int ilo, int ihi, long n, void* out, void* stream);
+int dg_aug_draw_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int B, int H, int W,
+                    float* uf, int* qi, void* stream);
+/* Adam with the (0-based, already-completed) step count in device memory: this call is step *step_dev + 1 */
+int dg_adam_ema_step_dev(float* p, const float* grad, float* m, float* v, float* ema, void* shadow, int shadow_dtype,
+                         long n, float gscale, float lr, float beta1, float beta2, float eps,
+                         const unsigned long long* step_dev, float ema_decay, void* stream);
+
 const char* dg_version(void);
 
 #ifdef __cplusplus

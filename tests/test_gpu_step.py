@@ -248,3 +248,24 @@ def test_checkpoint_roundtrip_and_generate(tmp_path):
     assert torch.isfinite(out["depth"]).all()
     with pytest.raises(RuntimeError):
         tr.G(torch.zeros(2, 8))  # CPU input: no fallback
+
+
+def test_graph_replay_matches_eager_launches(monkeypatch):
+    """the hipGraph-captured step (device-resident Philox / Adam counters) trains exactly like the eager launch
+    sequence: same seeds -> same parameters after 5 iterations (fp32; atomics make the last bits differ)"""
+    def run(graph):
+        monkeypatch.setenv("DUSTY_GAN_GRAPH", "1" if graph else "0")
+        torch.manual_seed(2024)
+        tr = make_trainer("dusty2", True, (32, 64), 8, 4, 16, 4)
+        sc = [dict(tr.step(i).items()) for i in range(5)]
+        assert (tr._graph is not None) == graph
+        return tr, sc
+    a, sa = run(True)
+    b, sb = run(False)
+    assert a.optim_G.step_count == b.optim_G.step_count == 5
+    for net in ("G", "D", "G_ema"):
+        fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
+        assert rel_l2(fa, fb) < 1e-5, net
+    for x, y in zip(sa, sb):
+        for k in x:
+            assert abs(x[k] - y[k]) < 1e-4 * max(1.0, abs(y[k])), k
