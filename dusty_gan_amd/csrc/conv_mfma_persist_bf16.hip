@@ -1,0 +1,4 @@
+// bf16 instantiations of the persistent implicit-GEMM conv (conv_mfma_persist_impl.h)
+#include "conv_mfma_persist_impl.h"
+
+int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream) { return persist::launch_dtype<bf16>(p, stream); }
