@@ -3,6 +3,7 @@
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream);
+int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_supported(const ConvP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
@@ -14,7 +15,8 @@ extern "C" {
 
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
-// force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error
+// force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
+//        4 large-tile persistent MFMA kernel or error
 int dg_conv(const DgConv* p, int force, void* stream) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
   if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
@@ -26,6 +28,7 @@ int dg_conv(const DgConv* p, int force, void* stream) {
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s) : DG_EUNSUPPORTED;
+  if (force == 4) return mfma_ok ? dg_conv_mfma_big_launch(p, s) : DG_EUNSUPPORTED;
   if (force == 3) return thin_ok ? dg_conv_thin_launch(p, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s);
   if (force == 0 && thin_ok) return dg_conv_thin_launch(p, s);

@@ -350,15 +350,21 @@ extern "C" int dg_conv_mfma_supported(const ConvP* p) {
   return 1;
 }
 
-int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream);
-int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream);
+int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream, int auto_rule);
+int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule);
 
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  static int persist = -1;  // DG_CONV_PERSIST=0 selects the one-tile-per-workgroup kernel below (A/B runs)
+  // layers that tile into 256-row M tiles go to the persistent large-tile kernel (conv_mfma_persist_impl.h);
+  // DG_CONV_PERSIST=0 keeps everything on the one-tile-per-workgroup kernel below, =2 uses large tiles wherever
+  // the geometry allows (A/B runs)
+  static int persist = -1;
   if (persist < 0) { const char* e = getenv("DG_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
-  if (persist)
-    return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream) : dg_conv_mfma_persist_launch_f32(p, stream);
+  if (persist) {
+    const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, persist == 1)
+                                          : dg_conv_mfma_persist_launch_f32(p, stream, persist == 1);
+    if (rc != DG_EUNSUPPORTED) return rc;
+  }
   const bool m128 = p->mode == MODE_GEMM ? false : (p->Wc % 128 == 0);
   const bool n128 = p->N % 128 == 0;
   if (p->in_dtype == DG_BF16) {
@@ -371,4 +377,10 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream) {
   if (m128) return launch_cfg<float, 128, 64>(p, stream);
   if (n128) return launch_cfg<float, 64, 128>(p, stream);
   return launch_cfg<float, 64, 64>(p, stream);
+}
+
+// large-tile persistent kernel wherever the geometry allows, else DG_EUNSUPPORTED (dg_conv force == 4; parity tests)
+int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream) {
+  if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
+  return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0) : dg_conv_mfma_persist_launch_f32(p, stream, 0);
 }

@@ -1,22 +1,27 @@
-// Persistent implicit-GEMM conv on the matrix cores (gfx950), the default kernel for every "fat" conv-like pass:
+// Persistent implicit-GEMM conv on the matrix cores (gfx950) with large tiles.
 //   Down forward / R1 tangent pass (MODE_S2, adj=0), Up forward (MODE_UP, adj=0), Down backward-data (MODE_UP, adj=1),
-//   Up backward-data (MODE_S2, adj=1) and the Proj GEMM (MODE_GEMM).
+//   Up backward-data (MODE_S2, adj=1).
 // Reference ops: models/gans/dcgan_eqlr.py:6-26,75-82 with models/ops/common.py Pad/EqualLR/FusedLeakyReLU fused
 // (padding = index arithmetic in the tile loader; EqualLR scale, bias, leaky-relu or its derivative mask and the
 // bias-gradient column sums in the epilogue).
 //
-// Same tiles, taps, swizzle and arithmetic as the one-tile-per-workgroup kernel in conv_mfma.hip, but
-//   * the grid is one residency wave (occupancy x CUs); each workgroup owns a CONTIGUOUS chunk of the tile order
-//     (N-tile fastest, then x-tile, column parity, row, sample) and steps through it with a carry chain - no
-//     divisions, and the A rows of one M-tile are re-read from L2 by the same workgroup for its N-tiles;
-//   * the LDS-DMA ring runs ACROSS tile boundaries: the first K step of the next tile is in flight during the last
-//     MFMAs and the epilogue of the current one (the one-tile kernel pays a bare DMA latency at every tile start);
-//   * DMA addressing is a wave-uniform 64-bit base (SGPRs) + a per-lane 32-bit offset that only changes with the
-//     tile or the W tap, so a K step issues its 8 pieces with no vector address math; the H taps of a row are
-//     packed into one 64-bit scalar per tile;
-//   * the epilogue is wave-private: each wave transposes its 16-row slabs through its own LDS strip (outside the
-//     ring) with inline-asm ds ops - no workgroup barrier and no compiler-inserted vmcnt(0) drain; the wait at
-//     the next tile's first step counts the epilogue's stores (vmcnt is in issue order) instead of draining them.
+// Why this kernel exists: the one-tile-per-workgroup kernel of conv_mfma.hip (128 x 128 tiles, 2 workgroups per CU)
+// issues 8 LDS-DMA pieces per 16 MFMAs per wave and measured DMA-only ~= MFMA-only ~= half of the combined time: it
+// is bound by the DMA issue / L1 path, not by latency (a persistent 128 x 128 variant with cross-tile prefetch ran
+// at the same speed).  The lever is bytes per flop, i.e. the tile: 256 x 256 (8 waves, one workgroup per CU) moves
+// half the bytes per MFMA.  What it takes for conv layers:
+//   * an M tile of 256 output pixels of ONE image row (and one column parity in MODE_UP) keeps the tap list
+//     workgroup-uniform; layers narrower than 256 build the tile from the SAME row segment of NSB consecutive
+//     samples (the tap list only depends on the row), so every fat layer gets 256-row tiles;
+//   * the grid is one residency wave; each workgroup owns a contiguous chunk of the tile order (N tile fastest,
+//     then x tile, column parity, row, sample group) and walks it with a carry chain - no divisions;
+//   * the LDS-DMA ring (NS stages of SB bytes of K per tile row) runs ACROSS tile boundaries with counted vmcnt
+//     waits (vmcnt retires in issue order, so the epilogue's stores are counted, not drained), one raw barrier per
+//     K step, and the DMA pieces of step s+NS-1 are issued between the MFMA groups of step s;
+//   * DMA addressing = wave-uniform 64-bit base (SGPRs) + per-lane 32-bit offset that only changes with the tile or
+//     the W tap; the H taps of a row are packed into one 64-bit scalar;
+//   * the epilogue is wave-private: each wave transposes its SR-row slabs through its own LDS strip (outside the
+//     ring) with inline-asm ds ops and writes whole 128-byte pixel rows - no workgroup barrier, no vmcnt(0) drain.
 #pragma once
 #include "mfma_common.h"
 
@@ -36,23 +41,22 @@ template <> struct StageWrite<float> {
   }
 };
 
-// position in the tile order; next() is the carry chain.  GEMM: xt is the M-tile index.
+// position in the tile order; bt = sample group (samples bt*NSB .. bt*NSB+NSB-1)
 struct Tile {
-  int nt, xt, px, Y, b;
+  int nt, xt, px, Y, bt;
 };
 
 template <int MODE>
 __device__ __forceinline__ bool next_tile(Tile& t, int tiles_n, int tiles_x, int rows) {  // true when Y changed
   if (++t.nt < tiles_n) return false;
   t.nt = 0;
-  if (MODE == MODE_GEMM) { ++t.xt; return false; }
   if (++t.xt < tiles_x) return false;
   t.xt = 0;
   if (MODE == MODE_UP) {
     if (++t.px < 2) return false;
     t.px = 0;
   }
-  if (++t.Y == rows) { t.Y = 0; ++t.b; }
+  if (++t.Y == rows) { t.Y = 0; ++t.bt; }
   return true;
 }
 
@@ -60,7 +64,6 @@ __device__ __forceinline__ bool next_tile(Tile& t, int tiles_n, int tiles_x, int
 template <int MODE>
 __device__ __forceinline__ int pack_htaps(int adj, int Y, int Hc, unsigned long long& list) {
   list = 0;
-  if (MODE == MODE_GEMM) return 1;
   int n = 0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -73,44 +76,50 @@ __device__ __forceinline__ int pack_htaps(int adj, int Y, int Hc, unsigned long 
   return n;
 }
 
-// waves are WM x WN over the tile; WM = 4 for 64-channel N tiles so that a wave's strip rows are whole 128-byte
-// pixel rows (two waves writing 64-byte halves of each line measured 2x slower on the N = 64 layers)
-template <int BM, int BN> struct Cfg {
-  static constexpr int WM = (BM == 128 && BN == 64) ? 4 : 2;
-  static constexpr int WN = 4 / WM;
-  static constexpr int OCC = 2;                           // workgroups per CU (3 measured slower on every layer)
+#define DG_WAITV(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// geometry passed by the launcher
+struct Geo {
+  int tiles_n, tiles_x, ntiles;
+  int SW, NSB, lsw;                            // M tile = NSB sample segments of SW = 1 << lsw columns
+  int dbg;
 };
 
-template <typename T, int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, int tiles_n, int tiles_x, int ntiles, int dbg) {
-  constexpr int SB = 128, NS = 2;              // bytes of K per tile row per stage; LDS stages
+template <typename T, int BM, int BN, int WM, int WN, int SB, int NS, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
+  constexpr int NWV = WM * WN;                 // waves
   constexpr int ES = sizeof(T);
   constexpr int BK = SB / ES;
   constexpr int EPC = 16 / ES;
-  constexpr int WM = Cfg<BM, BN>::WM, WN = Cfg<BM, BN>::WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32 x 32 MFMA blocks per wave
   constexpr int RPI = 1024 / SB;               // tile rows per DMA piece (1 KiB per wave instruction)
-  constexpr int CPR = SB / 16;
-  constexpr int KS = SB / 32;
+  constexpr int CPR = SB / 16;                 // 16-byte chunks per tile row
+  constexpr int KS = SB / 32;                  // MFMA k-steps per stage
   constexpr int STAGE = (BM + BN) * SB;
-  constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;
+  constexpr int IA = BM / RPI / NWV, IB = BN / RPI / NWV;
+  constexpr int IPT = IA + IB;                 // DMA pieces per wave per K step
+  constexpr int E = NS - 1;                    // DMA of step s+E is issued in the middle of step s
   constexpr int WC = BN / WN;                  // epilogue strip of one wave: SR pixel rows x WC channels (+16 B pad)
   constexpr int RB = WC * ES;
   constexpr int RS = RB + 16;
   constexpr int CR = RB / 16;                  // 16-byte chunks per strip row
-  constexpr int SR = (Cfg<BM, BN>::OCC == 3 && 8 * CR >= 64) ? 8 : 16;  // strip rows (8 keeps 3 workgroups per CU)
+  constexpr int SR = (ES == 4 && BM + BN >= 512) ? 8 : 16;
   constexpr int CPL = SR * CR / 64;            // chunks per lane per strip
   constexpr int STRIP = SR * RS;
   constexpr int NQ = 32 / SR;                  // strips per 32-row MFMA block
   constexpr int NST = TM * NQ * CPL;           // global stores per wave per tile epilogue
-  constexpr int nW = MODE == MODE_S2 ? 4 : (MODE == MODE_UP ? 2 : 1);
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + 4 * STRIP + BN * 4];
+  constexpr int nW = MODE == MODE_S2 ? 4 : 2;
+  static_assert(IA >= 1 && IB >= 1, "piece distribution");
+  static_assert(NS >= 3 && NS <= 4 && KS >= 2 && KS % 2 == 0 && 2 * IPT + NST <= 63, "ring / vmcnt immediates");
+  constexpr int NDB = 512;                     // bias-gradient accumulators (N <= 512 when dbias is wanted)
+  static_assert(NS * STAGE + NWV * STRIP + NDB * 4 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + NWV * STRIP + NDB * 4];
 
   // ---- this workgroup's chunk of the tile order
-  const int G = gridDim.x, g = blockIdx.x;
-  const int tq = ntiles / G, tr = ntiles % G;
-  const int t0 = g * tq + (g < tr ? g : tr);
-  const int tcount = tq + (g < tr ? 1 : 0);
+  const int G = gridDim.x, gi = blockIdx.x;
+  const int tq = g.ntiles / G, tr = g.ntiles % G;
+  const int t0 = gi * tq + (gi < tr ? gi : tr);
+  const int tcount = tq + (gi < tr ? 1 : 0);
   if (tcount == 0) return;
 
   const int tid = threadIdx.x;
@@ -118,77 +127,64 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
   const int Ws = MODE == MODE_S2 ? 2 * p.Wc : p.Wc, cmul = MODE == MODE_S2 ? 2 : 1;
   const int Wo = MODE == MODE_S2 ? p.Wc : 2 * p.Wc;
   const int rows = MODE == MODE_S2 ? p.Hc : 2 * p.Hc;
+  const int tiles_n = g.tiles_n, tiles_x = g.tiles_x;
 
   Tile first;
   {
     int mt = t0 / tiles_n;
     first.nt = t0 % tiles_n;
-    first.px = 0; first.Y = 0; first.b = 0;
-    if (MODE == MODE_GEMM) first.xt = mt;
-    else {
-      first.xt = mt % tiles_x; mt /= tiles_x;
-      if (MODE == MODE_UP) { first.px = mt & 1; mt >>= 1; }
-      first.Y = mt % rows; first.b = mt / rows;
-    }
+    first.px = 0;
+    first.xt = mt % tiles_x; mt /= tiles_x;
+    if (MODE == MODE_UP) { first.px = mt & 1; mt >>= 1; }
+    first.Y = mt % rows; first.bt = mt / rows;
     first.nt = __builtin_amdgcn_readfirstlane(first.nt); first.xt = __builtin_amdgcn_readfirstlane(first.xt);
     first.px = __builtin_amdgcn_readfirstlane(first.px); first.Y = __builtin_amdgcn_readfirstlane(first.Y);
-    first.b = __builtin_amdgcn_readfirstlane(first.b);
+    first.bt = __builtin_amdgcn_readfirstlane(first.bt);
   }
 
   const T* in = (const T*)p.in;
   const T* w = (const T*)p.w;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lrow = lane / CPR, pos = lane % CPR;
-  auto swz = [](int row) { return (row >> 1) & 7; };
+  auto swz = [](int row) { return SB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
-  // ---- issue side: runs one K step ahead of the compute side
+  // ---- issue side: runs D K-steps ahead of the compute side
   Tile ti = first;
   int i_left = tcount;                         // tiles not yet fully issued (including the current one)
-  unsigned long long hl;                       // remaining H taps of the current tile
-  int h_left;
-  unsigned long long hl_row;                   // tap list of row ti.Y (reused by every tile of the row)
+  unsigned long long hl = 0, hl_row;           // remaining H taps of the current tile / tap list of row ti.Y
+  int h_left = 0;
   int nh_row = pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl_row);
   int it_j = 0, it_kc = 0;
-  unsigned voffA[IA], voffB[IB];
-  int rowA[IA], pcA[IA];
-  const char* sA = nullptr;
+  unsigned voffA[IA], voffB[IB];               // per-lane byte offsets (A: per tile and W tap, B: constant)
+  int colA[IA];                                // tile-row column inside its sample segment
+  unsigned sampA[IA];                          // byte offset of the row's sample inside the sample group + swizzled chunk
+  const char* sA = nullptr;                    // wave-uniform bases
   const char* sB = nullptr;
 #pragma unroll
   for (int u = 0; u < IA; ++u) {
-    rowA[u] = (wave + 4 * u) * RPI + lrow;
-    pcA[u] = (pos ^ swz(rowA[u])) * 16;
+    const int row = (wave + NWV * u) * RPI + lrow;
+    colA[u] = row & (g.SW - 1);
+    sampA[u] = (unsigned)((row >> g.lsw) * (int)p.in_sb * ES + (pos ^ swz(row)) * 16);
   }
 #pragma unroll
   for (int u = 0; u < IB; ++u) {
-    const int row = (wave + 4 * u) * RPI + lrow;
+    const int row = (wave + NWV * u) * RPI + lrow;
     voffB[u] = (unsigned)(row * (int)p.w_sn * ES + (pos ^ swz(row)) * 16);
   }
   auto set_wtap = [&]() {                      // after the tile, the H tap or the W tap changed
     const int it_r = (int)(hl & 1023) >> 2, it_ky = (int)hl & 3;
-    int coff = 0, kx = 0;
+    int coff, kx;
     if (MODE == MODE_S2) { coff = it_j - 1; kx = it_j; }
-    else if (MODE == MODE_UP) {
-      if (ti.px == 0) { coff = it_j == 0 ? 0 : -1; kx = it_j == 0 ? 1 : 3; }
-      else { coff = it_j == 0 ? 1 : 0; kx = it_j == 0 ? 0 : 2; }
-    }
-    const int wt = MODE == MODE_GEMM ? 0 : it_ky * 4 + kx;
+    else if (ti.px == 0) { coff = it_j == 0 ? 0 : -1; kx = it_j == 0 ? 1 : 3; }
+    else { coff = it_j == 0 ? 1 : 0; kx = it_j == 0 ? 0 : 2; }
+    const int wt = it_ky * 4 + kx;
     sB = (const char*)(w + (long)wt * p.w_st + (long)(ti.nt * BN) * p.w_sn);
-    if (MODE == MODE_GEMM) {
-      sA = (const char*)in;
+    sA = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb + (long)it_r * Ws * p.in_sp);
 #pragma unroll
-      for (int u = 0; u < IA; ++u) {
-        int br = ti.xt * BM + rowA[u];
-        if (br >= p.B) br = p.B - 1;           // rows past the batch: duplicate data, dropped in the epilogue
-        voffA[u] = (unsigned)(br * (int)p.in_sb * ES + pcA[u]);
-      }
-    } else {
-      sA = (const char*)(in + (long)ti.b * p.in_sb + (long)it_r * Ws * p.in_sp);
-#pragma unroll
-      for (int u = 0; u < IA; ++u) {
-        int c = cmul * (ti.xt * BM + rowA[u]) + coff;
-        if (c < 0) c += Ws; else if (c >= Ws) c -= Ws;
-        voffA[u] = (unsigned)(c * (int)p.in_sp * ES + pcA[u]);
-      }
+    for (int u = 0; u < IA; ++u) {
+      int c = cmul * (ti.xt * BM + colA[u]) + coff;
+      if (c < 0) c += Ws; else if (c >= Ws) c -= Ws;
+      voffA[u] = (unsigned)(c * (int)p.in_sp * ES) + sampA[u];
     }
   };
   auto start_tile = [&]() { hl = hl_row; h_left = nh_row; it_j = 0; it_kc = 0; set_wtap(); };
@@ -204,13 +200,12 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
     if (next_tile<MODE>(ti, tiles_n, tiles_x, rows)) nh_row = pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl_row);
     start_tile();
   };
-  auto issue_dma = [&](int st) {
+  // piece pc (0 .. IPT-1) of the current issue step into stage st
+  auto issue_piece = [&](int st, int pc) {
     unsigned char* base = lds + st * STAGE;
     const unsigned k0b = (unsigned)it_kc * SB;
-#pragma unroll
-    for (int u = 0; u < IA; ++u) dma16(sA + k0b + voffA[u], base + (wave + 4 * u) * 1024);
-#pragma unroll
-    for (int u = 0; u < IB; ++u) dma16(sB + k0b + voffB[u], base + BM * SB + (wave + 4 * u) * 1024);
+    if (pc < IA) dma16(sA + k0b + voffA[pc], base + (wave + NWV * pc) * 1024);
+    else dma16(sB + k0b + voffB[pc - IA], base + BM * SB + (wave + NWV * (pc - IA)) * 1024);
   };
 
   const int wm = wave / WN, wn = wave % WN;
@@ -237,73 +232,128 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
   zero_acc();
 
   // Fragment reads are inline asm (a compiler-visible LDS load after an LDS-DMA makes hipcc drain vmcnt(0)); the reads
-  // of MFMA k-step ks+1 are issued before the MFMAs of ks, counted lgkmcnt + sched_barrier keep the order.
+  // of MFMA k-step ks+1 are issued before the MFMAs of ks, counted lgkmcnt + sched_barrier keep the order.  The DMA
+  // pieces of the step being prefetched are issued behind each MFMA group.
   i32x4 fa[2][TM], fb[2][TN];
   auto read_frags = [&](int set, unsigned a_addr, unsigned b_addr) {
-    LDS_READ128(fa[set][0], a_addr, 0);
-    if constexpr (TM == 2) LDS_READ128(fa[set][1], a_addr, 32 * SB);
-    LDS_READ128(fb[set][0], b_addr, 0);
-    if constexpr (TN == 2) LDS_READ128(fb[set][1], b_addr, 32 * SB);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) LDS_READ128(fa[set][i], a_addr + i * 32 * SB, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) LDS_READ128(fb[set][j], b_addr + j * 32 * SB, 0);
   };
-  auto compute = [&](unsigned st_off) {
-    read_frags(0, fragA[0] + st_off, fragB[0] + st_off);
+  auto mfma_group = [&](int set) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        read_frags((ks + 1) & 1, fragA[ks + 1] + st_off, fragB[ks + 1] + st_off);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          mma_tile((const T*)nullptr, fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < TN; ++j) mma_tile((const T*)nullptr, fa[set][i], fb[set][j], acc[i][j]);
+  };
+  // wait until all but the DMA of the `yd` youngest issued K steps (and, with `st`, the previous epilogue's NST
+  // stores, which are younger than the step waited for) have landed
+  auto wait_dma = [&](int yd, bool st) {
+    if (st) {
+      if (yd <= 0) DG_WAITV(NST);
+      else if (yd == 1) DG_WAITV(IPT + NST);
+      else DG_WAITV(2 * IPT + NST);
+    } else {
+      if (yd <= 0) DG_WAITV(0);
+      else if (yd == 1) DG_WAITV(IPT);
+      else DG_WAITV(2 * IPT);
     }
   };
 
   // ---- epilogue constants
   const unsigned strip = lds0 + NS * STAGE + wave * STRIP;
-  float* s_db = (float*)(lds + NS * STAGE + 4 * STRIP);
+  // bias-gradient column sums of ALL tiles of this workgroup accumulate in LDS (ds_add_f32 in inline asm, so that no
+  // compiler-visible LDS access sits behind an in-flight DMA) and are flushed once at the end of the kernel
+  float* s_db = (float*)(lds + NS * STAGE + NWV * STRIP);
+  const unsigned sdb0 = lds0 + NS * STAGE + NWV * STRIP;
   const bool want_db = p.dbias != nullptr;
+  if (want_db) {
+    for (int i = tid; i < NDB; i += 64 * NWV) s_db[i] = 0.f;
+    __syncthreads();
+  }
   T* out = (T*)p.out;
   const int part = lane % CR;                  // this lane's 16-byte chunk of the strip rows (64 % CR == 0)
   const unsigned wr_base = strip + (4 * lh) * RS + lr * ES;
   const unsigned rd_base = strip + (lane / CR) * RS + part * 16;
-  const bool counted = MODE != MODE_GEMM && !want_db && !(dbg & 4);  // epilogue store count per wave is exactly NST
+  const bool counted = !(g.dbg & 4);           // the epilogue issues exactly NST stores per wave
 
-  issue_dma(0);
-  advance();
-  unsigned gs = 0;                             // K-step counter of this workgroup; step gs lives in stage gs & 1
+  // ---- K loop.  Stage gs % NS holds step gs.  The barrier of a step sits in the MIDDLE of the previous one:
+  //        step gs:  MFMA group(s) of the first half
+  //                  wait DMA(gs+1) landed (counted vmcnt) ; s_barrier ; issue DMA(gs+E) into the stage step gs-1 used
+  //                  MFMA group(s) of the second half, with the first fragments of step gs+1 read behind them
+  //      so the barrier skew, the LDS read latency of the next step and the DMA issue all overlap MFMAs in flight.
+  //      The barrier orders (a) every wave's share of DMA(gs+1) against the reads that follow and (b) every wave's
+  //      reads of stage (gs-1) % NS (all done: everyone is inside step gs) against the DMA that refills it.
+  int issued = 0;                              // K steps whose DMA has been issued
+#pragma unroll
+  for (int d = 0; d < E; ++d) {
+    if (i_left > 0) {
+      if (!(g.dbg & 1)) {
+#pragma unroll
+        for (int pc = 0; pc < IPT; ++pc) issue_piece(d, pc);
+      }
+      advance();
+      ++issued;
+    }
+  }
+  wait_dma(issued - 1, false);
+  __builtin_amdgcn_s_barrier();
+  int gs = 0;                                  // K-step counter of this workgroup
+  int st_c = 0, st_i = E % NS;                 // stage of step gs / stage refilled during it
   Tile tc = first;
   unsigned long long dummy;
   int nh_c = pack_htaps<MODE>(p.adj, tc.Y, p.Hc, dummy);
   for (int c = 0; c < tcount; ++c) {
     const int nsteps = nh_c * nW * KC;
-    if (want_db && tid < BN) s_db[tid] = 0.f;
     for (int s = 0; s < nsteps; ++s, ++gs) {
-      // step gs has landed (only the previous epilogue's stores may still be in flight); everyone finished reading
-      // the other stage -> refill it with step gs+1, then compute step gs
-      if (counted && s == 0 && c > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (i_left > 0) {
-        if (!(dbg & 1)) issue_dma((gs + 1) & 1);
-        advance();
+      const unsigned st_off = (unsigned)st_c * STAGE;
+      const int st_n = st_c + 1 == NS ? 0 : st_c + 1;
+      const unsigned nx_off = (unsigned)st_n * STAGE;
+      const bool pref = s + 1 < nsteps;        // the next step belongs to this tile: read its first fragments early
+      const bool has_next = pref || c + 1 < tcount;
+      if (s == 0) read_frags(0, fragA[0] + st_off, fragB[0] + st_off);  // tile start: nothing was prefetched
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          read_frags((ks + 1) & 1, fragA[ks + 1] + st_off, fragB[ks + 1] + st_off);
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+        } else if (pref) {
+          read_frags(0, fragA[0] + nx_off, fragB[0] + nx_off);
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(g.dbg & 2)) mfma_group(ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == KS / 2 - 1 && has_next) {
+          // the stores of the previous tile's epilogue are younger than DMA(gs+1) during the first E-1 steps
+          wait_dma(issued - 2 - gs, counted && c > 0 && s < E - 1);
+          if (!counted) DG_WAITV(0);
+          __builtin_amdgcn_s_barrier();
+          if (i_left > 0) {
+            if (!(g.dbg & 1)) {
+#pragma unroll
+              for (int pc = 0; pc < IPT; ++pc) issue_piece(st_i, pc);
+            }
+            advance();
+            ++issued;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (!(dbg & 2)) compute((gs & 1) * STAGE);
+      st_c = st_n;
+      st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
-    if (!(dbg & 4)) {
+    if (!(g.dbg & 4)) {
       // ---- wave-private epilogue: TM x NQ strips of SR rows; lane (lr, lh) owns channel column lr of rows
       //      (e & 3) + 8 (e >> 2) + 4 lh of each 32 x 32 MFMA block
       const int colb = tc.nt * BN + wn * WC;   // first channel of this wave's strip
       const int n0 = tc.xt * BM;
-      long toff;                               // element offset of (tile row 0, strip column 0)
-      if (MODE == MODE_GEMM) toff = (long)n0 * p.out_sb + colb;
-      else toff = (long)tc.b * p.out_sb + ((long)tc.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + tc.px)) * p.out_sp + colb;
+      // element offset of (sample group, row Y, column n0 [+ parity], strip channel 0)
+      const long toff = (long)(tc.bt * g.NSB) * p.out_sb +
+                        ((long)tc.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + tc.px)) * p.out_sp + colb;
       char* obase = (char*)(out + toff);
       const char* abase = (const char*)((const T*)p.aux + toff);
       float csum[EPC];
@@ -313,32 +363,26 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = colb + j * 32 + lr;
-        bias[j] = (p.bias && n < p.N) ? p.bias[n % p.bias_mod] : 0.f;
+        bias[j] = p.bias ? p.bias[n % p.bias_mod] : 0.f;
       }
-      // byte offsets of this lane's chunks from the tile's wave-uniform base, and the leaky-relu mask source: all
-      // aux loads of the tile are issued up front (one exposed latency per tile, not one per strip)
-      unsigned off[TM][NQ][CPL];
-      bool ok[TM][NQ][CPL];
-      uint4 araw[TM][NQ][CPL];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+      // byte offset of this lane's chunk u of strip (i, q) from the tile's wave-uniform base
+      auto chunk_off = [&](int i, int q, int u) -> unsigned {
+        const int trow = wm * (BM / WM) + i * 32 + q * SR + u * (64 / CR) + lane / CR;
+        const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
+        return (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp + part * EPC) * ES);
+      };
+      // leaky-relu mask source, one 32-row block ahead of its use (double buffer)
+      uint4 araw[2][NQ][CPL];
+      auto load_aux = [&](int i) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int u = 0; u < CPL; ++u) {
-            const int trow = wm * (BM / WM) + i * 32 + q * SR + u * (64 / CR) + lane / CR;
-            ok[i][q][u] = true;                // N % BN == 0 (launch_dtype), so only GEMM rows past the batch drop
-            if (MODE == MODE_GEMM) {
-              ok[i][q][u] = n0 + trow < p.B;
-              off[i][q][u] = (unsigned)((trow * (int)p.out_sb + part * EPC) * ES);
-            } else {
-              off[i][q][u] = (unsigned)(((MODE == MODE_S2 ? trow : 2 * trow) * (int)p.out_sp + part * EPC) * ES);
-            }
-            if (p.epi == EPI_MASK)
-              araw[i][q][u] = ok[i][q][u] ? *(const uint4*)(abase + off[i][q][u]) : make_uint4(0, 0, 0, 0);
-          }
+          for (int u = 0; u < CPL; ++u) araw[i & 1][q][u] = *(const uint4*)(abase + chunk_off(i, q, u));
+      };
+      if (p.epi == EPI_MASK) load_aux(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        if (p.epi == EPI_MASK && i + 1 < TM) load_aux(i + 1);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -355,12 +399,13 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
           for (int u = 0; u < CPL; ++u) LDS_READ128(raw[u], rd_base + u * (64 / CR) * RS, 0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
+          float rs = 1.f;                      // per-sample weight of the bias gradient (strip rows share a sample)
+          if (want_db && p.rowscale) rs = p.rowscale[tc.bt * g.NSB + ((wm * (BM / WM) + i * 32 + q * SR) >> g.lsw)];
 #pragma unroll
           for (int u = 0; u < CPL; ++u) {
-            if (MODE == MODE_GEMM && !ok[i][q][u]) continue;
             T* v = (T*)&raw[u];
             if (p.epi == EPI_MASK) {
-              const T* av = (const T*)&araw[i][q][u];
+              const T* av = (const T*)&araw[i & 1][q][u];
 #pragma unroll
               for (int e = 0; e < EPC; ++e) {
                 const float f = (float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
@@ -369,9 +414,9 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
             }
             if (want_db) {
 #pragma unroll
-              for (int e = 0; e < EPC; ++e) csum[e] += (float)v[e];
+              for (int e = 0; e < EPC; ++e) csum[e] += (float)v[e] * rs;
             }
-            *(i32x4*)(obase + off[i][q][u]) = raw[u];
+            *(i32x4*)(obase + chunk_off(i, q, u)) = raw[u];
           }
         }
       }
@@ -381,36 +426,57 @@ __global__ __launch_bounds__(256, (Cfg<BM, BN>::OCC)) void conv_kernel(ConvP p, 
         for (int e = 0; e < EPC; ++e) {
           float v = csum[e];
           for (int d = CR; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-          if (lane < CR) atomicAdd(&s_db[wn * WC + part * EPC + e], v);
-        }
-        __syncthreads();
-        if (tid < BN && tc.nt * BN + tid < p.N) {
-          const float rs = p.rowscale ? p.rowscale[tc.b] : 1.f;
-          atomicAdd(&p.dbias[(tc.nt * BN + tid) % p.bias_mod], s_db[tid] * rs);
+          if (lane < CR) {
+            const unsigned a = sdb0 + (unsigned)(colb + part * EPC + e) * 4;
+            asm volatile("ds_add_f32 %0, %1" ::"v"(a), "v"(v) : "memory");
+          }
         }
       }
     }
     zero_acc();
     if (next_tile<MODE>(tc, tiles_n, tiles_x, rows)) nh_c = pack_htaps<MODE>(p.adj, tc.Y, p.Hc, dummy);
   }
+  if (want_db) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int n = tid; n < p.N; n += 64 * NWV) atomicAdd(&p.dbias[n % p.bias_mod], s_db[n]);
+  }
 }
 
-template <typename T, int BM, int BN, int MODE>
-int launch(const ConvP* p, hipStream_t stream) {
-  const int tiles_n = (p->N + BN - 1) / BN;
-  int tiles_x = 1;
-  long tiles_m;
-  if (MODE == MODE_S2) { tiles_x = p->Wc / BM; tiles_m = (long)p->B * p->Hc * tiles_x; }
-  else if (MODE == MODE_UP) { tiles_x = p->Wc / BM; tiles_m = (long)p->B * 2 * p->Hc * 2 * tiles_x; }
-  else tiles_m = (p->B + BM - 1) / BM;
-  const long ntiles = tiles_m * tiles_n;
-  if (ntiles <= 0 || ntiles > 0x7fffffffL) return DG_EINVAL;
+// geometry of a launch with BM x BN tiles; false when the layer does not tile that way
+template <int BM, int BN>
+bool make_geo(const ConvP* p, Geo& g) {
+  if (p->N % BN != 0) return false;
+  const int Wm = p->Wc;                        // width of an output row (S2) / of one column parity of it (UP)
+  if (Wm >= BM) {
+    if (Wm % BM != 0) return false;
+    g.SW = BM; g.NSB = 1; g.tiles_x = Wm / BM;
+  } else {
+    if (BM % Wm != 0 || Wm < 64 || (Wm & (Wm - 1)) != 0) return false;
+    g.NSB = BM / Wm;
+    if (p->B % g.NSB != 0) return false;
+    g.SW = Wm; g.tiles_x = 1;
+  }
+  g.lsw = 0;
+  while ((1 << g.lsw) < g.SW) ++g.lsw;
+  g.tiles_n = p->N / BN;
+  const long rows = p->mode == MODE_S2 ? p->Hc : 4L * p->Hc;  // UP: 2 Hc rows x 2 parities
+  const long nt = (long)(p->B / g.NSB) * rows * g.tiles_x * g.tiles_n;
+  if (nt <= 0 || nt > 0x7fffffffL) return false;
+  g.ntiles = (int)nt;
+  return true;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int SB, int NS, int MODE>
+int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
+  Geo g = g0;
   static int resident = 0;                     // workgroups the device holds at once
   if (!resident) {
     int occ = 0, dev = 0, cus = 0;
     HIP_CHECK_RET(hipGetDevice(&dev));
     HIP_CHECK_RET(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_CHECK_RET(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_kernel<T, BM, BN, MODE>, 256, 0));
+    HIP_CHECK_RET(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_kernel<T, BM, BN, WM, WN, SB, NS, MODE>,
+                                                               64 * WM * WN, 0));
     if (occ < 1) occ = 1;
     resident = occ * cus;
     const char* e = getenv("DG_CONV_WGS");
@@ -418,27 +484,41 @@ int launch(const ConvP* p, hipStream_t stream) {
   }
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-  const int G = (int)(ntiles < resident ? ntiles : resident);
-  conv_kernel<T, BM, BN, MODE><<<(unsigned)G, 256, 0, stream>>>(*p, tiles_n, tiles_x, (int)ntiles, dbg);
+  g.dbg = dbg;
+  const int G = g.ntiles < resident ? g.ntiles : resident;
+  conv_kernel<T, BM, BN, WM, WN, SB, NS, MODE><<<(unsigned)G, 64 * WM * WN, 0, stream>>>(*p, g);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
 
+// which tile the persistent kernel uses for this layer: 0 none (caller falls back to the 128-wide one-tile kernel),
+// 1 = 256 x 256, 2 = 256 x 128.  `auto_rule`: apply the measured selection (scripts/bench_conv.py, MI355X, bf16):
+// large tiles only pay when every CU gets a tile, and 256 x 128 only where the epilogue reads the leaky-relu
+// mask source (there the up-front aux prefetch wins; the linear / lrelu layers at N = 128 were 7-12 % slower).
+inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
+  if (p->mode != MODE_S2 && p->mode != MODE_UP) return 0;
+  const int es = p->in_dtype == DG_BF16 ? 2 : 4;
+  if (p->K % (64 / es) != 0) return 0;
+  if (p->dbias && (p->N > 512 || p->bias_mod < p->N)) return 0;
+  const int min_tiles = auto_rule ? 256 : 1;
+  if (make_geo<256, 256>(p, g) && g.ntiles >= min_tiles) return 1;
+  if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles && (!auto_rule || p->epi == EPI_MASK)) return 2;
+  return 0;
+}
+
 template <typename T>
-int launch_dtype(const ConvP* p, hipStream_t stream) {
-  const bool n128 = p->N % 128 == 0;
-  if (p->mode == MODE_GEMM) return n128 ? launch<T, 64, 128, MODE_GEMM>(p, stream) : launch<T, 64, 64, MODE_GEMM>(p, stream);
-  const bool m128 = p->Wc % 128 == 0;
-  if (p->mode == MODE_S2) {
-    if (m128 && n128) return launch<T, 128, 128, MODE_S2>(p, stream);
-    if (m128) return launch<T, 128, 64, MODE_S2>(p, stream);
-    if (n128) return launch<T, 64, 128, MODE_S2>(p, stream);
-    return launch<T, 64, 64, MODE_S2>(p, stream);
+int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
+  Geo g;
+  const int which = pick(p, g, auto_rule);
+  if (which == 1) {
+    return p->mode == MODE_S2 ? launch<T, 256, 256, 2, 4, 64, 4, MODE_S2>(p, g, stream)
+                              : launch<T, 256, 256, 2, 4, 64, 4, MODE_UP>(p, g, stream);
   }
-  if (m128 && n128) return launch<T, 128, 128, MODE_UP>(p, stream);
-  if (m128) return launch<T, 128, 64, MODE_UP>(p, stream);
-  if (n128) return launch<T, 64, 128, MODE_UP>(p, stream);
-  return launch<T, 64, 64, MODE_UP>(p, stream);
+  if (which == 2) {
+    return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 64, 4, MODE_S2>(p, g, stream)
+                              : launch<T, 256, 128, 4, 2, 64, 4, MODE_UP>(p, g, stream);
+  }
+  return DG_EUNSUPPORTED;
 }
 
 }  // namespace persist

@@ -86,7 +86,8 @@ typedef struct DgWgrad {
  *   their autograd backward-data passes (loss.backward() at trainers/dcgan_amp.py:235,309 and
  *   torch.autograd.grad(create_graph=True) at :218-223), and the R1 tangent pass (double backward, :229-235).
  * force: 0 = pick (MFMA implicit GEMM when the shape allows, else the thin LDS/VALU kernel for <=4-channel sides,
- * else the general direct kernel), 1 = direct, 2 = MFMA or error, 3 = thin or error.
+ * else the general direct kernel), 1 = direct, 2 = MFMA or error, 3 = thin or error, 4 = the large-tile (256-row)
+ * persistent MFMA kernel or error (what 0 / 2 pick for layers that fill the chip with such tiles).
  */
 int dg_conv(const DgConv* p, int force, void* stream);
 int dg_conv_mfma_supported(const DgConv* p);
