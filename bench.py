@@ -136,6 +136,17 @@ def cpu_baseline(args, arch):
                       f"CPU ops, {t:.2f} s"}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+    collected from inside the process; profiles/README.md says how the file was made).  None if not measured."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return round(json.load(f)[kernel]["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,8 +203,6 @@ def main():
     fl, f_g, f_d = flops_per_sample(args.shape, arch, args.gp)
     out["step_flops_fraction_of_mfma_peak"] = round(fl * args.batch * steps_s / 1e12 / PEAK_TFLOPS[args.precision], 4)
 
-    if rank == 0 and not args.no_roofline:
-        pass
     if not args.no_roofline:
         fam = roofline_pass(tr)
         if rank == 0 and fam:
@@ -202,7 +211,9 @@ def main():
             tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 2),
                                "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_TFLOPS[args.precision], 4), "traffic": None,
+                               "frac": round(tf / PEAK_TFLOPS[args.precision], 4), "traffic": pmc_traffic(name),
+                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                               "algorithmic_bytes_per_launch": round(f["bytes"] / f["n"]),
                                "launches": f["n"], "avg_launch_us": round(1e3 * f["ms"] / f["n"], 2)}
             out["kernel_families"] = {
                 k: {"ms_per_step": round(v["ms"] / 2, 3), "launches_per_step": v["n"] // 2,

@@ -1,14 +1,41 @@
-"""Aggregate a rocprofv3 --pmc counter_collection.csv per kernel family (short name) and counter."""
-import csv, sys, collections, re
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-for path in sys.argv[1:]:
+"""Aggregate rocprofv3 --pmc counter_collection.csv files per kernel function and counter.
+usage: python scripts/pmc_summary.py out.json a_counter_collection.csv [b_counter_collection.csv ...]
+Prints a table and writes {kernel: {counter: {"sum":, "dispatches":, "per_dispatch":}}} to out.json."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    """function identifier of an Itanium-mangled or plain kernel name (template arguments dropped)"""
+    if not name.startswith("_Z"):
+        return re.split(r"[<(]", name.replace("void ", ""))[0].strip()[:60]
+    s, parts = name[2:], []
+    if s.startswith("N"):
+        s = s[1:]
+    while s and s[0].isdigit():
+        m = re.match(r"(\d+)", s)
+        n = int(m.group(1))
+        parts.append(s[m.end():m.end() + n])
+        s = s[m.end() + n:]
+    return "::".join(p for p in parts if not p.startswith("_GLOBAL__N"))[:60]
+
+
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for path in sys.argv[2:]:
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            n = r["Kernel_Name"]
-            if not any(t in n for t in ("conv_kernel", "conv_mfma_kernel", "wgrad_mfma_kernel")): continue
-            k = n.split("Ev")[0][-60:]
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[(k, r["Counter_Name"])] += 1
+out = {}
 for k in sorted(agg):
-    print(k)
+    out[k] = {}
     for c, v in sorted(agg[k].items()):
-        print(f"   {c:32s} {v:.4g}  ({cnt[(k,c)]} dispatches)")
+        n = cnt[(k, c)]
+        out[k][c] = {"sum": v, "dispatches": n, "per_dispatch": v / n}
+        print(f"{k:44s} {c:28s} sum {v:.5g}  n {n}  per-dispatch {v / n:.5g}")
+json.dump(out, open(sys.argv[1], "w"), indent=1)
