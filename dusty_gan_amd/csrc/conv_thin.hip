@@ -414,6 +414,120 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// thin_wgrad_up_mfma (bf16, Ci == 64, Co <= 2, gradient pixel-major [fine pixel][2]): Head's weight gradient on the
+// matrix cores.   dW[(ky,kx,co) = 32][ci = 64] = sum over input pixels (r, xi) of  Bm[(ky,kx,co)][r, xi] * a[r, xi][ci]
+// The sum runs over INPUT pixels, so the 64-channel operand `a` is tap-independent and is read exactly once; the tap
+// structure sits in the thin operand: for input row r a block builds the 32 "im2col" rows
+//     Bm[(ky,kx,co)][xi] = g[fine row 2 (r - d_ky) + par_ky][fine col 2 ((xi - d_kx) mod Wc) + par_kx][co]
+// in LDS (zero where r - d_ky leaves the grid; the two reflected rows of models/ops/common.py:9-20 add their mirror
+// row: r = 1 takes fine row 0 through ky = 3, r = Hc-2 takes fine row 2Hc-1 through ky = 0 - the inverse of
+// dg_wgrad1d(1, ...)).  Each wave then walks its share of the row in 16-pixel K steps: Bm fragment by one
+// ds_read_b128, the `a` fragment from a wave-private [16][64] tile through the transposing read.  Waves are reduced
+// through LDS, then one fp32 atomic per element per block.
+#define WGU_ROWS_PB 2
+
+__global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Wc = p.Wc, Wf = 2 * p.Wc;
+  const int RSB = Wc * 2 + 16;                                       // im2col row stride (bytes), +16 B: bank spread
+  unsigned char* s_b = smem;                                         // [32 n][RSB]
+  unsigned char* s_t = smem + (size_t)32 * RSB;                      // [4 waves][16 px][144 B]
+  float* s_red = (float*)smem;                                       // [4 waves][32][64] fp32 (aliases s_b at the end)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long u0 = (long)blockIdx.x * WGU_ROWS_PB;
+  const bf16* A = (const bf16*)p.a;
+  const unsigned* G = (const unsigned*)p.g;                          // one dword = (co0, co1) of a fine pixel
+  const int lr = lane & 31, lh = lane >> 5;
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3; // transposing-read roles (see wgrad_mfma.hip)
+  unsigned char* my_t = s_t + wave * 16 * 144;
+  tw_f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int nchunk = Wc / 8;
+  const int b = (int)(u0 / p.Hc);
+  for (long u = u0; u < u0 + WGU_ROWS_PB; ++u) {
+    const int r = (int)(u % p.Hc);
+    __syncthreads();
+    // ---- im2col rows of input row r: task = (tap, chunk of 8 input pixels), both co at once
+    for (int t = tid; t < 16 * nchunk; t += 256) {
+      const int tap = t / nchunk, xi0 = (t % nchunk) * 8;
+      const int ky = tap >> 2, kx = tap & 3;
+      const int dky = ky == 0 ? 1 : (ky == 3 ? -1 : 0), pky = (ky == 0 || ky == 2) ? 1 : 0;
+      const int dkx = kx == 0 ? 1 : (kx == 3 ? -1 : 0), pkx = (kx == 0 || kx == 2) ? 1 : 0;
+      const int m = r - dky;
+      int fr0 = (m >= 0 && m < p.Hc) ? 2 * m + pky : -1;             // fine row of the regular term
+      int fr1 = -1;                                                  // mirror term of the reflected rows
+      if (ky == 3 && r == 1) fr1 = 0;
+      if (ky == 0 && r == p.Hc - 2) fr1 = 2 * p.Hc - 1;
+      if (fr0 < 0) { fr0 = fr1; fr1 = -1; }
+      unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};           // co0 / co1, 8 bf16 each
+      if (fr0 >= 0) {
+        const unsigned* g0 = G + (long)b * (p.g_sb / 2) + (long)fr0 * Wf;
+        const unsigned* g1 = fr1 >= 0 ? G + (long)b * (p.g_sb / 2) + (long)fr1 * Wf : nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int x = xi0 + j - dkx;
+          if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
+          unsigned v = g0[2 * x + pkx];
+          if (g1) {                                                  // sum of two gradient rows, rounded once to bf16
+            const unsigned w2 = g1[2 * x + pkx];
+            const float s0 = __builtin_bit_cast(float, v << 16) + __builtin_bit_cast(float, w2 << 16);
+            const float s1 = __builtin_bit_cast(float, v & 0xffff0000u) + __builtin_bit_cast(float, w2 & 0xffff0000u);
+            const bf16 h0 = (bf16)s0, h1 = (bf16)s1;
+            v = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+          }
+          const unsigned c0 = v & 0xffffu, c1 = v >> 16;
+          if (j & 1) { lo[j >> 1] |= c0 << 16; hi[j >> 1] |= c1 << 16; }
+          else { lo[j >> 1] = c0; hi[j >> 1] = c1; }
+        }
+      }
+      *(uint4*)(s_b + (size_t)(tap * 2 + 0) * RSB + xi0 * 2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      *(uint4*)(s_b + (size_t)(tap * 2 + 1) * RSB + xi0 * 2) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    }
+    __syncthreads();
+    const bf16* arow = A + (long)b * p.a_sb + (long)r * Wc * p.a_sp;
+    for (int xb = wave * 16; xb < Wc; xb += 64) {
+      // stage a[xb .. xb+15][0..63] (128 B per pixel) into this wave's tile: 2 x (64 lanes x 16 B)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int c = lane + 64 * v, row = c >> 3, part = c & 7;
+        *(uint4*)(my_t + row * 144 + part * 16) = *(const uint4*)(arow + (long)(xb + row) * p.a_sp + part * 8);
+      }
+      const tw_bf16x8 fa = *(const tw_bf16x8*)(s_b + (size_t)lr * RSB + (xb + 8 * lh) * 2);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const unsigned char* ptr = my_t + (8 * kh + q) * 144 + (jt * 32 + 16 * cb + 4 * pp) * 2;
+        const tw_bf16x4 l4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tw_bf16x4 __attribute__((address_space(3)))*)(ptr));
+        const tw_bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tw_bf16x4 __attribute__((address_space(3)))*)(ptr + 4 * 144));
+        const tw_bf16x8 fg = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fg, acc[jt], 0, 0, 0);
+      }
+    }
+  }
+  // reduce the 4 waves, then one atomic per element.  D layout: col = lane & 31 (ci), row = (e&3)+8(e>>2)+4 lh (n)
+  const float sc = p.scale * (p.rowscale ? p.rowscale[b] : 1.f);
+  __syncthreads();
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int nrow = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      s_red[(wave * 32 + nrow) * 64 + jt * 32 + lr] = acc[jt][e];
+    }
+  __syncthreads();
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int n = i >> 6, ci = i & 63, tap = n >> 1, co = n & 1;
+    if (co >= p.Co) continue;
+    const float v = s_red[i] + s_red[2048 + i] + s_red[4096 + i] + s_red[6144 + i];
+    atomicAdd(&p.dw[((long)tap * p.Ci + ci) * p.Co + co], v * sc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 int dg_conv_s2_mfma_supported(const ConvP* p);
 int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s);
 
@@ -476,6 +590,17 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
     const size_t lds = (size_t)4 * (2 * p->Wc + 2) * 4 + 4 * 16 * 144 + 4 * 32 * 64 * 4;
     if (lds <= 64 * 1024) {
       thin_wgrad_down_mfma_kernel<<<(unsigned)(units / WG_ROWS_PB), 256, lds, s>>>(*p);
+      HIP_CHECK_RET(hipGetLastError());
+      return DG_OK;
+    }
+  }
+  if (p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->Co <= 2 && p->a_sc == 1 &&
+      p->a_sp == 64 && p->g_sc == 1 && p->g_sp == 2 && p->g_sb % 2 == 0 && p->Wc % 64 == 0 && p->Hc >= 2 &&
+      p->Hc % WGU_ROWS_PB == 0) {
+    size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
+    if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
+    if (lds <= 64 * 1024) {
+      thin_wgrad_up_mfma_kernel<<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p);
       HIP_CHECK_RET(hipGetLastError());
       return DG_OK;
     }

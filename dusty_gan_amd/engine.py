@@ -340,13 +340,15 @@ class GEngine:
         hc, wc = self.grid[3]
         pl = (c.nheads * self.HW, 1, self.HW)
         # head weight gradient and backward-data (gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad)
-        o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw, pl,
-                st.fptr("head_w", st.grad), 1.0, g_dt=L.DG_F32)
-        if self.draw_pm is not None:  # bf16, <= 2 heads: pixel-major copy feeds the direct-fragment MFMA kernel
+        if self.draw_pm is not None:  # bf16, <= 2 heads: the pixel-major copy feeds the two thin MFMA kernels
+            o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw_pm,
+                    (self.HW * 2, 2, 1), st.fptr("head_w", st.grad), 1.0)
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw_pm, (self.HW * 2, 2, 1), self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
                    dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3])
         else:
+            o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw, pl,
+                    st.fptr("head_w", st.grad), 1.0, g_dt=L.DG_F32)
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw, pl, self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
                    dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], in_dt=L.DG_F32)

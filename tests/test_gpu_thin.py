@@ -172,3 +172,35 @@ def test_head_bwd_data_pixel_major_mfma(L, nh):
     torch.cuda.synchronize()
     assert rel_l2(from_nhwc(dp.float().cpu(), B, C0, Hc, Wc), ref) < 1e-2
     assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < 2e-2
+
+
+@pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2)])
+def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
+    """Head weight gradient through thin_wgrad_up_mfma (input-pixel-indexed im2col of the pixel-major bf16 head
+    gradient, incl. the mirror terms of the two reflected rows) against autograd of the reference op, with per-sample
+    weights."""
+    from dusty_gan_amd.engine import Ops
+    g = torch.Generator().manual_seed(70 + nh + Hc)
+    C0 = 64
+    dtype = torch.bfloat16
+    x = torch.randn(B, C0, Hc, Wc, generator=g).bfloat16().float()
+    ws = [torch.randn(C0, 1, 4, 4, generator=g).requires_grad_()] + \
+         ([torch.randn(C0, nh - 1, 4, 4, generator=g).requires_grad_()] if nh > 1 else [])
+    y = torch.cat([O.head(x, w, None, True) * math.sqrt(w.shape[1] * 16) for w in ws], dim=1)  # unscaled linear map
+    gy = torch.randn(y.shape, generator=g).bfloat16().float()
+    rs = torch.rand(B, generator=g) + 0.5
+    gws = torch.autograd.grad(y, ws, gy * rs.view(B, 1, 1, 1))
+    ref = torch.cat(list(gws), dim=1)  # [ci][co][ky][kx]
+    o = Ops(dtype)
+    o.force = 3
+    HW = 4 * Hc * Wc
+    draw_pm = torch.full((B, 2 * Hc, 2 * Wc, 2), 7.0)  # the unused second channel must not leak into channel 0
+    draw_pm[..., :nh] = gy.permute(0, 2, 3, 1)
+    draw_pm = draw_pm.to(DEV, dtype).contiguous()
+    xd = nhwc(x).to(DEV, dtype)
+    dw = torch.zeros(16, C0, nh, device=DEV)
+    o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw_pm, (HW * 2, 2, 1), dw.data_ptr(), 1.0,
+            rowscale=rs.to(DEV))
+    torch.cuda.synchronize()
+    got = dw.cpu().view(4, 4, C0, nh).permute(2, 3, 0, 1)
+    assert rel_l2(got, ref) < 1e-2
