@@ -49,8 +49,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
   const T* A = (const T*)p.a;
   const T* G = (const T*)p.g;
 
-  uint4 ra[UA], rg[UG];
-  auto load_tiles = [&](long u, int xc) {
+  // two register sets: the tiles of chunk j travel in set j & 1 and are issued TWO chunks before they are stored to
+  // LDS (the kernel is bound by the exposed global-load latency of its short chunks, not by bytes or instructions)
+  uint4 ra[2][UA], rg[2][UG];
+  auto load_tiles = [&](uint4 (&ra)[UA], uint4 (&rg)[UG], long u, int xc) {
     const int b = (int)(u / p.Hc), m = (int)(u % p.Hc);
     int rowa = 0, rowg = 0;
     if (p.wmode != 2) dg_wgrad1d(p.wmode, 0, m, p.Hc, ky, rowa, rowg);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
       rg[v] = x < p.Wc ? *(const uint4*)(gb + ((long)rowg * Wg + cg) * p.g_sp + part * EPC) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](const uint4 (&ra)[UA], const uint4 (&rg)[UG]) {
 #pragma unroll
     for (int v = 0; v < UA; ++v) {
       const int c = tid + 256 * v;
@@ -106,16 +108,28 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
     if (fabsf(cur_rs) < 1e-30f) cur_rs = cur_rs < 0.f ? -1e-30f : 1e-30f;
   }
   if (nchunks > 0) {
-    long u = u0;
+    long lu = u0;                              // loader position: the next chunk to ISSUE
+    int lxc = 0;
+    long issued = 0;
+    auto issue = [&](uint4 (&qa)[UA], uint4 (&qg)[UG]) {
+      if (issued < nchunks) {
+        load_tiles(qa, qg, lu, lxc);
+        if (++lxc == chunks_per_row) { lxc = 0; ++lu; }
+      }
+      ++issued;
+    };
+    long u = u0;                               // compute position
     int xc = 0;
-    load_tiles(u, xc);
-    store_tiles();
+    issue(ra[0], rg[0]);                       // chunk 0
+    store_tiles(ra[0], rg[0]);
+    issue(ra[1], rg[1]);                       // chunk 1
+    issue(ra[0], rg[0]);                       // chunk 2
     __syncthreads();
-    for (long s = 0; s < nchunks; ++s) {
+    auto one_chunk = [&](long s, uint4 (&na)[UA], uint4 (&ng)[UG]) {
+      // LDS holds chunk s; (na, ng) hold chunk s+1 (in flight or landed) and are refilled with chunk s+3
       const int cur_b = (int)(u / p.Hc);
       if (++xc == chunks_per_row) { xc = 0; ++u; }
       const bool more = s + 1 < nchunks;
-      if (more) load_tiles(u, xc);
       if constexpr (ES == 2) {
         // lane -> (row block q, column quad pp) inside its 16-lane group; group -> (k half, column block)
         const int g16 = lane >> 4, i16 = lane & 15;
@@ -161,9 +175,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
         }
       }
       if (p.rowscale && more) {
-        // Per-sample weights without a second accumulator set: the running sum is kept DIVIDED by the current
-        // sample's weight, so MFMAs add unscaled products; on a sample change it is rescaled by rs_old / rs_new
-        // (fp32 multiply: same relative error as summing rs_b * acc_b), and multiplied by the last weight at the end.
         const int next_b = (int)(u / p.Hc);
         if (next_b != cur_b) {
           float rn = p.rowscale[next_b];
@@ -178,9 +189,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
       }
       __syncthreads();
       if (more) {
-        store_tiles();
+        store_tiles(na, ng);
+        issue(na, ng);
         __syncthreads();
       }
+    };
+    for (long s = 0; s < nchunks; s += 2) {
+      one_chunk(s, ra[1], rg[1]);
+      if (s + 1 < nchunks) one_chunk(s + 1, ra[0], rg[0]);
     }
   }
 
