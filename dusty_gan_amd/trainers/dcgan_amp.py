@@ -283,6 +283,7 @@ class Trainer:
         import os
         self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
         self._graph, self._eager_steps = None, 0
+        self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
 
     # ------------------------------------------------------------------ helpers
     def sample_latents(self, B):
@@ -326,10 +327,36 @@ class Trainer:
         out["aug"] = [DiffAugment.params_to_device(rp, self.device) for rp in rand["aug"]]
         return out
 
+    def _coll(self, fn):
+        """Run a collective (or any host-side call that cannot be captured) at this point of the launch sequence.
+        Eager: call it.  While the step is being captured for replay: close the current hipGraph segment, remember
+        `fn`, open the next segment - the replay alternates graph launches and these calls in the same order.
+        `fn` must only touch tensors whose storage is the same on every step (flat buffers, preallocated outputs)."""
+        if self._cap is None:
+            fn()
+            return
+        self._cap_close()
+        self._cap.append(fn)
+        self._cap_open()
+
+    def _cap_open(self):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while this thread captures
+        ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self.world > 1 else "global")
+        ctx.__enter__()
+        self._cap_cur = (g, ctx)
+
+    def _cap_close(self):
+        g, ctx = self._cap_cur
+        ctx.__exit__(None, None, None)
+        self._cap.append(g)
+        self._cap_cur = None
+
     def _allreduce(self, store):
         """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
-        _, gscale = D_.allreduce_grads(store.grad)
-        return gscale
+        if self.world > 1:
+            self._coll(lambda: D_.allreduce_grads(store.grad))
+        return 1.0 / self.world
 
     # ------------------------------------------------------------------ D phase (reference :171-238)
     def optimize_D(self, reals=None, rands=None):
@@ -432,11 +459,16 @@ class Trainer:
             # (z [B,nz] and dL/da0 [B,h0*w0*C], 8.4 MB per rank in bf16) and forms the GLOBAL-batch gradient locally:
             # same sum, 3.5x less xGMI traffic, and the 268 MB never cross a link.
             geng = self._mb[0]["geng"]
-            zg = D_.all_gather_cat(geng.zT)
-            dg = D_.all_gather_cat(geng.dp[0])
+            if self._gather is None or self._gather[0].numel() != self.world * geng.zT.numel():
+                self._gather = (geng.zT.new_empty(self.world * geng.zT.numel()),
+                                geng.dp[0].new_empty(self.world * geng.dp[0].numel()))
+            zg, dg = self._gather
+            zT, dp0 = geng.zT, geng.dp[0]
+            self._coll(lambda: (D_.all_gather_into(zg, zT), D_.all_gather_into(dg, dp0)))
             geng.proj_wgrad(Gst, dg, zg, self.world * B)
-            tail = Gst.seg["proj_b"].off
-            _, gscale = D_.allreduce_grads(Gst.grad[tail:])
+            tail = Gst.grad[Gst.seg["proj_b"].off:]
+            self._coll(lambda: D_.allreduce_grads(tail))
+            gscale = 1.0 / self.world
         else:
             gscale = self._allreduce(Gst)
         # Adam + EMA fused (:312, :316)
@@ -465,11 +497,11 @@ class Trainer:
 
     def _graph_eligible(self, reals, rands):
         from .. import engine as E
-        return (self.world == 1 and reals is None and rands is None and self.use_graph and E.PROFILE is None
+        return (reals is None and rands is None and self.use_graph and E.PROFILE is None
                 and isinstance(getattr(self, "dataset", None), SyntheticLiDAR))
 
     def _step_graph(self):
-        """hipGraph replay of the whole iteration (single-GPU, device-resident data): the ~180 kernel launches of a
+        """hipGraph replay of the whole iteration (device-resident data): the ~180 kernel launches of a
         step cost ~5 ms of Python/ctypes time when issued one by one, more than the kernels themselves; captured once
         they replay from one host call.  Everything that changes between steps lives in device memory (Philox
         counters, Adam step counts, the input batch in a static buffer), so replays draw fresh randomness."""
@@ -481,16 +513,43 @@ class Trainer:
             self._g_pol = batch["depth"].to(self.device).clone()
             self._g_mask = batch["mask"].to(self.device).clone()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # One hipGraph per stretch between collectives (world > 1: gradient all-reduce of D, operand gather and
+            # tail all-reduce of G); a single graph when world == 1.  The segments share one memory pool, so a
+            # workspace allocated while capturing one segment stays valid in the next.
+            self._cap, self._cap_pool = [], torch.cuda.graph_pool_handle()
+            counts = (self.optim_D.step_count, self.optim_G.step_count)
+            try:
+                self._cap_open()
                 self._g_out = self._step_eager(reals=[self.fetch_reals({"depth": self._g_pol, "mask": self._g_mask})])
-            self._graph = g
+                self._cap_close()
+            except BaseException:
+                if self._cap_cur is not None:
+                    try:
+                        self._cap_cur[1].__exit__(None, None, None)
+                    except BaseException:
+                        pass
+                self._cap, self._cap_cur = None, None
+                if self.world == 1:
+                    raise
+                # multi-rank: a runtime that refuses the capture must not take the job down - nothing was executed,
+                # so restore the host mirrors and keep launching eagerly
+                import warnings
+                warnings.warn("hipGraph capture of the training step failed; continuing with eager launches")
+                self.optim_D.step_count, self.optim_G.step_count = counts
+                self.use_graph = False
+                self._mb = []
+                return self._step_eager(reals=[self.fetch_reals(batch)])
+            self._graph, self._cap = self._cap, None
             # the capture did not execute anything, but the host mirrors of the Adam step counts advanced once
             self.optim_D.step_count -= 1
             self.optim_G.step_count -= 1
         self._g_pol.copy_(batch["depth"], non_blocking=True)
         self._g_mask.copy_(batch["mask"], non_blocking=True)
-        self._graph.replay()
+        for item in self._graph:
+            if isinstance(item, torch.cuda.CUDAGraph):
+                item.replay()
+            else:
+                item()
         self.optim_D.step_count += 1
         self.optim_G.step_count += 1
         return self._g_out.clone()

@@ -67,3 +67,18 @@ def all_gather_cat(t):
     else:
         dist.all_gather(list(out.view(w, -1).unbind(0)), raw)
     return out.view(t.dtype)
+
+
+def all_gather_into(out, t):
+    """all-gather of a flat device tensor into the preallocated `out` (world * t.numel() elements, same dtype); the
+    storage of `out` is reused on every step so the consumers can sit inside a captured hipGraph"""
+    w = world_size()
+    raw = t.contiguous().view(torch.uint8)
+    dst = out.view(torch.uint8)
+    if w == 1:
+        dst.copy_(raw)
+    elif dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(dst, raw)
+    else:
+        dist.all_gather(list(dst.view(w, -1).unbind(0)), raw)
+    return out

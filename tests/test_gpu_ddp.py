@@ -85,3 +85,36 @@ def test_two_ranks_on_one_gpu_match_single_process():
             for k, v in s_ref.items():
                 assert abs(s_got[k] - v) < 1e-4 * max(1.0, abs(v)), k
     assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
+
+
+def graph_worker(rank, world, init_file, out_dir, use_graph):
+    from tests.test_gpu_step import make_trainer
+    os.environ["DUSTY_GAN_GRAPH"] = "1" if use_graph else "0"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.manual_seed(300)  # same seed on both ranks: same initial nets, same device RNG streams
+    tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
+    scal = [dict(tr.step(i).items()) for i in range(5)]
+    segs = 0 if tr._graph is None else sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
+    torch.save({"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": scal,
+                "segs": segs}, os.path.join(out_dir, f"g{int(use_graph)}_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_segmented_graph_matches_eager():
+    """world > 1: the step is replayed as hipGraph segments with the collectives (D gradient all-reduce, Proj operand
+    gather, G tail all-reduce) called between them; 5 iterations must train exactly like the eager launch sequence."""
+    res = {}
+    for use_graph in (True, False):
+        with tempfile.TemporaryDirectory() as td:
+            mp.spawn(graph_worker, args=(2, os.path.join(td, "init"), td, use_graph), nprocs=2, join=True)
+            res[use_graph] = [torch.load(os.path.join(td, f"g{int(use_graph)}_r{r}.pt")) for r in range(2)]
+    assert res[True][0]["segs"] == 4 and res[False][0]["segs"] == 0  # 3 collective points -> 4 graph segments
+    for r in range(2):
+        a, b = res[True][r], res[False][r]
+        for k in ("G", "D", "E"):
+            assert rel_l2(a[k], b[k]) < 1e-5, k
+        for x, y in zip(a["scal"], b["scal"]):
+            for k in x:
+                assert abs(x[k] - y[k]) < 1e-4 * max(1.0, abs(y[k])), k
+    assert torch.equal(res[True][0]["G"], res[True][1]["G"])
