@@ -154,8 +154,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU over RCCL ("nccl" on ROCm).  DUSTY_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on
+        # a single-GPU box (ranks share the device, buffers travel through the host) - a functional check, not a number.
+        backend = os.environ.get("DUSTY_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     tr, arch = make_trainer(args, rank, local_rank, world)

@@ -284,6 +284,7 @@ class Trainer:
         self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
         self._graph, self._eager_steps = None, 0
         self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
+        self._force_seg = os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"  # debug: split the graph at world == 1 too
 
     # ------------------------------------------------------------------ helpers
     def sample_latents(self, B):
@@ -356,6 +357,8 @@ class Trainer:
         """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
         if self.world > 1:
             self._coll(lambda: D_.allreduce_grads(store.grad))
+        elif self._force_seg:
+            self._coll(lambda: None)
         return 1.0 / self.world
 
     # ------------------------------------------------------------------ D phase (reference :171-238)
@@ -433,7 +436,7 @@ class Trainer:
         Gb, D = _backbone(self.G), self.D
         Gst, Dst = Gb.store, D.store
         self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
-        gather_proj = self.world > 1 and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
+        gather_proj = (self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
         deng = D.engine()
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -496,7 +499,14 @@ class Trainer:
         return scal if "gp" in self.criterion else torch.cat((scal[:3], scal[4:5]))
 
     def _graph_eligible(self, reals, rands):
+        import os
         from .. import engine as E
+        # world > 1: the segmented replay (collectives between hipGraph segments) is opt-in (DUSTY_GAN_GRAPH_DDP=1).  It
+        # matches the eager launches in tests/test_gpu_ddp.py, but two gloo ranks sharing one GPU at the benchmark's
+        # size produced garbage after a host-side stream synchronize in some runs (scripts/debug_ddp_graph.py) and the
+        # RCCL configuration cannot be validated on a one-GPU box, so multi-rank runs launch eagerly by default.
+        if self.world > 1 and os.environ.get("DUSTY_GAN_GRAPH_DDP", "0") != "1":
+            return False
         return (reals is None and rands is None and self.use_graph and E.PROFILE is None
                 and isinstance(getattr(self, "dataset", None), SyntheticLiDAR))
 

@@ -90,6 +90,7 @@ def test_two_ranks_on_one_gpu_match_single_process():
 def graph_worker(rank, world, init_file, out_dir, use_graph):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH"] = "1" if use_graph else "0"
+    os.environ["DUSTY_GAN_GRAPH_DDP"] = "1"  # the segmented replay is opt-in for world > 1
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     torch.manual_seed(300)  # same seed on both ranks: same initial nets, same device RNG streams
     tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
@@ -102,7 +103,7 @@ def graph_worker(rank, world, init_file, out_dir, use_graph):
 
 
 def test_two_ranks_segmented_graph_matches_eager():
-    """world > 1: the step is replayed as hipGraph segments with the collectives (D gradient all-reduce, Proj operand
+    """world > 1 (opt-in, DUSTY_GAN_GRAPH_DDP=1): the step is replayed as hipGraph segments with the collectives (D gradient all-reduce, Proj operand
     gather, G tail all-reduce) called between them; 5 iterations must train exactly like the eager launch sequence."""
     res = {}
     for use_graph in (True, False):
