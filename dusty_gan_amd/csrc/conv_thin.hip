@@ -10,6 +10,8 @@
 // the reflect / reflect-adjoint tap list is uniform, and writes whole 128-B channel rows per pixel.
 #include "common.h"
 
+#include <stdlib.h>
+
 // ---------------------------------------------------------------------------------------------------------
 // thin_smallk: block = (b, coarse row Y, 64 output columns); thread = 4 pixels x 4 channels (N == 64 per pass).
 #define SK_PX 64
@@ -528,6 +530,129 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// thin_up_mfma (bf16 in, K = 64 input channels -> N <= 4 output channels, MODE_UP): Head forward and Down1
+// backward-data on the matrix cores (models/gans/dcgan_eqlr.py:29-47 Head, :75-82 Down's input gradient).
+// One coarse input pixel produces 2 x 2 fine outputs x N channels = at most 16 values, each a dot product over a
+// subset of the 3 x 3 input neighbourhood x 64 channels.  That is a GEMM with
+//   M' = 16 rows (py, n, px),   K = (row offset dr, column offset dc, ci) = 9 x 64,   N' = coarse pixels,
+// run as v_mfma_f32_16x16x32_bf16 (18 per 16 pixels).  The weight operand - zero where a parity does not use a
+// neighbour, summed where the reflected rows of models/ops/common.py:9-20 fold two taps onto one source row,
+// adjoint extras included - only depends on the boundary class of the image row (interior / first / last): a prep
+// launch builds the 3 x 18 fragments from dg_tap1d into a device-global table and every wave keeps its class's 18
+// fragments in 72 VGPRs.  The activation rows m-1, m, m+1 of a 64-pixel tile are staged in LDS with full-line
+// loads (the layout thin_smalln uses) and read back as B fragments, one ds_read_b128 per MFMA.
+// Output row m' = (py * N + n) * 2 + px, so a lane's accumulator pairs are the two column parities of one output
+// row: planar fp32 outputs are written as float2, 128 contiguous bytes per 16 lanes.
+// The table is one per device: launches that use it must be ordered on one stream (they are: the step is one stream).
+typedef __attribute__((ext_vector_type(4))) float tw_f32x4;
+__device__ __attribute__((aligned(16))) unsigned char g_up_frag[3 * 18 * 1024];  // [class][frag][64 lanes][16 B]
+
+// class 0 interior (built at m = 1), 1 first row, 2 last row; frag f = ((dr + 1) * 3 + (dc + 1)) * 2 + half
+__global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
+  const int cls = blockIdx.x;
+  const int m = cls == 0 ? 1 : (cls == 1 ? 0 : p.Hc - 1);
+  if (cls == 0 && p.Hc < 3) return;
+  const int N = p.N;
+  const bf16* w = (const bf16*)p.w;
+  for (int e = threadIdx.x; e < 18 * 64 * 8; e += 256) {
+    const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+    const int half = f & 1, dc = (f >> 1) % 3 - 1, dr = (f >> 1) / 3 - 1;
+    const int mp = l & 15, ci = 32 * half + 8 * (l >> 4) + j;
+    const int px = mp & 1, q = mp >> 1, py = q / N, n = q % N;
+    float v = 0.f;
+    if (py < 2) {
+      // column tap of parity px at offset dc (circular axis): px 0: (dc 0, kx 1), (dc -1, kx 3); px 1: (dc +1, kx 0), (dc 0, kx 2)
+      int kx;
+      if (px == 0) kx = dc == 0 ? 1 : (dc == -1 ? 3 : -1);
+      else kx = dc == 1 ? 0 : (dc == 0 ? 2 : -1);
+      if (kx >= 0) {
+        for (int i = 0; i < 4; ++i) {
+          int r, ky;
+          if (dg_tap1d(MODE_UP, p.adj, 0, 2 * m + py, p.Hc, i, r, ky) && r - m == dr)
+            v += (float)w[(long)(ky * 4 + kx) * p.w_st + (long)n * p.w_sn + ci];
+        }
+      }
+    }
+    *(bf16*)(g_up_frag + (((cls * 18 + f) * 64 + l) * 8 + j) * 2) = (bf16)v;
+  }
+}
+
+#define TU_PX 64
+__global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p) {
+  constexpr int RB = 144;                                            // LDS pixel stride: 128 B of channels + 16 B
+  __shared__ __attribute__((aligned(16))) unsigned char s_in[3 * (TU_PX + 2) * RB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, Wc = p.Wc, Hc = p.Hc;
+  const int b = blockIdx.x / Hc, m = blockIdx.x % Hc;
+  const int cls = m == 0 ? 1 : (m == Hc - 1 ? 2 : 0);
+  const bf16* in = (const bf16*)p.in + (long)b * p.in_sb;
+  const int col = lane & 15, kg = lane >> 4;
+  tw_bf16x8 fa[18];
+#pragma unroll
+  for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(g_up_frag + ((cls * 18 + f) * 64 + lane) * 16);
+  for (int n0 = 0; n0 < Wc; n0 += TU_PX) {
+    __syncthreads();
+    for (int i = tid; i < 3 * (TU_PX + 2) * 8; i += 256) {
+      const int ch = i & 7, c = (i >> 3) % (TU_PX + 2), rr = (i >> 3) / (TU_PX + 2);
+      int r = m - 1 + rr;
+      r = r < 0 ? 0 : (r >= Hc ? Hc - 1 : r);                        // rows outside the grid carry zero weights
+      int cc = n0 - 1 + c;
+      if (cc < 0) cc += Wc; else if (cc >= Wc) cc -= Wc;
+      *(uint4*)(s_in + (rr * (TU_PX + 2) + c) * RB + ch * 16) = *(const uint4*)(in + ((long)r * Wc + cc) * p.in_sp + ch * 8);
+    }
+    __syncthreads();
+    const int xl = wave * 16 + col;                                  // this lane's pixel inside the tile
+    tw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const unsigned char* px_ = s_in + (rr * (TU_PX + 2) + xl + d) * RB + kg * 16;
+        const tw_bf16x8 b0 = *(const tw_bf16x8*)(px_);
+        const tw_bf16x8 b1 = *(const tw_bf16x8*)(px_ + 64);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 1], b1, acc, 0, 0, 0);
+      }
+    // D: column = pixel (lane & 15), rows 4 kg + j  ->  m' = 4 kg + j = (py * N + n) * 2 + px
+    const int x = n0 + xl;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = 2 * kg + h;
+      if (q >= 2 * N) continue;
+      const int py = q / N, n = q % N;
+      const float sc = p.nscale ? p.scale * p.nscale[n] : p.scale;
+      const float bias = p.bias ? p.bias[n % p.bias_mod] : 0.f;
+      const float v0 = acc[2 * h] * sc + bias, v1 = acc[2 * h + 1] * sc + bias;
+      const long o = (long)b * p.out_sb + ((long)(2 * m + py) * (2 * Wc) + 2 * x) * p.out_sp + (long)n * p.out_sn;
+      if (p.out_dtype == DG_F32 && p.out_sp == 1) {
+        *(float2*)((float*)p.out + o) = make_float2(v0, v1);
+      } else {
+        dg_st(p.out, o, p.out_dtype, v0);
+        dg_st(p.out, o + p.out_sp, p.out_dtype, v1);
+      }
+    }
+  }
+}
+
+int dg_conv_up_mfma_supported(const ConvP* p) {
+  if (p->mode != MODE_UP || !p->ring) return 0;
+  if (p->in_dtype != DG_BF16 || p->w_dtype != DG_BF16) return 0;
+  if (p->K != 64 || p->N < 1 || p->N > 4 || p->Wc % TU_PX != 0 || p->Hc < 2) return 0;
+  if (p->in_sk != 1 || p->w_sk != 1 || p->in_sp % 8 != 0 || p->in_sb % 8 != 0) return 0;
+  if (p->epi != EPI_LINEAR || p->dbias) return 0;
+  return 1;
+}
+
+int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
+  if (!dg_conv_up_mfma_supported(p)) return DG_EUNSUPPORTED;
+  thin_up_prep_kernel<<<3, 256, 0, s>>>(*p);
+  thin_up_mfma_kernel<<<(unsigned)((long)p->B * p->Hc), 256, 0, s>>>(*p);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 int dg_conv_s2_mfma_supported(const ConvP* p);
 int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s);
 
@@ -546,6 +671,7 @@ int dg_conv_thin_supported(const ConvP* p) {
 int dg_conv_thin_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_thin_supported(p)) return DG_EUNSUPPORTED;
   if (dg_conv_s2_mfma_supported(p)) return dg_conv_s2_mfma_launch(p, s);
+  if (dg_conv_up_mfma_supported(p)) return dg_conv_up_mfma_launch(p, s);
   if (p->mode == MODE_S2) {
     const int tiles_x = p->Wc / SK_PX;
     const unsigned grid = (unsigned)((long)p->B * p->Hc * tiles_x);
@@ -786,7 +912,10 @@ int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
   const int tiles_x = p->Wc / 32;
   const long ntiles = (long)p->B * p->Hc * tiles_x;
   long blocks = (ntiles + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  static long cap = 0;
+  // 2 blocks per CU: the per-wave weight preload amortises over more tiles (DG_S2_BLOCKS overrides)
+  if (!cap) { const char* e = getenv("DG_S2_BLOCKS"); cap = e ? atol(e) : 512; }
+  if (blocks > cap) blocks = cap;
   if (p->in_sp == 2) thin_s2_mfma_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
   else thin_s2_mfma_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
   HIP_CHECK_RET(hipGetLastError());
