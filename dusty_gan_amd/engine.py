@@ -151,6 +151,38 @@ class NetCfg:
             raise NotImplementedError("discriminator in_ch != 1 (the range-image path is single channel)")
 
 
+class SideStream:
+    """Second HIP stream for the weight-gradient kernels.  A layer's weight gradient and the backward-data pass that
+    continues the chain read the same tensors and write disjoint ones, and nothing consumes a weight gradient before
+    the optimizer - so the (latency-bound) wgrad kernels run beside the chain instead of between its links.  Inside a
+    hipGraph capture the fork / join events become graph edges.  `DUSTY_GAN_SIDE_STREAM=0` disables it."""
+    enabled = os.environ.get("DUSTY_GAN_SIDE_STREAM", "1") != "0"
+    _streams = {}
+    _dirty = set()
+
+    @classmethod
+    def fork(cls):
+        """context manager: work issued inside runs on the side stream, after everything issued so far"""
+        dev = torch.cuda.current_device()
+        if not cls.enabled or PROFILE is not None:
+            import contextlib
+            return contextlib.nullcontext()
+        side = cls._streams.get(dev)
+        if side is None:
+            side = cls._streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        cls._dirty.add(dev)
+        return torch.cuda.stream(side)
+
+    @classmethod
+    def join(cls):
+        """the current stream waits for everything issued to the side stream"""
+        dev = torch.cuda.current_device()
+        if dev in cls._dirty:
+            torch.cuda.current_stream().wait_stream(cls._streams[dev])
+            cls._dirty.discard(dev)
+
+
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
 
@@ -341,14 +373,16 @@ class GEngine:
         pl = (c.nheads * self.HW, 1, self.HW)
         # head weight gradient and backward-data (gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad)
         if self.draw_pm is not None:  # bf16, <= 2 heads: the pixel-major copy feeds the two thin MFMA kernels
-            o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw_pm,
-                    (self.HW * 2, 2, 1), st.fptr("head_w", st.grad), 1.0)
+            with SideStream.fork():
+                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw_pm,
+                        (self.HW * 2, 2, 1), st.fptr("head_w", st.grad), 1.0)
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw_pm, (self.HW * 2, 2, 1), self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
                    dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3])
         else:
-            o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw, pl,
-                    st.fptr("head_w", st.grad), 1.0, g_dt=L.DG_F32)
+            with SideStream.fork():
+                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw, pl,
+                        st.fptr("head_w", st.grad), 1.0, g_dt=L.DG_F32)
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw, pl, self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
                    dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], in_dt=L.DG_F32)
@@ -356,14 +390,17 @@ class GEngine:
             hc, wc = self.grid[i - 1]
             ci, co = chs[i - 1], chs[i]
             s = 1.0 / math.sqrt(co * 16)
-            o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
-                    (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), s)
+            with SideStream.fork():
+                o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
+                        (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), s)
             prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, self.dp[i], (4 * hc * wc * co, co, 1), self.dp[i - 1],
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
                    dbias=st.fptr(prev_b, st.grad), bias_mod=ci)
         if not skip_proj:
-            self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
+            with SideStream.fork():
+                self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
+        SideStream.join()
 
 
 class DEngine:
@@ -451,16 +488,18 @@ class DEngine:
     def wgrad(self, st, a_slot, g_slot, n, rowscale):
         """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot+b]) for the four Down layers."""
         c, o = self.cfg, self.ops
-        for i in range(1, 5):
-            hc, wc = self.grid[i]
-            ci, co = self.chs[i - 1], self.chs[i]
-            o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
-                    (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
-                    a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i])
+        with SideStream.fork():
+            for i in range(1, 5):
+                hc, wc = self.grid[i]
+                ci, co = self.chs[i - 1], self.chs[i]
+                o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
+                        (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
+                        a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i])
 
     def final_wgrad(self, st, slot, n, coef):
         """dwf += s_f * sum_b coef[b] * h4[slot+b]"""
         o, lib = self.ops, L.lib()
         nf = self.per[4]
-        L.check(lib.dg_batch_wsum(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n, nf,
-                                  st.fptr("final_w", st.grad), L.stream_ptr()), "dg_batch_wsum")
+        with SideStream.fork():
+            L.check(lib.dg_batch_wsum(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n,
+                                      nf, st.fptr("final_w", st.grad), L.stream_ptr()), "dg_batch_wsum")

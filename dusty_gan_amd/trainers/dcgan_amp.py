@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib as L
+from .. import engine as E
 from ..models import define_D, define_G
 from ..models.loss import GANLoss
 from ..utils import cycle, sigmoid_to_tanh, tanh_to_sigmoid  # noqa: F401  (re-exported like the reference)
@@ -405,6 +406,10 @@ class Trainer:
                 up = torch.cat([torch.ones(B, **f32), dy[B:]])
                 rs = torch.cat([dy[:B], torch.ones(B, **f32)])
                 deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
+                # (side stream) weight gradients of the real (weighted by dLoss/dy_real) + fake halves, beside the
+                # rest of the R1 chain
+                deng.wgrad(Dst, 0, 0, 2 * B, rs)
+                deng.final_wgrad(Dst, 0, 2 * B, dy)
                 g = torch.empty(B, 1, self.H, self.W, **f32)
                 deng.backward_input(Dst, 0, B, g)
                 ssq = torch.empty(B, **f32)
@@ -414,15 +419,14 @@ class Trainer:
                 vg = torch.empty_like(g)
                 L.check(lib.dg_scale(L.ptr(g), gp / self.n_acc / B, g.numel(), L.ptr(vg), sp), "dg_scale")
                 deng.forward(Dst, vg, 2 * B, tangent_of=0)
-                deng.wgrad(Dst, 0, 0, 2 * B, rs)       # real (weighted by dLoss/dy_real) + fake
                 deng.wgrad(Dst, 2 * B, 0, B, None)      # tangent (x) real chain
-                deng.final_wgrad(Dst, 0, 2 * B, dy)
                 deng.final_wgrad(Dst, 2 * B, B, None)
             else:
                 deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
                 deng.wgrad(Dst, 0, 0, 2 * B, None)
                 deng.final_wgrad(Dst, 0, 2 * B, dy)
             Dst.view("final_b", Dst.grad).add_(dy.sum())
+            E.SideStream.join()
             self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
         gscale = self._allreduce(Dst)
         self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype)  # :238
