@@ -43,9 +43,16 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
     ((float4*)v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     if (m) ((float4*)m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
     if (ema) ((float4*)ema)[i] = make_float4(ev[0], ev[1], ev[2], ev[3]);
-    if (shadow) {
-      T* sd = shadow + 4 * i;
-      sd[0] = (T)pv[0]; sd[1] = (T)pv[1]; sd[2] = (T)pv[2]; sd[3] = (T)pv[3];
+    if (shadow) {  // one 8- or 16-byte store per lane (four 2-byte stores were a quarter of this kernel's store instructions)
+      if constexpr (sizeof(T) == 2) {
+        const T h[4] = {(T)pv[0], (T)pv[1], (T)pv[2], (T)pv[3]};
+        uint2 pk;
+        pk.x = (unsigned)__builtin_bit_cast(unsigned short, h[0]) | ((unsigned)__builtin_bit_cast(unsigned short, h[1]) << 16);
+        pk.y = (unsigned)__builtin_bit_cast(unsigned short, h[2]) | ((unsigned)__builtin_bit_cast(unsigned short, h[3]) << 16);
+        ((uint2*)shadow)[i] = pk;
+      } else {
+        ((float4*)shadow)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      }
     }
   }
 }
