@@ -57,6 +57,85 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Adam + EMA for Proj.weight with its gradient computed IN the kernel.  Proj is a linear layer (nz -> h0*w0*C,
+// models/gans/dcgan_eqlr.py:6-13) whose [Np][K] fp32 gradient is 96 % of G's gradient bytes (268 MB at 64x1024):
+//     g[n'][k] = wscale * sum_b dp0[b][n'] * z[b][k]          (b < nb <= 64 samples)
+// costs 16 dot2 per element from LDS-resident operands, so forming it here instead of writing it with the wgrad GEMM
+// and reading it back removes 2 x 268 MB of HBM traffic from the step (beta1 == 0: exp_avg is never stored).
+// Operands bf16: z2[bp][k] = (z[2bp][k], z[2bp+1][k]) and dT[row][bp] = (dp0[2bp][row], dp0[2bp+1][row]) packed pairs.
+typedef __attribute__((ext_vector_type(2))) __bf16 ad_bf16x2;
+#define APF_ROWS 64
+
+template <typename ST>
+__global__ __launch_bounds__(256) void adam_proj_fused_kernel(float* __restrict__ p, float* __restrict__ v,
+                                                              float* __restrict__ ema, ST* __restrict__ shadow,
+                                                              const bf16* __restrict__ dp0, const bf16* __restrict__ zT,
+                                                              int nb, long Np, int K, float wscale, float gscale, float lr,
+                                                              float b2, float eps, float ema_decay,
+                                                              const unsigned long long* __restrict__ stepp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nbp = nb / 2;
+  unsigned* z2 = (unsigned*)smem;                    // [nbp][K]
+  unsigned* dT = z2 + (long)nbp * K;                 // [APF_ROWS][nbp]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * APF_ROWS;
+  const unsigned short* zr = (const unsigned short*)zT;
+  const unsigned short* dr = (const unsigned short*)dp0;
+  for (int i = tid; i < nbp * K; i += 256) {
+    const int bp = i / K, k = i - bp * K;
+    z2[i] = (unsigned)zr[(long)(2 * bp) * K + k] | ((unsigned)zr[(long)(2 * bp + 1) * K + k] << 16);
+  }
+  for (int i = tid; i < APF_ROWS * nbp; i += 256) {
+    const int row = i % APF_ROWS, bp = i / APF_ROWS;
+    unsigned d = 0;
+    if (r0 + row < Np) d = (unsigned)dr[(long)(2 * bp) * Np + r0 + row] | ((unsigned)dr[(long)(2 * bp + 1) * Np + r0 + row] << 16);
+    dT[row * nbp + bp] = d;
+  }
+  __syncthreads();
+  const float t = (float)(*stepp + 1ull);
+  const float inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, t));
+  const int quads = K / 4, kq = tid % quads, rpp = 256 / quads;
+  for (int row = tid / quads; row < APF_ROWS && r0 + row < Np; row += rpp) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int bp = 0; bp < nbp; ++bp) {
+      const ad_bf16x2 d = __builtin_bit_cast(ad_bf16x2, dT[row * nbp + bp]);
+      const uint4 z4 = *(const uint4*)(z2 + (long)bp * K + 4 * kq);
+      acc[0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ad_bf16x2, z4.x), d, acc[0], false);
+      acc[1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ad_bf16x2, z4.y), d, acc[1], false);
+      acc[2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ad_bf16x2, z4.z), d, acc[2], false);
+      acc[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ad_bf16x2, z4.w), d, acc[3], false);
+    }
+    const long i4 = ((r0 + row) * K) / 4 + kq;
+    const float4 v4 = ((const float4*)v)[i4];
+    const float4 p4 = ((const float4*)p)[i4];
+    const float4 e4 = ema ? ((const float4*)ema)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float pv[4] = {p4.x, p4.y, p4.z, p4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g = acc[k] * wscale * gscale;
+      const float vi = b2 * vv[k] + (1.f - b2) * g * g;
+      vv[k] = vi;
+      pv[k] = pv[k] - lr * (g / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+      ev[k] = ema_decay * ev[k] + (1.f - ema_decay) * pv[k];
+    }
+    ((float4*)p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    ((float4*)v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (ema) ((float4*)ema)[i4] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    if (shadow) {
+      if constexpr (sizeof(ST) == 2) {
+        const ST h[4] = {(ST)pv[0], (ST)pv[1], (ST)pv[2], (ST)pv[3]};
+        uint2 pk;
+        pk.x = (unsigned)__builtin_bit_cast(unsigned short, h[0]) | ((unsigned)__builtin_bit_cast(unsigned short, h[1]) << 16);
+        pk.y = (unsigned)__builtin_bit_cast(unsigned short, h[2]) | ((unsigned)__builtin_bit_cast(unsigned short, h[3]) << 16);
+        ((uint2*)shadow)[i4] = pk;
+      } else {
+        ((float4*)shadow)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,6 +412,27 @@ int dg_adam_ema_step_dev(float* p, const float* grad, float* m, float* v, float*
     adam_ema_kernel<bf16><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n4, gscale, 0.f, 0.f, beta1, beta2, eps, ema_decay, step_dev, lr);
   else
     adam_ema_kernel<float><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n4, gscale, 0.f, 0.f, beta1, beta2, eps, ema_decay, step_dev, lr);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+/* Adam(beta1 = 0) + EMA of Proj.weight [Np][K] with its gradient wscale * dp0^T z formed in the kernel (bf16
+ * operands, nb even and <= 64 rows).  DG_EUNSUPPORTED for other shapes: the caller then runs dg_wgrad + the plain Adam. */
+int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_dtype, const void* dp0, const void* zT,
+                       int op_dtype, int nb, long Np, int K, float wscale, float gscale, float lr, float beta2,
+                       float eps, const unsigned long long* step_dev, float ema_decay, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!p || !v || !dp0 || !zT || !step_dev) return DG_EINVAL;
+  if (op_dtype != DG_BF16 || nb < 2 || nb > 64 || nb % 2 != 0 || K % 4 != 0 || K / 4 > 256 || 256 % (K / 4) != 0 ||
+      Np <= 0)
+    return DG_EUNSUPPORTED;
+  const size_t lds = ((size_t)(nb / 2) * K + (size_t)APF_ROWS * (nb / 2)) * 4;
+  if (lds > 64 * 1024) return DG_EUNSUPPORTED;
+  const unsigned grid = (unsigned)((Np + APF_ROWS - 1) / APF_ROWS);
+  if (shadow && shadow_dtype == DG_BF16)
+    adam_proj_fused_kernel<bf16><<<grid, 256, lds, s>>>(p, v, ema, (bf16*)shadow, (const bf16*)dp0, (const bf16*)zT, nb, Np, K, wscale, gscale, lr, beta2, eps, ema_decay, step_dev);
+  else
+    adam_proj_fused_kernel<float><<<grid, 256, lds, s>>>(p, v, ema, (float*)shadow, (const bf16*)dp0, (const bf16*)zT, nb, Np, K, wscale, gscale, lr, beta2, eps, ema_decay, step_dev);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

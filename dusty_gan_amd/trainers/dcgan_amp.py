@@ -12,6 +12,7 @@ What differs underneath:
   * the G-phase D(real) forward of the reference (:259) is dead code for non-relativistic losses and is not run;
   * scalars are gathered with ONE packed all-reduce and read back lazily.
 """
+import math
 import os.path as osp
 from collections import OrderedDict
 
@@ -119,6 +120,8 @@ class FlatAdam:
         state = {}
         if self.step_count > 0:
             if self.betas[0] == 0.0 and getattr(self, "_last_gscale", None) is not None:
+                if getattr(self, "regen_grad", None) is not None:
+                    self.regen_grad()  # a gradient the fused optimizer kernel never materialised (Proj.weight)
                 st.m.copy_(st.grad * self._last_gscale)  # exp_avg of torch.optim.Adam at beta1 = 0
             ms, vs = self._param_views(st.m), self._param_views(st.v)
             for i, (m, v) in enumerate(zip(ms, vs)):
@@ -161,25 +164,45 @@ class FlatAdam:
         if pos < st.n:
             st.grad[pos:].zero_()
 
-    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32):
+    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None):
+        """fused_proj = (dp0, zT, op_dtype, nb, Np, K, wscale): the first segment of the store is Proj.weight [Np][K] and
+        its gradient is NOT in st.grad - the kernel forms wscale * dp0^T zT itself (dg_adam_proj_fused).  Returns
+        False (and does nothing) if that kernel refuses the shape, so the caller can fall back."""
         st = self.store
         if self._step_dev is None or self._step_dev.device != st.flat.device:
             self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=st.flat.device)
-        self.step_count += 1
-        self._last_gscale = gscale
         # beta1 == 0 (the reference's solver): exp_avg == scaled gradient, so the kernel neither reads nor writes it
         m_ptr = None if self.betas[0] == 0.0 else L.ptr(st.m)
         lib = L.lib()
+        sdt = L.dtype_code(shadow_dtype)
+        ses = 2 if shadow_dtype == torch.bfloat16 else 4
+        ema_ptr = L.ptr(ema_store.flat) if ema_store is not None else None
+        off = 0
+        if fused_proj is not None:
+            dp0, zT, op_dt, nb, Np, K, wscale = fused_proj
+            if self.betas[0] != 0.0:
+                return False
+            rc = lib.dg_adam_proj_fused(L.ptr(st.flat), L.ptr(st.v), ema_ptr, L.ptr(st.shadow), sdt, L.ptr(dp0), L.ptr(zT),
+                                        op_dt, nb, Np, K, wscale, gscale, self.lr, self.betas[1], self.eps,
+                                        L.ptr(self._step_dev), ema_decay, L.stream_ptr())
+            if rc == L.DG_EUNSUPPORTED:
+                return False
+            L.check(rc, "dg_adam_proj_fused")
+            off = Np * K
+        self.step_count += 1
+        self._last_gscale = gscale
         # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
-        L.check(lib.dg_adam_ema_step_dev(L.ptr(st.flat), L.ptr(st.grad), m_ptr, L.ptr(st.v),
-                                         L.ptr(ema_store.flat) if ema_store is not None else None, L.ptr(st.shadow),
-                                         L.dtype_code(shadow_dtype), st.n, gscale, self.lr, self.betas[0],
+        L.check(lib.dg_adam_ema_step_dev(L.ptr(st.flat) + 4 * off, L.ptr(st.grad) + 4 * off,
+                                         None if m_ptr is None else m_ptr + 4 * off, L.ptr(st.v) + 4 * off,
+                                         None if ema_ptr is None else ema_ptr + 4 * off, L.ptr(st.shadow) + ses * off,
+                                         sdt, st.n - off, gscale, self.lr, self.betas[0],
                                          self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
                 "dg_adam_ema_step_dev")
         L.check(lib.dg_counter_add(L.ptr(self._step_dev), 1, L.stream_ptr()), "dg_counter_add")
         st.refresh_transposed()
         if ema_store is not None:
             ema_store._seen_version = -1  # its shadows are rebuilt lazily when G_ema is used
+        return True
 
 
 def _store(net):
@@ -286,6 +309,7 @@ class Trainer:
         self._graph, self._eager_steps = None, 0
         self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
         self._force_seg = os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"  # debug: split the graph at world == 1 too
+        self._fuse_proj_ok = os.environ.get("DUSTY_GAN_FUSE_PROJ", "1") != "0"
 
     # ------------------------------------------------------------------ helpers
     def sample_latents(self, B):
@@ -441,6 +465,11 @@ class Trainer:
         Gst, Dst = Gb.store, D.store
         self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
         gather_proj = (self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
+        fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
+                     and next(iter(Gst.seg)) == "proj_w" and Gst.seg["proj_w"].off == 0 and self._fuse_proj_ok
+                     and self.optim_G.betas[0] == 0.0 and E.PROFILE is None)
+        if not fuse_proj:
+            self.optim_G.regen_grad = None
         deng = D.engine()
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -459,7 +488,8 @@ class Trainer:
             dx = torch.empty(B, 1, self.H, self.W, **f32)
             deng.backward_input(Dst, 0, B, dx)
             ddepth = self.A.backward(dx, rand["aug"][3])
-            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj)
+            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj)
+        fused = None
         if gather_proj:
             # Proj.weight is 96 % of G's gradient bytes (268 MB fp32) and the last tensor backward produces.  It is a
             # plain linear layer, so instead of all-reducing its gradient every rank gathers the tiny operands
@@ -478,9 +508,21 @@ class Trainer:
             gscale = 1.0 / self.world
         else:
             gscale = self._allreduce(Gst)
-        # Adam + EMA fused (:312, :316)
-        self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
-                          shadow_dtype=self.dtype)
+            if fuse_proj:
+                geng = self._mb[0]["geng"]
+                c = geng.cfg
+                Np = c.h0 * c.w0 * c.ch[3]
+                fused = (geng.dp[0], geng.zT, L.dtype_code(self.dtype), B, Np, c.nz, 1.0 / math.sqrt(Np))
+                self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, geng.dp[0], geng.zT, B, False)
+        # Adam + EMA fused (:312, :316); single-GPU bf16 runs also fold Proj.weight's gradient GEMM into the kernel
+        ok = self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
+                               shadow_dtype=self.dtype, fused_proj=fused)
+        if not ok:  # shape the fused kernel does not take: materialise the gradient and run the plain optimizer
+            self.optim_G.regen_grad()
+            self.optim_G.regen_grad = None
+            self._fuse_proj_ok = False
+            self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
+                              shadow_dtype=self.dtype)
         self._mb = []
         return scal
 

@@ -387,6 +387,37 @@ def test_losses_fetch_reals_adam(L):
     assert torch.equal(sh.cpu(), pd.cpu().bfloat16())
 
 
+@pytest.mark.parametrize("nb,Np,K", [(4, 200, 8), (32, 1000, 512), (64, 130, 256)])
+def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
+    """dg_adam_proj_fused (Proj.weight's gradient GEMM inside the optimizer kernel) against the oracle's Adam applied to
+    the explicitly formed gradient wscale * dp0^T z of the same bf16 operands, incl. EMA, bf16 shadow, device step."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(nb + K)
+    dp0 = torch.randn(nb, Np, generator=g).bfloat16()
+    z = torch.randn(nb, K, generator=g).bfloat16()
+    wscale, gscale, lr, b2, eps, decay, step = 1.0 / math.sqrt(Np), 0.5, 0.002, 0.99, 1e-8, 0.9, 3
+    grad = (dp0.float().t() @ z.float()) * wscale  # [Np][K]
+    p, v, ema = (torch.randn(Np * K, generator=g) for _ in range(3))
+    v.abs_()
+    pc, mc, vc, ec = p.clone(), torch.zeros_like(p), v.clone(), ema.clone()
+    O.adam_update(pc, grad.reshape(-1) * gscale, mc, vc, step + 1, lr, 0.0, b2)
+    ec = decay * ec + (1 - decay) * pc
+    pd, vd, ed = (t.to(DEV) for t in (p, v, ema))
+    sh = torch.empty(Np * K, device=DEV, dtype=torch.bfloat16)
+    dpd, zd = dp0.to(DEV).contiguous(), z.to(DEV).contiguous()
+    stepd = torch.full((1,), step, dtype=torch.int64, device=DEV)
+    L.check(lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), ed.data_ptr(), sh.data_ptr(), L.DG_BF16, dpd.data_ptr(),
+                                   zd.data_ptr(), L.DG_BF16, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(),
+                                   decay, None), "dg_adam_proj_fused")
+    torch.cuda.synchronize()
+    assert rel_l2(pd.cpu(), pc) < 1e-5 and rel_l2(vd.cpu(), vc) < 1e-4 and rel_l2(ed.cpu(), ec) < 1e-5
+    assert torch.equal(sh.cpu(), pd.cpu().bfloat16())
+    # shapes the kernel refuses (the trainer then forms the gradient with dg_wgrad)
+    assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_BF16, dpd.data_ptr(), zd.data_ptr(),
+                                  L.DG_F32, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay,
+                                  None) == L.DG_EUNSUPPORTED
+
+
 def test_philox_known_answer(L):
     """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors):
     counter=0,key=0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8; counter=ff..,key=ff.. -> 408f276d 41c83b0e a20bc7c6 6d5451fd"""

@@ -30,6 +30,8 @@ def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False
 
 
 def grads_by_name(optim):
+    if getattr(optim, "regen_grad", None) is not None:
+        optim.regen_grad()  # Proj.weight's gradient when the optimizer kernel formed it on the fly (bf16, one GPU)
     st = optim.store
     views = optim._param_views(st.grad)
     return {k: v.detach().cpu() for (k, _), v in zip(optim.net.named_parameters(), views)}
