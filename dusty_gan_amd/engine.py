@@ -354,7 +354,7 @@ class GEngine:
         self.ops.wgrad(2, 1, 1, 1, nb, Np, c.nz, dp0, (0, Np, 1), zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
                        1.0 / math.sqrt(Np), accumulate=int(accumulate))
 
-    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False):
+    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, join=True):
         """ddepth [B,1,H,W] fp32 = dLoss/d(output depth).  Accumulates every G parameter gradient into st.grad
         (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309)."""
         c, o, lib = self.cfg, self.ops, L.lib()
@@ -400,7 +400,8 @@ class GEngine:
         if not skip_proj:
             with SideStream.fork():
                 self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
-        SideStream.join()
+        if join:  # join=False: the caller joins after work that does not need the weight gradients (fused Proj Adam)
+            SideStream.join()
 
 
 class DEngine:

@@ -181,14 +181,17 @@ class FlatAdam:
         if fused_proj is not None:
             dp0, zT, op_dt, nb, Np, K, wscale = fused_proj
             if self.betas[0] != 0.0:
+                E.SideStream.join()
                 return False
             rc = lib.dg_adam_proj_fused(L.ptr(st.flat), L.ptr(st.v), ema_ptr, L.ptr(st.shadow), sdt, L.ptr(dp0), L.ptr(zT),
                                         op_dt, nb, Np, K, wscale, gscale, self.lr, self.betas[1], self.eps,
                                         L.ptr(self._step_dev), ema_decay, L.stream_ptr())
             if rc == L.DG_EUNSUPPORTED:
+                E.SideStream.join()
                 return False
             L.check(rc, "dg_adam_proj_fused")
             off = Np * K
+        E.SideStream.join()  # the remaining segments need the weight gradients still running on the side stream
         self.step_count += 1
         self._last_gscale = gscale
         # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
@@ -488,7 +491,8 @@ class Trainer:
             dx = torch.empty(B, 1, self.H, self.W, **f32)
             deng.backward_input(Dst, 0, B, dx)
             ddepth = self.A.backward(dx, rand["aug"][3])
-            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj)
+            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj,
+                                join=not fuse_proj)
         fused = None
         if gather_proj:
             # Proj.weight is 96 % of G's gradient bytes (268 MB fp32) and the last tensor backward produces.  It is a
