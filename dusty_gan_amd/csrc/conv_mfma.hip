@@ -22,10 +22,15 @@
 //   * blockIdx is remapped so each XCD (private L2) walks a contiguous range of M-tiles across all their N-tiles
 #include "mfma_common.h"
 
+#ifndef DG_CONV_SETPRIO
+#define DG_CONV_SETPRIO 1
+#endif
+
 template <typename T, int BM, int BN, int SB, int NS>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n, int tiles_x, int dbg) {
   // SB = bytes of K per row per pipeline stage (64 or 128), NS = LDS stages (prefetch distance NS-1)
   constexpr int ES = sizeof(T);
+  constexpr bool PRIO = DG_CONV_SETPRIO;
   constexpr int BK = SB / ES;          // channels per K step
   constexpr int EPC = 16 / ES;         // elements per 16-byte chunk
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -177,11 +182,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (PRIO && !(dbg & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           mma_tile((const T*)nullptr, fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      if (PRIO && !(dbg & 8)) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
