@@ -549,12 +549,13 @@ __device__ __attribute__((aligned(16))) unsigned char g_up_frag[3 * 18 * 1024]; 
 
 // class 0 interior (built at m = 1), 1 first row, 2 last row; frag f = ((dr + 1) * 3 + (dc + 1)) * 2 + half
 __global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
-  const int cls = blockIdx.x;
+  const int cls = blockIdx.y;                    // one element per thread: 36 blocks per class
   const int m = cls == 0 ? 1 : (cls == 1 ? 0 : p.Hc - 1);
   if (cls == 0 && p.Hc < 3) return;
   const int N = p.N;
   const bf16* w = (const bf16*)p.w;
-  for (int e = threadIdx.x; e < 18 * 64 * 8; e += 256) {
+  {
+    const int e = blockIdx.x * 256 + threadIdx.x;
     const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
     const int half = f & 1, dc = (f >> 1) % 3 - 1, dr = (f >> 1) / 3 - 1;
     const int mp = l & 15, ci = 32 * half + 8 * (l >> 4) + j;
@@ -646,7 +647,7 @@ int dg_conv_up_mfma_supported(const ConvP* p) {
 
 int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_up_mfma_supported(p)) return DG_EUNSUPPORTED;
-  thin_up_prep_kernel<<<3, 256, 0, s>>>(*p);
+  thin_up_prep_kernel<<<dim3(36, 3), 256, 0, s>>>(*p);
   thin_up_mfma_kernel<<<(unsigned)((long)p->B * p->Hc), 256, 0, s>>>(*p);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
