@@ -793,26 +793,56 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
   float csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-  const long gw = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  // each wave owns a CONTIGUOUS range of tiles and walks (x tile, row, sample) with a carry chain: the three 64-bit
+  // divisions of a strided decode cost more than the four MFMAs of a tile
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  const int nt = (int)ntiles, tq = nt / nw, tr = nt % nw;
+  const int t0 = gw * tq + (gw < tr ? gw : tr), tcnt = tq + (gw < tr ? 1 : 0);
+  int xt = t0 % tiles_x, Y = (t0 / tiles_x) % p.Hc, b = t0 / (tiles_x * p.Hc);
   unsigned char* my = s_t[wave];
-  for (long t = gw; t < ntiles; t += nw) {
-    const int xt = (int)(t % tiles_x);
-    const int Y = (int)((t / tiles_x) % p.Hc), b = (int)(t / ((long)tiles_x * p.Hc));
-    const int X = xt * 32 + lr;                  // this lane's output pixel (as A-fragment row)
-    const bf16* img = in + (long)b * p.in_sb;
-    // one 16-byte window of input row r starting at fine column c0 (circular): 4 (CP=2) or 2 (CP=4) pixels
-    auto window = [&](int r, int c0) -> uint4 {
-      constexpr int NPX = 8 / CP;
-      if (c0 >= 0 && c0 + NPX <= Wf) return *(const uint4*)(img + ((long)r * Wf + c0) * CP);
-      unsigned d[4];
+  // one 16-byte window of input row r of sample bb starting at fine column c0 (circular): 4 (CP=2) or 2 (CP=4) pixels
+  auto window_of = [&](int bb, int r, int c0) -> uint4 {
+    constexpr int NPX = 8 / CP;
+    const bf16* img = in + (long)bb * p.in_sb;
+    if (c0 >= 0 && c0 + NPX <= Wf) return *(const uint4*)(img + ((long)r * Wf + c0) * CP);
+    unsigned d[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {              // dword q = pixel q (CP=2) or half pixel (CP=4)
-        int cc = c0 + (CP == 2 ? q : (q >> 1));
-        if (cc < 0) cc += Wf; else if (cc >= Wf) cc -= Wf;
-        d[q] = *(const unsigned*)(img + ((long)r * Wf + cc) * CP + (CP == 2 ? 0 : (q & 1) * 2));
-      }
-      return make_uint4(d[0], d[1], d[2], d[3]);
-    };
+    for (int q = 0; q < 4; ++q) {              // dword q = pixel q (CP=2) or half pixel (CP=4)
+      int cc = c0 + (CP == 2 ? q : (q >> 1));
+      if (cc < 0) cc += Wf; else if (cc >= Wf) cc -= Wf;
+      d[q] = *(const unsigned*)(img + ((long)r * Wf + cc) * CP + (CP == 2 ? 0 : (q & 1) * 2));
+    }
+    return make_uint4(d[0], d[1], d[2], d[3]);
+  };
+  // the A fragments of tile (xt_, Y_, b_): NS 16-byte loads per lane
+  auto load_frags = [&](int xt_, int Y_, int b_, uint4 (&a)[NS]) {
+    const int X_ = xt_ * 32 + lr;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int ky = CP == 2 ? 2 * s + lh : s;
+      int r = 2 * Y_ - 1 + ky;
+      bool ok = true;
+      if (!p.adj) { if (r < 0) r = -r; if (r >= Hf) r = 2 * Hf - 2 - r; }
+      else ok = r >= 0 && r < Hf;
+      const int c0 = 2 * X_ - 1 + (CP == 2 ? 0 : 2 * lh);
+      a[s] = ok ? window_of(b_, r, c0) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  float bias2[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) bias2[jt] = p.bias ? p.bias[(jt * 32 + lr) % p.bias_mod] : 0.f;
+  uint4 a_next[NS];
+  if (tcnt > 0) load_frags(xt, Y, b, a_next);
+  for (int ti = 0; ti < tcnt; ++ti) {
+    // the fragments of the NEXT tile are requested before this tile's MFMAs and epilogue
+    uint4 a_cur[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a_cur[s] = a_next[s];
+    int nxt = xt + 1, nY = Y, nb = b;
+    if (nxt == tiles_x) { nxt = 0; if (++nY == p.Hc) { nY = 0; ++nb; } }
+    if (ti + 1 < tcnt) load_frags(nxt, nY, nb, a_next);
+    const int X = xt * 32 + lr;                  // this lane's output pixel (as A-fragment row)
+    auto window = [&](int r, int c0) -> uint4 { return window_of(b, r, c0); };
     tw_f32x16 acc[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -820,15 +850,7 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
       for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const int ky = CP == 2 ? 2 * s + lh : s;
-      int r = 2 * Y - 1 + ky;
-      bool ok = true;
-      if (!p.adj) { if (r < 0) r = -r; if (r >= Hf) r = 2 * Hf - 2 - r; }
-      else ok = r >= 0 && r < Hf;
-      const int c0 = 2 * X - 1 + (CP == 2 ? 0 : 2 * lh);
-      uint4 a = make_uint4(0, 0, 0, 0);
-      if (ok) a = window(r, c0);
-      const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a);
+      const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a_cur[s]);
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[s][jt], acc[jt], 0, 0, 0);
     }
@@ -851,11 +873,21 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
         for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][jt], acc[jt], 0, 0, 0);
       }
     }
-    // ---- epilogue: D[row = pixel][col = channel]; transpose through the wave's LDS patch
+    // ---- epilogue: D[row = pixel][col = channel]; transpose through the wave's LDS patch.  The leaky-relu mask
+    //      source of the tile is requested first so that its latency hides behind the transposition.
+    const long obase = (long)b * p.out_sb + ((long)Y * p.Wc + xt * 32) * p.out_sp;
+    uint4 araw[4];
+    if (p.epi == EPI_MASK) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * u, row = c >> 3, part = c & 7;
+        araw[u] = *(const uint4*)((const bf16*)p.aux + obase + (long)row * p.out_sp + part * 8);
+      }
+    }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const int n = jt * 32 + lr;
-      const float bias = p.bias ? p.bias[n % p.bias_mod] : 0.f;
+      const float bias = bias2[jt];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -864,7 +896,6 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
         *(bf16*)(my + row * 144 + n * 2) = (bf16)v;
       }
     }
-    const long obase = (long)b * p.out_sb + ((long)Y * p.Wc + xt * 32) * p.out_sp;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = lane + 64 * u, row = c >> 3, part = c & 7;   // part == lane & 7 for every u
@@ -872,8 +903,7 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
       uint4 raw = *(const uint4*)(my + row * 144 + part * 16);
       bf16* v = (bf16*)&raw;
       if (p.epi == EPI_MASK) {
-        const uint4 araw = *(const uint4*)((const bf16*)p.aux + o);
-        const bf16* av = (const bf16*)&araw;
+        const bf16* av = (const bf16*)&araw[u];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2));
       }
@@ -884,6 +914,7 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
       }
       *(uint4*)((bf16*)p.out + o) = raw;
     }
+    xt = nxt; Y = nY; b = nb;
   }
   if (p.dbias) {
 #pragma unroll
