@@ -585,7 +585,12 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, Wc = p.Wc, Hc = p.Hc;
-  const int b = blockIdx.x / Hc, m = blockIdx.x % Hc;
+  // XCD-aware, bijective block remap (blocks id and id+8 share an XCD): consecutive image rows - which re-read each
+  // other's input rows - land on ONE XCD's L2 instead of being fetched from the fabric by three of them
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int b = logical / Hc, m = logical % Hc;
   const int cls = m == 0 ? 1 : (m == Hc - 1 ? 2 : 0);
   const bf16* in = (const bf16*)p.in + (long)b * p.in_sb;
   const int col = lane & 15, kg = lane >> 4;
