@@ -49,7 +49,9 @@ def parse():
 def make_trainer(args, rank, local_rank, world):
     from dusty_gan_amd.trainers.dcgan_amp import Trainer
     from dusty_gan_amd.utils.config import load_config
-    arch = args.arch or ("none" if world == 1 else "dusty2")
+    # the metric's configuration (BASELINE.json configs[1]: dcgan_eqlr baseline, 64x1024, 32 images per GPU) at every N,
+    # so that the 1/2/4/8-GPU values are one weak-scaling series; --arch dusty1|dusty2 selects the DUSty variants
+    arch = args.arch or "none"
     model = {"none": "dcgan_eqlr", "dusty1": "dusty1_dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
     ov = [f"model={model}", "dataset=synthetic", f"dataset.shape=[{args.shape[0]},{args.shape[1]}]",
           f"solver.batch_size={args.batch * world}", f"solver.loss.gp={args.gp}",
