@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
 // through LDS, then one fp32 atomic per element per block.
 #define WGU_ROWS_PB 2
 
-__global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p) {
+__global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int gpair) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Wc = p.Wc, Wf = 2 * p.Wc;
   const int RSB = Wc * 2 + 16;                                       // im2col row stride (bytes), +16 B: bank spread
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long u0 = (long)blockIdx.x * WGU_ROWS_PB;
   const bf16* A = (const bf16*)p.a;
-  const unsigned* G = (const unsigned*)p.g;                          // one dword = (co0, co1) of a fine pixel
+  const unsigned* G = (const unsigned*)p.g + gpair;                  // one dword = channels (2 gpair, 2 gpair + 1) of a fine pixel
+  const int gsd = (int)p.g_sp / 2;                                   // dwords per fine pixel (1: two channels, 2: four)
   const int lr = lane & 31, lh = lane >> 5;
   const int g16 = lane >> 4, i16 = lane & 15;
   const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3; // transposing-read roles (see wgrad_mfma.hip)
@@ -468,15 +469,15 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p) {
       if (fr0 < 0) { fr0 = fr1; fr1 = -1; }
       unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};           // co0 / co1, 8 bf16 each
       if (fr0 >= 0) {
-        const unsigned* g0 = G + (long)b * (p.g_sb / 2) + (long)fr0 * Wf;
-        const unsigned* g1 = fr1 >= 0 ? G + (long)b * (p.g_sb / 2) + (long)fr1 * Wf : nullptr;
+        const unsigned* g0 = G + (long)b * (p.g_sb / 2) + (long)fr0 * Wf * gsd;
+        const unsigned* g1 = fr1 >= 0 ? G + (long)b * (p.g_sb / 2) + (long)fr1 * Wf * gsd : nullptr;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           int x = xi0 + j - dkx;
           if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
-          unsigned v = g0[2 * x + pkx];
+          unsigned v = g0[(2 * x + pkx) * gsd];
           if (g1) {                                                  // sum of two gradient rows, rounded once to bf16
-            const unsigned w2 = g1[2 * x + pkx];
+            const unsigned w2 = g1[(2 * x + pkx) * gsd];
             const float s0 = __builtin_bit_cast(float, v << 16) + __builtin_bit_cast(float, w2 << 16);
             const float s1 = __builtin_bit_cast(float, v & 0xffff0000u) + __builtin_bit_cast(float, w2 & 0xffff0000u);
             const bf16 h0 = (bf16)s0, h1 = (bf16)s1;
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p) {
     }
   __syncthreads();
   for (int i = tid; i < 32 * 64; i += 256) {
-    const int n = i >> 6, ci = i & 63, tap = n >> 1, co = n & 1;
+    const int n = i >> 6, ci = i & 63, tap = n >> 1, co = 2 * gpair + (n & 1);
     if (co >= p.Co) continue;
     const float v = s_red[i] + s_red[2048 + i] + s_red[4096 + i] + s_red[6144 + i];
     atomicAdd(&p.dw[((long)tap * p.Ci + ci) * p.Co + co], v * sc);
@@ -726,13 +727,14 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
       return DG_OK;
     }
   }
-  if (p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->Co <= 2 && p->a_sc == 1 &&
-      p->a_sp == 64 && p->g_sc == 1 && p->g_sp == 2 && p->g_sb % 2 == 0 && p->Wc % 64 == 0 && p->Hc >= 2 &&
-      p->Hc % WGU_ROWS_PB == 0) {
+  if (p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->a_sc == 1 &&
+      p->a_sp == 64 && p->g_sc == 1 && (p->g_sp == 2 || p->g_sp == 4) && p->Co <= p->g_sp && p->g_sb % 2 == 0 &&
+      p->Wc % 64 == 0 && p->Hc >= 2 && p->Hc % WGU_ROWS_PB == 0) {
     size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
     if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
     if (lds <= 64 * 1024) {
-      thin_wgrad_up_mfma_kernel<<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p);
+      for (int gpair = 0; 2 * gpair < p->Co; ++gpair)  // one pass per pair of gradient channels
+        thin_wgrad_up_mfma_kernel<<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p, gpair);
       HIP_CHECK_RET(hipGetLastError());
       return DG_OK;
     }
@@ -878,6 +880,21 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
         for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][jt], acc[jt], 0, 0, 0);
       }
     }
+    if (p.adj && CP == 4 && (Y == 1 || Y == p.Hc - 2)) {
+      // CP = 4: a k-step is one kernel row, so the two reflect-adjoint extras are one more k-step each with the
+      // weights of ky = 3 (row 0 into Y == 1) / ky = 0 (row Hf-1 into Y == Hc-2)
+      const int c0 = 2 * X - 1 + 2 * lh;
+      if (Y == 1) {
+        const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, window(0, c0));
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[NS - 1][jt], acc[jt], 0, 0, 0);
+      }
+      if (Y == p.Hc - 2) {
+        const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, window(Hf - 1, c0));
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][jt], acc[jt], 0, 0, 0);
+      }
+    }
     // ---- epilogue: D[row = pixel][col = channel]; transpose through the wave's LDS patch.  The leaky-relu mask
     //      source of the tile is requested first so that its latency hides behind the transposition.
     const long obase = (long)b * p.out_sb + ((long)Y * p.Wc + xt * 32) * p.out_sp;
@@ -939,7 +956,6 @@ int dg_conv_s2_mfma_supported(const ConvP* p) {
   if (p->N != 64 || p->K > 4 || p->Wc % 32 != 0 || p->Hc < 4) return 0;
   const int cp = p->in_sp;  // padded channel count of the input tensor
   if ((cp != 2 && cp != 4) || p->K > cp || p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1 || p->out_sp != 64) return 0;
-  if (cp == 4 && p->adj) return 0;  // (3-head backward-data stays on the VALU kernel)
   if (p->dbias && p->bias_mod != 64) return 0;
   return 1;
 }

@@ -284,8 +284,9 @@ class GEngine:
         HW = c.H * c.W
         self.gout = torch.empty(B, c.nheads, c.H, c.W, dtype=torch.float32, device=device)
         self.draw = torch.empty_like(self.gout)
-        self.draw_pm = (torch.empty(B, c.H, c.W, 2, dtype=torch.bfloat16, device=device)
-                        if (T == torch.bfloat16 and c.nheads <= 2 and c.ring) else None)
+        self.cp = 2 if c.nheads <= 2 else 4  # channel padding of the pixel-major head gradient
+        self.draw_pm = (torch.empty(B, c.H, c.W, self.cp, dtype=torch.bfloat16, device=device)
+                        if (T == torch.bfloat16 and c.nheads <= 4 and c.ring) else None)
         self.mask = torch.empty(B, max(c.nheads - 1, 1), c.H, c.W, dtype=torch.float32, device=device)
         self.depth = torch.empty(B, 1, c.H, c.W, dtype=torch.float32, device=device)
         self.zT = torch.empty(B * c.nz, dtype=T, device=device)
@@ -367,16 +368,17 @@ class GEngine:
                                      L.ptr(self.noise_image) if arch == 2 else None,
                                      L.ptr(self.mask) if arch else None, L.ptr(ddepth), arch, c.tau, c.drop_const, B,
                                      self.HW, s_depth, s_conf, L.ptr(self.draw), st.fptr("head_b", st.grad),
-                                     L.ptr(self.draw_pm), 2, sp),
+                                     L.ptr(self.draw_pm), self.cp, sp),
                 "dg_head_post_bwd")
         hc, wc = self.grid[3]
         pl = (c.nheads * self.HW, 1, self.HW)
         # head weight gradient and backward-data (gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad)
-        if self.draw_pm is not None:  # bf16, <= 2 heads: the pixel-major copy feeds the two thin MFMA kernels
+        if self.draw_pm is not None:  # bf16: the pixel-major copy feeds the two thin MFMA kernels
+            cp = self.cp
             with SideStream.fork():
                 o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw_pm,
-                        (self.HW * 2, 2, 1), st.fptr("head_w", st.grad), 1.0)
-            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw_pm, (self.HW * 2, 2, 1), self.dp[3],
+                        (self.HW * cp, cp, 1), st.fptr("head_w", st.grad), 1.0)
+            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw_pm, (self.HW * cp, cp, 1), self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
                    dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3])
         else:

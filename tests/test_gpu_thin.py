@@ -141,7 +141,7 @@ def test_head_thin(L, dtype, nh):
     assert rel_l2(got, torch.cat(list(gws), dim=1)) < tol
 
 
-@pytest.mark.parametrize("nh", [1, 2])
+@pytest.mark.parametrize("nh", [1, 2, 3])
 def test_head_bwd_data_pixel_major_mfma(L, nh):
     """Head backward-data through the direct-fragment MFMA kernel (thin_s2_mfma, adjoint boundary incl. the
     reflect-adjoint extra taps at rows 1 and H-2) from the pixel-major bf16 copy of the head gradient."""
@@ -160,21 +160,22 @@ def test_head_bwd_data_pixel_major_mfma(L, nh):
     o = Ops(dtype)
     o.force = 3
     HW = 4 * Hc * Wc
-    draw_pm = torch.zeros(B, 2 * Hc, 2 * Wc, 2)
+    cp = 2 if nh <= 2 else 4                     # channel padding of the pixel-major gradient
+    draw_pm = torch.zeros(B, 2 * Hc, 2 * Wc, cp)
     draw_pm[..., :nh] = gy.permute(0, 2, 3, 1)
     draw_pm = draw_pm.to(DEV, dtype).contiguous()
     shadow = torch.cat(ws, dim=1).permute(2, 3, 0, 1).contiguous().to(DEV, dtype)  # [tap][n = ci][k = co]
     prevd = nhwc(prev).to(DEV, dtype)
     dp = torch.empty(B * Hc * Wc * C0, device=DEV, dtype=dtype)
     db = torch.zeros(C0, device=DEV)
-    o.conv(L.MODE_S2, 1, True, B, Hc, Wc, nh, C0, draw_pm, (HW * 2, 2, 1), dp, (Hc * Wc * C0, C0, 1),
+    o.conv(L.MODE_S2, 1, True, B, Hc, Wc, nh, C0, draw_pm, (HW * cp, cp, 1), dp, (Hc * Wc * C0, C0, 1),
            shadow.data_ptr(), 1.0, L.EPI_MASK, aux=prevd, dbias=db.data_ptr(), bias_mod=C0)
     torch.cuda.synchronize()
     assert rel_l2(from_nhwc(dp.float().cpu(), B, C0, Hc, Wc), ref) < 1e-2
     assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < 2e-2
 
 
-@pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2)])
+@pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2), (3, 4, 64, 2)])
 def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
     """Head weight gradient through thin_wgrad_up_mfma (input-pixel-indexed im2col of the pixel-major bf16 head
     gradient, incl. the mirror terms of the two reflected rows) against autograd of the reference op, with per-sample
@@ -194,12 +195,13 @@ def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
     o = Ops(dtype)
     o.force = 3
     HW = 4 * Hc * Wc
-    draw_pm = torch.full((B, 2 * Hc, 2 * Wc, 2), 7.0)  # the unused second channel must not leak into channel 0
+    cp = 2 if nh <= 2 else 4
+    draw_pm = torch.full((B, 2 * Hc, 2 * Wc, cp), 7.0)  # unused padding channels must not leak into the real ones
     draw_pm[..., :nh] = gy.permute(0, 2, 3, 1)
     draw_pm = draw_pm.to(DEV, dtype).contiguous()
     xd = nhwc(x).to(DEV, dtype)
     dw = torch.zeros(16, C0, nh, device=DEV)
-    o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw_pm, (HW * 2, 2, 1), dw.data_ptr(), 1.0,
+    o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw_pm, (HW * cp, cp, 1), dw.data_ptr(), 1.0,
             rowscale=rs.to(DEV))
     torch.cuda.synchronize()
     got = dw.cpu().view(4, 4, C0, nh).permute(2, 3, 0, 1)
