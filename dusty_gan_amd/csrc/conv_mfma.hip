@@ -9,15 +9,17 @@
 //   * one workgroup = 256 threads = 4 waves (2 x 2), tile BM x BN with BM,BN in {64,128}
 //   * an M-tile lies inside ONE output row (and one column parity in MODE_UP) so the tap list - including the
 //     reflect-adjoint extra taps - is workgroup-uniform (scalar control flow, no per-lane predication)
-//   * K step = 128 bytes of channels (64 bf16 / 32 f32) per tap
-//   * PIPE_DMA (default): tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no
-//     ds_write), two LDS buffers, ONE barrier per K step, the next tile's DMA in flight during the MFMAs.  LDS rows
-//     are 128 B unpadded; bank conflicts are removed by an XOR swizzle applied on the per-lane SOURCE address
-//     (lane -> chunk ^ ((row >> 1) & 7)) and undone on the fragment reads (conflict-free for every ds_read_b128
-//     16-lane group).  Measured before the change: with every global load removed the register-staged kernel
-//     only went 394 -> 444 TFLOP/s, i.e. it was bound by ds_write_b128 (79 B/clk/CU) + two barriers per step.
-//   * PIPE_REG: the register-staged pipeline (global -> VGPR -> ds_write, rows padded to 144 B), kept for A/B runs
-//     (DG_CONV_PIPE=reg).
+//   * K step = SB bytes of channels per tap (128: 64 bf16 / 32 f32), moved global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR staging, no ds_write) into an NS-stage ring (default 128 B x 2), ONE raw
+//     s_barrier per K step, counted vmcnt, the next step's DMA in flight during the MFMAs.  LDS rows are unpadded;
+//     bank conflicts are removed by an XOR swizzle applied on the per-lane SOURCE address (lane -> chunk ^ ((row >> 1)
+//     & 7)) and undone on the fragment reads (conflict-free for every ds_read_b128 16-lane group; SQ_LDS_BANK_CONFLICT
+//     = 0).  Measured before the change: with every global load removed the register-staged kernel only went
+//     394 -> 444 TFLOP/s, i.e. it was bound by ds_write_b128 (79 B/clk/CU) + two barriers per step.
+//   * fragment reads are inline-asm ds_read_b128 with counted lgkmcnt: a compiler-visible LDS read behind an in-flight
+//     LDS-DMA makes hipcc drain vmcnt(0) first, which serialised DMA and MFMA in the first DMA version; the tap
+//     iterator is scalar code on the issue side only (no LDS tap table) for the same reason.
+//   * s_setprio(1) around the MFMA groups: +2.5-3 % (same-box A/B, DG_CONV_DBG=8 switches it off).
 //   * bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact fp32, the parity mode)
 //   * blockIdx is remapped so each XCD (private L2) walks a contiguous range of M-tiles across all their N-tiles
 #include "mfma_common.h"
