@@ -709,8 +709,8 @@ int dg_wgrad_thin_supported(const WgradP* p) {
   if (!p->ring) return 0;
   if (p->wmode == 0)
     return p->Ci <= 4 && p->Co % 64 == 0 &&
-           (size_t)4 * (2 * p->Wc + 2) * (p->Ci <= 2 ? 2 : 4) * sizeof(float) <= 64 * 1024;
-  if (p->wmode == 1) return p->Co <= 4 && p->Ci % 64 == 0 && (size_t)2 * 2 * p->Wc * 4 * sizeof(float) <= 64 * 1024;
+           (size_t)4 * (2 * p->Wc + 2) * (p->Ci <= 2 ? 2 : 4) * sizeof(float) <= 160 * 1024;
+  if (p->wmode == 1) return p->Co <= 4 && p->Ci % 64 == 0 && (size_t)2 * 2 * p->Wc * 4 * sizeof(float) <= 160 * 1024;
   return 0;
 }
 
@@ -721,7 +721,10 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (p->wmode == 0 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 2 && p->Co == 64 && p->a_sc == 1 &&
       p->g_sc == 1 && p->a_sp == 2 && p->g_sp == 64 && p->Wc % 64 == 0 && p->Hc % WG_ROWS_PB == 0) {
     const size_t lds = (size_t)4 * (2 * p->Wc + 2) * 4 + 4 * 16 * 144 + 4 * 32 * 64 * 4;
-    if (lds <= 64 * 1024) {
+    if (lds <= 160 * 1024) {
+      if (lds > 64 * 1024)  // 2048-wide images: opt in to more than the default 64 KiB of dynamic LDS
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_wgrad_down_mfma_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       thin_wgrad_down_mfma_kernel<<<(unsigned)(units / WG_ROWS_PB), 256, lds, s>>>(*p);
       HIP_CHECK_RET(hipGetLastError());
       return DG_OK;
@@ -732,7 +735,10 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
       p->Wc % 64 == 0 && p->Hc >= 2 && p->Hc % WGU_ROWS_PB == 0) {
     size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
     if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
-    if (lds <= 64 * 1024) {
+    if (lds <= 160 * 1024) {
+      if (lds > 64 * 1024)
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_wgrad_up_mfma_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       for (int gpair = 0; 2 * gpair < p->Co; ++gpair)  // one pass per pair of gradient channels
         thin_wgrad_up_mfma_kernel<<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p, gpair);
       HIP_CHECK_RET(hipGetLastError());
@@ -740,13 +746,20 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
     }
   }
   if (p->wmode == 0) {
+    const size_t lds = (size_t)4 * (2 * p->Wc + 2) * (p->Ci <= 2 ? 2 : 4) * sizeof(float);
+    if (lds > 64 * 1024)
+      HIP_CHECK_RET(hipFuncSetAttribute(p->Ci <= 2 ? (const void*)thin_wgrad_down_kernel<2> : (const void*)thin_wgrad_down_kernel<4>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int cb = 0; cb < p->Co; cb += 64) {
-      if (p->Ci <= 2) thin_wgrad_down_kernel<2><<<grid, 256, (size_t)4 * (2 * p->Wc + 2) * 2 * sizeof(float), s>>>(*p, cb);
-      else thin_wgrad_down_kernel<4><<<grid, 256, (size_t)4 * (2 * p->Wc + 2) * 4 * sizeof(float), s>>>(*p, cb);
+      if (p->Ci <= 2) thin_wgrad_down_kernel<2><<<grid, 256, lds, s>>>(*p, cb);
+      else thin_wgrad_down_kernel<4><<<grid, 256, lds, s>>>(*p, cb);
     }
   } else {
+    const size_t lds = (size_t)2 * 2 * p->Wc * 4 * sizeof(float);
+    if (lds > 64 * 1024)
+      HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_wgrad_up_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int cb = 0; cb < p->Ci; cb += 64)
-      thin_wgrad_up_kernel<4><<<grid, 256, (size_t)2 * 2 * p->Wc * 4 * sizeof(float), s>>>(*p, cb);
+      thin_wgrad_up_kernel<4><<<grid, 256, lds, s>>>(*p, cb);
   }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
