@@ -21,7 +21,7 @@ def L():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Hc,Wc,B", [(4, 64, 3), (16, 128, 2)])
+@pytest.mark.parametrize("Hc,Wc,B", [(4, 64, 3), (16, 128, 2), (4, 1024, 1)])  # last: 2048-wide images (> 64 KiB LDS in the wgrad)
 def test_down1_thin(L, dtype, Hc, Wc, B):
     from dusty_gan_amd.engine import Ops
     g = torch.Generator().manual_seed(Hc + Wc)
@@ -175,7 +175,8 @@ def test_head_bwd_data_pixel_major_mfma(L, nh):
     assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < 2e-2
 
 
-@pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2), (3, 4, 64, 2)])
+@pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2), (3, 4, 64, 2),
+                                         (2, 2, 1024, 1)])  # 2048-wide images: > 64 KiB of dynamic LDS
 def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
     """Head weight gradient through thin_wgrad_up_mfma (input-pixel-indexed im2col of the pixel-major bf16 head
     gradient, incl. the mirror terms of the two reflected rows) against autograd of the reference op, with per-sample
