@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_kernel(WgradP p, int ci_bas
 typedef __attribute__((ext_vector_type(8))) __bf16 tw_bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 tw_bf16x4;
 typedef __attribute__((ext_vector_type(16))) float tw_f32x16;
-#define WG_ROWS_PB 4
+#define WG_ROWS_PB 2
 
 __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
