@@ -493,8 +493,9 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
 
 // which tile the persistent kernel uses for this layer: 0 none (caller falls back to the 128-wide one-tile kernel),
 // 1 = 256 x 256, 2 = 256 x 128.  `auto_rule`: apply the measured selection (scripts/bench_conv.py, MI355X, bf16):
-// large tiles only pay when every CU gets a tile, and 256 x 128 only where the epilogue reads the leaky-relu
-// mask source (there the up-front aux prefetch wins; the linear / lrelu layers at N = 128 were 7-12 % slower).
+// large tiles only pay when every CU gets a tile; 256 x 128 where the epilogue reads the leaky-relu mask source (the
+// up-front aux prefetch wins) or N >= 256 (Down4 / Up1 forward: -15..17 %); the linear / lrelu layers at N = 128 were
+// 7-12 % slower and stay on the 128-wide kernel.
 inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   if (p->mode != MODE_S2 && p->mode != MODE_UP) return 0;
   const int es = p->in_dtype == DG_BF16 ? 2 : 4;
@@ -502,7 +503,7 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   if (p->dbias && (p->N > 512 || p->bias_mod < p->N)) return 0;
   const int min_tiles = auto_rule ? 256 : 1;
   if (make_geo<256, 256>(p, g) && g.ntiles >= min_tiles) return 1;
-  if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles && (!auto_rule || p->epi == EPI_MASK)) return 2;
+  if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles && (!auto_rule || p->epi == EPI_MASK || p->N >= 256)) return 2;
   return 0;
 }
 
