@@ -1,9 +1,13 @@
 // extern "C" dispatchers of the conv-like passes (include/dusty_gan_hip.h).
 #include "common.h"
 
+#include <stdlib.h>
+
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream);
+int dg_wgrad_mfma_dma_supported(const WgradP* p);
+int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, hipStream_t stream);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_supported(const ConvP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
@@ -47,6 +51,11 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
   const bool thin_ok = dg_wgrad_thin_supported(p);
+  // bf16 Down / Up layers: LDS-DMA ring version (wgrad_mfma_dma.hip); DG_WGRAD_DMA=0 keeps the register-staged kernel
+  static int use_dma = -1;
+  if (use_dma < 0) { const char* e = getenv("DG_WGRAD_DMA"); use_dma = e ? atoi(e) : 1; }
+  if (use_dma && (force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
+    return dg_wgrad_mfma_dma_launch(p, accumulate, s);
   if (force == 2) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
   if (!accumulate) {

@@ -1,0 +1,260 @@
+// Weight-gradient GEMM on the matrix cores with an LDS-DMA ring (bf16, Down = wmode 0, Up = wmode 1):
+//   dW[tap][ci][co] += scale * sum_b rs[b] sum_pixels A[src_a][ci] G[src_g][co]
+// Autograd counterpart in the reference: the weight gradients of nn.Conv2d / nn.ConvTranspose2d inside EqualLR
+// (models/gans/dcgan_eqlr.py:9,24,80; models/ops/common.py:132-133), incl. the R1 double-backward terms.
+//
+// Same GEMM view and fragment reads as wgrad_mfma.hip (M = ci, N = co, K = pixels, ds_read_b64_tr_b16), but the tiles
+// go global -> LDS by LDS-DMA into a 4-stage ring of 32-pixel chunks with counted vmcnt waits and ONE raw barrier per
+// chunk: the register-staged kernel is bound by the exposed load latency of its short chunks (its waves are parked
+// 33 % and issue address arithmetic 43 % of the time, profiles/r01f_pmc_sq_summary.csv); the ring keeps three chunks in
+// flight with no staging registers and no per-chunk 64-bit address math.
+//   * LDS rows are unpadded (DMA pieces are lane-linear); the 4-row x 64-byte footprint of a transposing read is
+//     spread over the banks by an XOR swizzle of the 64-byte column group with the row (applied on the DMA source
+//     address, undone in the read address, which only depends on the lane);
+//   * transposing reads are inline asm (a compiler-visible LDS read behind an in-flight DMA drains vmcnt(0)).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BKP = 32;  // coarse pixels per ring stage
+constexpr int NS = 4;    // ring stages
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+#define DG_WAITV(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define TR16(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+
+template <int WMODE, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n, int accumulate) {
+  constexpr int RA = BM * 2, RG = BN * 2;                 // LDS row bytes (one pixel)
+  constexpr int STA = BKP * RA, STG = BKP * RG, STAGE = STA + STG;
+  constexpr int PA = STA / 1024 / 4, PG = STG / 1024 / 4;  // DMA pieces per wave per stage
+  constexpr int IPT = PA + PG;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  static_assert(PA >= 1 && PG >= 1, "tile too small for the piece distribution");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+
+  const int tid = threadIdx.x;
+  const int ct = blockIdx.x % tiles_n, mt = blockIdx.x / tiles_n;
+  const int ci0 = mt * BM, co0 = ct * BN;
+  const int tap = blockIdx.y, ky = tap >> 2, kx = tap & 3;
+  const long units = (long)p.B * p.Hc;
+  const long u0 = units * blockIdx.z / gridDim.z, u1 = units * (blockIdx.z + 1) / gridDim.z;
+  const int cpr = p.Wc / BKP;                             // chunks per row
+  const long nchunks = (u1 - u0) * cpr;
+  const int Wa = WMODE == 0 ? 2 * p.Wc : p.Wc;
+  const int Wg = WMODE == 1 ? 2 * p.Wc : p.Wc;
+  const bf16* A = (const bf16*)p.a;
+  const bf16* G = (const bf16*)p.g;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int asp = (int)p.a_sp, gsp = (int)p.g_sp;
+
+  // ---- DMA side.  Piece = 1 KiB = 64 lanes x 16 B = (1024 / row bytes) whole rows; lane -> (row in piece, chunk);
+  //      the chunk's 64-byte group is XORed with the row (256-byte rows: row & 3; 128-byte rows: (row >> 1) & 1).
+  constexpr int CA = RA / 16, CG = RG / 16;               // 16-byte chunks per row
+  constexpr int RPA = 64 / CA, RPG = 64 / CG;             // rows per piece
+  auto swz = [](int row, int rowbytes) { return rowbytes == 256 ? (row & 3) : ((row >> 1) & 1); };
+  int rowA[PA], chA[PA], rowG[PG], chG[PG];
+#pragma unroll
+  for (int v = 0; v < PA; ++v) {
+    const int r = (wave + 4 * v) * RPA + lane / CA, c = lane % CA;
+    rowA[v] = r;
+    chA[v] = ((((c >> 2) ^ swz(r, RA)) << 2) | (c & 3)) * 8;   // source element offset inside the pixel's channels
+  }
+#pragma unroll
+  for (int v = 0; v < PG; ++v) {
+    const int r = (wave + 4 * v) * RPG + lane / CG, c = lane % CG;
+    rowG[v] = r;
+    chG[v] = ((((c >> 2) ^ swz(r, RG)) << 2) | (c & 3)) * 8;
+  }
+  long iu = u0;                                           // issue position (unit, chunk in row)
+  int ixc = 0;
+  const bf16* abase = A;
+  const bf16* gbase = G;
+  auto set_unit = [&](long u) {
+    const int b = (int)(u / p.Hc), m = (int)(u % p.Hc);
+    int rowa, rowg;
+    dg_wgrad1d(WMODE, 0, m, p.Hc, ky, rowa, rowg);
+    abase = A + (long)b * p.a_sb + (long)rowa * Wa * p.a_sp + ci0;
+    gbase = G + (long)b * p.g_sb + (long)rowg * Wg * p.g_sp + co0;
+  };
+  set_unit(iu);
+  auto issue = [&](int st) {
+    unsigned char* base = lds + st * STAGE;
+#pragma unroll
+    for (int v = 0; v < PA; ++v) {
+      const int x = ixc * BKP + rowA[v];
+      int ca;
+      if (WMODE == 0) { ca = 2 * x + kx - 1; if (ca < 0) ca += Wa; else if (ca >= Wa) ca -= Wa; }
+      else { ca = x + (kx == 0 ? 1 : (kx == 3 ? -1 : 0)); if (ca < 0) ca += Wa; else if (ca >= Wa) ca -= Wa; }
+      dma16(abase + (unsigned)(ca * asp + chA[v]), base + (wave + 4 * v) * 1024);
+    }
+#pragma unroll
+    for (int v = 0; v < PG; ++v) {
+      const int x = ixc * BKP + rowG[v];
+      const int cg = WMODE == 1 ? 2 * x + ((kx == 0 || kx == 2) ? 1 : 0) : x;
+      dma16(gbase + (unsigned)(cg * gsp + chG[v]), base + STA + (wave + 4 * v) * 1024);
+    }
+    if (++ixc == cpr) { ixc = 0; ++iu; if (iu < u1) set_unit(iu); }
+  };
+
+  // ---- read side: lane -> (row block q, column quad pp) inside its 16-lane group; group -> (k half, column block)
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  unsigned offA[TM], offG[TN];                            // byte offset of this lane's lo read at kq = 0, stage 0
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int colb = (wm * (BM / 2) + i * 32 + 16 * cb + 4 * pp) * 2;
+    offA[i] = lds0 + (8 * kh + q) * RA + ((((colb >> 6) ^ swz(q, RA)) << 6) | (colb & 63));
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int colb = (wn * (BN / 2) + j * 32 + 16 * cb + 4 * pp) * 2;
+    offG[j] = lds0 + STA + (8 * kh + q) * RG + ((((colb >> 6) ^ swz(q, RG)) << 6) | (colb & 63));
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float cur_rs = 1.f;
+  if (p.rowscale && nchunks > 0) {
+    cur_rs = p.rowscale[(int)(u0 / p.Hc)];
+    if (fabsf(cur_rs) < 1e-30f) cur_rs = cur_rs < 0.f ? -1e-30f : 1e-30f;
+  }
+
+  // ---- ring: chunk s lives in stage s % NS; at the top of chunk s wait until it landed (NS-2 younger chunks may
+  //      still fly), barrier (everyone's share landed, everyone finished reading stage (s-1) % NS), refill that
+  //      stage with chunk s + NS - 1, compute chunk s
+  long issued = 0;
+  for (; issued < NS - 1 && issued < nchunks; ++issued) issue((int)(issued % NS));
+  long cu = u0;
+  int cxc = 0;
+  for (long s = 0; s < nchunks; ++s) {
+    const long younger = issued - 1 - s;
+    if (younger <= 0) DG_WAITV(0);
+    else if (younger == 1) DG_WAITV(IPT);
+    else DG_WAITV(2 * IPT);
+    __builtin_amdgcn_s_barrier();
+    if (issued < nchunks) { issue((int)(issued % NS)); ++issued; }
+    const unsigned so = (unsigned)((s % NS) * STAGE);
+#pragma unroll
+    for (int kq = 0; kq < BKP / 16; ++kq) {
+      i32x2 alo[TM], ahi[TM], glo[TN], ghi[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        TR16(alo[i], offA[i] + so + kq * 16 * RA, 0);
+        TR16(ahi[i], offA[i] + so + kq * 16 * RA, 4 * RA);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        TR16(glo[j], offG[j] + so + kq * 16 * RG, 0);
+        TR16(ghi[j], offG[j] + so + kq * 16 * RG, 4 * RG);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const i32x4 fa = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
+          const i32x4 fg = {glo[j][0], glo[j][1], ghi[j][0], ghi[j][1]};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fg),
+                                                              acc[i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // per-sample weights: running sum kept divided by the current sample's weight (wgrad_mfma.hip)
+    const int cur_b = (int)(cu / p.Hc);
+    if (++cxc == cpr) { cxc = 0; ++cu; }
+    if (p.rowscale && s + 1 < nchunks) {
+      const int next_b = (int)(cu / p.Hc);
+      if (next_b != cur_b) {
+        float rn = p.rowscale[next_b];
+        if (fabsf(rn) < 1e-30f) rn = rn < 0.f ? -1e-30f : 1e-30f;
+        const float ratio = cur_rs / rn;
+        cur_rs = rn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] *= ratio;
+      }
+    }
+  }
+
+  // D layout: col = lane & 31 (co), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (ci)
+  float* dw = p.dw + (long)tap * p.Ci * p.Co;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int co = co0 + wn * (BN / 2) + j * 32 + lr;
+        const float v = acc[i][j][e] * (p.scale * cur_rs);
+        float* dst = dw + (long)ci * p.Co + co;
+        if (accumulate) atomicAdd(dst, v);
+        else *dst = v;
+      }
+}
+
+template <int WMODE, int BM, int BN>
+int launch_dma(const WgradP* p, int accumulate, hipStream_t stream) {
+  const int tiles_m = p->Ci / BM, tiles_n = p->Co / BN;
+  const long units = (long)p->B * p->Hc;
+  const long tiles = (long)tiles_m * tiles_n * 16;
+  long split = 1;
+  if (accumulate) {
+    split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
+    if (split > units) split = units;
+    if (split < 1) split = 1;
+  }
+  dim3 grid((unsigned)(tiles_m * tiles_n), 16u, (unsigned)split);
+  wgrad_dma_kernel<WMODE, BM, BN><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+}  // namespace
+
+int dg_wgrad_mfma_dma_supported(const WgradP* p) {
+  if (p->a_dtype != DG_BF16 || p->g_dtype != DG_BF16) return 0;
+  if (p->wmode != 0 && p->wmode != 1) return 0;
+  if (!p->ring || p->a_sc != 1 || p->g_sc != 1) return 0;
+  if (p->Ci % 64 != 0 || p->Co % 64 != 0 || p->Wc % BKP != 0 || p->Hc < 2) return 0;
+  if (p->a_sp % 8 != 0 || p->g_sp % 8 != 0) return 0;      // 16-byte DMA granules
+  return 1;
+}
+
+int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, hipStream_t stream) {
+  if (!dg_wgrad_mfma_dma_supported(p)) return DG_EUNSUPPORTED;
+  const bool m128 = p->Ci % 128 == 0, n128 = p->Co % 128 == 0;
+  if (p->wmode == 0) {
+    if (m128 && n128) return launch_dma<0, 128, 128>(p, accumulate, stream);
+    if (m128) return launch_dma<0, 128, 64>(p, accumulate, stream);
+    if (n128) return launch_dma<0, 64, 128>(p, accumulate, stream);
+    return launch_dma<0, 64, 64>(p, accumulate, stream);
+  }
+  if (m128 && n128) return launch_dma<1, 128, 128>(p, accumulate, stream);
+  if (m128) return launch_dma<1, 128, 64>(p, accumulate, stream);
+  if (n128) return launch_dma<1, 64, 128>(p, accumulate, stream);
+  return launch_dma<1, 64, 64>(p, accumulate, stream);
+}
