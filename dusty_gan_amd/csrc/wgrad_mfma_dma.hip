@@ -155,30 +155,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
     __builtin_amdgcn_s_barrier();
     if (issued < nchunks) { issue((int)(issued % NS)); ++issued; }
     const unsigned so = (unsigned)((s % NS) * STAGE);
-#pragma unroll
-    for (int kq = 0; kq < BKP / 16; ++kq) {
-      i32x2 alo[TM], ahi[TM], glo[TN], ghi[TN];
+    // the reads of k-step kq+1 are issued before the MFMAs of kq (two fragment sets, counted lgkmcnt)
+    i32x2 alo[2][TM], ahi[2][TM], glo[2][TN], ghi[2][TN];
+    auto read_set = [&](int set, int kq) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        TR16(alo[i], offA[i] + so + kq * 16 * RA, 0);
-        TR16(ahi[i], offA[i] + so + kq * 16 * RA, 4 * RA);
+        TR16(alo[set][i], offA[i] + so + kq * 16 * RA, 0);
+        TR16(ahi[set][i], offA[i] + so + kq * 16 * RA, 4 * RA);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        TR16(glo[j], offG[j] + so + kq * 16 * RG, 0);
-        TR16(ghi[j], offG[j] + so + kq * 16 * RG, 4 * RG);
+        TR16(glo[set][j], offG[j] + so + kq * 16 * RG, 0);
+        TR16(ghi[set][j], offG[j] + so + kq * 16 * RG, 4 * RG);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    read_set(0, 0);
+#pragma unroll
+    for (int kq = 0; kq < BKP / 16; ++kq) {
+      if (kq + 1 < BKP / 16) {
+        read_set((kq + 1) & 1, kq + 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const i32x4 fa = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
-          const i32x4 fg = {glo[j][0], glo[j][1], ghi[j][0], ghi[j][1]};
+          const i32x4 fa = {alo[kq & 1][i][0], alo[kq & 1][i][1], ahi[kq & 1][i][0], ahi[kq & 1][i][1]};
+          const i32x4 fg = {glo[kq & 1][j][0], glo[kq & 1][j][1], ghi[kq & 1][j][0], ghi[kq & 1][j][1]};
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fg),
                                                               acc[i][j], 0, 0, 0);
         }
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // per-sample weights: running sum kept divided by the current sample's weight (wgrad_mfma.hip)
