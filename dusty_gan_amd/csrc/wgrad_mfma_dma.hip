@@ -23,8 +23,8 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int BKP = 32;  // coarse pixels per ring stage
-constexpr int NS = 4;    // ring stages
+constexpr int BKP = 64;  // coarse pixels per ring stage
+constexpr int NS = 2;    // ring stages
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
