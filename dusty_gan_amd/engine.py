@@ -155,8 +155,10 @@ class SideStream:
     """Second HIP stream for the weight-gradient kernels.  A layer's weight gradient and the backward-data pass that
     continues the chain read the same tensors and write disjoint ones, and nothing consumes a weight gradient before
     the optimizer - so the (latency-bound) wgrad kernels run beside the chain instead of between its links.  Inside a
-    hipGraph capture the fork / join events become graph edges.  `DUSTY_GAN_SIDE_STREAM=0` disables it."""
-    enabled = os.environ.get("DUSTY_GAN_SIDE_STREAM", "1") != "0"
+    hipGraph capture the fork / join events become graph edges.  Opt-in (`DUSTY_GAN_SIDE_STREAM=1`): it was worth ~1 %
+    while the weight-gradient kernel was latency-bound; with the LDS-DMA version (wgrad_mfma_dma.hip) both streams
+    compete for the same DMA / LDS path and the step is 1.3 % FASTER on one stream (same-box A/B, 3.77 vs 3.82 ms)."""
+    enabled = os.environ.get("DUSTY_GAN_SIDE_STREAM", "0") == "1"
     _streams = {}
     _dirty = set()
 
