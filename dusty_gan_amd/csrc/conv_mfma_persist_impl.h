@@ -103,7 +103,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
   constexpr int RB = WC * ES;
   constexpr int RS = RB + 16;
   constexpr int CR = RB / 16;                  // 16-byte chunks per strip row
-  constexpr int SR = (ES == 4 && BM + BN >= 512) ? 8 : 16;
+  constexpr int NDB0 = 512;
+  // strip rows: 16 unless the ring + 16-row strips would not fit the 160 KiB of LDS
+  constexpr int SR = (NS * STAGE + NWV * 16 * RS + NDB0 * 4 > 160 * 1024) ? 8 : 16;
   constexpr int CPL = SR * CR / 64;            // chunks per lane per strip
   constexpr int STRIP = SR * RS;
   constexpr int NQ = 32 / SR;                  // strips per 32-row MFMA block
@@ -492,10 +494,9 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
 }
 
 // which tile the persistent kernel uses for this layer: 0 none (caller falls back to the 128-wide one-tile kernel),
-// 1 = 256 x 256, 2 = 256 x 128.  `auto_rule`: apply the measured selection (scripts/bench_conv.py, MI355X, bf16):
-// large tiles only pay when every CU gets a tile; 256 x 128 where the epilogue reads the leaky-relu mask source (the
-// up-front aux prefetch wins) or N >= 256 (Down4 / Up1 forward: -15..17 %); the linear / lrelu layers at N = 128 were
-// 7-12 % slower and stay on the 128-wide kernel.
+// 1 = 256 x 256, 2 = 256 x 128.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
+// than 256 such tiles lose badly).  With 128-byte stages the 256 x 128 tile wins on every layer that tiles that way
+// (scripts/bench_conv.py, MI355X, bf16: -7...-17 % per layer against the 128-wide kernel).
 inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   if (p->mode != MODE_S2 && p->mode != MODE_UP) return 0;
   const int es = p->in_dtype == DG_BF16 ? 2 : 4;
@@ -503,7 +504,7 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   if (p->dbias && (p->N > 512 || p->bias_mod < p->N)) return 0;
   const int min_tiles = auto_rule ? 256 : 1;
   if (make_geo<256, 256>(p, g) && g.ntiles >= min_tiles) return 1;
-  if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles && (!auto_rule || p->epi == EPI_MASK || p->N >= 256)) return 2;
+  if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles) return 2;
   return 0;
 }
 
@@ -516,6 +517,15 @@ int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
                               : launch<T, 256, 256, 2, 4, 64, 4, MODE_UP>(p, g, stream);
   }
   if (which == 2) {
+    // bf16: 128-byte stages x 3 (one barrier per 64 channels, 8-row epilogue strips to fit the LDS) measured 8-12 %
+    // faster than 64 x 4 on every layer of this tile; DG_CONV_SB128=0 switches back (A/B runs)
+    static int sb128 = -1;
+    if (sb128 < 0) { const char* e = getenv("DG_CONV_SB128"); sb128 = e ? atoi(e) : 1; }
+    if constexpr (sizeof(T) == 2) {
+      if (sb128 && p->K % 64 == 0)
+        return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream)
+                                  : launch<T, 256, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream);
+    }
     return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 64, 4, MODE_S2>(p, g, stream)
                               : launch<T, 256, 128, 4, 2, 64, 4, MODE_UP>(p, g, stream);
   }
