@@ -494,7 +494,7 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
 }
 
 // which tile the persistent kernel uses for this layer: 0 none (caller falls back to the 128-wide one-tile kernel),
-// 1 = 256 x 256, 2 = 256 x 128.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
+// 1 = 256 x 256, 2 = 256 x 128, 3 = 256 x 64.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
 // than 256 such tiles lose badly).  With 128-byte stages the 256 x 128 tile wins on every layer that tiles that way
 // (scripts/bench_conv.py, MI355X, bf16: -7...-17 % per layer against the 128-wide kernel).
 inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
@@ -505,6 +505,9 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   const int min_tiles = auto_rule ? 256 : 1;
   if (make_geo<256, 256>(p, g) && g.ntiles >= min_tiles) return 1;
   if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles) return 2;
+  // 64-channel layers: 256 x 64 tiles (8 waves of 32 x 64) where the epilogue reads the mask source (Down2 backward-data
+  // -14 %); the lrelu layer of that shape (Up3 forward) measured 5 % slower and stays on the 128-wide kernel
+  if (p->N == 64 && (!auto_rule || p->epi == EPI_MASK) && make_geo<256, 64>(p, g) && g.ntiles >= min_tiles) return 3;
   return 0;
 }
 
@@ -528,6 +531,13 @@ int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
     }
     return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 64, 4, MODE_S2>(p, g, stream)
                               : launch<T, 256, 128, 4, 2, 64, 4, MODE_UP>(p, g, stream);
+  }
+  if (which == 3) {
+    if constexpr (sizeof(T) == 2) {
+      if (p->K % 64 == 0)
+        return p->mode == MODE_S2 ? launch<T, 256, 64, 8, 1, 128, 3, MODE_S2>(p, g, stream)
+                                  : launch<T, 256, 64, 8, 1, 128, 3, MODE_UP>(p, g, stream);
+    }
   }
   return DG_EUNSUPPORTED;
 }

@@ -87,6 +87,7 @@ CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct, 2 = MFMA,
     (256, 128, 4, 128, 2, True, torch.bfloat16, 4),
     (128, 128, 2, 512, 1, True, torch.bfloat16, 4),
     (128, 256, 4, 64, 8, True, torch.bfloat16, 4),
+    (64, 128, 2, 256, 1, True, torch.bfloat16, 4),   # backward-data: 256 x 64 tiles (8 waves of 32 x 64)
 ]
 
 
