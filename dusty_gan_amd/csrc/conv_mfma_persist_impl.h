@@ -494,7 +494,7 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
 }
 
 // which tile the persistent kernel uses for this layer: 0 none (caller falls back to the 128-wide one-tile kernel),
-// 1 = 256 x 256, 2 = 256 x 128, 3 = 256 x 64.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
+// 1 = 256 x 256, 2 = 256 x 128, 3 = 256 x 64, 4 = 128 x 128.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
 // than 256 such tiles lose badly).  With 128-byte stages the 256 x 128 tile wins on every layer that tiles that way
 // (scripts/bench_conv.py, MI355X, bf16: -7...-17 % per layer against the 128-wide kernel).
 inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
@@ -508,6 +508,11 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   // 64-channel layers: 256 x 64 tiles (8 waves of 32 x 64) where the epilogue reads the mask source (Down2 backward-data
   // -14 %); the lrelu layer of that shape (Up3 forward) measured 5 % slower and stays on the 128-wide kernel
   if (p->N == 64 && (!auto_rule || p->epi == EPI_MASK) && make_geo<256, 64>(p, g) && g.ntiles >= min_tiles) return 3;
+  // layers with too few 256-row tiles (the 4 x 64 maps at batch 32): 128 x 128 tiles on 8 waves of 32 x 64, built from
+  // two samples' row segments where the map is 64 wide (Up1 backward-data -13 %, Down4 forward at B = 32 -10 %)
+  static int t128 = -1;  // DG_CONV_T128=0 switches it off (A/B runs)
+  if (t128 < 0) { const char* e = getenv("DG_CONV_T128"); t128 = e ? atoi(e) : 1; }
+  if (t128 && make_geo<128, 128>(p, g) && g.ntiles >= min_tiles) return 4;
   return 0;
 }
 
@@ -531,6 +536,13 @@ int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
     }
     return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 64, 4, MODE_S2>(p, g, stream)
                               : launch<T, 256, 128, 4, 2, 64, 4, MODE_UP>(p, g, stream);
+  }
+  if (which == 4) {
+    if constexpr (sizeof(T) == 2) {
+      if (p->K % 64 == 0)
+        return p->mode == MODE_S2 ? launch<T, 128, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream)
+                                  : launch<T, 128, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream);
+    }
   }
   if (which == 3) {
     if constexpr (sizeof(T) == 2) {
