@@ -75,6 +75,9 @@ PROTOTYPES = {
     "dg_diffaug_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_nsgan_d": [_P, _P, _I, _F, _P, _P, _P, _P],
     "dg_nsgan_g": [_P, _I, _F, _P, _P, _P],
+    "dg_nsgan_d_step": [_P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
+    "dg_nsgan_g_step": [_P, _I, _F, _P, _P, _P],
+    "dg_mean_acc": [_P, _I, _P, _P],
     "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
     "dg_sample_sum": [_P, _I, _L, _I, _P, _P],
     "dg_scale": [_P, _F, _L, _P, _P],

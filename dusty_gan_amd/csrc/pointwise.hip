@@ -346,6 +346,58 @@ __global__ __launch_bounds__(256) void nsgan_g_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) scal[0] = s / B;
 }
 
+// The D-phase bookkeeping around the loss in one launch (trainers/dcgan_amp.py:203-238): loss + dLoss/dy as
+// nsgan_d_kernel, plus the two per-sample vectors the R1 schedule feeds the backward with (up = [1 .. 1 | dy_fake],
+// rs = [dy_real | 1 .. 1]; either may be null), the running sums of the logged scalars (acc[0..2] +=) and the
+// final bias gradient (dfinal_b += sum dy).  Replaces eight tiny torch kernels per step.
+__global__ __launch_bounds__(256) void nsgan_d_step_kernel(const float* __restrict__ y_real,
+                                                           const float* __restrict__ y_fake, int B, float w_gan,
+                                                           float* __restrict__ dy, float* __restrict__ up,
+                                                           float* __restrict__ rs, float* __restrict__ acc,
+                                                           float* __restrict__ dfinal_b) {
+  __shared__ float red[16];
+  float sr = 0.f, sf = 0.f, lr = 0.f, lf = 0.f, sd = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float r = y_real[i], f = y_fake[i];
+    sr += r; sf += f;
+    lr += softplus_f(-r); lf += softplus_f(f);
+    const float dr = -w_gan * sigmoid_f(-r) / (float)B, df = w_gan * sigmoid_f(f) / (float)B;
+    dy[i] = dr; dy[B + i] = df;
+    if (up) { up[i] = 1.f; up[B + i] = df; }
+    if (rs) { rs[i] = dr; rs[B + i] = 1.f; }
+    sd += dr + df;
+  }
+  const float a = dg_block_sum(sr, red), b = dg_block_sum(sf, red);
+  const float c = dg_block_sum(lr, red), d = dg_block_sum(lf, red), e = dg_block_sum(sd, red);
+  if (threadIdx.x == 0) {
+    acc[0] += a / B; acc[1] += b / B; acc[2] += c / B + d / B;
+    if (dfinal_b) dfinal_b[0] += e;
+  }
+}
+
+// acc[0] += loss_G ; dy = d(w_gan*loss_G)/dy_fake
+__global__ __launch_bounds__(256) void nsgan_g_step_kernel(const float* __restrict__ y_fake, int B, float w_gan,
+                                                           float* __restrict__ dy, float* __restrict__ acc) {
+  __shared__ float red[16];
+  float l = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float f = y_fake[i];
+    l += softplus_f(-f);
+    dy[i] = -w_gan * sigmoid_f(-f) / (float)B;
+  }
+  const float s = dg_block_sum(l, red);
+  if (threadIdx.x == 0) acc[0] += s / B;
+}
+
+// acc[0] += mean(x[0..n))   (R1 penalty of the micro-batch: mean of the per-sample squared-gradient sums)
+__global__ __launch_bounds__(256) void mean_acc_kernel(const float* __restrict__ x, int n, float* __restrict__ acc) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  const float t = dg_block_sum(s, red);
+  if (threadIdx.x == 0) acc[0] += t / n;
+}
+
 // fetch_reals (trainers/dcgan_amp.py:154-160; utils/lidar.py:31-36; utils/__init__.py:70-73)
 __global__ void fetch_reals_kernel(const float* __restrict__ pol, const float* __restrict__ mask, float min_d,
                                    float max_d, float drop_const, long n, float* __restrict__ out) {
@@ -537,6 +589,28 @@ int dg_scale(const float* x, float a, long n, float* y, void* s_) {
 int dg_logistic_noise(const float* u1, const float* u2, float eps, long n, float* out, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   logistic_noise_kernel<<<nblk(n), 256, 0, s>>>(u1, u2, eps, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_nsgan_d_step(const float* y_real, const float* y_fake, int B, float w_gan, float* dy, float* up, float* rs,
+                    float* acc, float* dfinal_b, void* s_) {
+  if (!y_real || !y_fake || !dy || !acc || B <= 0) return DG_EINVAL;
+  nsgan_d_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(y_real, y_fake, B, w_gan, dy, up, rs, acc, dfinal_b);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_nsgan_g_step(const float* y_fake, int B, float w_gan, float* dy, float* acc, void* s_) {
+  if (!y_fake || !dy || !acc || B <= 0) return DG_EINVAL;
+  nsgan_g_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(y_fake, B, w_gan, dy, acc);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_mean_acc(const float* x, int n, float* acc, void* s_) {
+  if (!x || !acc || n <= 0) return DG_EINVAL;
+  mean_acc_kernel<<<1, 256, 0, (hipStream_t)s_>>>(x, n, acc);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

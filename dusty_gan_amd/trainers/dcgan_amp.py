@@ -422,16 +422,15 @@ class Trainer:
             self.A.apply(x_real, rand["aug"][0], out=xcat[:B])  # :199
             self.A.apply(synth["depth"], rand["aug"][1], out=xcat[B:])  # :200
             y = deng.forward(Dst, xcat, 0)  # :203-204, real | fake in one pass
+            # loss + dLoss/dy + the R1 schedule's per-sample vectors + scalar sums + final-bias gradient: one launch
+            # chain upstream `up`: 1 for the real half (that IS d sum(y_real)/dx, :218-223), dLoss/dy for the fake half;
+            # `rs`: the real half's ordinary backward is the same chain weighted per sample by dLoss/dy_real
             dy = torch.empty(2 * B, **f32)
-            sc = torch.empty(3, **f32)
-            L.check(lib.dg_nsgan_d(L.ptr(y), L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(dy) + 4 * B, L.ptr(sc), sp),
-                    "dg_nsgan_d")
-            scal[0:3] += sc
+            up = torch.empty(2 * B, **f32) if gp > 0 else None
+            rs = torch.empty(2 * B, **f32) if gp > 0 else None
+            L.check(lib.dg_nsgan_d_step(L.ptr(y), L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs),
+                                        L.ptr(scal), Dst.fptr("final_b", Dst.grad), sp), "dg_nsgan_d_step")
             if gp > 0:
-                # chain upstream: 1 for the real half (that IS d sum(y_real)/dx, :218-223), dLoss/dy for the fake half;
-                # the real half's ordinary backward is the same chain weighted per sample by dLoss/dy_real.
-                up = torch.cat([torch.ones(B, **f32), dy[B:]])
-                rs = torch.cat([dy[:B], torch.ones(B, **f32)])
                 deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
                 # (side stream) weight gradients of the real (weighted by dLoss/dy_real) + fake halves, beside the
                 # rest of the R1 chain
@@ -441,7 +440,7 @@ class Trainer:
                 deng.backward_input(Dst, 0, B, g)
                 ssq = torch.empty(B, **f32)
                 L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
-                scal[3] += ssq.mean()  # :229
+                L.check(lib.dg_mean_acc(L.ptr(ssq), B, L.ptr(scal) + 12, sp), "dg_mean_acc")  # :229
                 # R1 double backward: tangent v = d(gp/2 * mean_b |g_b|^2)/dg = (gp/B) g, pushed forward through D
                 vg = torch.empty_like(g)
                 L.check(lib.dg_scale(L.ptr(g), gp / self.n_acc / B, g.numel(), L.ptr(vg), sp), "dg_scale")
@@ -452,7 +451,6 @@ class Trainer:
                 deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
                 deng.wgrad(Dst, 0, 0, 2 * B, None)
                 deng.final_wgrad(Dst, 0, 2 * B, dy)
-            Dst.view("final_b", Dst.grad).add_(dy.sum())
             E.SideStream.join()
             self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
         gscale = self._allreduce(Dst)
@@ -484,9 +482,7 @@ class Trainer:
             x_aug = self.A.apply(mb["synth"]["depth"], rand["aug"][3])  # :256
             y = deng.forward(Dst, x_aug, 0)  # :260, updated D
             dy = torch.empty(B, **f32)
-            sc = torch.empty(1, **f32)
-            L.check(lib.dg_nsgan_g(L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(sc), sp), "dg_nsgan_g")
-            scal[4:5] += sc
+            L.check(lib.dg_nsgan_g_step(L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp), "dg_nsgan_g_step")
             deng.backward_data(Dst, 0, B, dy, None, want_dbias=False)
             dx = torch.empty(B, 1, self.H, self.W, **f32)
             deng.backward_input(Dst, 0, B, dx)

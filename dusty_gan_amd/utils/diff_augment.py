@@ -55,8 +55,14 @@ class DiffAugment(nn.Module):
         return out
 
     def _args(self, rp, B, device):
-        z_f = torch.zeros(B, dtype=torch.float32, device=device)
-        z_i = torch.zeros(B, dtype=torch.int32, device=device)
+        # stand-ins for parameters a policy does not draw: zeros, allocated once per (B, device) - two fill kernels per
+        # call were ~10 of the step's ~90 tiny launches
+        key = (B, str(device))
+        if getattr(self, "_zeros_key", None) != key:
+            self._zeros = (torch.zeros(B, dtype=torch.float32, device=device),
+                           torch.zeros(B, dtype=torch.int32, device=device))
+            self._zeros_key = key
+        z_f, z_i = self._zeros
         g = lambda k, z: L.ptr(rp[k]) if k in rp else L.ptr(z)
         keep = (z_f, z_i)
         return (g("u_b", z_f), g("u_c", z_f), g("t_h", z_i), g("t_w", z_i), g("o_x", z_i), g("o_y", z_i)), keep

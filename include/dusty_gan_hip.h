@@ -137,6 +137,14 @@ int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const in
 int dg_nsgan_d(const float* y_real, const float* y_fake, int B, float w_gan, float* dy_real, float* dy_fake,
                float* scal, void* stream);
 int dg_nsgan_g(const float* y_fake, int B, float w_gan, float* dy, float* scal, void* stream);
+/* The same losses with the step's bookkeeping folded in (trainers/dcgan_amp.py:203-238,305-309): dy [2B] = dLoss/dy
+ * (real | fake); up [2B] = [1..1 | dy_fake] and rs [2B] = [dy_real | 1..1] (the R1 schedule's per-sample vectors, either
+ * may be NULL); acc[0..2] += (mean y_real, mean y_fake, loss_D); *dfinal_b += sum dy (the final conv's bias gradient).
+ * dg_nsgan_g_step: acc[0] += loss_G.  dg_mean_acc: acc[0] += mean(x[0..n)). */
+int dg_nsgan_d_step(const float* y_real, const float* y_fake, int B, float w_gan, float* dy, float* up, float* rs,
+                    float* acc, float* dfinal_b, void* stream);
+int dg_nsgan_g_step(const float* y_fake, int B, float w_gan, float* dy, float* acc, void* stream);
+int dg_mean_acc(const float* x, int n, float* acc, void* stream);
 
 /* ---- Trainer.fetch_reals  trainers/dcgan_amp.py:154-160 (utils/lidar.py:31-36, utils/__init__.py:70-73) -- */
 int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,

@@ -388,6 +388,36 @@ def test_losses_fetch_reals_adam(L):
     assert torch.equal(sh.cpu(), pd.cpu().bfloat16())
 
 
+def test_nsgan_step_kernels_match_plain_ones(L):
+    """dg_nsgan_d_step / dg_nsgan_g_step / dg_mean_acc (loss + the step's per-sample vectors and running sums in one
+    launch) against dg_nsgan_d / dg_nsgan_g, which test_losses_fetch_reals_adam pins to the reference's GANLoss."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    B = 37
+    yr, yf = torch.randn(B, generator=g).to(DEV), torch.randn(B, generator=g).to(DEV)
+    dy0, sc0 = torch.empty(2 * B, device=DEV), torch.empty(3, device=DEV)
+    L.check(lib.dg_nsgan_d(yr.data_ptr(), yf.data_ptr(), B, 0.5, dy0.data_ptr(), dy0.data_ptr() + 4 * B, sc0.data_ptr(), None))
+    dy, up, rs = (torch.empty(2 * B, device=DEV) for _ in range(3))
+    acc = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0], device=DEV)
+    fb = torch.tensor([0.25], device=DEV)
+    L.check(lib.dg_nsgan_d_step(yr.data_ptr(), yf.data_ptr(), B, 0.5, dy.data_ptr(), up.data_ptr(), rs.data_ptr(),
+                                acc.data_ptr(), fb.data_ptr(), None))
+    assert torch.equal(dy, dy0)
+    assert torch.equal(up, torch.cat([torch.ones(B, device=DEV), dy0[B:]]))
+    assert torch.equal(rs, torch.cat([dy0[:B], torch.ones(B, device=DEV)]))
+    assert torch.allclose(acc[:3], torch.tensor([1.0, 2.0, 3.0], device=DEV) + sc0, atol=1e-6)
+    assert abs(float(fb) - 0.25 - float(dy0.sum())) < 1e-6
+    dg0, sg0 = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    L.check(lib.dg_nsgan_g(yf.data_ptr(), B, 0.5, dg0.data_ptr(), sg0.data_ptr(), None))
+    dg = torch.empty(B, device=DEV)
+    L.check(lib.dg_nsgan_g_step(yf.data_ptr(), B, 0.5, dg.data_ptr(), acc.data_ptr() + 16, None))
+    assert torch.equal(dg, dg0) and abs(float(acc[4]) - 5.0 - float(sg0)) < 1e-6
+    L.check(lib.dg_mean_acc(yr.data_ptr(), B, acc.data_ptr() + 12, None))
+    assert abs(float(acc[3]) - 4.0 - float(yr.mean())) < 1e-6
+    # NULL per-sample vectors (no R1) are allowed
+    L.check(lib.dg_nsgan_d_step(yr.data_ptr(), yf.data_ptr(), B, 0.5, dy.data_ptr(), None, None, acc.data_ptr(), None, None))
+
+
 @pytest.mark.parametrize("nb,Np,K", [(4, 200, 8), (32, 1000, 512), (64, 130, 256)])
 def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
     """dg_adam_proj_fused (Proj.weight's gradient GEMM inside the optimizer kernel) against the oracle's Adam applied to
