@@ -84,6 +84,7 @@ PROTOTYPES = {
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dg_cast": [_P, _P, _I, _L, _P],
     "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
+    "dg_transpose_shadow_multi": [_P, _P, _I, _I, _I, _P],
     "dg_philox_bits": [_U64, _U64, _U64, _L, _P, _P],
     "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],

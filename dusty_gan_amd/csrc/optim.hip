@@ -136,6 +136,36 @@ __global__ __launch_bounds__(256) void adam_proj_fused_kernel(float* __restrict_
   }
 }
 
+// all conv segments of a network in one launch: desc[5 i + (0..4)] = (source element offset in `master`, destination
+// pointer, Ci, Co, first tile index); a tile = (tap, 32 x 32 block of [ci][co]) as in transpose_shadow_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_shadow_multi_kernel(const float* __restrict__ master,
+                                                                     const long long* __restrict__ desc, int nseg) {
+  __shared__ float tile[32][33];
+  int sidx = 0;
+  for (int i = 1; i < nseg; ++i)
+    if ((long long)blockIdx.x >= desc[5 * i + 4]) sidx = i;
+  const long long* d = desc + 5 * sidx;
+  const int Ci = (int)d[2], Co = (int)d[3];
+  const int tci = (Ci + 31) / 32, tco = (Co + 31) / 32;
+  int t = (int)(blockIdx.x - d[4]);
+  const int tap = t / (tci * tco);
+  t -= tap * tci * tco;
+  const int ci0 = (t / tco) * 32, co0 = (t % tco) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = master + d[0] + (long)tap * Ci * Co;
+  T* dst = (T*)d[1] + (long)tap * Ci * Co;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    tile[r][tx] = (ci < Ci && co < Co) ? src[(long)ci * Co + co] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    if (ci < Ci && co < Co) dst[(long)co * Ci + ci] = (T)tile[tx][r];
+  }
+}
+
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -433,6 +463,16 @@ int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_
     adam_proj_fused_kernel<bf16><<<grid, 256, lds, s>>>(p, v, ema, (bf16*)shadow, (const bf16*)dp0, (const bf16*)zT, nb, Np, K, wscale, gscale, lr, beta2, eps, ema_decay, step_dev);
   else
     adam_proj_fused_kernel<float><<<grid, 256, lds, s>>>(p, v, ema, (float*)shadow, (const bf16*)dp0, (const bf16*)zT, nb, Np, K, wscale, gscale, lr, beta2, eps, ema_decay, step_dev);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_transpose_shadow_multi(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                              void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!master || !desc_dev || nseg <= 0 || total_tiles <= 0) return DG_EINVAL;
+  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg);
+  else transpose_shadow_multi_kernel<float><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

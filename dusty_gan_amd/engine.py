@@ -56,6 +56,7 @@ class ParamStore:
         self.v = None
         self.shadow = None  # T copy of flat (same offsets)
         self.coci = {}  # name -> transposed conv shadow [16][co][ci] in T
+        self._tdesc = None  # device descriptor table of refresh_transposed
         self.shadow_dtype = None
         self._seen_version = -1
 
@@ -72,6 +73,7 @@ class ParamStore:
             if t is not None:
                 setattr(self, k, fn(t))
         self.coci = {k: fn(v) for k, v in self.coci.items()}
+        self._tdesc = None  # the descriptor table holds the old pointers
         self._seen_version = -1
 
     @property
@@ -93,21 +95,29 @@ class ParamStore:
         if self.shadow is None or self.shadow_dtype != dtype or self.shadow.device != self.flat.device:
             self.shadow = torch.empty(self.n, dtype=dtype, device=self.flat.device)
             self.coci = {}
+            self._tdesc = None
             self.shadow_dtype = dtype
         L.check(lib.dg_cast(L.ptr(self.flat), L.ptr(self.shadow), L.dtype_code(dtype), self.n, st), "dg_cast")
         self.refresh_transposed()
         self._seen_version = ver
 
     def refresh_transposed(self):
+        """[tap][ci][co] fp32 master -> [tap][co][ci] T shadow of every conv segment, one launch per network"""
         lib, st = L.lib(), L.stream_ptr()
-        for name, s in self.seg.items():
-            if s.kind != "conv":
-                continue
-            _, _, ci, co = s.shape
-            if name not in self.coci:
+        convs = [(name, s) for name, s in self.seg.items() if s.kind == "conv"]
+        if not convs:
+            return
+        if self._tdesc is None or self._tdesc_dtype != self.shadow_dtype or self._tdesc.device != self.flat.device:
+            desc, tiles = [], 0
+            for name, s in convs:
+                _, _, ci, co = s.shape
                 self.coci[name] = torch.empty(16 * ci * co, dtype=self.shadow_dtype, device=self.flat.device)
-            L.check(lib.dg_transpose_shadow(L.ptr(self.flat) + 4 * s.off, L.ptr(self.coci[name]),
-                                            L.dtype_code(self.shadow_dtype), ci, co, st), "dg_transpose_shadow")
+                desc += [s.off, L.ptr(self.coci[name]), ci, co, tiles]
+                tiles += 16 * ((ci + 31) // 32) * ((co + 31) // 32)
+            self._tdesc = torch.tensor(desc, dtype=torch.int64).to(self.flat.device)
+            self._tdesc_tiles, self._tdesc_dtype = tiles, self.shadow_dtype
+        L.check(lib.dg_transpose_shadow_multi(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
+                                              L.dtype_code(self.shadow_dtype), st), "dg_transpose_shadow_multi")
 
     def sptr(self, name):
         """device pointer of the T shadow of a segment"""

@@ -160,6 +160,10 @@ int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema
                      void* stream);
 int dg_cast(const float* src, void* dst, int dtype, long n, void* stream);
 int dg_transpose_shadow(const float* master, void* dst, int dtype, int Ci, int Co, void* stream);
+/* every conv segment of a network in one launch: desc_dev[5 i + (0..4)] = (source element offset in master, destination
+ * pointer, Ci, Co, first tile index), tiles = 16 taps x ceil(Ci/32) x ceil(Co/32) per segment (device memory) */
+int dg_transpose_shadow_multi(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                              void* stream);
 
 /* ---- Philox4x32-10 draws (the reference uses torch's device RNG: trainers/dcgan_amp.py:151-152, models/dusty.py:33-34,
  *      utils/diff_augment.py:27-28,59-60,86-87) --------------------------------------------------------------- */
