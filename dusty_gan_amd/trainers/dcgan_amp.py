@@ -345,7 +345,7 @@ class Trainer:
 
     def _draw_rand(self, B):
         return {"z": self.sample_latents(B), "noise": self._sample_noise(B),
-                "aug": [self.A.draw(B, self.H, self.W, self.device) for _ in range(4)]}
+                "aug": self.A.draw_sets(4, B, self.H, self.W, self.device)}
 
     def _prep_rand(self, rand, B):
         if rand is None:

@@ -37,13 +37,23 @@ class DiffAugment(nn.Module):
         return self._rng
 
     def draw(self, B, H, W, device):
+        return self.draw_sets(1, B, H, W, device)[0]
+
+    def draw_sets(self, n, B, H, W, device):
+        """`n` independent parameter sets in ONE launch.  Set k, sample b uses Philox counter offset 2 (k B + b), i.e.
+        exactly the numbers `n` consecutive draw() calls produce."""
         r = self.rng(device)
-        uf = torch.empty(3, B, dtype=torch.float32, device=device)
-        qi = torch.empty(4, B, dtype=torch.int32, device=device)
-        L.check(L.lib().dg_aug_draw_dev(r.seed, r.stream_id, L.ptr(r.ctr), B, H, W, L.ptr(uf), L.ptr(qi),
+        uf = torch.empty(3, n * B, dtype=torch.float32, device=device)
+        qi = torch.empty(4, n * B, dtype=torch.int32, device=device)
+        L.check(L.lib().dg_aug_draw_dev(r.seed, r.stream_id, L.ptr(r.ctr), n * B, H, W, L.ptr(uf), L.ptr(qi),
                                         L.stream_ptr()), "dg_aug_draw_dev")
-        r.advance(2 * B)
-        return {"u_b": uf[0], "u_s": uf[1], "u_c": uf[2], "t_h": qi[0], "t_w": qi[1], "o_x": qi[2], "o_y": qi[3]}
+        r.advance(2 * n * B)
+        sets = []
+        for k in range(n):
+            sl = slice(k * B, (k + 1) * B)
+            sets.append({"u_b": uf[0, sl], "u_s": uf[1, sl], "u_c": uf[2, sl], "t_h": qi[0, sl], "t_w": qi[1, sl],
+                         "o_x": qi[2, sl], "o_y": qi[3, sl]})
+        return sets
 
     @staticmethod
     def params_to_device(rp, device):
