@@ -494,7 +494,7 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
 }
 
 // which tile the persistent kernel uses for this layer: 0 none (caller falls back to the 128-wide one-tile kernel),
-// 1 = 256 x 256, 2 = 256 x 128, 3 = 256 x 64, 4 = 128 x 128.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
+// 2 = 256 x 128, 3 = 256 x 64, 4 = 128 x 128.  `auto_rule`: large tiles only when every CU gets one (measured: layers with fewer
 // than 256 such tiles lose badly).  With 128-byte stages the 256 x 128 tile wins on every layer that tiles that way
 // (scripts/bench_conv.py, MI355X, bf16: -7...-17 % per layer against the 128-wide kernel).
 inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
@@ -503,7 +503,8 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   if (p->K % (64 / es) != 0) return 0;
   if (p->dbias && (p->N > 512 || p->bias_mod < p->N)) return 0;
   const int min_tiles = auto_rule ? 256 : 1;
-  if (make_geo<256, 256>(p, g) && g.ntiles >= min_tiles) return 1;
+  // (a 256 x 256 tile on 64-byte stages x 4 - all the LDS allows - measured equal to 256 x 128 on 128-byte stages on the
+  // two layers that have enough of them, so it is not instantiated)
   if (make_geo<256, 128>(p, g) && g.ntiles >= min_tiles) return 2;
   // 64-channel layers: 256 x 64 tiles (8 waves of 32 x 64) where the epilogue reads the mask source (Down2 backward-data
   // -14 %); the lrelu layer of that shape (Up3 forward) measured 5 % slower and stays on the 128-wide kernel
@@ -520,10 +521,6 @@ template <typename T>
 int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
   Geo g;
   const int which = pick(p, g, auto_rule);
-  if (which == 1) {
-    return p->mode == MODE_S2 ? launch<T, 256, 256, 2, 4, 64, 4, MODE_S2>(p, g, stream)
-                              : launch<T, 256, 256, 2, 4, 64, 4, MODE_UP>(p, g, stream);
-  }
   if (which == 2) {
     // bf16: 128-byte stages x 3 (one barrier per 64 channels, 8-row epilogue strips to fit the LDS) measured 8-12 %
     // faster than 64 x 4 on every layer of this tile; DG_CONV_SB128=0 switches back (A/B runs)
