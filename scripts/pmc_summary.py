@@ -11,7 +11,7 @@ import sys
 def short(name):
     """function identifier of an Itanium-mangled or plain kernel name (template arguments dropped)"""
     if not name.startswith("_Z"):
-        return re.split(r"[<(]", name.replace("void ", ""))[0].strip()[:60]
+        return re.split(r"[<(]", name.replace("void ", "").replace("(anonymous namespace)::", ""))[0].strip()[:60]
     s, parts = name[2:], []
     if s.startswith("N"):
         s = s[1:]
