@@ -118,7 +118,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + NWV * STRIP + NDB * 4];
 
   // ---- this workgroup's chunk of the tile order
-  const int G = gridDim.x, gi = blockIdx.x;
+  // XCD-aware, bijective chunk assignment (blocks id and id+8 share an XCD): the chunks of one XCD are CONTIGUOUS in
+  // the tile order, so the input rows that neighbouring chunks share (vertical tap overlap) are fetched into one L2
+  // instead of being pulled from the fabric by several (PMC: 294 MB/launch against 112 MB algorithmic without it)
+  const int G = gridDim.x;
+  const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7;
+  const int gi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tq = g.ntiles / G, tr = g.ntiles % G;
   const int t0 = gi * tq + (gi < tr ? gi : tr);
   const int tcount = tq + (gi < tr ? 1 : 0);
