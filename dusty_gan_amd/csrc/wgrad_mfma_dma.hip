@@ -45,11 +45,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   const int tid = threadIdx.x;
-  const int ct = blockIdx.x % tiles_n, mt = blockIdx.x / tiles_n;
+  // XCD-aware, bijective remap of the (tile, tap, split) grid (blocks id and id+8 share an XCD): the 16 taps x tiles of
+  // one K split read the same pixel rows, so each XCD gets a contiguous range of splits and fetches their rows once
+  const int nwg = gridDim.x * gridDim.y * gridDim.z;
+  const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
+  const int ct = bx % tiles_n, mt = bx / tiles_n;
   const int ci0 = mt * BM, co0 = ct * BN;
-  const int tap = blockIdx.y, ky = tap >> 2, kx = tap & 3;
+  const int tap = by, ky = tap >> 2, kx = tap & 3;
   const long units = (long)p.B * p.Hc;
-  const long u0 = units * blockIdx.z / gridDim.z, u1 = units * (blockIdx.z + 1) / gridDim.z;
+  const long u0 = units * bz / gridDim.z, u1 = units * (bz + 1) / gridDim.z;
   const int cpr = p.Wc / BKP;                             // chunks per row
   const long nchunks = (u1 - u0) * cpr;
   const int Wa = WMODE == 0 ? 2 * p.Wc : p.Wc;
