@@ -8,8 +8,10 @@
 // Why this kernel exists: the one-tile-per-workgroup kernel of conv_mfma.hip (128 x 128 tiles, 2 workgroups per CU)
 // issues 8 LDS-DMA pieces per 16 MFMAs per wave and measured DMA-only ~= MFMA-only ~= half of the combined time: it
 // is bound by the DMA issue / L1 path, not by latency (a persistent 128 x 128 variant with cross-tile prefetch ran
-// at the same speed).  The lever is bytes per flop, i.e. the tile: 256 x 256 (8 waves, one workgroup per CU) moves
-// half the bytes per MFMA.  What it takes for conv layers:
+// at the same speed).  The lever is bytes per flop, i.e. the tile, plus fewer barriers per byte (128-byte stages).
+// Shipped tiles: 256 x 128 (8 waves, the default for every layer with >= 256 tiles), 256 x 64 (N == 64 layers with
+// the mask epilogue) and 128 x 128 with 8 waves (small layers); 256 x 256 only fits the LDS with 64-byte stages x 4,
+// measured equal to 256 x 128 on 128-byte stages x 3, and is not instantiated.  What it takes for conv layers:
 //   * an M tile of 256 output pixels of ONE image row (and one column parity in MODE_UP) keeps the tap list
 //     workgroup-uniform; layers narrower than 256 build the tile from the SAME row segment of NSB consecutive
 //     samples (the tap list only depends on the row), so every fat layer gets 256-row tiles;

@@ -389,6 +389,120 @@ __global__ __launch_bounds__(256) void nsgan_g_step_kernel(const float* __restri
   if (threadIdx.x == 0) acc[0] += s / B;
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// All seven GANLoss metrics (models/loss.py:39-61 loss_D, :66-85 loss_G) as one kernel.  Every metric is
+//   loss = mean_i phi_r(a_i) + mean_i phi_f(b_i),   a = y_real - [rel] mean(y_fake),  b = y_fake - [rel] mean(y_real)
+// with phi from a small family; `rel` marks the relativistic-average metrics (average_diff, loss.py:11-18).
+//   d loss / d y_real_i = phi_r'(a_i)/B - [rel] mean_j phi_f'(b_j) / B      (and symmetrically for y_fake)
+enum { PHI_NONE = 0, PHI_SOFTPLUS = 1, PHI_LINEAR = 2, PHI_SQUARE = 3, PHI_HINGE = 4 };
+struct GanForm {
+  int kr, kf;        // phi family of the real / fake term
+  float sr, sf;      // sign applied to the argument: softplus(s x), s x, relu(1 + s x)
+  float cr, cf;      // target of the square: (x - c)^2
+  int rel;
+};
+
+// value and derivative of phi(kind, s, c) at x
+__device__ __forceinline__ void gan_phi(int kind, float s, float c, float x, float& v, float& d) {
+  switch (kind) {
+    case PHI_SOFTPLUS: v = softplus_f(s * x); d = s * sigmoid_f(s * x); break;
+    case PHI_LINEAR: v = s * x; d = s; break;
+    case PHI_SQUARE: v = (x - c) * (x - c); d = 2.f * (x - c); break;
+    case PHI_HINGE: { const float t = 1.f + s * x; v = t > 0.f ? t : 0.f; d = t > 0.f ? s : 0.f; } break;
+    default: v = 0.f; d = 0.f;
+  }
+}
+
+static int gan_form(int metric, int mode_g, float smoothing, GanForm* f) {
+  // rows follow models/loss.py:39-61 (D) and :66-85 (G)
+  const GanForm D[7] = {
+      {PHI_SOFTPLUS, PHI_SOFTPLUS, -1.f, 1.f, 0.f, 0.f, 0},      // nsgan
+      {PHI_LINEAR, PHI_LINEAR, -1.f, 1.f, 0.f, 0.f, 0},          // wgan
+      {PHI_SQUARE, PHI_SQUARE, 0.f, 0.f, smoothing, 0.f, 0},     // lsgan (label_real * smoothing, label_fake = 0)
+      {PHI_HINGE, PHI_HINGE, -1.f, 1.f, 0.f, 0.f, 0},            // hinge
+      {PHI_SOFTPLUS, PHI_SOFTPLUS, -1.f, 1.f, 0.f, 0.f, 1},      // ragan
+      {PHI_HINGE, PHI_HINGE, -1.f, 1.f, 0.f, 0.f, 1},            // rahinge
+      {PHI_SQUARE, PHI_SQUARE, 0.f, 0.f, 1.f, -1.f, 1}};         // ralsgan
+  const GanForm G[7] = {
+      {PHI_NONE, PHI_SOFTPLUS, 0.f, -1.f, 0.f, 0.f, 0},          // nsgan
+      {PHI_NONE, PHI_LINEAR, 0.f, -1.f, 0.f, 0.f, 0},            // wgan
+      {PHI_NONE, PHI_SQUARE, 0.f, 0.f, 0.f, 1.f, 0},             // lsgan (target 1, not smoothed: loss.py:71-72)
+      {PHI_NONE, PHI_LINEAR, 0.f, -1.f, 0.f, 0.f, 0},            // hinge
+      {PHI_SOFTPLUS, PHI_SOFTPLUS, 1.f, -1.f, 0.f, 0.f, 1},      // ragan
+      {PHI_HINGE, PHI_HINGE, 1.f, -1.f, 0.f, 0.f, 1},            // rahinge
+      {PHI_SQUARE, PHI_SQUARE, 0.f, 0.f, -1.f, 1.f, 1}};         // ralsgan
+  if (metric < 0 || metric > 6) return DG_EUNSUPPORTED;
+  *f = mode_g ? G[metric] : D[metric];
+  return DG_OK;
+}
+
+// One block.  D mode (mode_g = 0): dy = [d/dy_real | d/dy_fake] of w_gan * loss, up / rs / dfinal_b / acc[0..2] as in
+// nsgan_d_step_kernel.  G mode: only the fake half carries a gradient (D(real) is data, trainers/dcgan_amp.py:259);
+// dy = d(w_gan * loss)/dy_fake, acc[0] += loss; y_real may be null unless the metric is relativistic.
+__global__ __launch_bounds__(256) void gan_step_kernel(GanForm fm, int mode_g, const float* __restrict__ y_real,
+                                                       const float* __restrict__ y_fake, int B, float w_gan,
+                                                       float* __restrict__ dy, float* __restrict__ up,
+                                                       float* __restrict__ rs, float* __restrict__ acc,
+                                                       float* __restrict__ dfinal_b) {
+  __shared__ float red[16];
+  __shared__ float bc;
+  auto bsum = [&](float v) {  // block sum, broadcast to every thread
+    const float r = dg_block_sum(v, red);
+    __syncthreads();
+    if (threadIdx.x == 0) bc = r;
+    __syncthreads();
+    return bc;
+  };
+  const bool has_r = (fm.kr != PHI_NONE) || !mode_g;
+  float sr = 0.f, sf = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    if (has_r) sr += y_real[i];
+    sf += y_fake[i];
+  }
+  const float mr = bsum(sr) / B, mf = bsum(sf) / B;
+  const float offr = fm.rel ? mf : 0.f, offf = fm.rel ? mr : 0.f;
+  float lsum = 0.f, dsr = 0.f, dsf = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    float v, d;
+    if (fm.kr != PHI_NONE) {
+      gan_phi(fm.kr, fm.sr, fm.cr, y_real[i] - offr, v, d);
+      lsum += v; dsr += d;
+    }
+    gan_phi(fm.kf, fm.sf, fm.cf, y_fake[i] - offf, v, d);
+    lsum += v; dsf += d;
+  }
+  const float loss = bsum(lsum) / B;
+  const float mdr = bsum(dsr) / B, mdf = bsum(dsf) / B;
+  const float k = w_gan / (float)B;
+  float sd = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    float v, d, dr = 0.f;
+    if (fm.kr != PHI_NONE) {
+      gan_phi(fm.kr, fm.sr, fm.cr, y_real[i] - offr, v, d);
+      dr = k * (d - (fm.rel ? mdf : 0.f));
+    }
+    gan_phi(fm.kf, fm.sf, fm.cf, y_fake[i] - offf, v, d);
+    const float df = k * (d - (fm.rel ? mdr : 0.f));
+    if (mode_g) {
+      dy[i] = df;
+    } else {
+      dy[i] = dr; dy[B + i] = df;
+      if (up) { up[i] = 1.f; up[B + i] = df; }
+      if (rs) { rs[i] = dr; rs[B + i] = 1.f; }
+      sd += dr + df;
+    }
+  }
+  const float e = dg_block_sum(sd, red);
+  if (threadIdx.x == 0) {
+    if (mode_g) {
+      acc[0] += loss;
+    } else {
+      acc[0] += mr; acc[1] += mf; acc[2] += loss;
+      if (dfinal_b) dfinal_b[0] += e;
+    }
+  }
+}
+
 // acc[0] += mean(x[0..n))   (R1 penalty of the micro-batch: mean of the per-sample squared-gradient sums)
 __global__ __launch_bounds__(256) void mean_acc_kernel(const float* __restrict__ x, int n, float* __restrict__ acc) {
   __shared__ float red[16];
@@ -604,6 +718,30 @@ int dg_nsgan_d_step(const float* y_real, const float* y_fake, int B, float w_gan
 int dg_nsgan_g_step(const float* y_fake, int B, float w_gan, float* dy, float* acc, void* s_) {
   if (!y_fake || !dy || !acc || B <= 0) return DG_EINVAL;
   nsgan_g_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(y_fake, B, w_gan, dy, acc);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_gan_d_step(int metric, float smoothing, const float* y_real, const float* y_fake, int B, float w_gan,
+                  float* dy, float* up, float* rs, float* acc, float* dfinal_b, void* s_) {
+  if (!y_real || !y_fake || !dy || !acc || B <= 0) return DG_EINVAL;
+  GanForm fm;
+  const int rc = gan_form(metric, 0, smoothing, &fm);
+  if (rc != DG_OK) return rc;
+  gan_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(fm, 0, y_real, y_fake, B, w_gan, dy, up, rs, acc, dfinal_b);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, float w_gan, float* dy, float* acc,
+                  void* s_) {
+  if (!y_fake || !dy || !acc || B <= 0) return DG_EINVAL;
+  GanForm fm;
+  const int rc = gan_form(metric, 1, 1.f, &fm);
+  if (rc != DG_OK) return rc;
+  if (fm.kr != PHI_NONE && !y_real) return DG_EINVAL;  // relativistic metrics read D(real) (models/loss.py:76-85)
+  gan_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(fm, 1, y_real, y_fake, B, w_gan, dy, nullptr, nullptr, acc,
+                                                  nullptr);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

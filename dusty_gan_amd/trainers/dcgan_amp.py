@@ -276,8 +276,7 @@ class Trainer:
         # losses (reference :104-113)
         self.loss_weight = dict(self.cfg.solver.loss)
         self.criterion = {"gan": GANLoss(self.cfg.solver.gan_mode)}
-        if self.criterion["gan"].metric != "nsgan":
-            raise NotImplementedError("only gan_mode=nsgan has fused loss kernels (SURVEY.md §8f row 4)")
+        self.gan_code = self.criterion["gan"].code  # NotImplementedError for an unknown metric (models/loss.py:63)
         if self.loss_weight.get("gp", 0) > 0.0:
             self.criterion["gp"] = True
         if self.loss_weight.get("pl", 0) > 0.0:
@@ -428,8 +427,9 @@ class Trainer:
             dy = torch.empty(2 * B, **f32)
             up = torch.empty(2 * B, **f32) if gp > 0 else None
             rs = torch.empty(2 * B, **f32) if gp > 0 else None
-            L.check(lib.dg_nsgan_d_step(L.ptr(y), L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs),
-                                        L.ptr(scal), Dst.fptr("final_b", Dst.grad), sp), "dg_nsgan_d_step")
+            L.check(lib.dg_gan_d_step(self.gan_code, float(self.criterion["gan"].smoothing), L.ptr(y),
+                                      L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs), L.ptr(scal),
+                                      Dst.fptr("final_b", Dst.grad), sp), "dg_gan_d_step")
             if gp > 0:
                 deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
                 # (side stream) weight gradients of the real (weighted by dLoss/dy_real) + fake halves, beside the
@@ -478,11 +478,21 @@ class Trainer:
         for j, sync in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
             mb = self._mb[j]
             rand = mb["rand"]
-            # :255/:259 A(real) and D(real) feed only relativistic losses; nsgan's loss_G ignores them (loss.py:68-69)
-            x_aug = self.A.apply(mb["synth"]["depth"], rand["aug"][3])  # :256
-            y = deng.forward(Dst, x_aug, 0)  # :260, updated D
+            # :255/:259 A(real) and D(real) feed only the relativistic losses (loss.py:76-85); the other metrics'
+            # loss_G never reads pred_real (loss.py:66-75), so that pass is not run for them
             dy = torch.empty(B, **f32)
-            L.check(lib.dg_nsgan_g_step(L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp), "dg_nsgan_g_step")
+            if self.criterion["gan"].relativistic:
+                xcat = torch.empty(2 * B, 1, self.H, self.W, **f32)  # fake first: its slots 0..B carry the backward
+                self.A.apply(mb["synth"]["depth"], rand["aug"][3], out=xcat[:B])  # :256
+                self.A.apply(mb["x_real"], rand["aug"][2], out=xcat[B:])  # :255
+                y = deng.forward(Dst, xcat, 0)  # :259-260, updated D
+                y_real = L.ptr(y) + 4 * B
+            else:
+                x_aug = self.A.apply(mb["synth"]["depth"], rand["aug"][3])  # :256
+                y = deng.forward(Dst, x_aug, 0)  # :260, updated D
+                y_real = None
+            L.check(lib.dg_gan_g_step(self.gan_code, y_real, L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp),
+                    "dg_gan_g_step")
             deng.backward_data(Dst, 0, B, dy, None, want_dbias=False)
             dx = torch.empty(B, 1, self.H, self.W, **f32)
             deng.backward_input(Dst, 0, B, dx)

@@ -144,6 +144,20 @@ int dg_nsgan_g(const float* y_fake, int B, float w_gan, float* dy, float* scal, 
 int dg_nsgan_d_step(const float* y_real, const float* y_fake, int B, float w_gan, float* dy, float* up, float* rs,
                     float* acc, float* dfinal_b, void* stream);
 int dg_nsgan_g_step(const float* y_fake, int B, float w_gan, float* dy, float* acc, void* stream);
+
+/* ---- GANLoss, all metrics  models/loss.py:39-61 (loss_D), :66-85 (loss_G) ------------------------------------
+ * metric: DG_GAN_* below (the reference's `solver.gan_mode` strings in models/loss.py order).  Same outputs as the
+ * nsgan entries above: D step writes dy = [d/dy_real | d/dy_fake] of w_gan * loss_D, the R1 schedule's `up` / `rs`
+ * vectors (nullable), acc[0..2] += (mean y_real, mean y_fake, loss_D), dfinal_b += sum(dy) (nullable).  G step writes
+ * dy = d(w_gan * loss_G)/dy_fake and acc[0] += loss_G; y_real = D(real) logits, required by the relativistic
+ * metrics (ragan / rahinge / ralsgan, average_diff models/loss.py:11-18) and ignored (may be NULL) otherwise.
+ * `smoothing` = GANLoss.smoothing (lsgan's real label, models/loss.py:46).  DG_EUNSUPPORTED for an unknown metric. */
+enum { DG_GAN_NSGAN = 0, DG_GAN_WGAN = 1, DG_GAN_LSGAN = 2, DG_GAN_HINGE = 3, DG_GAN_RAGAN = 4, DG_GAN_RAHINGE = 5,
+       DG_GAN_RALSGAN = 6 };
+int dg_gan_d_step(int metric, float smoothing, const float* y_real, const float* y_fake, int B, float w_gan, float* dy,
+                  float* up, float* rs, float* acc, float* dfinal_b, void* stream);
+int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, float w_gan, float* dy, float* acc,
+                  void* stream);
 int dg_mean_acc(const float* x, int n, float* acc, void* stream);
 
 /* ---- Trainer.fetch_reals  trainers/dcgan_amp.py:154-160 (utils/lidar.py:31-36, utils/__init__.py:70-73) -- */

@@ -9,6 +9,7 @@ captures every random draw by replaying torch's global generator, and stores inp
 are then both checked against these files without the reference present.
 
 usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+        python tests/golden/make_golden.py gan_modes  (only the six step_*_<gan_mode>.npz files)
 """
 import importlib.util
 import os
@@ -316,8 +317,22 @@ def make_ops_golden():
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_gan_mode_goldens():
+    """the six config-reachable `solver.gan_mode`s besides nsgan (models/loss.py:42-61,70-85), one step each; the
+    relativistic ones are the only metrics whose G phase reads D(real) (trainers/dcgan_amp.py:255,259)"""
+    make_step_golden("none_wgan", "none", True, seed=21, steps=1, B=3, gan_mode="wgan")
+    make_step_golden("none_lsgan", "none", True, seed=22, steps=1, B=3, gan_mode="lsgan")
+    make_step_golden("dusty1_hinge", "dusty1", True, seed=23, steps=1, B=3, gan_mode="hinge")
+    make_step_golden("dusty2_ragan", "dusty2", True, seed=24, steps=1, B=3, gan_mode="ragan")
+    make_step_golden("dusty1_rahinge", "dusty1", True, seed=25, steps=1, B=3, gan_mode="rahinge", gp=0.0)
+    make_step_golden("dusty2_ralsgan", "dusty2", True, seed=26, steps=1, B=3, gan_mode="ralsgan")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["gan_modes"]:  # only the fixtures added after the first set (the others stay byte-identical)
+        make_gan_mode_goldens()
+        sys.exit(0)
     make_ops_golden()
     make_step_golden("none_ring", "none", True, seed=11)
     make_step_golden("dusty1_ring", "dusty1", True, seed=12)
@@ -327,3 +342,4 @@ if __name__ == "__main__":
     # a mid-size case closer to the production channel plan (still CPU-seconds)
     make_step_golden("dusty2_mid", "dusty2", True, seed=16, in_ch=32, ch_base=16, ch_max=64, shape=(64, 128), B=3,
                      steps=1)
+    make_gan_mode_goldens()

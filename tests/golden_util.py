@@ -7,7 +7,9 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-STEP_CASES = ["none_ring", "dusty1_ring", "dusty2_ring", "dusty2_noring", "dusty2_nogp", "dusty2_mid"]
+STEP_CASES = ["none_ring", "dusty1_ring", "dusty2_ring", "dusty2_noring", "dusty2_nogp", "dusty2_mid",
+              # one per remaining `solver.gan_mode` (models/loss.py:42-61,70-85)
+              "none_wgan", "none_lsgan", "dusty1_hinge", "dusty2_ragan", "dusty1_rahinge", "dusty2_ralsgan"]
 
 
 def load(name):

@@ -388,6 +388,57 @@ def test_losses_fetch_reals_adam(L):
     assert torch.equal(sh.cpu(), pd.cpu().bfloat16())
 
 
+GAN_METRICS = ["nsgan", "wgan", "lsgan", "hinge", "ragan", "rahinge", "ralsgan"]
+
+
+@pytest.mark.parametrize("metric", GAN_METRICS)
+def test_gan_step_kernels_all_metrics(L, metric):
+    """dg_gan_d_step / dg_gan_g_step: loss values against the reference's GANLoss (tests/golden/ops.npz), gradients
+    w.r.t. the logits against autograd through the oracle's restatement (pinned to the same vectors on CPU), and
+    the step bookkeeping (up / rs / acc / final-bias sum)."""
+    from dusty_gan_amd.models.loss import GANLoss, METRICS
+    lib = L.lib()
+    ops = load("ops")
+    code = METRICS.index(metric)
+    pr, pf = torch.from_numpy(ops["ganloss/pred_real"]).view(-1), torch.from_numpy(ops["ganloss/pred_fake"]).view(-1)
+    crit = GANLoss(metric)
+    assert abs(float(crit(pr.to(DEV), pf.to(DEV), "D")) - float(ops[f"ganloss/{metric}/D"])) < 1e-5
+    assert abs(float(crit(pr.to(DEV), pf.to(DEV), "G")) - float(ops[f"ganloss/{metric}/G"])) < 1e-5
+    g = torch.Generator().manual_seed(5)
+    for B in (1, 37, 300):
+        yr, yf = torch.randn(B, generator=g) * 1.5, torch.randn(B, generator=g) * 1.5
+        a, b = yr.clone().requires_grad_(), yf.clone().requires_grad_()
+        loss = O.gan_loss(metric, a, b, "D")
+        gr, gf = torch.autograd.grad(0.5 * loss, [a, b])
+        dy, up, rs = (torch.empty(2 * B, device=DEV) for _ in range(3))
+        acc = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0], device=DEV)
+        fb = torch.tensor([0.25], device=DEV)
+        yrd, yfd = yr.to(DEV), yf.to(DEV)
+        L.check(lib.dg_gan_d_step(code, 1.0, yrd.data_ptr(), yfd.data_ptr(), B, 0.5, dy.data_ptr(), up.data_ptr(),
+                                  rs.data_ptr(), acc.data_ptr(), fb.data_ptr(), None))
+        assert (dy.cpu() - torch.cat([gr, gf])).abs().max() < 2e-6 * max(1.0, 37 / B), (metric, B)
+        assert torch.equal(up, torch.cat([torch.ones(B, device=DEV), dy[B:]]))
+        assert torch.equal(rs, torch.cat([dy[:B], torch.ones(B, device=DEV)]))
+        want = torch.tensor([1.0 + float(yr.mean()), 2.0 + float(yf.mean()), 3.0 + float(loss.detach())])
+        assert torch.allclose(acc[:3].cpu(), want, atol=1e-5)
+        assert abs(float(fb) - 0.25 - float(dy.sum())) < 1e-5
+        a, b = yr.clone(), yf.clone().requires_grad_()
+        loss_g = O.gan_loss(metric, a, b, "G")
+        (gg,) = torch.autograd.grad(0.5 * loss_g, [b])
+        dg = torch.empty(B, device=DEV)
+        L.check(lib.dg_gan_g_step(code, yrd.data_ptr(), yfd.data_ptr(), B, 0.5, dg.data_ptr(), acc.data_ptr() + 16, None))
+        assert (dg.cpu() - gg).abs().max() < 2e-6 * max(1.0, 37 / B), (metric, B)
+        assert abs(float(acc[4]) - 5.0 - float(loss_g)) < 1e-5
+        rc = lib.dg_gan_g_step(code, None, yfd.data_ptr(), B, 0.5, dg.data_ptr(), acc.data_ptr() + 16, None)
+        assert (rc != 0) == crit.relativistic  # D(real) is only optional for the non-relativistic metrics
+    assert lib.dg_gan_d_step(7, 1.0, yrd.data_ptr(), yfd.data_ptr(), B, 0.5, dy.data_ptr(), None, None,
+                             acc.data_ptr(), None, None) != 0
+    with pytest.raises(NotImplementedError):
+        GANLoss("nope")(pr.to(DEV), pf.to(DEV), "D")
+    with pytest.raises(ValueError):
+        crit(pr.to(DEV), pf.to(DEV), "X")
+
+
 def test_nsgan_step_kernels_match_plain_ones(L):
     """dg_nsgan_d_step / dg_nsgan_g_step / dg_mean_acc (loss + the step's per-sample vectors and running sums in one
     launch) against dg_nsgan_d / dg_nsgan_g, which test_losses_fetch_reals_adam pins to the reference's GANLoss."""

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False, n_acc=1):
+def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False, n_acc=1, gan_mode="nsgan"):
     from dusty_gan_amd.trainers.dcgan_amp import Trainer
     from dusty_gan_amd.utils.config import load_config
     model = {"none": "dcgan_eqlr", "dusty1": "dusty1_dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
@@ -25,7 +25,7 @@ def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False
                        f"model.gen.in_ch={in_ch}", f"model.gen.ch_base={ch_base}", f"model.gen.ch_max={ch_max}",
                        f"model.dis.ch_base={ch_base}", f"model.dis.ch_max={ch_max}", f"model.ring={str(ring).lower()}",
                        f"solver.batch_size={B * n_acc}", f"solver.loss.gp={gp}", f"enable_amp={str(amp).lower()}",
-                       f"solver.num_accumulation={n_acc}", "dataset.pool=1"])
+                       f"solver.num_accumulation={n_acc}", "dataset.pool=1", f"solver.gan_mode={gan_mode}"])
     return Trainer(cfg, {"gpu": 0, "ngpus": 1, "batch_size": B, "num_workers": 0})
 
 
@@ -43,7 +43,8 @@ def test_step_matches_reference_golden(case):
     arch, ring = str(g["meta/arch"]), bool(g["meta/ring"])
     B, steps = int(g["meta/B"]), int(g["meta/steps"])
     tr = make_trainer(arch, ring, tuple(int(v) for v in g["meta/shape"]), int(g["meta/in_ch"]),
-                      int(g["meta/ch_base"]), int(g["meta/ch_max"]), B, gp=float(g["meta/gp"]))
+                      int(g["meta/ch_base"]), int(g["meta/ch_max"]), B, gp=float(g["meta/gp"]),
+                      gan_mode=str(g["meta/gan_mode"]))
     tr.G.load_state_dict(sub(g, "init/G"))
     tr.D.load_state_dict(sub(g, "init/D"))
     tr.G_ema.load_state_dict(sub(g, "init/G"))
@@ -71,18 +72,35 @@ def test_step_matches_reference_golden(case):
                 assert (synth[k] != v).float().mean() < 1e-3
             else:
                 assert rel_l2(synth[k], v) < tol, k
+        # relativistic-average losses: sum_i dLoss/dy_i == 0 identically, so the final conv's bias gradient is zero and
+        # the reference's stored value is fp32 rounding noise (~1e-7) whose SIGN Adam then turns into a +-lr update
+        noise = {"5.module.bias"} if str(g["meta/gan_mode"]).startswith("ra") else set()
         for k, v in sub(g, f"{pre}/grad_D").items():
+            if k in noise:
+                assert float(v.abs().max()) < 1e-6 and float(gD[k].abs().max()) < 1e-6
+                continue
             assert rel_l2(gD[k], v) < tol, ("grad_D", k)
         for k, v in sub(g, f"{pre}/grad_G").items():
             assert rel_l2(gG[k], v) < tol, ("grad_G", k)
         for tag, net in (("G", tr.G), ("D", tr.D), ("G_ema", tr.G_ema)):
             sd = net.state_dict()
             for k, v in sub(g, f"{pre}/after/{tag}").items():
+                if tag == "D" and noise and f"{pre}/grad_D/{k}" in g.files:
+                    # same story per channel: a bias whose units have the same slope for every sample gets
+                    # (sum_i dy_i) * const == 0; compare where the gradient is not rounding noise, bound the rest
+                    gref = torch.from_numpy(g[f"{pre}/grad_D/{k}"])
+                    live = gref.abs() > 1e-4 * gref.abs().max() if k not in noise else torch.zeros_like(gref, dtype=torch.bool)
+                    assert float((sd[k].cpu() - v).abs().max()) <= 2 * float(g["meta/lr"]) * 1.001, (tag, k)
+                    if live.any():
+                        assert rel_l2(sd[k].cpu()[live], v[live]) < tol, (tag, k)
+                    continue
                 assert rel_l2(sd[k].cpu(), v) < tol, (tag, k)
     # Adam state round trip in torch.optim.Adam's format
     sdo = tr.optim_D.state_dict()
     names = [k for k, _ in tr.D.named_parameters()]
     for i, k in enumerate(names):
+        if k in noise:
+            continue
         assert rel_l2(sdo["state"][i]["exp_avg_sq"], g[f"final/optim_D/{k}/exp_avg_sq"]) < tol
         assert int(sdo["state"][i]["step"]) == steps
 
@@ -252,13 +270,14 @@ def test_checkpoint_roundtrip_and_generate(tmp_path):
         tr.G(torch.zeros(2, 8))  # CPU input: no fallback
 
 
-def test_graph_replay_matches_eager_launches(monkeypatch):
+@pytest.mark.parametrize("gan_mode", ["nsgan", "rahinge"])
+def test_graph_replay_matches_eager_launches(monkeypatch, gan_mode):
     """the hipGraph-captured step (device-resident Philox / Adam counters) trains exactly like the eager launch
     sequence: same seeds -> same parameters after 5 iterations (fp32; atomics make the last bits differ)"""
     def run(graph):
         monkeypatch.setenv("DUSTY_GAN_GRAPH", "1" if graph else "0")
         torch.manual_seed(2024)
-        tr = make_trainer("dusty2", True, (32, 64), 8, 4, 16, 4)
+        tr = make_trainer("dusty2", True, (32, 64), 8, 4, 16, 4, gan_mode=gan_mode)
         sc = [dict(tr.step(i).items()) for i in range(5)]
         assert (tr._graph is not None) == graph
         return tr, sc

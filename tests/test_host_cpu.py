@@ -60,6 +60,15 @@ def test_error_codes_without_gpu(built):
     with pytest.raises(built.DgError):
         built.check(built.DG_EUNSUPPORTED, "x")
     assert built.policy_mask(["brightness", "cutout"]) == 17
+    # GANLoss dispatch: the reference's seven metric names (models/loss.py:39-61), anything else is NotImplementedError
+    from dusty_gan_amd.models.loss import GANLoss, METRICS
+    assert [GANLoss(m).code for m in METRICS] == list(range(7))
+    assert [m for m in METRICS if GANLoss(m).relativistic] == ["ragan", "rahinge", "ralsgan"]
+    with pytest.raises(NotImplementedError):
+        GANLoss("nope").code
+    one = (C.c_float * 1)()
+    assert lib.dg_gan_d_step(0, 1.0, None, one, 1, 1.0, one, None, None, one, None, None) == built.DG_EINVAL
+    assert lib.dg_gan_g_step(0, None, None, 1, 1.0, one, one, None) == built.DG_EINVAL
     with pytest.raises(KeyError):
         built.policy_mask(["nope"])
 
