@@ -53,7 +53,7 @@ class DgWgrad(C.Structure):
     ]
 
 
-_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
+_P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64
 
 # name -> argtypes (all return int except dg_version); mirrors include/dusty_gan_hip.h one to one
 PROTOTYPES = {
@@ -81,6 +81,9 @@ PROTOTYPES = {
     "dg_gan_g_step": [_I, _P, _P, _I, _F, _P, _P, _P],
     "dg_mean_acc": [_P, _I, _P, _P],
     "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
+    "dg_scan_to_polar": [_P, _I, _I, _I, _I, _I, _I, _P, _D, _D, _F, _P, _P, _P, _P, _P],
+    "dg_inv_to_xyz": [_P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P],
+    "dg_unit_map": [_P, _L, _I, _P, _P],
     "dg_sample_sum": [_P, _I, _L, _I, _P, _P],
     "dg_scale": [_P, _F, _L, _P, _P],
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],

@@ -241,6 +241,7 @@ class Trainer:
         self.H, self.W = int(H), int(W)
         self.lidar = LiDAR(num_ring=H, num_points=W, min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth,
                            angle_file=osp.join(cfg.dataset.root, "angles.pt") if cfg.dataset.get("root") else None)
+        self.lidar.to(self.device)
 
         self.G.to(self.device)
         self.D.to(self.device)
@@ -259,8 +260,8 @@ class Trainer:
 
         self.ema_decay = 0.5 ** (self.cfg.solver.batch_size / (self.cfg.solver.smoothing_kimg * 1000))
 
-        # data: the hot path is fed from a device-resident pool for `dataset.name == synthetic`; file datasets are
-        # the "next" row of SURVEY.md §8f -- any iterator of {"depth","mask"} batches can be passed as `loader`.
+        # data (reference :80-90): a device-resident synthetic pool for `dataset.name == synthetic`, the file datasets
+        # through the device-side scan pipeline (datasets/scans.py), or any iterator of {"depth","mask"} batches
         if loader is not None:
             self.loader = loader
         elif str(self.cfg.dataset.name) == "synthetic":
@@ -269,9 +270,11 @@ class Trainer:
                                           min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth)
             self.loader = cycle(self.dataset)
         else:
-            raise NotImplementedError(
-                f"dataset '{self.cfg.dataset.name}': the file-based KITTI/MPO input path is outside this round's "
-                "scope (SURVEY.md §8f row 1); pass dataset=synthetic or give Trainer(..., loader=<iterator>)")
+            from ..datasets import ScanLoader, define_dataset
+            self.dataset = define_dataset(self.cfg.dataset, phase="train")  # NotImplementedError for unknown names
+            self.loader = cycle(ScanLoader(self.dataset, self.local_batch, self.device, world=_world(), rank=_rank(),
+                                           num_workers=int(local_cfg["num_workers"] if isinstance(local_cfg, dict)
+                                                           else local_cfg.num_workers)))
 
         # losses (reference :104-113)
         self.loss_weight = dict(self.cfg.solver.loss)
@@ -563,8 +566,9 @@ class Trainer:
         # RCCL configuration cannot be validated on a one-GPU box, so multi-rank runs launch eagerly by default.
         if self.world > 1 and os.environ.get("DUSTY_GAN_GRAPH_DDP", "0") != "1":
             return False
+        # the replay copies each batch into static device buffers, so the loader must yield fixed-shape device batches
         return (reals is None and rands is None and self.use_graph and E.PROFILE is None
-                and isinstance(getattr(self, "dataset", None), SyntheticLiDAR))
+                and getattr(getattr(self, "dataset", None), "graph_safe", False))
 
     def _step_graph(self):
         """hipGraph replay of the whole iteration (device-resident data): the ~180 kernel launches of a
@@ -631,8 +635,10 @@ class Trainer:
 
     # ------------------------------------------------------------------ inference / checkpoints
     def postprocess(self, synth):
-        """reference :327-329 adds points/normals via utils.postprocess (visualisation; out of scope): pass-through"""
-        return synth
+        """reference :327-329 -> utils.postprocess (utils/__init__.py:163-178): [0,1] depth maps, sigmoid confidence and
+        the point map on the sensor's angle grid (surface normals, a rendering aid, are not produced)"""
+        from ..utils.lidar import postprocess
+        return postprocess(synth, self.lidar)
 
     @torch.no_grad()
     def generate(self, ema=False):

@@ -1,16 +1,38 @@
-"""The one LiDAR coordinate helper on the hot path -- reference: utils/lidar.py:31-36 (Coordinate.invert_depth),
-used by Trainer.fetch_reals (trainers/dcgan_amp.py:154-160).  The spherical projection / point-cloud parts of the
-reference's LiDAR class are post-processing and out of scope."""
+"""LiDAR coordinate helper -- reference: utils/lidar.py:11-68,111-130 (Coordinate / LiDAR).
+
+On the training path it provides `fetch_reals` (Coordinate.invert_depth :31-36 fused with sigmoid_to_tanh and the
+drop-constant fill of Trainer.fetch_reals, trainers/dcgan_amp.py:154-160).  On the output side it turns generated
+inverse depth into the unit-space point map (`inv_to_xyz` :58-65 with revert_depth / pol_to_xyz) on the sensor's
+angle grid (`angles.pt`, resized like LiDAR.init_coordmap :127-130).  All arithmetic is in csrc/ (pointwise.hip,
+lidar_io.hip); `points_to_depth` (:67-108, used by the reconstruction demo only) is not built.
+"""
+import os
+
 import torch
+import torch.nn.functional as F
 
 from .. import _lib as L
 
 
 class LiDAR:
-    def __init__(self, num_ring, num_points, min_depth, max_depth, angle_file=None):
+    def __init__(self, num_ring, num_points, min_depth, max_depth, angle_file=None, drop_const=0.0):
         self.H, self.W = num_ring, num_points
         self.min_depth, self.max_depth = float(min_depth), float(max_depth)
-        self.angle_file = angle_file  # only needed for xyz post-processing, which this engine does not do
+        self.drop_const = float(drop_const)  # Coordinate's own default (utils/lidar.py:12), NOT the generator's -1
+        self.angle_file = angle_file
+        self.angle = None  # [1,2,H,W] (elevation, azimuth); the synthetic dataset has no angle file
+        if angle_file is not None and os.path.exists(angle_file):
+            self.angle = self.init_coordmap(self.H, self.W)
+
+    def init_coordmap(self, H, W):
+        """utils/lidar.py:127-130 (one-time setup: a bilinear resize of the 2 x 64 x 2048 average-angle table)"""
+        angle = torch.load(self.angle_file, map_location="cpu")[None].float()
+        return F.interpolate(angle, size=(H, W), mode="bilinear")
+
+    def to(self, device):
+        if self.angle is not None:
+            self.angle = self.angle.to(device).contiguous()
+        return self
 
     def fetch_reals(self, pol, mask, drop_const):
         """pol [B,1,H,W] in [0,1], mask [B,1,H,W] {0,1} float -> inverse depth in [-1,1], dropped pixels = drop_const"""
@@ -20,3 +42,52 @@ class LiDAR:
         L.check(L.lib().dg_fetch_reals(L.ptr(pol), L.ptr(mask), self.min_depth, self.max_depth, float(drop_const),
                                        pol.numel(), L.ptr(out), L.stream_ptr()), "dg_fetch_reals")
         return out, mask
+
+    def inv_to_xyz(self, inv_depth, tol=1e-8, from_tanh=False, return_depth=False):
+        """utils/lidar.py:58-65.  inv_depth [B,1,H,W] in [0,1] (or the generator's [-1,1] output with from_tanh=True,
+        which applies utils/__init__.py:168 first) -> points [B,3,H,W] in unit space (metres / max_depth)."""
+        if self.angle is None:
+            raise RuntimeError(f"no angle grid: {self.angle_file!r} does not exist (utils/lidar.py:120)")
+        if not inv_depth.is_cuda:
+            raise RuntimeError("inv_to_xyz runs on the GPU only (no CPU fallback)")
+        x = inv_depth.contiguous().float()
+        B, _, H, W = x.shape
+        assert (H, W) == (self.H, self.W) and x.shape[1] == 1
+        if self.angle.device != x.device:
+            self.to(x.device)
+        pts = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+        d01 = torch.empty_like(x) if return_depth else None
+        L.check(L.lib().dg_inv_to_xyz(L.ptr(x), L.ptr(self.angle), B, H, W, int(from_tanh), self.min_depth,
+                                      self.max_depth, self.drop_const, float(tol), L.ptr(d01), L.ptr(pts),
+                                      L.stream_ptr()), "dg_inv_to_xyz")
+        return (pts, d01) if return_depth else pts
+
+
+def unit_map(x, mode):
+    """utils.postprocess's elementwise branches (utils/__init__.py:169-172): mode 0 tanh_to_sigmoid+clamp, 1 sigmoid"""
+    if not x.is_cuda:
+        raise RuntimeError("postprocess runs on the GPU only (no CPU fallback)")
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    L.check(L.lib().dg_unit_map(L.ptr(x), x.numel(), mode, L.ptr(y), L.stream_ptr()), "dg_unit_map")
+    return y
+
+
+def postprocess(synth, lidar, tol=1e-8):
+    """utils.postprocess utils/__init__.py:163-178: depth / depth_orig -> [0,1], confidence -> sigmoid, + "points".
+    The surface-normal image (:177, a rendering aid) is not produced.  Without an angle grid (synthetic dataset)
+    "points" is omitted."""
+    out = {}
+    for key, value in synth.items():
+        if key == "depth":
+            if lidar.angle is not None:
+                out["points"], out["depth"] = lidar.inv_to_xyz(value, tol, from_tanh=True, return_depth=True)
+            else:
+                out["depth"] = unit_map(value, 0)
+        elif key == "depth_orig":
+            out["depth_orig"] = unit_map(value, 0)
+        elif key == "confidence":
+            out["confidence"] = unit_map(value, 1)
+        else:
+            out[key] = value
+    return out

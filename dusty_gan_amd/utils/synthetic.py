@@ -9,6 +9,8 @@ from .rng import Philox
 
 
 class SyntheticLiDAR:
+    graph_safe = True  # fixed-shape device batches (see Trainer._graph_eligible)
+
     def __init__(self, batch, H, W, device, seed=1234, pool=4, min_depth=0.9, max_depth=120.0):
         rng = Philox(seed, device, stream_id=9)
         self.batches = []

@@ -164,6 +164,29 @@ int dg_mean_acc(const float* x, int n, float* acc, void* stream);
 int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,
                    float* out, void* stream);
 
+/* ---- data formats either side of the step ---------------------------------------------
+ * dg_scan_to_polar: KITTIOdometry.preprocess + .transform  datasets/kitti.py:54-77, optionally fused with
+ * Trainer.fetch_reals (trainers/dcgan_amp.py:154-160).  scan [B,Hs,Ws,C] fp32 = the projected scans written by
+ * process_kitti.py:76-118 (x, y, z[, reflectance] per cell, C >= 3; C == 4 is read with 16-byte loads); flip [B]
+ * bytes (NULL = no horizontal flip; TF.hflip precedes the resize); H x W = cfg.dataset.shape, NEAREST resize =
+ * torch's legacy nearest (src = min(floor(dst * in / out), in - 1)).  Outputs (NCHW fp32): pol [B,1,H,W] =
+ * (|xyz| - min) / (max - min), mask [B,1,H,W] in {0,1} = |xyz| > 0 & > min & < max, invalid cells zeroed;
+ * xyz [B,3,H,W] = xyz / max_depth (nullable); x_real [B,1,H,W] = the network input fetch_reals would make of
+ * (pol, mask) with drop_const (nullable).
+ * dg_inv_to_xyz: utils.postprocess's depth branch + Coordinate.inv_to_xyz  utils/__init__.py:163-178,
+ * utils/lidar.py:38-68.  in [B,1,H,W]: generator depth in [-1,1] (from_tanh = 1: tanh_to_sigmoid + clamp first) or
+ * inverse depth in [0,1]; angle [2,H,W] = (elevation, azimuth) grid of LiDAR.init_coordmap (:127-130);
+ * drop_const / tol as Coordinate (0 / 1e-8 by default).  depth01 [B,1,H,W] (nullable) receives the [0,1] inverse
+ * depth, points [B,3,H,W] the unit-space point map. */
+int dg_scan_to_polar(const float* scan, int B, int Hs, int Ws, int C, int H, int W, const unsigned char* flip,
+                     double min_depth, double max_depth, float drop_const, float* pol, float* mask, float* xyz,
+                     float* x_real, void* stream);
+int dg_inv_to_xyz(const float* in, const float* angle, int B, int H, int W, int from_tanh, float min_depth,
+                  float max_depth, float drop_const, float tol, float* depth01, float* points, void* stream);
+/* utils.postprocess's other branches (utils/__init__.py:169-172): mode 0 = tanh_to_sigmoid(x).clamp(0,1)
+ * (depth_orig), mode 1 = sigmoid(x) (confidence) */
+int dg_unit_map(const float* x, long n, int mode, float* y, void* stream);
+
 /* ---- small reductions / helpers --------------------------------------------------------------------------- */
 int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */
 int dg_scale(const float* x, float a, long n, float* y, void* stream);

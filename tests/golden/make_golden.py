@@ -10,8 +10,10 @@ are then both checked against these files without the reference present.
 
 usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
         python tests/golden/make_golden.py gan_modes  (only the six step_*_<gan_mode>.npz files)
+        python tests/golden/make_golden.py lidar      (only lidar.npz)
 """
 import importlib.util
+import math
 import os
 import sys
 import types
@@ -317,6 +319,41 @@ def make_ops_golden():
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_lidar_golden():
+    """utils/lidar.py vectors from the reference's own LiDAR class: the angle grid resize of
+    init_coordmap, invert_depth / revert_depth, pol_to_xyz and inv_to_xyz.  The angle file is data made here (the
+    reference ships none): elevation rows + azimuth columns with per-cell jitter, like process_kitti.py:150-197."""
+    import tempfile
+    lidar = _load_lidar()
+    torch.manual_seed(31)
+    Hs, Ws, H, W, B = 8, 64, 8, 32, 3
+    pitch = torch.linspace(0.05, -0.42, Hs)[:, None].expand(Hs, Ws) + 0.002 * torch.randn(Hs, Ws)
+    yaw = torch.linspace(math.pi, -math.pi, Ws)[None, :].expand(Hs, Ws) + 0.002 * torch.randn(Hs, Ws)
+    angle_src = torch.stack([pitch, yaw]).contiguous()
+    d = {"angle_src": angle_src.numpy(), "meta/shape": np.array([H, W]), "meta/min_depth": np.array(0.9),
+         "meta/max_depth": np.array(120.0), "meta/torch": np.array(torch.__version__)}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "angles.pt")
+        torch.save(angle_src, path)
+        L = lidar.LiDAR(num_ring=H, num_points=W, min_depth=0.9, max_depth=120.0, angle_file=path)
+    d["angle"] = L.angle.numpy()
+    inv = torch.rand(B, 1, H, W)
+    inv[torch.rand(B, 1, H, W) < 0.2] = 0.0  # dropped points (drop_const of Coordinate = 0)
+    d["inv"] = inv.numpy()
+    d["revert_depth/norm"] = L.revert_depth(inv[inv > 0]).numpy()
+    d["revert_depth/metric"] = L.revert_depth(inv[inv > 0], norm=False).numpy()
+    d["invert_depth"] = L.invert_depth(L.revert_depth(inv[inv > 0])).numpy()
+    d["points"] = L.inv_to_xyz(inv.clone()).numpy()
+    d["pol_to_xyz"] = L.pol_to_xyz(inv).numpy()
+    gen = torch.tanh(torch.randn(B, 1, H, W) * 1.5)
+    gen[torch.rand(B, 1, H, W) < 0.2] = -1.0  # dusty drop_const in tanh space -> 0 after tanh_to_sigmoid
+    d["gen_depth"] = gen.numpy()
+    d["gen_points"] = L.inv_to_xyz(((gen + 1.0) / 2.0).clamp_(0, 1)).numpy()  # utils/__init__.py:168,176
+    path = os.path.join(HERE, "lidar.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def make_gan_mode_goldens():
     """the six config-reachable `solver.gan_mode`s besides nsgan (models/loss.py:42-61,70-85), one step each; the
     relativistic ones are the only metrics whose G phase reads D(real) (trainers/dcgan_amp.py:255,259)"""
@@ -330,6 +367,9 @@ def make_gan_mode_goldens():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["lidar"]:
+        make_lidar_golden()
+        sys.exit(0)
     if sys.argv[1:] == ["gan_modes"]:  # only the fixtures added after the first set (the others stay byte-identical)
         make_gan_mode_goldens()
         sys.exit(0)
@@ -343,3 +383,4 @@ if __name__ == "__main__":
     make_step_golden("dusty2_mid", "dusty2", True, seed=16, in_ch=32, ch_base=16, ch_max=64, shape=(64, 128), B=3,
                      steps=1)
     make_gan_mode_goldens()
+    make_lidar_golden()

@@ -125,3 +125,76 @@ def test_train_step_matches_reference(case):
         for k in opt:
             assert rel_l2(opt[k]["v"], g[f"final/optim_{tag}/{k}/exp_avg_sq"]) < 1e-4
             assert rel_l2(opt[k]["m"], g[f"final/optim_{tag}/{k}/exp_avg"]) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data formats either side of the step: oracle/lidar_oracle.py
+# ---------------------------------------------------------------------------------------------------------------
+def test_lidar_oracle_matches_reference():
+    """utils/lidar.py restatement against vectors from the reference's LiDAR class (tests/golden/lidar.npz)"""
+    from oracle import lidar_oracle as LO
+    g = load("lidar")
+    H, W = (int(v) for v in g["meta/shape"])
+    mn, mx = float(g["meta/min_depth"]), float(g["meta/max_depth"])
+    angle = LO.init_coordmap(t(g["angle_src"]), H, W)
+    assert rel_l2(angle, g["angle"]) < 1e-6
+    inv = t(g["inv"])
+    live = inv[inv > 0]
+    assert rel_l2(LO.revert_depth(live, mn, mx), g["revert_depth/norm"]) < 1e-6
+    assert rel_l2(LO.revert_depth(live, mn, mx, norm=False), g["revert_depth/metric"]) < 1e-6
+    pol = LO.revert_depth(live, mn, mx)
+    back, _ = O.fetch_reals(pol, torch.ones_like(pol))
+    assert rel_l2((back + 1) / 2, g["invert_depth"]) < 1e-6
+    assert rel_l2(LO.pol_to_xyz(inv, angle), g["pol_to_xyz"]) < 1e-6
+    pts = LO.inv_to_xyz(inv, angle, mn, mx)
+    assert rel_l2(pts, g["points"]) < 1e-6
+    assert torch.equal(pts[:, :1][inv == 0], torch.zeros_like(pts[:, :1][inv == 0]))  # dropped points sit at the origin
+    out = LO.postprocess({"depth": t(g["gen_depth"]), "confidence": torch.zeros(1)}, angle, mn, mx)
+    assert rel_l2(out["points"], g["gen_points"]) < 1e-6
+    assert float(out["confidence"]) == 0.5
+
+
+def test_scan_to_polar_restatement_properties():
+    """datasets/kitti.py:54-77 restatement (parity unpinned against the reference class, see the oracle header):
+    hand-computed cells, range mask at the boundaries, zeroing, hflip-before-resize and the NEAREST index rule."""
+    from oracle import lidar_oracle as LO
+    Hs, Ws = 4, 16
+    pts = np.zeros((Hs, Ws, 4), np.float32)
+    pts[0, 0, :3] = (3.0, 4.0, 0.0)        # |.| = 5
+    pts[0, 2, :3] = (0.0, 0.0, 0.5)        # below min_depth -> invalid
+    pts[1, 4, :3] = (0.0, 120.0, 0.0)      # == max_depth -> invalid (strict <)
+    pts[1, 6, :3] = (0.0, 0.9, 0.0)        # == min_depth -> invalid (strict >)
+    pts[2, 14, :3] = (1.0, 2.0, 2.0)       # |.| = 3
+    pts[..., 3] = 0.7                      # reflectance is ignored for the depth modality
+    out = LO.scan_to_polar(pts, (4, 8))
+    assert out["depth"].shape == (1, 4, 8) and out["mask"].dtype == torch.bool and out["xyz"].shape == (3, 4, 8)
+    assert int(out["mask"].sum()) == 2
+    assert abs(float(out["depth"][0, 0, 0]) - (5.0 - 0.9) / 119.1) < 1e-7    # source column 0 -> 0
+    assert abs(float(out["depth"][0, 2, 7]) - (3.0 - 0.9) / 119.1) < 1e-7    # source column 14 -> 7 (src = 2 * dst)
+    assert torch.allclose(out["xyz"][:, 2, 7], torch.tensor([1.0, 2.0, 2.0]) / 120.0)
+    assert float(out["depth"][0, 0, 1]) == 0.0 and float(out["depth"][0, 1, 2]) == 0.0 and float(out["depth"][0, 1, 3]) == 0.0
+    fl = LO.scan_to_polar(pts, (4, 8), flip=True)
+    # flipped source column of (0,0) is 15 -> lands on an odd column that NEAREST (src = 2 * dst) never samples
+    assert int(fl["mask"].sum()) == 0
+    pts[0, 1, :3] = (3.0, 4.0, 0.0)
+    fl = LO.scan_to_polar(pts, (4, 8), flip=True)
+    assert bool(fl["mask"][0, 0, 7])       # flipped column 14 -> output column 7
+    # non-integer ratio: torch's legacy nearest, src = floor(dst * in / out)
+    out = LO.scan_to_polar(pts, (3, 5))
+    src_w = [int(np.floor(i * np.float32(16 / 5))) for i in range(5)]
+    src_h = [int(np.floor(i * np.float32(4 / 3))) for i in range(3)]
+    full = LO.scan_to_polar(pts, (4, 16))
+    assert torch.equal(out["depth"], full["depth"][:, src_h][:, :, src_w])
+
+
+@pytest.mark.parametrize("n,world", [(10, 1), (10, 4), (3, 8), (257, 2)])
+def test_sampler_restatement_matches_torch(n, world):
+    """oracle sampler == torch.utils.data.distributed.DistributedSampler as the reference builds it (:88)"""
+    from oracle import lidar_oracle as LO
+    from torch.utils.data.distributed import DistributedSampler
+    for rank in range(world):
+        ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank))
+        assert LO.sampler_indices(n, world, rank) == ref
+    idx = LO.sampler_indices(n, world, 0)
+    bs = LO.batches(idx, 2)
+    assert all(len(b) == 2 for b in bs) and len(bs) == len(idx) // 2
