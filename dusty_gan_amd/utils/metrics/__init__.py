@@ -1,0 +1,4 @@
+"""Validation metrics on MI355X -- reference: utils/metrics/ (SURVEY.md §8f row 3)."""
+from .cov_mmd_1nna import compute_cov_mmd_1nna  # noqa: F401
+from .distance import chamfer_distance_matrix, chamfer_dir  # noqa: F401
+from .jsd import compute_jsd  # noqa: F401

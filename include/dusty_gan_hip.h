@@ -187,6 +187,23 @@ int dg_inv_to_xyz(const float* in, const float* angle, int B, int H, int W, int 
  * (depth_orig), mode 1 = sigmoid(x) (confidence) */
 int dg_unit_map(const float* x, long n, int mode, float* y, void* stream);
 
+/* ---- validation metrics (the reference's CUDA extensions and their torch drivers) -------
+ * dg_fps: furthest point sampling  utils/sampling/fps/furthest_point_sampling.cu:97-207 (+ gather_points :38-60 when
+ * `out` is given).  xyz [B,n,3] fp32, m <= n samples per cloud, temp [B,n] fp32 workspace, idx [B,m] int32, out
+ * [B,m,3] (nullable) = the sampled points (downsample_point_clouds, furthest_point_sampling.py:84-93).  Starts at
+ * index 0, skips points with |p|^2 <= 1e-3, ties resolved in the reference launcher's thread order.
+ * dg_chamfer_dir: all-pairs directed Chamfer means L[i][j] = mean_{p in A_i} min_{q in B_j} |p - q|^2 for A [Na,n,3],
+ * B [Nb,m,3] -> L [Na,Nb]; compute_cd(A_i, B_j) of utils/metrics/cov_mmd_1nna.py:20-22 = L_AB[i][j] + L_BA[j][i]
+ * (chamfer_distance.cu / nnsearch chamfer_distance.cpp:41-66).  One launch per matrix instead of the reference's
+ * Python loop over i (:34-50).
+ * dg_grid_vote: JSD occupancy histogram  utils/metrics/jsd.py:24-79: counters[argmin_k |p - grid_k|^2] += 1 for
+ * every point (first index on ties); pts [P,3], grid [Ng,3] (unit_cube_grid_point_cloud :11-21), counters [Ng]
+ * accumulate.  dg_jsd: _jensen_shannon_divergence :96-107 of two counter vectors -> out[0]. */
+int dg_fps(const float* xyz, int B, int n, int m, float* temp, int* idx, float* out, void* stream);
+int dg_chamfer_dir(const float* A, int Na, int n, const float* Bc, int Nb, int m, float* L, void* stream);
+int dg_grid_vote(const float* pts, long P, const float* grid, int Ng, float* counters, void* stream);
+int dg_jsd(const float* P, const float* Q, int n, float* out, void* stream);
+
 /* ---- small reductions / helpers --------------------------------------------------------------------------- */
 int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */
 int dg_scale(const float* x, float a, long n, float* y, void* stream);

@@ -11,6 +11,7 @@ are then both checked against these files without the reference present.
 usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
         python tests/golden/make_golden.py gan_modes  (only the six step_*_<gan_mode>.npz files)
         python tests/golden/make_golden.py lidar      (only lidar.npz)
+        python tests/golden/make_golden.py metrics    (only metrics.npz)
 """
 import importlib.util
 import math
@@ -354,6 +355,30 @@ def make_lidar_golden():
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_metrics_golden():
+    """utils/metrics/jsd.py (plain torch, importable) on seeded clouds: the occupancy-grid counters of both sets and the
+    divergence.  Clouds live in the radius-0.5 ball like trainers/dcgan_amp.py:387 feeds them
+    (unit-space points / 2), with a share of dropped points at the origin."""
+    jsd = _load(os.path.join(REF, "utils", "metrics", "jsd.py"), "ref_jsd")
+    torch.manual_seed(41)
+    d = {"meta/resolution": np.array(28), "meta/torch": np.array(torch.__version__)}
+    sets = {}
+    for name, scale in (("gen", 0.22), ("ref", 0.3)):
+        v = torch.randn(6, 200, 3)
+        r = torch.rand(6, 200, 1) ** (1 / 3) * 0.5 * (0.4 + scale)
+        pts = v / v.norm(dim=2, keepdim=True) * r.clamp(max=0.5)
+        pts[torch.rand(6, 200) < 0.1] = 0.0
+        sets[name] = pts
+        d[f"pcs_{name}"] = pts.numpy()
+        _, counters = jsd.entropy_of_occupancy_grid(pts, 28, True, 128, False)
+        d[f"counters_{name}"] = counters.numpy()
+    d["jsd"] = np.array(jsd.compute_jsd(sets["gen"], sets["ref"], verbose=False))
+    d["grid"] = jsd.unit_cube_grid_point_cloud(28, True, "cpu")[0].numpy()
+    path = os.path.join(HERE, "metrics.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def make_gan_mode_goldens():
     """the six config-reachable `solver.gan_mode`s besides nsgan (models/loss.py:42-61,70-85), one step each; the
     relativistic ones are the only metrics whose G phase reads D(real) (trainers/dcgan_amp.py:255,259)"""
@@ -367,6 +392,9 @@ def make_gan_mode_goldens():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["metrics"]:
+        make_metrics_golden()
+        sys.exit(0)
     if sys.argv[1:] == ["lidar"]:
         make_lidar_golden()
         sys.exit(0)
@@ -384,3 +412,4 @@ if __name__ == "__main__":
                      steps=1)
     make_gan_mode_goldens()
     make_lidar_golden()
+    make_metrics_golden()

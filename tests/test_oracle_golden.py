@@ -198,3 +198,75 @@ def test_sampler_restatement_matches_torch(n, world):
     idx = LO.sampler_indices(n, world, 0)
     bs = LO.batches(idx, 2)
     assert all(len(b) == 2 for b in bs) and len(bs) == len(idx) // 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# validation metrics: oracle/metrics_oracle.py
+# ---------------------------------------------------------------------------------------------------------------
+def test_jsd_oracle_matches_reference():
+    """utils/metrics/jsd.py restatement against the reference's own outputs (tests/golden/metrics.npz)"""
+    from oracle import metrics_oracle as MO
+    g = load("metrics")
+    assert torch.equal(MO.unit_cube_grid(int(g["meta/resolution"])), t(g["grid"]))
+    for name in ("gen", "ref"):
+        assert torch.equal(MO.grid_counters(g[f"pcs_{name}"]), t(g[f"counters_{name}"]))
+    assert abs(MO.compute_jsd(g["pcs_gen"], g["pcs_ref"]) - float(g["jsd"])) < 1e-6
+
+
+def test_fps_and_chamfer_restatements():
+    """parity-unpinned restatements (the reference's CUDA extensions cannot run here): literal loops of the cited
+    sources on tiny inputs against the vectorised oracle"""
+    from oracle import metrics_oracle as MO
+    rng = np.random.default_rng(3)
+    xyz = rng.normal(0, 0.3, (70, 3)).astype(np.float32)
+    xyz[5] = xyz[9] = 0.0                     # dropped points: never candidates (mag <= 1e-3)
+    xyz[40] = xyz[12]                         # exact duplicate -> exact distance ties
+    idx = MO.fps(xyz, 20)
+    # literal thread-order emulation of furthest_point_sampling.cu:115-206 with T = opt_n_threads(70) = 64 threads
+    T = MO.opt_n_threads(70)
+    assert T == 64
+    temp = np.full(70, 1e10, np.float32)
+    old, want = 0, [0]
+    for j in range(1, 20):
+        best, besti = np.full(T, -1.0, np.float32), np.zeros(T, np.int64)
+        for tid in range(T):
+            for k in range(tid, 70, T):
+                x2 = xyz[k]
+                if (x2[0] * x2[0]) + (x2[1] * x2[1]) + (x2[2] * x2[2]) <= np.float32(1e-3):
+                    continue
+                dd = x2 - xyz[old]
+                d = (dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]
+                d2 = min(d, temp[k])
+                temp[k] = d2
+                if d2 > best[tid]:
+                    best[tid], besti[tid] = d2, k
+        w = T // 2
+        while w >= 1:  # __update: keeps the lower thread unless the upper one is strictly greater
+            for tid in range(w):
+                if best[tid + w] > best[tid]:
+                    best[tid], besti[tid] = best[tid + w], besti[tid + w]
+            w //= 2
+        old = int(besti[0])
+        want.append(old)
+    assert idx.tolist() == want
+    assert len(set(idx.tolist())) == 20 and 5 not in idx and 9 not in idx
+    assert MO.fps(np.zeros((10, 3), np.float32), 4).tolist() == [0, 0, 0, 0]  # nothing is a candidate: besti stays 0
+    # Chamfer: literal nnsearch (chamfer_distance.cpp:41-66) on two tiny sets
+    A = rng.normal(0, 0.3, (2, 9, 3)).astype(np.float32)
+    B = rng.normal(0, 0.3, (3, 7, 3)).astype(np.float32)
+    L = MO.chamfer_dir(A, B)
+    for i in range(2):
+        for j in range(3):
+            tot = 0.0
+            for p in A[i]:
+                tot += min(float(np.float32(((q - p) * (q - p)).sum())) for q in B[j])
+            assert abs(float(L[i, j]) - tot / 9) < 1e-6
+    M = MO.pairwise_cd(A, A)
+    assert torch.allclose(M, M.t()) and float(M.diag().abs().max()) == 0.0
+    # COV / MMD / 1-NNA on a hand-made matrix
+    M_rg = torch.tensor([[0.1, 0.9, 0.8], [0.7, 0.2, 0.9]])
+    r = MO.cov_mmd(M_rg)
+    assert abs(r["mmd"] - 0.15) < 1e-6 and abs(r["mmd-sample"] - (0.1 + 0.2 + 0.8) / 3) < 1e-6 and r["cov"] == 1.0
+    s = MO.nna(torch.tensor([[0.0, 0.5], [0.5, 0.0]]), M_rg, torch.tensor([[0.0, .3, .3], [.3, 0.0, .05], [.3, .05, 0.0]]))
+    # nearest neighbours: r0 -> g0 (0.1), r1 -> g1 (0.2), g0 -> r0, g1 -> g2, g2 -> g1  => predictions 0,0,1,0,0
+    assert (s["tp"], s["fp"], s["fn"], s["tn"]) == (0.0, 1.0, 2.0, 2.0) and abs(s["accuracy"] - 0.4) < 1e-6
