@@ -88,6 +88,9 @@ PROTOTYPES = {
     "dg_chamfer_dir": [_P, _I, _I, _P, _I, _I, _P, _P],
     "dg_grid_vote": [_P, _L, _P, _I, _P, _P],
     "dg_jsd": [_P, _P, _I, _P, _P],
+    "dg_pyr_down": [_P, _L, _I, _I, _P, _P],
+    "dg_pyr_up_sub": [_P, _P, _L, _I, _I, _P],
+    "dg_extract_patches": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "dg_sample_sum": [_P, _I, _L, _I, _P, _P],
     "dg_scale": [_P, _F, _L, _P, _P],
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],

@@ -236,6 +236,81 @@ __global__ __launch_bounds__(1024) void jsd_kernel(const float* __restrict__ P, 
   if (threadIdx.x == 0) out[0] = c - (a + b) / 2.f;
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// SWD descriptors (utils/metrics/swd.py:23-68): Laplacian pyramid levels and patch gathering.
+// Gaussian taps [1,4,6,4,1] (x) [1,4,6,4,1] / 256 with reflect padding 2 (get_kernel :16-21, pyramid_down :24-30).
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+__device__ __constant__ float GAUSS5[5] = {1.f / 16.f, 4.f / 16.f, 6.f / 16.f, 4.f / 16.f, 1.f / 16.f};
+
+// out [P,H/2,W/2] = gaussian 5x5, stride 2, of reflect-padded in [P,H,W]   (P = B*C planes)
+__global__ __launch_bounds__(256) void pyr_down_kernel(const float* __restrict__ in, long planes, int H, int W,
+                                                       float* __restrict__ out) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long n = planes * Ho * Wo;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+  const float* src = in + (i / ((long)Wo * Ho)) * H * W;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const int yy = reflect_idx(2 * y + a - 2, H);
+    float row = 0.f;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) row += GAUSS5[b] * src[(long)yy * W + reflect_idx(2 * x + b - 2, W)];
+    acc += GAUSS5[a] * row;
+  }
+  out[i] = acc;
+}
+
+// fine [P,H,W] -= pyramid_up(coarse [P,H/2,W/2])   (pyramid_up :33-42, laplacian_pyramid :45-50): zero-insertion
+// puts coarse(i,j) at the ODD position (2i+1, 2j+1) of an H x W plane (the transposed conv's centre tap, last row /
+// column cropped), then reflect pad 2 and the 5x5 gaussian times 4.
+__global__ __launch_bounds__(256) void pyr_up_sub_kernel(float* __restrict__ fine, const float* __restrict__ coarse,
+                                                         long planes, int H, int W) {
+  const long n = planes * H * W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const int Hc = H / 2, Wc = W / 2;
+  const float* src = coarse + (i / ((long)W * H)) * Hc * Wc;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const int yy = reflect_idx(y + a - 2, H);
+    if (!(yy & 1)) continue;
+    float row = 0.f;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const int xx = reflect_idx(x + b - 2, W);
+      if (xx & 1) row += GAUSS5[b] * src[(long)(yy >> 1) * Wc + (xx >> 1)];
+    }
+    acc += GAUSS5[a] * row;
+  }
+  fine[i] -= 4.f * acc;
+}
+
+// out [B,NP,C,ph,pw] = the patches of img [B,C,H,W] whose top-left corners are inds[k] = y * (W - pw + 1) + x
+// (extract_patches :53-62: unfold + index_select; the same positions for every image of the minibatch)
+__global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ img, int B, int C, int H, int W, int ph,
+                                                      int pw, const long* __restrict__ inds, int NP,
+                                                      float* __restrict__ out) {
+  const long n = (long)B * NP * C * ph * pw;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int dx = (int)(i % pw), dy = (int)((i / pw) % ph);
+  const int c = (int)((i / ((long)pw * ph)) % C);
+  const int k = (int)((i / ((long)pw * ph * C)) % NP);
+  const int b = (int)(i / ((long)pw * ph * C * NP));
+  const long pos = inds[k];
+  const int nW = W - pw + 1;
+  const int y = (int)(pos / nW) + dy, x = (int)(pos % nW) + dx;
+  out[i] = img[(((long)b * C + c) * H + y) * W + x];
+}
+
 }  // namespace
 
 extern "C" {
@@ -279,6 +354,31 @@ int dg_grid_vote(const float* pts, long P, const float* grid, int Ng, float* cou
 int dg_jsd(const float* P, const float* Q, int n, float* out, void* s_) {
   if (!P || !Q || !out || n <= 0) return DG_EINVAL;
   jsd_kernel<<<1, 1024, 0, (hipStream_t)s_>>>(P, Q, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_pyr_down(const float* in, long planes, int H, int W, float* out, void* s_) {
+  if (!in || !out || planes <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1)) return DG_EINVAL;
+  const long n = planes * (H / 2) * (W / 2);
+  pyr_down_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)s_>>>(in, planes, H, W, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_pyr_up_sub(float* fine, const float* coarse, long planes, int H, int W, void* s_) {
+  if (!fine || !coarse || planes <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1)) return DG_EINVAL;
+  const long n = planes * H * W;
+  pyr_up_sub_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)s_>>>(fine, coarse, planes, H, W);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_extract_patches(const float* img, int B, int C, int H, int W, int ph, int pw, const long* inds, int NP,
+                       float* out, void* s_) {
+  if (!img || !inds || !out || B <= 0 || C <= 0 || ph <= 0 || pw <= 0 || ph > H || pw > W || NP <= 0) return DG_EINVAL;
+  const long n = (long)B * NP * C * ph * pw;
+  patches_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)s_>>>(img, B, C, H, W, ph, pw, inds, NP, out);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -165,11 +165,12 @@ class ScanLoader:
     graph_safe = True  # fixed-shape device batches: the hipGraph-replayed step can copy them into its static inputs
 
     def __init__(self, dataset, batch_size, device, world=1, rank=0, num_workers=4, prefetch=2, seed=0,
-                 shuffle=True, want_xyz=False):
+                 shuffle=True, want_xyz=False, drop_last=True):
         if len(dataset) == 0:
             raise FileNotFoundError(f"no scans under {dataset.root} for split '{dataset.split}'")
         self.dataset, self.B, self.device = dataset, int(batch_size), torch.device(device)
         self.world, self.rank, self.seed, self.shuffle, self.want_xyz = world, rank, seed, shuffle, want_xyz
+        self.drop_last = drop_last  # False = the reference's validation loader (trainers/dcgan_amp.py:94-101)
         probe = dataset.read(0)
         if probe.ndim != 3 or probe.shape[-1] < 3:
             raise ValueError(f"{dataset.datalist[0]}: expected a [rings, points, >=3] array, got {probe.shape}")
@@ -180,7 +181,8 @@ class ScanLoader:
         self.epoch = 0
 
     def __len__(self):
-        return len(sampler_indices(len(self.dataset), self.world, self.rank, shuffle=False)) // self.B
+        n = len(sampler_indices(len(self.dataset), self.world, self.rank, shuffle=False))
+        return n // self.B if self.drop_last else -(-n // self.B)
 
     def _read_into(self, dst, index):
         path = self.dataset.datalist[index]
@@ -208,12 +210,14 @@ class ScanLoader:
     def _submit(self, slot, idxs, rng):
         slot.copied.synchronize()  # no-op for a never-recorded event
         slot.futs = [self.pool.submit(self._read_into, slot.host[j], i) for j, i in enumerate(idxs)]
+        slot.n = len(idxs)  # < B only for the last batch of a drop_last=False loader
         # `flip = self.flip and random.random() > 0.5` (datasets/kitti.py:70), drawn per sample from a seeded stream
         slot.flip = torch.from_numpy((rng.random(self.B) > 0.5).astype(np.uint8)) if self.dataset.flip else None
 
     def __iter__(self):
         idx = sampler_indices(len(self.dataset), self.world, self.rank, self.seed, 0, self.shuffle)
-        batches = [idx[i:i + self.B] for i in range(0, len(idx) - self.B + 1, self.B)]  # drop_last=True
+        stop = len(idx) - self.B + 1 if self.drop_last else len(idx)
+        batches = [idx[i:i + self.B] for i in range(0, stop, self.B)]
         rng = np.random.default_rng([self.seed, self.rank, self.epoch])
         self.epoch += 1
         ds = self.dataset
@@ -235,7 +239,8 @@ class ScanLoader:
                 s.dev.copy_(s.pinned, non_blocking=True)
                 s.copied.record(self.copy_stream)
             cur.wait_event(s.copied)
-            out = scan_to_polar(s.dev, ds.shape, ds.min_depth, ds.max_depth, flip=s.flip, want_xyz=self.want_xyz)
+            out = scan_to_polar(s.dev[:s.n], ds.shape, ds.min_depth, ds.max_depth,
+                                flip=None if s.flip is None else s.flip[:s.n], want_xyz=self.want_xyz)
             s.consumed = torch.cuda.Event()
             s.consumed.record(cur)
             if nxt < len(batches):

@@ -241,6 +241,8 @@ class Trainer:
         self.H, self.W = int(H), int(W)
         self.lidar = LiDAR(num_ring=H, num_points=W, min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth,
                            angle_file=osp.join(cfg.dataset.root, "angles.pt") if cfg.dataset.get("root") else None)
+        if str(cfg.dataset.name) == "synthetic":
+            self.lidar.use_nominal_angles()
         self.lidar.to(self.device)
 
         self.G.to(self.device)
@@ -648,9 +650,51 @@ class Trainer:
         synth = net(self.fixed_noise)
         return self.postprocess({k: v.clone() for k, v in synth.items()})
 
-    def validation(self):
-        raise NotImplementedError("validation metrics (SWD/JSD/COV-MMD-1NNA, FPS/Chamfer kernels) are the 'next' rows "
-                                  "of SURVEY.md §8f, not part of the training hot path")
+    def _val_batches(self):
+        """the validation set as device batches {"depth","mask"} (reference :92-101: the 'val' split, drop_last=False)"""
+        if isinstance(getattr(self, "dataset", None), SyntheticLiDAR):
+            return list(self.dataset)  # the resident pool doubles as the validation set
+        if getattr(self, "val_dataset", None) is None:
+            from ..datasets import ScanLoader, define_dataset
+            self.val_dataset = define_dataset(self.cfg.dataset, phase="val")
+            nw = int(self.local_cfg["num_workers"] if isinstance(self.local_cfg, dict) else self.local_cfg.num_workers)
+            self.val_loader = ScanLoader(self.val_dataset, self.local_batch, self.device, num_workers=nw,
+                                         shuffle=True, drop_last=False)
+        return self.val_loader
+
+    @torch.no_grad()
+    def validation(self, swd_rand=None, return_data=False):
+        """reference :342-393: real (validation split) vs synthetic (G_ema) sets of equal size N ->
+        SWD on the 2-D inverse-depth maps, JSD on the halved point clouds, COV / MMD / 1-NNA with the Chamfer distance
+        on clouds downsampled to `solver.validation.num_points` by furthest point sampling.  Every stage runs on the
+        GPU (csrc/lidar_io.hip, csrc/metrics.hip); returns dict[str,float] with the reference's keys."""
+        from ..utils.metrics import compute_cov_mmd_1nna, compute_jsd, compute_swd
+        from ..utils.sampling import downsample_point_clouds
+        num_points = int(self.cfg.solver.validation.num_points)
+
+        def inv_to_xyz(inv):
+            xyz = self.lidar.inv_to_xyz(inv, 1e-8, from_tanh=True)  # tanh_to_sigmoid(.).clamp_(0,1) fused (:345)
+            xyz = xyz.flatten(2).transpose(1, 2).contiguous()        # (B,N,3)
+            return downsample_point_clouds(xyz, num_points)
+
+        self.G_ema.eval()
+        data = {"real-2d": [], "real-3d": [], "fake-2d": [], "fake-3d": []}
+        for item in self._val_batches():
+            x_real, _ = self.fetch_reals(item)
+            data["real-2d"].append(x_real)
+            data["real-3d"].append(inv_to_xyz(x_real))
+        N = sum(t.shape[0] for t in data["real-2d"])
+        for _ in range(0, N, self.local_batch):
+            x_fake = self.G_ema(latent=self.sample_latents(self.local_batch))["depth"]
+            data["fake-2d"].append(x_fake)
+            data["fake-3d"].append(inv_to_xyz(x_fake))
+        for key in data:
+            data[key] = torch.cat(data[key], dim=0)[:N]
+        scores = {}
+        scores.update(compute_swd(data["fake-2d"], data["real-2d"], rand=swd_rand))
+        scores["jsd"] = compute_jsd(data["fake-3d"] / 2.0, data["real-3d"] / 2.0)
+        scores.update(compute_cov_mmd_1nna(data["fake-3d"], data["real-3d"], 512, ("cd",)))
+        return (scores, data) if return_data else scores
 
     def state(self, step):
         def sd(m):

@@ -6,6 +6,7 @@ inverse depth into the unit-space point map (`inv_to_xyz` :58-65 with revert_dep
 angle grid (`angles.pt`, resized like LiDAR.init_coordmap :127-130).  All arithmetic is in csrc/ (pointwise.hip,
 lidar_io.hip); `points_to_depth` (:67-108, used by the reconstruction demo only) is not built.
 """
+import math
 import os
 
 import torch
@@ -23,6 +24,14 @@ class LiDAR:
         self.angle = None  # [1,2,H,W] (elevation, azimuth); the synthetic dataset has no angle file
         if angle_file is not None and os.path.exists(angle_file):
             self.angle = self.init_coordmap(self.H, self.W)
+
+    def use_nominal_angles(self, fov_up_deg=2.0, fov_down_deg=-24.8):
+        """An analytic angle grid (evenly spaced rings over the HDL-64E field of view, azimuth pi .. -pi like
+        process_kitti.py:101-103) for the synthetic dataset, which has no angles.pt."""
+        pitch = torch.linspace(math.radians(fov_up_deg), math.radians(fov_down_deg), self.H)[:, None].expand(self.H, self.W)
+        yaw = -(torch.arange(self.W).float() + 0.5) / self.W * 2 * math.pi + math.pi
+        self.angle = torch.stack([pitch, yaw[None, :].expand(self.H, self.W)])[None].contiguous()
+        return self
 
     def init_coordmap(self, H, W):
         """utils/lidar.py:127-130 (one-time setup: a bilinear resize of the 2 x 64 x 2048 average-angle table)"""

@@ -2,3 +2,4 @@
 from .cov_mmd_1nna import compute_cov_mmd_1nna  # noqa: F401
 from .distance import chamfer_distance_matrix, chamfer_dir  # noqa: F401
 from .jsd import compute_jsd  # noqa: F401
+from .swd import compute_swd  # noqa: F401

@@ -203,6 +203,14 @@ int dg_fps(const float* xyz, int B, int n, int m, float* temp, int* idx, float* 
 int dg_chamfer_dir(const float* A, int Na, int n, const float* Bc, int Nb, int m, float* L, void* stream);
 int dg_grid_vote(const float* pts, long P, const float* grid, int Ng, float* counters, void* stream);
 int dg_jsd(const float* P, const float* Q, int n, float* out, void* stream);
+/* SWD descriptors  utils/metrics/swd.py:16-62.  dg_pyr_down: pyramid_down (:24-30) on `planes` = B*C images
+ * [H,W] -> [H/2,W/2] (H, W even).  dg_pyr_up_sub: fine -= pyramid_up(coarse) (:33-50), in place.
+ * dg_extract_patches: extract_patches (:53-62) for given positions: out [B,NP,C,ph,pw], inds [NP] int64 =
+ * y * (W - pw + 1) + x of each patch's top-left corner (the reference draws them with randperm). */
+int dg_pyr_down(const float* in, long planes, int H, int W, float* out, void* stream);
+int dg_pyr_up_sub(float* fine, const float* coarse, long planes, int H, int W, void* stream);
+int dg_extract_patches(const float* img, int B, int C, int H, int W, int ph, int pw, const long* inds, int NP,
+                       float* out, void* stream);
 
 /* ---- small reductions / helpers --------------------------------------------------------------------------- */
 int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */

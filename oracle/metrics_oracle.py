@@ -7,10 +7,12 @@ Restates, with numpy / stock torch CPU ops:
                                           path `nnsearch`; the CUDA kernel computes the same quantity)
   * COV / MMD / 1-NNA                     utils/metrics/cov_mmd_1nna.py:20-148
   * JSD on the occupancy grid             utils/metrics/jsd.py:11-116
+  * sliced Wasserstein distance           utils/metrics/swd.py:16-151 (random draws injected)
 
 Parity pin:
-  * JSD: utils/metrics/jsd.py is plain torch and importable here; tests/golden/metrics.npz holds its outputs
-    (grid counters and the divergence) for seeded clouds -> pinned.
+  * JSD and SWD: utils/metrics/jsd.py and swd.py are plain torch and importable here; tests/golden/metrics.npz holds
+    their outputs for seeded inputs (JSD: grid counters and the divergence; SWD: every score, with the reference's
+    randperm / randn draws captured by replaying the generator) -> pinned.
   * FPS, Chamfer, COV/MMD/1-NNA: the reference runs them through CUDA extensions that are JIT-compiled at import
     (`torch.utils.cpp_extension.load` of .cu files, nvcc absent here; cov_mmd_1nna.py imports them at module level), so
     none of it can be executed in this image -> PARITY UNPINNED against the reference; restated from the sources
@@ -177,3 +179,100 @@ def jensen_shannon_divergence(P, Q):
 def compute_jsd(pcs_gen, pcs_ref, resolution=28):
     """compute_jsd jsd.py:110-116"""
     return jensen_shannon_divergence(grid_counters(pcs_gen, resolution), grid_counters(pcs_ref, resolution)).item()
+
+
+# --------------------------------------------------------------------------
+# utils/metrics/swd.py  (plain torch, importable here -> pinned by tests/golden/metrics.npz "swd/*")
+# --------------------------------------------------------------------------
+def _gauss_kernel(weight):
+    """get_kernel swd.py:16-21"""
+    k = torch.tensor(weight).float()
+    k = torch.outer(k, k)
+    k /= k.sum()
+    return k[None, None]
+
+
+def pyramid_down(image):
+    """swd.py:24-30"""
+    C = image.shape[1]
+    g = _gauss_kernel([1, 4, 6, 4, 1]).repeat(C, 1, 1, 1)
+    return torch.nn.functional.conv2d(torch.nn.functional.pad(image, (2, 2, 2, 2), mode="reflect"), g, stride=2,
+                                      padding=0, groups=C)
+
+
+def pyramid_up(image):
+    """swd.py:33-42"""
+    C = image.shape[1]
+    dil = _gauss_kernel([0, 1, 0]).repeat(C, 1, 1, 1)
+    dilated = torch.nn.functional.conv_transpose2d(image, dil, stride=2, padding=0, groups=C)
+    padded = torch.nn.functional.pad(dilated[..., :-1, :-1], (2, 2, 2, 2), mode="reflect")
+    g = _gauss_kernel([1, 4, 6, 4, 1]).repeat(C, 1, 1, 1) * 4
+    return torch.nn.functional.conv2d(padded, g, stride=1, padding=0, groups=C)
+
+
+def laplacian_pyramid(images, num_levels):
+    """swd.py:45-50 (the reference subtracts in place, i.e. it also modifies the caller's batch slice)"""
+    pyramid = [images.clone()]
+    for _ in range(1, num_levels):
+        pyramid.append(pyramid_down(pyramid[-1]))
+        pyramid[-2] = pyramid[-2] - pyramid_up(pyramid[-1])
+    return pyramid
+
+
+def extract_patches(minibatch, patch_size, inds):
+    """swd.py:53-62 with the randperm draw injected: inds = randperm(nH*nW)[:num_patches]"""
+    pH, pW = patch_size
+    patches = minibatch.unfold(2, pH, 1).unfold(3, pW, 1)
+    B, C, nH, nW, pH, pW = patches.shape
+    patches = patches.reshape(B, C, nH * nW, pH, pW).transpose(1, 2)
+    return patches.index_select(dim=1, index=inds)
+
+
+def swd_num_levels(H, W):
+    """swd.py:131-132"""
+    return int(np.log2(min(H, W) // 16) + 1)
+
+
+def swd_patch_counts(H, W, num_levels, patch_size=(7, 7)):
+    """number of patch positions per pyramid level (the N of randperm(N), swd.py:60)"""
+    return [((H >> l) - patch_size[0] + 1) * ((W >> l) - patch_size[1] + 1) for l in range(num_levels)]
+
+
+def finalize_descriptors(desc):
+    """swd.py:73-80"""
+    desc = torch.cat(desc, dim=0)
+    B, N, C, H, W = desc.shape
+    C_std, C_mean = torch.std_mean(desc, dim=(0, 1, 3, 4), keepdim=True)
+    desc = (desc - C_mean) / (C_std + 1e-8)
+    return desc.reshape(-1, C * H * W)
+
+
+def sliced_wasserstein_distance(desc1, desc2, dirs_list):
+    """swd.py:83-96 with the direction draws injected: dirs_list[r] = randn(D, dirs_per_repeat) BEFORE normalisation"""
+    distances = []
+    for dirs in dirs_list:
+        dirs = dirs / torch.std(dirs, dim=0, keepdim=True)
+        proj1, _ = torch.sort(torch.matmul(desc1, dirs), dim=0)
+        proj2, _ = torch.sort(torch.matmul(desc2, dirs), dim=0)
+        distances.append(torch.mean(torch.abs(proj1 - proj2)))
+    return torch.mean(torch.stack(distances))
+
+
+def compute_swd(image1, image2, rand, patch_size=(7, 7), batch_size=128):
+    """compute_swd swd.py:99-151.  rand = {"inds": [minibatch][set][level] -> LongTensor[num_patches],
+    "dirs": [level][repeat] -> Tensor[D, dirs_per_repeat]} in the reference's draw order."""
+    image1, image2 = torch.as_tensor(image1).float(), torch.as_tensor(image2).float()
+    B, C, H, W = image1.shape
+    L = swd_num_levels(H, W)
+    desc1, desc2 = [[] for _ in range(L)], [[] for _ in range(L)]
+    for mb, i in enumerate(range(0, B, batch_size)):
+        for which, (img, desc) in enumerate(((image1, desc1), (image2, desc2))):
+            pyr = laplacian_pyramid(img[i:i + batch_size], L)
+            for l in range(L):
+                desc[l].append(extract_patches(pyr[l], patch_size, rand["inds"][mb][which][l]))
+    result = {}
+    for l in range(L):
+        result["swd-" + str(16 << l)] = sliced_wasserstein_distance(finalize_descriptors(desc1[l]),
+                                                                    finalize_descriptors(desc2[l]), rand["dirs"][l])
+    result["swd-mean"] = sum(result.values()) / len(result)
+    return {k: v.item() for k, v in result.items()}

@@ -374,6 +374,30 @@ def make_metrics_golden():
         d[f"counters_{name}"] = counters.numpy()
     d["jsd"] = np.array(jsd.compute_jsd(sets["gen"], sets["ref"], verbose=False))
     d["grid"] = jsd.unit_cube_grid_point_cloud(28, True, "cpu")[0].numpy()
+    # utils/metrics/swd.py (plain torch): scores for seeded images, with the reference's random draws captured by
+    # replaying the generator in compute_swd's draw order (per minibatch: set 1 levels, set 2 levels; then per level
+    # dir_repeats direction matrices)
+    swd = _load(os.path.join(REF, "utils", "metrics", "swd.py"), "ref_swd")
+    B, C, H, W, bs, npatch, reps, ndirs = 6, 1, 32, 64, 4, 128, 4, 128
+    torch.manual_seed(43)
+    img1 = torch.tanh(torch.randn(B, C, H, W))
+    img2 = torch.tanh(torch.randn(B, C, H, W) * 0.7 + 0.1)
+    d["swd/image1"], d["swd/image2"] = img1.numpy(), img2.numpy()
+    state = torch.get_rng_state()
+    scores = swd.compute_swd(img1.clone(), img2.clone(), batch_size=bs)  # (the reference modifies its inputs in place)
+    torch.set_rng_state(state)
+    L = int(np.log2(min(H, W) // 16) + 1)
+    counts = [((H >> l) - 6) * ((W >> l) - 6) for l in range(L)]
+    for mb in range(-(-B // bs)):
+        for which in range(2):
+            for l in range(L):
+                d[f"swd/inds/{mb}/{which}/{l}"] = torch.randperm(counts[l])[:npatch].numpy()
+    for l in range(L):
+        for r in range(reps):
+            d[f"swd/dirs/{l}/{r}"] = torch.randn(C * 49, ndirs).numpy()
+    for k, v in scores.items():
+        d[f"swd/score/{k}"] = np.array(v)
+    d["swd/meta"] = np.array([bs, npatch, reps, ndirs])
     path = os.path.join(HERE, "metrics.npz")
     np.savez_compressed(path, **d)
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")

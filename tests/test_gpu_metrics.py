@@ -102,3 +102,40 @@ def test_jsd_matches_reference_golden():
     ca = grid_counters(torch.from_numpy(a).to(DEV)).cpu()
     assert torch.equal(ca, MO.grid_counters(a))
     assert abs(compute_jsd(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)) - MO.compute_jsd(a, b)) < 1e-5
+
+
+def test_swd_matches_reference_golden():
+    """utils/metrics/swd.py: pyramid / patch kernels + projections, with the reference's captured random draws,
+    against the reference's scores (1e-4) and level by level against the oracle's pyramid (1e-5)"""
+    from dusty_gan_amd.utils.metrics import compute_swd
+    from dusty_gan_amd.utils.metrics.swd import extract_patches, laplacian_pyramid
+    from tests.test_oracle_golden import swd_rand
+    g = load("metrics")
+    rand, bs = swd_rand(g)
+    i1, i2 = torch.from_numpy(g["swd/image1"]), torch.from_numpy(g["swd/image2"])
+    got = compute_swd(i1.to(DEV), i2.to(DEV), batch_size=bs, rand=rand)
+    assert set(got) == {"swd-16", "swd-32", "swd-mean"}
+    for k, v in got.items():
+        assert abs(v - float(g[f"swd/score/{k}"])) < 1e-4 * max(1.0, abs(v)), (k, v, float(g[f"swd/score/{k}"]))
+    pyr = laplacian_pyramid(i1.to(DEV), 2)
+    ref = MO.laplacian_pyramid(i1, 2)
+    for a, b in zip(pyr, ref):
+        assert a.shape == b.shape and rel_l2(a.cpu(), b) < 1e-5
+    big = torch.randn(3, 2, 64, 256)  # 3 levels, 2 channels
+    for a, b in zip(laplacian_pyramid(big.to(DEV), 3), MO.laplacian_pyramid(big, 3)):
+        assert rel_l2(a.cpu(), b) < 1e-5
+    inds = torch.tensor([0, 5, 58 * 250 - 1, 777])
+    pa = extract_patches(big.to(DEV), (7, 7), 4, inds).cpu()
+    assert torch.equal(pa, MO.extract_patches(big, (7, 7), inds))
+    # own draws: finite, deterministic under a seeded device generator, ~0 for identical sets
+    torch.manual_seed(0)
+    s1 = compute_swd(big.to(DEV), (big * 0.5).to(DEV))
+    torch.manual_seed(0)
+    s2 = compute_swd(big.to(DEV), (big * 0.5).to(DEV))
+    assert s1 == s2 and set(s1) == {"swd-16", "swd-32", "swd-64", "swd-mean"} and all(np.isfinite(v) for v in s1.values())
+    # identical sets sampled at identical positions are at distance exactly 0
+    counts = MO.swd_patch_counts(64, 256, 3)
+    one = [torch.randperm(c)[:128] for c in counts]
+    rand0 = {"inds": [[one, one]], "dirs": [[torch.randn(2 * 49, 128) for _ in range(4)] for _ in range(3)]}
+    same = compute_swd(big.to(DEV), big.clone().to(DEV), rand=rand0)
+    assert same["swd-mean"] == 0.0

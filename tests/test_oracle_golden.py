@@ -270,3 +270,25 @@ def test_fps_and_chamfer_restatements():
     s = MO.nna(torch.tensor([[0.0, 0.5], [0.5, 0.0]]), M_rg, torch.tensor([[0.0, .3, .3], [.3, 0.0, .05], [.3, .05, 0.0]]))
     # nearest neighbours: r0 -> g0 (0.1), r1 -> g1 (0.2), g0 -> r0, g1 -> g2, g2 -> g1  => predictions 0,0,1,0,0
     assert (s["tp"], s["fp"], s["fn"], s["tn"]) == (0.0, 1.0, 2.0, 2.0) and abs(s["accuracy"] - 0.4) < 1e-6
+
+
+def swd_rand(g):
+    from oracle import metrics_oracle as MO
+    bs, npatch, reps, nd = (int(v) for v in g["swd/meta"])
+    B, C, H, W = g["swd/image1"].shape
+    L = MO.swd_num_levels(H, W)
+    inds = [[[t(g[f"swd/inds/{mb}/{w}/{l}"]) for l in range(L)] for w in range(2)] for mb in range(-(-B // bs))]
+    dirs = [[t(g[f"swd/dirs/{l}/{r}"]) for r in range(reps)] for l in range(L)]
+    return {"inds": inds, "dirs": dirs}, bs
+
+
+def test_swd_oracle_matches_reference():
+    """utils/metrics/swd.py restatement, fed the reference's own captured draws, against the reference's scores"""
+    from oracle import metrics_oracle as MO
+    g = load("metrics")
+    rand, bs = swd_rand(g)
+    got = MO.compute_swd(g["swd/image1"], g["swd/image2"], rand, batch_size=bs)
+    assert set(got) == {"swd-16", "swd-32", "swd-mean"}
+    for k, v in got.items():
+        assert abs(v - float(g[f"swd/score/{k}"])) < 1e-6, k
+    assert MO.swd_patch_counts(32, 64, 2) == [26 * 58, 10 * 26]
