@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--clouds", type=int, default=4071)
     ap.add_argument("--points", type=int, default=512)
     ap.add_argument("--fps-clouds", type=int, default=256)
+    ap.add_argument("--validation", action="store_true", help="also time a full Trainer.validation() at 64x1024")
     args = ap.parse_args()
     from dusty_gan_amd.utils.metrics import chamfer_dir, compute_cov_mmd_1nna, compute_jsd
     from dusty_gan_amd.utils.sampling import downsample_point_clouds
@@ -68,6 +69,26 @@ def main():
     t0 = time.perf_counter()
     MO.fps(full[0].cpu().numpy(), n)
     res["cpu_oracle_fps_ms_per_cloud"] = round((time.perf_counter() - t0) * 1e3, 1)
+    if args.validation:
+        # the whole reference validation pass (trainers/dcgan_amp.py:342-393) at the KITTI size: N real + N generated
+        # 64x1024 scans -> point maps -> FPS to 512 -> SWD + JSD + COV/MMD/1-NNA(CD)
+        from dusty_gan_amd.trainers.dcgan_amp import Trainer
+        from dusty_gan_amd.utils.config import load_config
+        del ref, gen, full
+        torch.cuda.empty_cache()
+        pool = -(-args.clouds // 32)
+        cfg = load_config(["model=dusty2_dcgan_eqlr", "dataset=synthetic", "dataset.shape=[64,1024]",
+                           "solver.batch_size=32", f"dataset.pool={pool}", "enable_amp=true"])
+        tr = Trainer(cfg, {"gpu": 0, "ngpus": 1, "batch_size": 32, "num_workers": 0})
+        tr.validation()  # warm-up (workspaces, sort plans)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sc = tr.validation()
+        torch.cuda.synchronize()
+        res["validation_s"] = round(time.perf_counter() - t0, 2)
+        res["validation_N"] = pool * 32
+        res["validation_scores"] = {k: round(v, 5) for k, v in sc.items() if k in ("swd-mean", "jsd", "mmd-cd", "cov-cd",
+                                                                                    "1-nn-accuracy-cd")}
     print(json.dumps(res))
 
 
