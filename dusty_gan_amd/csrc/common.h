@@ -125,6 +125,19 @@ __host__ __device__ inline void dg_wgrad1d(int wmode, int circ, int m, int Nc, i
 typedef DgConv ConvP;
 typedef DgWgrad WgradP;
 
+// Optional optimizer epilogue (ADAM = true; Proj.weight in data-parallel runs): the finished gradient tile never goes to
+// memory -- Adam (beta1 = 0, so no first moment), the EMA of G_ema and the bf16/fp32 shadow are applied to the
+// parameter tile in place.  Reference: optim.Adam.step + ema_inplace, trainers/dcgan_amp.py:312,316,30-35.
+struct AdamEpi {
+  float *p, *v, *ema;
+  void* shadow;
+  int shadow_bf16;
+  float gscale, lr, b2, eps, ema_decay;
+  const unsigned long long* stepp;
+};
+
+int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream);
+
 __device__ __forceinline__ float dg_ld(const void* p, long i, int dtype) {
   return dtype == DG_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
 }

@@ -1,6 +1,7 @@
 // Optimizer / parameter-state kernels: fused Adam (+EMA, + low-precision shadow write), the transposed weight
 // shadow used by the MFMA forward kernels, and the Philox4x32-10 generator for z / Gumbel / DiffAugment draws.
 #include "common.h"
+#include <cstdlib>
 
 // torch.optim.Adam (no weight decay / amsgrad) as configured at trainers/dcgan_amp.py:116-125, fused with
 // ema_inplace (:30-35) and with the T-typed shadow copy the conv kernels read.  All buffers are flat.
@@ -453,11 +454,26 @@ int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_
                        float eps, const unsigned long long* step_dev, float ema_decay, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (!p || !v || !dp0 || !zT || !step_dev) return DG_EINVAL;
-  if (op_dtype != DG_BF16 || nb < 2 || nb > 64 || nb % 2 != 0 || K % 4 != 0 || K / 4 > 256 || 256 % (K / 4) != 0 ||
-      Np <= 0)
-    return DG_EUNSUPPORTED;
+  if (op_dtype != DG_BF16 || Np <= 0 || nb < 2) return DG_EUNSUPPORTED;
   const size_t lds = ((size_t)(nb / 2) * K + (size_t)APF_ROWS * (nb / 2)) * 4;
-  if (lds > 64 * 1024) return DG_EUNSUPPORTED;
+  const bool valu_ok = nb <= 64 && nb % 2 == 0 && K % 4 == 0 && K / 4 <= 256 && 256 % (K / 4) == 0 && lds <= 64 * 1024;
+  // The MFMA gradient GEMM with the optimizer as its epilogue takes every batch size when Np and K are multiples of 128
+  // and measured 6 % faster than the LDS-resident VALU kernel even at nb = 32 (scripts/bench_proj_adam.py: 311 vs
+  // 331 us); DG_PROJ_ADAM_MFMA=0 keeps the VALU kernel wherever it applies (A/B switch).
+  static const int use_mfma = [] { const char* e = getenv("DG_PROJ_ADAM_MFMA"); return e ? atoi(e) : 1; }();
+  const bool mfma_ok = Np % 128 == 0 && K % 128 == 0;
+  if (!valu_ok || (use_mfma && mfma_ok)) {
+    // (wgrad_mfma.hip; also the only fused path for nb > 64, i.e. the all-gathered global batch of a multi-GPU run);
+    // shapes neither kernel takes -> DG_EUNSUPPORTED -> caller's unfused path
+    WgradP w{};
+    w.wmode = 2; w.ring = 1; w.B = 1; w.Hc = 1; w.Wc = nb; w.Ci = (int)Np; w.Co = K;
+    w.a = dp0; w.a_sb = 0; w.a_sp = Np; w.a_sc = 1;
+    w.g = zT; w.g_sb = 0; w.g_sp = K; w.g_sc = 1;
+    w.dw = nullptr; w.scale = wscale; w.rowscale = nullptr; w.a_dtype = DG_BF16; w.g_dtype = DG_BF16;
+    AdamEpi ad{p, v, ema, shadow, shadow && shadow_dtype == DG_BF16 ? 1 : 0, gscale, lr, beta2, eps, ema_decay, step_dev};
+    if (Np > 0x7fffffffL) return DG_EUNSUPPORTED;
+    return dg_wgrad_mfma_adam_launch(&w, &ad, s);
+  }
   const unsigned grid = (unsigned)((Np + APF_ROWS - 1) / APF_ROWS);
   if (shadow && shadow_dtype == DG_BF16)
     adam_proj_fused_kernel<bf16><<<grid, 256, lds, s>>>(p, v, ema, (bf16*)shadow, (const bf16*)dp0, (const bf16*)zT, nb, Np, K, wscale, gscale, lr, beta2, eps, ema_decay, step_dev);

@@ -20,8 +20,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // coarse pixels per K chunk: 64 (bf16) / 32 (fp32)
 #define BKP_OF(es) ((es) == 2 ? 64 : 32)
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, int accumulate) {
+// AdamEpi (common.h): optional optimizer epilogue, ADAM = true (Proj.weight in data-parallel runs)
+template <typename T, int BM, int BN, bool ADAM = false>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, int accumulate, AdamEpi ad = AdamEpi{}) {
   constexpr int ES = sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int BKP = BKP_OF(ES);
@@ -201,6 +202,69 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
   }
 
   // D layout: col = lane & 31 (co), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (ci)
+  if constexpr (ADAM) {
+    // The accumulator layout gives each lane 4-byte pieces of 16 different rows; Adam streams five arrays, so the
+    // tile is first transposed through LDS (64 rows at a time, the rows of one wave-row) and then walked with 16-byte
+    // accesses, 32 lanes covering one 512-byte row segment.
+    static_assert(BM == 128 && BN == 128 && sizeof(lds) >= 64 * BN * 4, "ADAM epilogue: 128 x 128 tiles");
+    const float t = (float)(*ad.stepp + 1ull);
+    const float inv_sqrt_bc2 = rsqrtf(1.f - powf(ad.b2, t));
+    const float gmul = p.scale * cur_rs * ad.gscale;
+    float* stage = (float*)lds;
+    __syncthreads();  // every wave is done reading the operand tiles
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wm == half) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + wn * (BN / 2) + j * 32 + lr] = acc[i][j][e];
+      }
+      __syncthreads();
+      const int c4 = tid & 31;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = rr * 8 + (tid >> 5);
+        const int ci = ci0 + half * 64 + row, co = co0 + c4 * 4;
+        if (ci < p.Ci && co < p.Co) {
+          const long i4 = ((long)ci * p.Co + co) / 4;
+          const float4 g4 = *(const float4*)(stage + row * BN + c4 * 4);
+          const float4 v4 = ((const float4*)ad.v)[i4];
+          const float4 p4 = ((const float4*)ad.p)[i4];
+          const float4 e4 = ad.ema ? ((const float4*)ad.ema)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          float gv[4] = {g4.x, g4.y, g4.z, g4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w};
+          float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float g = gv[k] * gmul;
+            const float vi = ad.b2 * vv[k] + (1.f - ad.b2) * g * g;
+            vv[k] = vi;
+            pv[k] = pv[k] - ad.lr * (g / (sqrtf(vi) * inv_sqrt_bc2 + ad.eps));
+            ev[k] = ad.ema_decay * ev[k] + (1.f - ad.ema_decay) * pv[k];
+          }
+          ((float4*)ad.p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+          ((float4*)ad.v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+          if (ad.ema) ((float4*)ad.ema)[i4] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+          if (ad.shadow) {
+            if (ad.shadow_bf16) {
+              const bf16 h[4] = {(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+              uint2 pk;
+              pk.x = (unsigned)__builtin_bit_cast(unsigned short, h[0]) | ((unsigned)__builtin_bit_cast(unsigned short, h[1]) << 16);
+              pk.y = (unsigned)__builtin_bit_cast(unsigned short, h[2]) | ((unsigned)__builtin_bit_cast(unsigned short, h[3]) << 16);
+              ((uint2*)ad.shadow)[i4] = pk;
+            } else {
+              ((float4*)ad.shadow)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   float* dw = p.dw + (long)tap * p.Ci * p.Co;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -233,6 +297,19 @@ static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
   }
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ntap, (unsigned)split);
   wgrad_mfma_kernel<T, BM, BN><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// Proj.weight's gradient GEMM with the optimizer folded into its epilogue (optim.hip dg_adam_proj_fused dispatches here
+// when the batch is too large for its LDS-resident VALU kernel, i.e. the all-gathered global batch of multi-GPU runs)
+int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream) {
+  if (p->wmode != 2 || p->a_dtype != DG_BF16 || p->g_dtype != DG_BF16 || p->a_sc != 1 || p->g_sc != 1)
+    return DG_EUNSUPPORTED;
+  if (p->Ci % 128 != 0 || p->Co % 128 != 0 || p->rowscale) return DG_EUNSUPPORTED;
+  const int tiles_m = p->Ci / 128, tiles_n = p->Co / 128;
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, 1);  // no K split: every tile sees the whole batch
+  wgrad_mfma_kernel<bf16, 128, 128, true><<<grid, 256, 0, stream>>>(*p, tiles_n, 0, *ad);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -474,7 +474,9 @@ class Trainer:
         fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
                      and next(iter(Gst.seg)) == "proj_w" and Gst.seg["proj_w"].off == 0 and self._fuse_proj_ok
                      and self.optim_G.betas[0] == 0.0 and E.PROFILE is None)
-        if not fuse_proj:
+        fuse_gathered = (gather_proj and self.dtype == torch.bfloat16 and Gst.seg["proj_w"].off == 0
+                         and self._fuse_proj_ok and self.optim_G.betas[0] == 0.0 and E.PROFILE is None)
+        if not (fuse_proj or fuse_gathered):
             self.optim_G.regen_grad = None
         deng = D.engine()
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
@@ -517,7 +519,16 @@ class Trainer:
             zg, dg = self._gather
             zT, dp0 = geng.zT, geng.dp[0]
             self._coll(lambda: (D_.all_gather_into(zg, zT), D_.all_gather_into(dg, dp0)))
-            geng.proj_wgrad(Gst, dg, zg, self.world * B)
+            nbg = self.world * B
+            if fuse_gathered:
+                # ... and the global-batch gradient is not even written: the optimizer forms it tile by tile in the
+                # epilogue of the gradient GEMM (dg_adam_proj_fused -> MFMA path for nb > 64)
+                c = geng.cfg
+                Np = c.h0 * c.w0 * c.ch[3]
+                fused = (dg, zg, L.dtype_code(self.dtype), nbg, Np, c.nz, 1.0 / math.sqrt(Np))
+                self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, dg, zg, nbg, False)
+            else:
+                geng.proj_wgrad(Gst, dg, zg, nbg)
             tail = Gst.grad[Gst.seg["proj_b"].off:]
             self._coll(lambda: D_.allreduce_grads(tail))
             gscale = 1.0 / self.world

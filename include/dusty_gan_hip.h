@@ -253,8 +253,11 @@ int dg_adam_ema_step_dev(float* p, const float* grad, float* m, float* v, float*
 
 /* Adam (beta1 = 0) + EMA of Proj.weight [Np][K] with its weight gradient wscale * dp0^T z (trainers/dcgan_amp.py:309,312:
  * loss_G.backward() + optim_G.step() for that one tensor) formed inside the kernel from the bf16 operands dp0 [nb][Np]
- * and zT [nb][K]: the 268 MB gradient is never written.  DG_EUNSUPPORTED unless op_dtype is bf16, nb is even and
- * <= 64 and K is 256, 512 or 1024 - the caller then uses dg_wgrad + dg_adam_ema_step_dev. */
+ * and zT [nb][K]: the 268 MB gradient is never written.  Two kernels behind it: an LDS-resident VALU kernel for the
+ * per-GPU batch (nb even, <= 64, operands fit 64 KB of LDS) and, for larger nb (the all-gathered global batch of a
+ * data-parallel run), the MFMA gradient GEMM with the optimizer as its epilogue (Np % 128 == 0, K % 128 == 0).
+ * DG_EUNSUPPORTED for anything else (op_dtype not bf16, other shapes) - the caller then uses dg_wgrad +
+ * dg_adam_ema_step_dev. */
 int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_dtype, const void* dp0, const void* zT,
                        int op_dtype, int nb, long Np, int K, float wscale, float gscale, float lr, float beta2,
                        float eps, const unsigned long long* step_dev, float ema_decay, void* stream);

@@ -469,7 +469,9 @@ def test_nsgan_step_kernels_match_plain_ones(L):
     L.check(lib.dg_nsgan_d_step(yr.data_ptr(), yf.data_ptr(), B, 0.5, dy.data_ptr(), None, None, acc.data_ptr(), None, None))
 
 
-@pytest.mark.parametrize("nb,Np,K", [(4, 200, 8), (32, 1000, 512), (64, 130, 256)])
+@pytest.mark.parametrize("nb,Np,K", [(4, 200, 8), (32, 1000, 512), (64, 130, 256),
+                                     # larger (all-gathered) batches: the optimizer runs as the epilogue of the MFMA GEMM
+                                     (64, 1024, 512), (128, 256, 128), (256, 384, 512), (100, 128, 256), (6, 128, 128)])
 def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
     """dg_adam_proj_fused (Proj.weight's gradient GEMM inside the optimizer kernel) against the oracle's Adam applied to
     the explicitly formed gradient wscale * dp0^T z of the same bf16 operands, incl. EMA, bf16 shadow, device step."""
@@ -498,6 +500,10 @@ def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
     assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_BF16, dpd.data_ptr(), zd.data_ptr(),
                                   L.DG_F32, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay,
                                   None) == L.DG_EUNSUPPORTED
+    if nb > 64:  # neither the LDS-resident kernel (batch) nor the MFMA epilogue (Np % 128) takes this one
+        assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_BF16, dpd.data_ptr(),
+                                      zd.data_ptr(), L.DG_BF16, nb, Np - 64, K, wscale, gscale, lr, b2, eps,
+                                      stepd.data_ptr(), decay, None) == L.DG_EUNSUPPORTED
 
 
 def test_philox_known_answer(L):
