@@ -84,6 +84,7 @@ PROTOTYPES = {
     "dg_scan_to_polar": [_P, _I, _I, _I, _I, _I, _I, _P, _D, _D, _F, _P, _P, _P, _P, _P],
     "dg_inv_to_xyz": [_P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P],
     "dg_unit_map": [_P, _L, _I, _P, _P],
+    "dg_normals": [_P, _I, _I, _I, _I, _P, _P],
     "dg_fps": [_P, _I, _I, _I, _P, _P, _P, _P],
     "dg_chamfer_dir": [_P, _I, _I, _P, _I, _I, _P, _P],
     "dg_grid_vote": [_P, _L, _P, _I, _P, _P],

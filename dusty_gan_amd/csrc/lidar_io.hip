@@ -104,6 +104,65 @@ __global__ __launch_bounds__(256) void unit_map_kernel(const float* __restrict__
   y[i] = mode == 0 ? fminf(fmaxf((v + 1.f) / 2.f, 0.f), 1.f) : 1.f / (1.f + __expf(-v));
 }
 
+// Surface normals of a point map, "closest" mode (utils/geometry.py:38-127 estimate_surface_normal with d = 2, then
+// xyz_to_normal utils/__init__.py:215-219): the 8 neighbours at distance d (rows padded with +inf, columns circular);
+// candidate k pairs neighbour k with neighbour k + 2; the pair with the smallest |p1 - a| + |p2 - a| (first on ties)
+// gives n = (p1 - a) x (p2 - a) / (|.| + 1e-8); output = clamp((-n + 1) / 2, 0, 1) with NaN -> 0 before the map.
+__global__ __launch_bounds__(256) void normals_kernel(const float* __restrict__ pts, int B, int H, int W, int d,
+                                                      float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long hw = (long)H * W, n = (long)B * hw;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const float* base = pts + (i / hw) * 3 * hw;
+  const int DH[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, DW[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+  const float inf = __builtin_inff();
+  float nb[8][3];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int yy = y + DH[k] * d;
+    int xx = (x + DW[k] * d) % W;
+    if (xx < 0) xx += W;
+    const bool ok = yy >= 0 && yy < H;
+    const long o = (long)(ok ? yy : 0) * W + xx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nb[k][c] = ok ? base[c * hw + o] : inf;
+  }
+  const long oa = (long)y * W + x;
+  const float a0 = base[oa], a1 = base[hw + oa], a2 = base[2 * hw + oa];
+  float dist[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float u0 = nb[k][0] - a0, u1 = nb[k][1] - a1, u2 = nb[k][2] - a2;
+    dist[k] = sqrtf((u0 * u0 + u1 * u1) + u2 * u2);
+  }
+  float best = 0.f;
+  int bk = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float s = dist[k] + dist[(k + 2) & 7];
+    if (k == 0 || s < best) { best = s; bk = k; }
+  }
+  float v1[3], v2[3];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)  // register-indexed select (no dynamic indexing into nb)
+    if (k == bk) {
+      const int k2 = (k + 2) & 7;
+      v1[0] = nb[k][0] - a0; v1[1] = nb[k][1] - a1; v1[2] = nb[k][2] - a2;
+      v2[0] = nb[k2][0] - a0; v2[1] = nb[k2][1] - a1; v2[2] = nb[k2][2] - a2;
+    }
+  float c0 = v1[1] * v2[2] - v1[2] * v2[1], c1 = v1[2] * v2[0] - v1[0] * v2[2], c2 = v1[0] * v2[1] - v1[1] * v2[0];
+  const float len = sqrtf((c0 * c0 + c1 * c1) + c2 * c2) + 1e-8f;
+  float r[3] = {-(c0 / len), -(c1 / len), -(c2 / len)};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = r[c] != r[c] ? 0.f : r[c];
+    v = (v + 1.f) / 2.f;
+    out[(i / hw) * 3 * hw + c * hw + oa] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,6 +195,14 @@ int dg_inv_to_xyz(const float* inv, const float* angle, int B, int H, int W, int
   const long n = (long)B * H * W;
   inv_to_xyz_kernel<<<nblk(n), 256, 0, (hipStream_t)s_>>>(inv, angle, B, H, W, from_tanh, min_depth, max_depth,
                                                            drop_const, tol, depth01, points);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_normals(const float* points, int B, int H, int W, int d, float* out, void* s_) {
+  if (!points || !out || B <= 0 || H <= 0 || W <= 0 || d <= 0) return DG_EINVAL;
+  const long n = (long)B * H * W;
+  normals_kernel<<<nblk(n), 256, 0, (hipStream_t)s_>>>(points, B, H, W, d, out);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

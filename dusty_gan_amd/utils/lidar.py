@@ -4,7 +4,7 @@ On the training path it provides `fetch_reals` (Coordinate.invert_depth :31-36 f
 drop-constant fill of Trainer.fetch_reals, trainers/dcgan_amp.py:154-160).  On the output side it turns generated
 inverse depth into the unit-space point map (`inv_to_xyz` :58-65 with revert_depth / pol_to_xyz) on the sensor's
 angle grid (`angles.pt`, resized like LiDAR.init_coordmap :127-130).  All arithmetic is in csrc/ (pointwise.hip,
-lidar_io.hip); `points_to_depth` (:67-108, used by the reconstruction demo only) is not built.
+lidar_io.hip, incl. the surface-normal image of utils/geometry.py); `points_to_depth` (:67-108, used by the reconstruction demo only) is not built.
 """
 import math
 import os
@@ -82,10 +82,23 @@ def unit_map(x, mode):
     return y
 
 
-def postprocess(synth, lidar, tol=1e-8):
-    """utils.postprocess utils/__init__.py:163-178: depth / depth_orig -> [0,1], confidence -> sigmoid, + "points".
-    The surface-normal image (:177, a rendering aid) is not produced.  Without an angle grid (synthetic dataset)
-    "points" is omitted."""
+def xyz_to_normal(xyz, mode="closest"):
+    """utils/__init__.py:215-219 -> estimate_surface_normal utils/geometry.py:38-127 (d = 2): point map [B,3,H,W] ->
+    normal image [B,3,H,W] in [0,1]"""
+    if mode != "closest":
+        raise NotImplementedError(mode)
+    if not xyz.is_cuda:
+        raise RuntimeError("xyz_to_normal runs on the GPU only (no CPU fallback)")
+    xyz = xyz.contiguous().float()
+    B, _, H, W = xyz.shape
+    out = torch.empty_like(xyz)
+    L.check(L.lib().dg_normals(L.ptr(xyz), B, H, W, 2, L.ptr(out), L.stream_ptr()), "dg_normals")
+    return out
+
+
+def postprocess(synth, lidar, tol=1e-8, normal_mode="closest"):
+    """utils.postprocess utils/__init__.py:163-178: depth / depth_orig -> [0,1], confidence -> sigmoid, + "points" and
+    "normals".  Without an angle grid there is no point map and both are omitted."""
     out = {}
     for key, value in synth.items():
         if key == "depth":
@@ -99,4 +112,6 @@ def postprocess(synth, lidar, tol=1e-8):
             out["confidence"] = unit_map(value, 1)
         else:
             out[key] = value
+    if "points" in out:
+        out["normals"] = xyz_to_normal(out["points"], mode=normal_mode)
     return out

@@ -186,6 +186,9 @@ int dg_inv_to_xyz(const float* in, const float* angle, int B, int H, int W, int 
 /* utils.postprocess's other branches (utils/__init__.py:169-172): mode 0 = tanh_to_sigmoid(x).clamp(0,1)
  * (depth_orig), mode 1 = sigmoid(x) (confidence) */
 int dg_unit_map(const float* x, long n, int mode, float* y, void* stream);
+/* xyz_to_normal(points, mode="closest")  utils/__init__.py:215-219 -> estimate_surface_normal utils/geometry.py:38-127
+ * (d = 2): points [B,3,H,W] -> normal image [B,3,H,W] in [0,1] */
+int dg_normals(const float* points, int B, int H, int W, int d, float* out, void* stream);
 
 /* ---- validation metrics (the reference's CUDA extensions and their torch drivers) -------
  * dg_fps: furthest point sampling  utils/sampling/fps/furthest_point_sampling.cu:97-207 (+ gather_points :38-60 when

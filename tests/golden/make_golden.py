@@ -350,6 +350,13 @@ def make_lidar_golden():
     gen[torch.rand(B, 1, H, W) < 0.2] = -1.0  # dusty drop_const in tanh space -> 0 after tanh_to_sigmoid
     d["gen_depth"] = gen.numpy()
     d["gen_points"] = L.inv_to_xyz(((gen + 1.0) / 2.0).clamp_(0, 1)).numpy()  # utils/__init__.py:168,176
+    # surface-normal images of both point maps (utils/geometry.py is plain torch; xyz_to_normal of utils/__init__.py:215-219
+    # restated around it: utils/__init__.py itself cannot be imported here, see the top of this file)
+    geometry = _load(os.path.join(REF, "utils", "geometry.py"), "ref_geometry")
+    for tag, pts in (("normals", d["points"]), ("gen_normals", d["gen_points"])):
+        nrm = -geometry.estimate_surface_normal(torch.from_numpy(pts), mode="closest")
+        nrm[nrm != nrm] = 0.0
+        d[tag] = ((nrm + 1.0) / 2.0).clamp_(0.0, 1.0).numpy()
     path = os.path.join(HERE, "lidar.npz")
     np.savez_compressed(path, **d)
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")

@@ -74,8 +74,18 @@ def test_inv_to_xyz_and_postprocess_match_reference_golden(tmp_path):
     conf = torch.randn(3, 2, H, W)
     out = postprocess({"depth": gen.to(DEV), "depth_orig": gen.to(DEV), "confidence": conf.to(DEV),
                        "mask": torch.ones(1, device=DEV)}, lidar)
-    assert set(out) == {"depth", "depth_orig", "confidence", "mask", "points"}
+    assert set(out) == {"depth", "depth_orig", "confidence", "mask", "points", "normals"}
     assert rel_l2(out["points"].cpu(), g["gen_points"]) < 1e-5
+    # normal images: from the reference's own point maps (argmin ties / near-ties would make a pixel jump, so the
+    # reference points are the input here), then end to end
+    from dusty_gan_amd.utils.lidar import xyz_to_normal
+    for a, b in (("points", "normals"), ("gen_points", "gen_normals")):
+        nrm = xyz_to_normal(torch.from_numpy(g[a]).to(DEV)).cpu()
+        # n = c / (|c| + 1e-8) with c a cross product of short, sometimes nearly collinear difference vectors: the
+        # rounding of c is amplified by |v1||v2| / |c|, so single pixels move by up to ~1e-3 while the image agrees to 1e-5
+        err = (nrm - torch.from_numpy(g[b])).abs()
+        assert float(err.mean()) < 1e-5 and float(err.max()) < 5e-3, (a, float(err.mean()), float(err.max()))
+    assert float((out["normals"].cpu() - torch.from_numpy(g["gen_normals"])).abs().mean()) < 1e-3
     assert torch.allclose(out["depth"].cpu(), ((gen + 1) / 2).clamp(0, 1), atol=1e-7)
     assert torch.equal(out["depth"], out["depth_orig"])
     assert torch.allclose(out["confidence"].cpu(), torch.sigmoid(conf), atol=1e-6)
@@ -85,7 +95,7 @@ def test_inv_to_xyz_and_postprocess_match_reference_golden(tmp_path):
     bare = LiDAR(H, W, 0.9, 120.0, angle_file=None)
     with pytest.raises(RuntimeError):
         bare.inv_to_xyz(inv.to(DEV))
-    assert "points" not in postprocess({"depth": gen.to(DEV)}, bare)
+    assert set(postprocess({"depth": gen.to(DEV)}, bare)) == {"depth"}
 
 
 def write_kitti_tree(root, Hs, Ws, counts, seed=0):
@@ -180,6 +190,7 @@ def test_trainer_trains_from_scan_files(tmp_path):
     assert tr._graph is not None
     out = tr.generate(ema=True)
     assert out["points"].shape == (4, 3, 32, 64) and torch.isfinite(out["points"]).all()
+    assert out["normals"].shape == (4, 3, 32, 64) and 0.0 <= float(out["normals"].min()) <= float(out["normals"].max()) <= 1.0
     assert float(out["depth"].min()) >= 0.0 and float(out["depth"].max()) <= 1.0
     r = out["points"].norm(dim=1, keepdim=True)  # unit space: |p| = metric depth / max_depth wherever a point exists
     assert float(r.max()) <= 1.0 + 1e-5

@@ -152,6 +152,8 @@ def test_lidar_oracle_matches_reference():
     out = LO.postprocess({"depth": t(g["gen_depth"]), "confidence": torch.zeros(1)}, angle, mn, mx)
     assert rel_l2(out["points"], g["gen_points"]) < 1e-6
     assert float(out["confidence"]) == 0.5
+    assert float((out["normals"] - t(g["gen_normals"])).abs().max()) < 1e-6
+    assert float((LO.xyz_to_normal(t(g["points"])) - t(g["normals"])).abs().max()) < 1e-6
 
 
 def test_scan_to_polar_restatement_properties():
