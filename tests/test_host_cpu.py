@@ -166,3 +166,39 @@ def test_philox_oracle_known_answers():
     assert philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
     assert list(bits(0, 0, 0, 1)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+
+
+def test_scan_dataset_file_lists_and_sampler(tmp_path):
+    """datasets/kitti.py:46-52 and datasets/mpo.py:45-52 file lists, split tables and the loader's sample order
+    (host logic only: no scan is decoded here)"""
+    import numpy as np
+    from dusty_gan_amd.datasets import KITTIOdometry, SparseMPO, define_dataset
+    from dusty_gan_amd.datasets.scans import KITTI_CONFIG, MPO_CONFIG, sampler_indices
+    from oracle import lidar_oracle as LO
+    for seq, n in ((0, 3), (8, 2), (16, 1)):
+        d = tmp_path / "kitti" / "sequences" / f"{seq:02d}" / "velodyne"
+        d.mkdir(parents=True)
+        for i in range(n):
+            np.save(d / f"{i:06d}.npy", np.zeros((2, 4, 4), np.float32))
+    k = KITTIOdometry(str(tmp_path / "kitti"), "train", shape=(2, 4))
+    assert len(k) == 3 and all("/00/velodyne/" in p for p in k.datalist) and k.datalist == sorted(k.datalist)
+    assert len(KITTIOdometry(str(tmp_path / "kitti"), "val")) == 2 and len(KITTIOdometry(str(tmp_path / "kitti"), "custom")) == 1
+    assert KITTI_CONFIG["split"]["train"] == [0, 1, 2, 3, 4, 5, 6, 7, 9, 10] and KITTI_CONFIG["split"]["val"] == [8]
+    assert "Number of datapoints: 3" in repr(k)
+    (tmp_path / "mpo" / "Data").mkdir(parents=True)
+    for name in ("class0_set000_scan00001", "class1_set000_scan00002", "class0_set007_scan00001", "class0_set010_scan00001"):
+        np.save(tmp_path / "mpo" / "Data" / f"{name}.npy", np.zeros((2, 4, 4), np.float32))
+    m = SparseMPO(str(tmp_path / "mpo"), "train", shape=(2, 4))
+    assert len(m) == 2 and len(SparseMPO(str(tmp_path / "mpo"), "val")) == 1 and len(SparseMPO(str(tmp_path / "mpo"), "test")) == 1
+    assert MPO_CONFIG["split"]["test"] == [8, 9, 10]
+    with pytest.raises(AssertionError):
+        KITTIOdometry(str(tmp_path / "kitti"), "train", modality=("reflectance",))  # '"depth" is required'
+    with pytest.raises(NotImplementedError):
+        KITTIOdometry(str(tmp_path / "kitti"), "train", modality=("depth", "reflectance"))
+    from dusty_gan_amd.utils.config import load_config
+    cfg = load_config(["dataset=sparse_mpo", f"dataset.root={tmp_path / 'mpo'}"]).dataset
+    ds = define_dataset(cfg, "train")
+    assert isinstance(ds, SparseMPO) and ds.flip is True and define_dataset(cfg, "val").flip is False
+    for n, world in ((10, 1), (10, 4), (3, 8)):
+        for rank in range(world):
+            assert sampler_indices(n, world, rank) == LO.sampler_indices(n, world, rank)
