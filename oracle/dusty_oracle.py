@@ -360,11 +360,11 @@ PARAM_BUFFERS = ("drop_const",)
 class StepConfig:
     """The live solver/model keys used inside Trainer.step."""
 
-    def __init__(self, arch="none", ring=True, tau=1.0, gan_mode="nsgan", w_gan=1.0, w_gp=1.0,
+    def __init__(self, arch="none", ring=True, tau=1.0, gan_mode="nsgan", w_gan=1.0, w_gp=1.0, w_pl=0.0,
                  lr_g=0.002, lr_d=0.002, beta1=0.0, beta2=0.99, ema_decay=0.998,
                  policy=("brightness", "saturation", "contrast", "translation", "cutout")):
         self.arch, self.ring, self.tau = arch, ring, tau
-        self.gan_mode, self.w_gan, self.w_gp = gan_mode, w_gan, w_gp
+        self.gan_mode, self.w_gan, self.w_gp, self.w_pl = gan_mode, w_gan, w_gp, w_pl
         self.lr_g, self.lr_d, self.beta1, self.beta2 = lr_g, lr_d, beta1, beta2
         self.ema_decay = ema_decay
         self.policy = tuple(policy)
@@ -438,6 +438,22 @@ def train_step(G, D, G_ema, opt_G, opt_D, step_no, cfg, x_real, rand, return_gra
     loss_gan_g = gan_loss(cfg.gan_mode, y_real2, y_fake2, "G")
     loss_G = cfg.w_gan * loss_gan_g
     scalars["loss/G/adversarial"] = loss_gan_g.detach()
+    if cfg.w_pl > 0:  # path-length regularisation :268-306 (no GradScaler: its scale / unscale pair cancels)
+        pl = rand["pl"]  # {"z": [B//2,nz], "noise": Gumbel noise of that forward, "y": randn_like(x_pl), "pl_ema": 0-dim}
+        z_pl = pl["z"].clone().requires_grad_()
+        x_pl = generator(G, z_pl, cfg.arch, pl.get("noise"), cfg.tau, cfg.ring, training=True)["depth"]  # :276-277
+        noise_pl = pl["y"] / math.sqrt(x_pl.shape[2] * x_pl.shape[3])  # :278-279
+        outputs = (x_pl * noise_pl).sum()
+        (grads,) = torch.autograd.grad(outputs=outputs, inputs=[z_pl], create_graph=True)  # :282-287
+        pl_lengths = torch.sqrt(grads.pow(2).sum(dim=-1))  # :294-295
+        pl_ema = pl["pl_ema"].lerp(pl_lengths.mean(), 0.01)  # :297 (the mean stays in the graph)
+        extras["pl_ema"] = pl_ema.detach().clone()  # :298
+        pl_penalty = (pl_lengths - pl_ema).pow(2).mean()  # :300
+        scalars["loss/G/path_length/baseline"] = pl_ema.detach()
+        scalars["loss/G/path_length"] = pl_penalty.detach()
+        loss_G = loss_G + cfg.w_pl * pl_penalty + 0.0 * x_pl[0, 0, 0, 0]  # :305-306
+        if return_grads:
+            extras["pl_grads_z"] = grads.detach().clone()
     g_keys = [k for k in G if k not in PARAM_BUFFERS]
     g_params = [G[k] for k in g_keys]
     g_grads = torch.autograd.grad(loss_G, g_params, allow_unused=True)

@@ -10,6 +10,7 @@ are then both checked against these files without the reference present.
 
 usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
         python tests/golden/make_golden.py gan_modes  (only the six step_*_<gan_mode>.npz files)
+        python tests/golden/make_golden.py pl         (only the three step_*_pl.npz files)
         python tests/golden/make_golden.py lidar      (only lidar.npz)
         python tests/golden/make_golden.py metrics    (only metrics.npz)
 """
@@ -127,7 +128,7 @@ def sd_np(module, prefix):
 
 
 def make_step_golden(name, arch, ring, seed, in_ch=8, ch_base=4, ch_max=16, shape=(32, 64), B=2, steps=2,
-                     gan_mode="nsgan", gp=1.0):
+                     gan_mode="nsgan", gp=1.0, pl=0.0):
     torch.manual_seed(seed)
     cfg = make_cfg(arch, in_ch, ch_base, ch_max, list(shape), ring)
     G = models.define_G(cfg)
@@ -147,11 +148,12 @@ def make_step_golden(name, arch, ring, seed, in_ch=8, ch_base=4, ch_max=16, shap
     data = {"meta/arch": np.array(arch), "meta/ring": np.array(ring), "meta/shape": np.array(shape),
             "meta/in_ch": np.array(in_ch), "meta/ch_base": np.array(ch_base), "meta/ch_max": np.array(ch_max),
             "meta/B": np.array(B), "meta/steps": np.array(steps), "meta/gan_mode": np.array(gan_mode),
-            "meta/gp": np.array(gp), "meta/lr": np.array(lr), "meta/beta1": np.array(b1), "meta/beta2": np.array(b2),
+            "meta/gp": np.array(gp), "meta/pl": np.array(pl), "meta/lr": np.array(lr), "meta/beta1": np.array(b1), "meta/beta2": np.array(b2),
             "meta/ema_decay": np.array(decay), "meta/torch": np.array(torch.__version__)}
     data.update(sd_np(G, "init/G"))
     data.update(sd_np(D, "init/D"))
 
+    pl_ema_state = torch.tensor(0.0)  # trainers/dcgan_amp.py:112 register_buffer-like state
     for it in range(steps):
         pre = f"s{it}"
         # synthetic "dataset" batch (polar depth in [0,1] + validity mask), then fetch_reals (:154-160)
@@ -208,7 +210,31 @@ def make_step_golden(name, arch, ring, seed, in_ch=8, ch_base=4, ch_max=16, shap
         y_real2, y_fake2 = D(x_real_aug2.detach()), D(x_fake_aug2)
         loss_gan_g = crit(y_real2, y_fake2, "G")
         sc["loss/G/adversarial"] = loss_gan_g.item()
-        (1.0 * loss_gan_g).backward()
+        loss_G = 1.0 * loss_gan_g
+        if pl > 0:  # path-length regularisation, trainers/dcgan_amp.py:268-306 (GradScaler's scale / unscale cancels)
+            B_pl = B // 2
+            z_pl = torch.randn(B_pl, in_ch)
+            data[f"{pre}/pl/z"] = z_pl.numpy().copy()
+            z_pl.requires_grad_()
+            synth_pl, noise2 = run_and_capture(lambda: G(latent=z_pl), lambda: capture_gumbel(arch, B_pl, H, W))
+            for k, v in noise2.items():
+                data[f"{pre}/pl/noise/{k}"] = v.numpy()
+            x_pl = synth_pl["depth"]
+            y_pl = torch.randn_like(x_pl)
+            data[f"{pre}/pl/y"] = y_pl.numpy().copy()
+            data[f"{pre}/pl/pl_ema"] = pl_ema_state.numpy().copy()
+            noise_pl = y_pl / np.sqrt(np.prod(x_pl.shape[2:]))
+            outputs = (x_pl * noise_pl).sum()
+            (grads_z,) = torch.autograd.grad(outputs=outputs, inputs=[z_pl], create_graph=True, only_inputs=True)
+            pl_lengths = torch.sqrt(grads_z.pow(2).sum(dim=-1))
+            pl_ema = pl_ema_state.lerp(pl_lengths.mean(), 0.01)
+            pl_ema_state.copy_(pl_ema.detach())
+            pl_penalty = (pl_lengths - pl_ema).pow(2).mean()
+            sc["loss/G/path_length/baseline"] = pl_ema_state.item()
+            sc["loss/G/path_length"] = pl_penalty.item()
+            data[f"{pre}/pl/grads_z"] = grads_z.detach().numpy().copy()
+            loss_G = loss_G + pl * pl_penalty + 0.0 * x_pl[0, 0, 0, 0]
+        loss_G.backward()
         for k, p in G.named_parameters():
             data[f"{pre}/grad_G/{k}"] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy()
         optG.step()
@@ -410,6 +436,14 @@ def make_metrics_golden():
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_pl_goldens():
+    """path-length regularisation on (solver.loss.pl = 2, the value commented in configs/solver/nsgan_eqlr.yaml:21), two
+    steps so the running baseline pl_ema is exercised; B = 4 -> B_pl = 2"""
+    make_step_golden("none_pl", "none", True, seed=31, steps=2, B=4, pl=2.0)
+    make_step_golden("dusty1_pl", "dusty1", True, seed=32, steps=2, B=4, pl=2.0)
+    make_step_golden("dusty2_pl", "dusty2", True, seed=33, steps=2, B=4, pl=2.0)
+
+
 def make_gan_mode_goldens():
     """the six config-reachable `solver.gan_mode`s besides nsgan (models/loss.py:42-61,70-85), one step each; the
     relativistic ones are the only metrics whose G phase reads D(real) (trainers/dcgan_amp.py:255,259)"""
@@ -423,6 +457,9 @@ def make_gan_mode_goldens():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["pl"]:
+        make_pl_goldens()
+        sys.exit(0)
     if sys.argv[1:] == ["metrics"]:
         make_metrics_golden()
         sys.exit(0)
@@ -442,5 +479,6 @@ if __name__ == "__main__":
     make_step_golden("dusty2_mid", "dusty2", True, seed=16, in_ch=32, ch_base=16, ch_max=64, shape=(64, 128), B=3,
                      steps=1)
     make_gan_mode_goldens()
+    make_pl_goldens()
     make_lidar_golden()
     make_metrics_golden()
