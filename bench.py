@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--shape", type=int, nargs=2, default=[64, 1024])
     ap.add_argument("--gp", type=float, default=1.0, help="R1 weight (solver.loss.gp); 0 disables R1")
+    ap.add_argument("--pl", type=float, default=0.0, help="path-length weight (solver.loss.pl); 0 = the shipped solver")
     ap.add_argument("--no-augment", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -54,7 +55,7 @@ def make_trainer(args, rank, local_rank, world):
     arch = args.arch or "none"
     model = {"none": "dcgan_eqlr", "dusty1": "dusty1_dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
     ov = [f"model={model}", "dataset=synthetic", f"dataset.shape=[{args.shape[0]},{args.shape[1]}]",
-          f"solver.batch_size={args.batch * world}", f"solver.loss.gp={args.gp}",
+          f"solver.batch_size={args.batch * world}", f"solver.loss.gp={args.gp}", f"solver.loss.pl={args.pl}",
           f"enable_amp={'true' if args.precision == 'bf16' else 'false'}"]
     if args.no_augment:
         ov.append("solver.augment=[]")
@@ -206,7 +207,7 @@ def main():
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": f"{'dcgan_eqlr baseline' if arch == 'none' else arch + '_dcgan_eqlr'}, "
                                   f"{args.shape[0]}x{args.shape[1]}, batch {args.batch}/GPU x {world}, "
-                                  f"R1 {'on' if args.gp > 0 else 'off'}, DiffAugment {'off' if args.no_augment else 'on'}, "
+                                  f"R1 {'on' if args.gp > 0 else 'off'}, {'path-length reg on, ' if args.pl > 0 else ''}DiffAugment {'off' if args.no_augment else 'on'}, "
                                   "Adam+EMA, random-init weights",
                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
            "scalars_last_step": {k: round(v, 5) for k, v in scal.items()}}

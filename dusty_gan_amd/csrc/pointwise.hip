@@ -198,6 +198,150 @@ __global__ void head_post_bwd_kernel(const float* __restrict__ gout, const float
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Path-length regularisation (trainers/dcgan_amp.py:268-306), the pieces that are not convolutions.
+//
+// head_post_bwd2_kernel: the SECOND-order part of the head post-processing.  With x = depth output, h = the head conv
+// outputs (h0 raw depth, h1 / h2 confidence logits), y the upstream of x and th the forward-mode tangent of h along
+// the latent direction v, the tangent of the first-order backward d x / d h_i * y is  y * sum_j H_ij th_j  with H the
+// Hessian of x in h as autograd sees it (hard masks carry the straight-through derivative sp' = sp (1 - sp) / tau,
+// which is itself differentiable: sp'' = sp' (1 - 2 sp) / tau):
+//   H00 = m (-2 t)(1 - t^2)   H01 = mi sp' (1 - t^2)   H02 = mp si' (1 - t^2)
+//   H11 = (t - c) mi sp''     H12 = (t - c) sp' si'    H22 = (t - c) mp si''        (t = tanh h0, c = drop_const)
+// Outputs as head_post_bwd_kernel: draw2 (scaled by the head's EqualLR scale), the pixel-major bf16 copy, and the
+// head-bias gradient sums.
+__global__ void head_post_bwd2_kernel(const float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                      const float* __restrict__ noise_image, const float* __restrict__ mask,
+                                      const float* __restrict__ ddepth, const float* __restrict__ thead, int arch,
+                                      float inv_tau, float drop_const, int B, long HW, float s_depth, float s_conf,
+                                      float* __restrict__ draw, float* __restrict__ dbias, bf16* __restrict__ draw_pm,
+                                      int cp) {
+  __shared__ float red[16];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)B * HW; idx += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / HW);
+    const long p = idx - (long)b * HW;
+    const int nch = 1 + (arch == 0 ? 0 : arch);
+    const float* g = gout + (long)b * nch * HW + p;
+    const float* th = thead + (long)b * nch * HW + p;
+    float* d = draw + (long)b * nch * HW + p;
+    const float t = g[0], dt = 1.f - t * t, y = ddepth[idx];
+    const float t0 = th[0];
+    float d0, d1 = 0.f, d2 = 0.f;
+    if (arch == 0) {
+      d0 = y * (-2.f * t * dt) * t0;
+    } else {
+      const float sp = 1.f / (1.f + __expf(-(g[HW] + noise_pixel[idx]) * inv_tau));
+      const float sp1 = sp * (1.f - sp) * inv_tau, sp2 = sp1 * (1.f - 2.f * sp) * inv_tau;
+      const float t1 = th[HW], tc = t - drop_const;
+      if (arch == 1) {
+        const float mp = mask[idx];
+        d0 = y * (mp * (-2.f * t * dt) * t0 + sp1 * dt * t1);
+        d1 = y * (sp1 * dt * t0 + tc * sp2 * t1);
+      } else {
+        const float mp = mask[(long)b * 2 * HW + p], mi = mask[(long)b * 2 * HW + HW + p];
+        const float si = 1.f / (1.f + __expf(-(g[2 * HW] + noise_image[b]) * inv_tau));
+        const float si1 = si * (1.f - si) * inv_tau, si2 = si1 * (1.f - 2.f * si) * inv_tau;
+        const float t2 = th[2 * HW];
+        d0 = y * (mp * mi * (-2.f * t * dt) * t0 + mi * sp1 * dt * t1 + mp * si1 * dt * t2);
+        d1 = y * (mi * sp1 * dt * t0 + tc * mi * sp2 * t1 + tc * sp1 * si1 * t2);
+        d2 = y * (mp * si1 * dt * t0 + tc * sp1 * si1 * t1 + tc * mp * si2 * t2);
+        d[2 * HW] = d2 * s_conf;
+      }
+      d[HW] = d1 * s_conf;
+    }
+    d[0] = d0 * s_depth;
+    if (draw_pm) {
+      bf16* q = draw_pm + idx * cp;
+      q[0] = (bf16)(d0 * s_depth);
+      if (cp > 1) q[1] = (bf16)(arch >= 1 ? d1 * s_conf : 0.f);
+      if (cp > 2) q[2] = (bf16)(arch >= 2 ? d2 * s_conf : 0.f);
+      if (cp > 3) q[3] = (bf16)0.f;
+    }
+    a0 += d0; a1 += d1; a2 += d2;
+  }
+  if (dbias) {
+    const float s0 = dg_block_sum(a0, red);
+    if (threadIdx.x == 0) atomicAdd(&dbias[0], s0);
+    if (arch >= 1) { const float s1 = dg_block_sum(a1, red); if (threadIdx.x == 0) atomicAdd(&dbias[1], s1); }
+    if (arch >= 2) { const float s2 = dg_block_sum(a2, red); if (threadIdx.x == 0) atomicAdd(&dbias[2], s2); }
+  }
+}
+
+// dz[b][k] += scale * sum_n dp0[b][n] W[n][k]: the last link of d(sum x y)/dz through Proj (:282-287).  One workgroup
+// per slab of PZ_ROWS weight rows (read once, coalesced along k); dp0's slab sits in LDS; split-K by atomics.
+constexpr int PZ_ROWS = 256, PZ_BMAX = 32;
+template <typename TD, typename TW>
+__global__ __launch_bounds__(256) void proj_bwd_z_kernel(const TD* __restrict__ dp0, const TW* __restrict__ w, int B,
+                                                         long Np, int K, float scale, float* __restrict__ dz) {
+  __shared__ float s_d[PZ_BMAX][PZ_ROWS];
+  const long n0 = (long)blockIdx.x * PZ_ROWS;
+  const int rows = (int)min((long)PZ_ROWS, Np - n0);
+  for (int b0 = 0; b0 < B; b0 += PZ_BMAX) {
+    const int nb = min(PZ_BMAX, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * PZ_ROWS; i += 256) {
+      const int b = i / PZ_ROWS, r = i % PZ_ROWS;
+      s_d[b][r] = r < rows ? (float)dp0[(long)(b0 + b) * Np + n0 + r] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+      float acc[PZ_BMAX];
+#pragma unroll
+      for (int b = 0; b < PZ_BMAX; ++b) acc[b] = 0.f;
+      for (int r = 0; r < rows; ++r) {
+        const float wv = (float)w[(n0 + r) * K + k];
+#pragma unroll
+        for (int b = 0; b < PZ_BMAX; ++b) acc[b] += s_d[b][r] * wv;
+      }
+#pragma unroll
+      for (int b = 0; b < PZ_BMAX; ++b)
+        if (b < nb) atomicAdd(&dz[(long)(b0 + b) * K + k], acc[b] * scale);
+    }
+  }
+}
+
+// |J^T y| per sample, the running baseline and the penalty (:294-300), and v = w * d penalty / d dz, the direction of
+// the forward-over-reverse pass.  pl_ema (device scalar) is updated in place; acc[0] += baseline, acc[1] += penalty.
+// The baseline a = ema + 0.01 (mean l - ema) stays in the graph in the reference (lerp of a live mean), hence the
+// second term of  dP/dl_b = (2/B) [(l_b - a) - 0.01 mean_c (l_c - a)].
+__global__ __launch_bounds__(256) void pl_penalty_kernel(const float* __restrict__ dz, int B, int K, float w,
+                                                         float* __restrict__ pl_ema, float* __restrict__ v,
+                                                         float* __restrict__ acc) {
+  __shared__ float len[256];
+  __shared__ float bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = wave; b < B; b += 4) {  // one wave per sample
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) { const float x = dz[(long)b * K + k]; s += x * x; }
+    s = dg_wave_sum(s);
+    if (lane == 0) len[b] = sqrtf(s);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mu = 0.f;
+    for (int b = 0; b < B; ++b) mu += len[b];
+    mu /= (float)B;
+    const float ema = pl_ema[0];
+    const float a = ema + 0.01f * (mu - ema);
+    float pen = 0.f, dev = 0.f;
+    for (int b = 0; b < B; ++b) { const float e = len[b] - a; pen += e * e; dev += e; }
+    pl_ema[0] = a;
+    acc[0] += a;
+    acc[1] += pen / (float)B;
+    bc[0] = a;
+    bc[1] = dev / (float)B;
+  }
+  __syncthreads();
+  const float a = bc[0], mdev = bc[1];
+  for (long i = tid; i < (long)B * K; i += 256) {
+    const int b = (int)(i / K);
+    const float l = len[b];
+    const float dl = (2.f / (float)B) * ((l - a) - 0.01f * mdev);
+    v[i] = l > 0.f ? w * dl * dz[i] / l : 0.f;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // Per-sample reductions: out[b] = sum_i f(x[b][i]) with f = identity (sq=0) or square (sq=1).  One block per
 // (sample, slab); slabs are combined with atomics (out must be zeroed by the caller).
 __global__ __launch_bounds__(256) void sample_sum_kernel(const float* __restrict__ x, long n, int sq,
@@ -742,6 +886,43 @@ int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, f
   if (fm.kr != PHI_NONE && !y_real) return DG_EINVAL;  // relativistic metrics read D(real) (models/loss.py:76-85)
   gan_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(fm, 1, y_real, y_fake, B, w_gan, dy, nullptr, nullptr, acc,
                                                   nullptr);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_head_post_bwd2(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
+                      const float* ddepth, const float* thead, int arch, float tau, float drop_const, int B, long HW,
+                      float s_depth, float s_conf, float* draw, float* dbias, void* draw_pm, int cp, void* s_) {
+  if (!gout || !ddepth || !thead || !draw || B <= 0 || HW <= 0 || arch < 0 || arch > 2) return DG_EINVAL;
+  if (arch >= 1 && (!noise_pixel || !mask)) return DG_EINVAL;
+  if (arch == 2 && !noise_image) return DG_EINVAL;
+  const long n = (long)B * HW;
+  const int hb = (int)min((long)1024, (n + 255) / 256);
+  head_post_bwd2_kernel<<<hb, 256, 0, (hipStream_t)s_>>>(gout, noise_pixel, noise_image, mask, ddepth, thead, arch,
+                                                         1.f / tau, drop_const, B, HW, s_depth, s_conf, draw, dbias,
+                                                         (bf16*)draw_pm, cp);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_proj_bwd_z(const void* dp0, int dp_dtype, const void* w, int w_dtype, int B, long Np, int K, float scale,
+                  float* dz, void* s_) {
+  if (!dp0 || !w || !dz || B <= 0 || Np <= 0 || K <= 0) return DG_EINVAL;
+  hipStream_t s = (hipStream_t)s_;
+  const unsigned grid = (unsigned)((Np + PZ_ROWS - 1) / PZ_ROWS);
+  if (dp_dtype == DG_BF16 && w_dtype == DG_BF16)
+    proj_bwd_z_kernel<bf16, bf16><<<grid, 256, 0, s>>>((const bf16*)dp0, (const bf16*)w, B, Np, K, scale, dz);
+  else if (dp_dtype == DG_F32 && w_dtype == DG_F32)
+    proj_bwd_z_kernel<float, float><<<grid, 256, 0, s>>>((const float*)dp0, (const float*)w, B, Np, K, scale, dz);
+  else
+    return DG_EUNSUPPORTED;
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_pl_penalty(const float* dz, int B, int K, float w, float* pl_ema, float* v, float* acc, void* s_) {
+  if (!dz || !pl_ema || !v || !acc || B <= 0 || B > 256 || K <= 0) return DG_EINVAL;
+  pl_penalty_kernel<<<1, 256, 0, (hipStream_t)s_>>>(dz, B, K, w, pl_ema, v, acc);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

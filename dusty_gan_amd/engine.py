@@ -367,9 +367,14 @@ class GEngine:
         self.ops.wgrad(2, 1, 1, 1, nb, Np, c.nz, dp0, (0, Np, 1), zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
                        1.0 / math.sqrt(Np), accumulate=int(accumulate))
 
-    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, join=True):
+    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, join=True, data_only=False):
         """ddepth [B,1,H,W] fp32 = dLoss/d(output depth).  Accumulates every G parameter gradient into st.grad
-        (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309)."""
+        (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309).  data_only: just the backward-data chain
+        (self.draw, self.dp[3..0] = gradients w.r.t. the pre-activations), no parameter gradient is touched - the
+        first half of the path-length regulariser's d(sum x y)/dz."""
+        if data_only:
+            return self._backward_chain(st, ddepth, self.draw, self.draw_pm, self.dp, acts=None, chain=None,
+                                        second_of=None)
         c, o, lib = self.cfg, self.ops, L.lib()
         B = ddepth.shape[0]
         sp = L.stream_ptr()
@@ -416,6 +421,108 @@ class GEngine:
                 self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
         if join:  # join=False: the caller joins after work that does not need the weight gradients (fused Proj Adam)
             SideStream.join()
+
+
+    # ------------------------------------------------------------------ path-length regulariser (trainers/dcgan_amp.py:268-306)
+    def _backward_chain(self, st, ddepth, draw, draw_pm, dp, acts, chain, second_of, thead=None):
+        """One walk down the generator from the head to Proj's pre-activation.
+        acts is None  : data only (first-order chain of d(sum x y)/dz).
+        acts given    : the forward-over-reverse walk.  `draw`/`dp` receive the TANGENT gradient chain (upstream =
+                        Hessian of the head post-processing applied to `thead`); weight gradients accumulate
+                        a (x) tangent-chain + tangent-activations (x) first-order chain, bias gradients the sums of
+                        the tangent chain.  acts = tangent activations, chain = (draw1, draw_pm1, dp1) of the
+                        first-order walk."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        B = ddepth.shape[0]
+        sp = L.stream_ptr()
+        chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
+        arch = ARCH_ID[c.arch]
+        s_depth, s_conf = self.head_scales
+        full = acts is not None
+        g = st.grad
+        common = (L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
+                  L.ptr(self.noise_image) if arch == 2 else None, L.ptr(self.mask) if arch else None, L.ptr(ddepth))
+        if full:
+            L.check(lib.dg_head_post_bwd2(*common, L.ptr(thead), arch, c.tau, c.drop_const, B, self.HW, s_depth, s_conf,
+                                          L.ptr(draw), st.fptr("head_b", g), L.ptr(draw_pm), self.cp, sp),
+                    "dg_head_post_bwd2")
+        else:
+            L.check(lib.dg_head_post_bwd(*common, arch, c.tau, c.drop_const, B, self.HW, s_depth, s_conf, L.ptr(draw),
+                                         None, L.ptr(draw_pm), self.cp, sp), "dg_head_post_bwd")
+        hc, wc = self.grid[3]
+        pl = (c.nheads * self.HW, 1, self.HW)
+        pm = draw_pm is not None
+        cp = self.cp
+        gsrc, gstr, gdt = (draw_pm, (self.HW * cp, cp, 1), None) if pm else (draw, pl, L.DG_F32)
+        if full:
+            draw1, draw_pm1, dp1 = chain
+            g1 = (draw_pm1, (self.HW * cp, cp, 1), None) if pm else (draw1, pl, L.DG_F32)
+            for a_src, (gs, gst, gd) in ((self.a[3], (gsrc, gstr, gdt)), (acts[3], g1)):
+                kw = {} if gd is None else {"g_dt": gd}
+                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, a_src, (hc * wc * chs[3], chs[3], 1), gs, gst,
+                        st.fptr("head_w", g), 1.0, **kw)
+        kw = {} if gdt is None else {"in_dt": gdt}
+        o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], gsrc, gstr, dp[3], (hc * wc * chs[3], chs[3], 1),
+               st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3], dbias=st.fptr("up3_b", g) if full else None,
+               bias_mod=chs[3], **kw)
+        for i in (3, 2, 1):
+            hc, wc = self.grid[i - 1]
+            ci, co = chs[i - 1], chs[i]
+            s = 1.0 / math.sqrt(co * 16)
+            if full:
+                for a_src, g_src in ((self.a[i - 1], dp[i]), (acts[i - 1], chain[2][i])):
+                    o.wgrad(1, c.ring, B, hc, wc, ci, co, a_src, (hc * wc * ci, ci, 1), g_src, (4 * hc * wc * co, co, 1),
+                            st.fptr(f"up{i}_w", g), s)
+            prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
+            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, dp[i], (4 * hc * wc * co, co, 1), dp[i - 1],
+                   (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
+                   dbias=st.fptr(prev_b, g) if full else None, bias_mod=ci)
+        if full:
+            self.proj_wgrad(st, dp[0], self.zT, B, True)        # z (x) tangent chain
+            self.proj_wgrad(st, chain[2][0], self.vT, B, True)  # v (x) first-order chain
+
+    def grad_z(self, st: ParamStore):
+        """d(sum x y)/dz [B,nz] fp32 from the data-only backward's dp[0] (Proj: a0 = lrelu(s z W^T + b))"""
+        c = self.cfg
+        B = self.ws_B
+        Np = c.h0 * c.w0 * c.ch[3]
+        dz = torch.zeros(B, c.nz, dtype=torch.float32, device=self.dp[0].device)
+        L.check(L.lib().dg_proj_bwd_z(L.ptr(self.dp[0]), self.ops.dt, st.sptr("proj_w"), self.ops.dt, B, Np, c.nz,
+                                      1.0 / math.sqrt(Np), L.ptr(dz), L.stream_ptr()), "dg_proj_bwd_z")
+        return dz
+
+    def tangent_forward(self, st: ParamStore, v):
+        """Forward-mode derivative of the head pre-activations along the latent direction v [B,nz]: the generator with
+        the saved leaky-relu masks, no biases.  Fills self.ta[0..3] (tangent activations) and self.tout [B,heads,H,W]."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        B = v.shape[0]
+        chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
+        if getattr(self, "ta", None) is None or self.ta[0].numel() != self.a[0].numel():
+            self.ta = [torch.empty_like(t) for t in self.a]
+            self.dp2 = [torch.empty_like(t) for t in self.a]
+            self.vT = torch.empty_like(self.zT)
+            self.tout = torch.empty_like(self.gout)
+            self.draw2 = torch.empty_like(self.gout)
+            self.draw_pm2 = None if self.draw_pm is None else torch.empty_like(self.draw_pm)
+        L.check(lib.dg_cast(L.ptr(v.contiguous().float()), L.ptr(self.vT), o.dt, B * c.nz, L.stream_ptr()), "dg_cast")
+        Np = c.h0 * c.w0 * chs[0]
+        o.conv(L.MODE_GEMM, 0, 1, B, 1, 1, c.nz, Np, self.vT, (c.nz, 0, 1), self.ta[0], (Np, 0, 1), st.sptr("proj_w"),
+               1.0 / math.sqrt(Np), L.EPI_MASK, aux=self.a[0])
+        for i in (1, 2, 3):
+            hc, wc = self.grid[i - 1]
+            ci, co = chs[i - 1], chs[i]
+            o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, ci, co, self.ta[i - 1], (hc * wc * ci, ci, 1), self.ta[i],
+                   (4 * hc * wc * co, co, 1), L.ptr(st.coci[f"up{i}_w"]), 1.0 / math.sqrt(co * 16), L.EPI_MASK,
+                   aux=self.a[i])
+        hc, wc = self.grid[3]
+        o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.ta[3], (hc * wc * chs[3], chs[3], 1), self.tout,
+               (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR, out_dt=L.DG_F32,
+               nscale=self.nscale)
+
+    def backward_second(self, st: ParamStore, y):
+        """the parameter gradient of <v, d(sum x y)/dz> (v folded into the tangents): accumulates into st.grad"""
+        self._backward_chain(st, y, self.draw2, self.draw_pm2, self.dp2, acts=self.ta,
+                             chain=(self.draw, self.draw_pm, self.dp), second_of=True, thead=self.tout)
 
 
 class DEngine:

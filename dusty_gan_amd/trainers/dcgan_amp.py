@@ -10,6 +10,7 @@ What differs underneath:
     sample by dLoss/dy_real) as the real batch's ordinary backward pass, and the R1 double backward is a
     forward-mode tangent pass through the saved leaky-relu masks (SURVEY.md §7 "hard parts");
   * the G-phase D(real) forward of the reference (:259) is dead code for non-relativistic losses and is not run;
+  * the path-length regulariser (solver.loss.pl > 0) is a forward-over-reverse pass (Trainer._path_length);
   * scalars are gathered with ONE packed all-reduce and read back lazily.
 """
 import math
@@ -285,7 +286,9 @@ class Trainer:
         if self.loss_weight.get("gp", 0) > 0.0:
             self.criterion["gp"] = True
         if self.loss_weight.get("pl", 0) > 0.0:
-            raise NotImplementedError("path-length regularisation (loss.pl > 0) is outside the hot path scope")
+            self.criterion["pl"] = True  # path-length regularisation (reference :109-111, :268-306)
+        self.pl_ema = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._geng_pl = None
 
         # optimizers (reference :116-125)
         betas = (float(self.cfg.solver.lr.beta1), float(self.cfg.solver.lr.beta2))
@@ -303,6 +306,8 @@ class Trainer:
             self.G_ema.load_state_dict(sd["G_ema"])
             self.optim_G.load_state_dict(sd["optim_G"])
             self.optim_D.load_state_dict(sd["optim_D"])
+            if "pl" in self.criterion and sd.get("pl_ema") is not None:
+                self.pl_ema.copy_(torch.as_tensor(sd["pl_ema"]).reshape(1))
 
         self.n_acc = int(self.cfg.solver.num_accumulation)
         self.rng = Philox(torch.initial_seed() + 7919 * _rank(), self.device, stream_id=1)
@@ -358,6 +363,11 @@ class Trainer:
         nz = rand.get("noise")
         out["noise"] = None if not nz else {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in nz.items()}
         out["aug"] = [DiffAugment.params_to_device(rp, self.device) for rp in rand["aug"]]
+        if "pl" in rand:  # injected draws of the path-length block (parity tests)
+            pl = rand["pl"]
+            f = lambda t: torch.as_tensor(t).to(self.device, torch.float32)
+            out["pl"] = {"z": f(pl["z"]), "y": f(pl["y"]), "pl_ema": f(pl["pl_ema"]).reshape(1),
+                         "noise": None if not pl.get("noise") else {k: f(v) for k, v in pl["noise"].items()}}
         return out
 
     def _coll(self, fn):
@@ -413,7 +423,8 @@ class Trainer:
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         self._mb = []
         dev = self.device
-        scal = torch.zeros(5, dtype=torch.float32, device=dev)  # real, fake, adv, gp, G adv (sums over micro-batches)
+        # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
+        scal = torch.zeros(7, dtype=torch.float32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         for j, sync in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
             if reals is not None:
@@ -469,9 +480,11 @@ class Trainer:
         B = self.local_batch
         Gb, D = _backbone(self.G), self.D
         Gst, Dst = Gb.store, D.store
-        self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
-        gather_proj = (self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
-        fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
+        pl_on = "pl" in self.criterion  # its two extra gradient terms need Proj.weight's gradient materialised
+        self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 and not pl_on else ())
+        gather_proj = ((self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
+                       and not pl_on)
+        fuse_proj = (not gather_proj and not pl_on and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
                      and next(iter(Gst.seg)) == "proj_w" and Gst.seg["proj_w"].off == 0 and self._fuse_proj_ok
                      and self.optim_G.betas[0] == 0.0 and E.PROFILE is None)
         fuse_gathered = (gather_proj and self.dtype == torch.bfloat16 and Gst.seg["proj_w"].off == 0
@@ -506,6 +519,8 @@ class Trainer:
             ddepth = self.A.backward(dx, rand["aug"][3])
             mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj,
                                 join=not fuse_proj)
+            if pl_on:
+                self._path_length(Gst, rand.get("pl"), B // 2, scal)
         fused = None
         if gather_proj:
             # Proj.weight is 96 % of G's gradient bytes (268 MB fp32) and the last tensor backward produces.  It is a
@@ -552,6 +567,39 @@ class Trainer:
         self._mb = []
         return scal
 
+    def _path_length(self, Gst, inj, B_pl, scal):
+        """Path-length regularisation (reference :268-306) for one micro-batch: accumulates
+        d[w_pl * mean_b (|J_b^T y_b| - a)^2]/d theta into Gst.grad without autograd.  With v = d penalty / d(J^T y) held
+        fixed, <v, J^T y> = <J v, y'(h) y>, so the parameter gradient is a forward-over-reverse pass: the reverse
+        (data-only) chain gives J^T y, a forward tangent pass along v gives J v through the saved leaky-relu masks,
+        the head's Hessian couples the two, and one more walk down the generator accumulates
+        activations (x) tangent-chain + tangent-activations (x) first-order-chain (engine.GEngine._backward_chain)."""
+        from ..engine import GEngine
+        lib, sp = L.lib(), L.stream_ptr()
+        if self._geng_pl is None:
+            self._geng_pl = GEngine(self._g_engines()[0].cfg, self.dtype)
+        geng = self._geng_pl
+        nz = int(self.cfg.model.gen.in_ch)
+        if inj is not None:
+            z, noise, y = inj["z"], inj["noise"], inj["y"]
+            self.pl_ema.copy_(inj["pl_ema"])
+        else:
+            z = self.sample_latents(B_pl)                       # :272-273
+            noise = self._sample_noise(B_pl)                    # the Gumbel draws of G(z_pl), :277
+            y = self.rng.normal(B_pl * self.H * self.W).view(B_pl, 1, self.H, self.W)   # randn_like(x_pl), :279
+        geng.forward(Gst, z, noise, training=True)              # :277
+        yv = torch.empty_like(y)
+        L.check(lib.dg_scale(L.ptr(y), 1.0 / math.sqrt(self.H * self.W), y.numel(), L.ptr(yv), sp), "dg_scale")  # :280
+        geng.backward(Gst, yv, data_only=True)                  # :282-287, down to Proj's pre-activation ...
+        dz = geng.grad_z(Gst)                                   # ... and through Proj to z
+        self._pl_dz = dz  # (kept for the parity tests: the reference's `grads`, :282-290)
+        v = torch.empty_like(dz)
+        w = float(self.loss_weight["pl"]) / self.n_acc
+        L.check(lib.dg_pl_penalty(L.ptr(dz), B_pl, nz, w, L.ptr(self.pl_ema), L.ptr(v), L.ptr(scal) + 20, sp),
+                "dg_pl_penalty")                                # :294-303
+        geng.tangent_forward(Gst, v)
+        geng.backward_second(Gst, yv)                           # the `loss_G.backward()` share of the penalty, :309
+
     def _scalar_keys(self):
         keys = ["loss/D/output/real", "loss/D/output/fake", "loss/D/adversarial"]
         idx = [0, 1, 2]
@@ -560,6 +608,9 @@ class Trainer:
             idx.append(3)
         keys.append("loss/G/adversarial")
         idx.append(4)
+        if "pl" in self.criterion:
+            keys += ["loss/G/path_length/baseline", "loss/G/path_length"]
+            idx += [5, 6]
         return keys, idx
 
     def _step_eager(self, reals=None, rands=None):
@@ -568,7 +619,8 @@ class Trainer:
         scal = self.optimize_G()
         scal = scal / self.n_acc
         # (slices, not a Python index list: that would be a host-to-device copy, illegal during graph capture)
-        return scal if "gp" in self.criterion else torch.cat((scal[:3], scal[4:5]))
+        end = 7 if "pl" in self.criterion else 5
+        return scal[:end] if "gp" in self.criterion else torch.cat((scal[:3], scal[4:end]))
 
     def _graph_eligible(self, reals, rands):
         import os
@@ -711,7 +763,8 @@ class Trainer:
         def sd(m):
             return OrderedDict((k, v.detach().cpu().contiguous()) for k, v in m.state_dict().items())
         return {"step": step, "G": sd(self.G), "D": sd(self.D), "G_ema": sd(self.G_ema),
-                "optim_G": self.optim_G.state_dict(), "optim_D": self.optim_D.state_dict(), "pl_ema": None}
+                "optim_G": self.optim_G.state_dict(), "optim_D": self.optim_D.state_dict(),
+                "pl_ema": self.pl_ema.detach().cpu().reshape(()) if "pl" in self.criterion else None}
 
     def save_models(self, suffix, step, directory="models"):
         """reference :395-409 (same keys, reference-shaped tensors)"""

@@ -428,7 +428,7 @@ def test_gan_step_kernels_all_metrics(L, metric):
         dg = torch.empty(B, device=DEV)
         L.check(lib.dg_gan_g_step(code, yrd.data_ptr(), yfd.data_ptr(), B, 0.5, dg.data_ptr(), acc.data_ptr() + 16, None))
         assert (dg.cpu() - gg).abs().max() < 2e-6 * max(1.0, 37 / B), (metric, B)
-        assert abs(float(acc[4]) - 5.0 - float(loss_g)) < 1e-5
+        assert abs(float(acc[4]) - 5.0 - float(loss_g.detach())) < 1e-5
         rc = lib.dg_gan_g_step(code, None, yfd.data_ptr(), B, 0.5, dg.data_ptr(), acc.data_ptr() + 16, None)
         assert (rc != 0) == crit.relativistic  # D(real) is only optional for the non-relativistic metrics
     assert lib.dg_gan_d_step(7, 1.0, yrd.data_ptr(), yfd.data_ptr(), B, 0.5, dy.data_ptr(), None, None,
