@@ -90,6 +90,7 @@ PROTOTYPES = {
     "dg_normals": [_P, _I, _I, _I, _I, _P, _P],
     "dg_fps": [_P, _I, _I, _I, _P, _P, _P, _P],
     "dg_chamfer_dir": [_P, _I, _I, _P, _I, _I, _P, _P],
+    "dg_emd": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
     "dg_grid_vote": [_P, _L, _P, _I, _P, _P],
     "dg_jsd": [_P, _P, _I, _P, _P],
     "dg_pyr_down": [_P, _L, _I, _I, _P, _P],

@@ -311,6 +311,79 @@ __global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ 
   out[i] = img[(((long)b * C + c) * H + y) * W + x];
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Earth mover's distance, approximate matching (utils/metrics/distance/emd/earth_mover_distance.cu:28-190 approxmatch,
+// :218-262 matchcost): ten annealing levels exp(-4^j d^2), j = 7 .. -1, then 0; per level the three sweeps of the
+// reference (left ratios, right consumption, matched mass).  The match matrix is never stored: matchcost is linear in
+// it, so the cost sum_{k,l} match[l][k] d^2(k,l) is accumulated while the mass is produced.  One workgroup per cloud
+// pair, both clouds and the four mass vectors in LDS.  (i, j) = (blockIdx.y, blockIdx.x), or the diagonal pairing
+// (i = j) when `paired`.
+__global__ __launch_bounds__(512) void emd_kernel(const float* __restrict__ A, int n, const float* __restrict__ Bc,
+                                                  int m, int Nb, int paired, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char emd_lds[];
+  float4* p1 = (float4*)emd_lds;            // [n]
+  float4* p2 = p1 + n;                      // [m]
+  float* remainL = (float*)(p2 + m);        // [n]
+  float* remainR = remainL + n;             // [m]
+  float* ratioL = remainR + m;              // [n]
+  float* ratioR = ratioL + n;               // [m]
+  __shared__ float red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int j = blockIdx.x, i = paired ? blockIdx.x : blockIdx.y;
+  const float* a = A + (long)i * n * 3;
+  const float* b = Bc + (long)j * m * 3;
+  const float multiL = n >= m ? 1.f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.f;
+  for (int k = tid; k < n; k += nt) { p1[k] = make_float4(a[k * 3], a[k * 3 + 1], a[k * 3 + 2], 0.f); remainL[k] = multiL; }
+  for (int l = tid; l < m; l += nt) { p2[l] = make_float4(b[l * 3], b[l * 3 + 1], b[l * 3 + 2], 0.f); remainR[l] = multiR; }
+  __syncthreads();
+  float cost = 0.f;
+  for (int lev = 7; lev >= -2; --lev) {
+    const float level = lev == -2 ? 0.f : -powf(4.0f, (float)lev);
+    for (int k = tid; k < n; k += nt) {
+      const float4 x = p1[k];
+      float suml = 1e-9f;
+      for (int l = 0; l < m; ++l) {
+        const float4 q = p2[l];
+        const float d = (q.x - x.x) * (q.x - x.x) + (q.y - x.y) * (q.y - x.y) + (q.z - x.z) * (q.z - x.z);
+        suml += __expf(level * d) * remainR[l];
+      }
+      ratioL[k] = remainL[k] / suml;
+    }
+    __syncthreads();
+    for (int l = tid; l < m; l += nt) {
+      const float4 q = p2[l];
+      float sumr = 0.f;
+      for (int k = 0; k < n; ++k) {
+        const float4 x = p1[k];
+        const float d = (q.x - x.x) * (q.x - x.x) + (q.y - x.y) * (q.y - x.y) + (q.z - x.z) * (q.z - x.z);
+        sumr += __expf(level * d) * ratioL[k];
+      }
+      const float r = remainR[l];
+      sumr *= r;
+      const float consumption = fminf(r / (sumr + 1e-9f), 1.0f);
+      ratioR[l] = consumption * r;
+      remainR[l] = fmaxf(0.0f, r - sumr);
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += nt) {
+      const float4 x = p1[k];
+      const float rl = ratioL[k];
+      float suml = 0.f;
+      for (int l = 0; l < m; ++l) {
+        const float4 q = p2[l];
+        const float d = (q.x - x.x) * (q.x - x.x) + (q.y - x.y) * (q.y - x.y) + (q.z - x.z) * (q.z - x.z);
+        const float w = __expf(level * d) * rl * ratioR[l];
+        cost += w * d;       // matchcost (:218-262): match[l][k] * d, summed over levels
+        suml += w;
+      }
+      remainL[k] = fmaxf(0.0f, remainL[k] - suml);
+    }
+    __syncthreads();
+  }
+  const float tot = dg_block_sum(cost, red);
+  if (tid == 0) out[paired ? (long)i : (long)i * Nb + j] = tot;
+}
+
 }  // namespace
 
 extern "C" {
@@ -379,6 +452,23 @@ int dg_extract_patches(const float* img, int B, int C, int H, int W, int ph, int
   if (!img || !inds || !out || B <= 0 || C <= 0 || ph <= 0 || pw <= 0 || ph > H || pw > W || NP <= 0) return DG_EINVAL;
   const long n = (long)B * NP * C * ph * pw;
   patches_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)s_>>>(img, B, C, H, W, ph, pw, inds, NP, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_emd(const float* A, int Na, int n, const float* Bc, int Nb, int m, int paired, float* out, void* s_) {
+  if (!A || !Bc || !out || Na <= 0 || Nb <= 0 || n <= 0 || m <= 0) return DG_EINVAL;
+  if (paired && Na != Nb) return DG_EINVAL;
+  const size_t lds = (size_t)(n + m) * (16 + 8);
+  if (lds > 150 * 1024) return DG_EUNSUPPORTED;
+  static bool opted = false;
+  if (!opted) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)emd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    opted = true;
+  }
+  const dim3 grid(Nb, paired ? 1 : Na);
+  if (grid.y > 65535) return DG_EUNSUPPORTED;
+  emd_kernel<<<grid, 512, lds, (hipStream_t)s_>>>(A, n, Bc, m, Nb, paired, out);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

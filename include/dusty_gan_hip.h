@@ -218,6 +218,11 @@ int dg_normals(const float* points, int B, int H, int W, int d, float* out, void
  * accumulate.  dg_jsd: _jensen_shannon_divergence :96-107 of two counter vectors -> out[0]. */
 int dg_fps(const float* xyz, int B, int n, int m, float* temp, int* idx, float* out, void* stream);
 int dg_chamfer_dir(const float* A, int Na, int n, const float* Bc, int Nb, int m, float* L, void* stream);
+/* dg_emd: approximate earth mover's distance  utils/metrics/distance/emd/earth_mover_distance.cu (approxmatch :28-190
+ * + matchcost :218-262 fused; the [m,n] match matrix is never stored).  paired = 1: out[i] = emd(A_i, B_i) (Na == Nb,
+ * the extension's semantics); paired = 0: out [Na,Nb] for all pairs.  The value is the raw cost (compute_emd of
+ * utils/metrics/cov_mmd_1nna.py:12-17 divides by the point count). */
+int dg_emd(const float* A, int Na, int n, const float* Bc, int Nb, int m, int paired, float* out, void* stream);
 int dg_grid_vote(const float* pts, long P, const float* grid, int Ng, float* counters, void* stream);
 int dg_jsd(const float* P, const float* Q, int n, float* out, void* stream);
 /* SWD descriptors  utils/metrics/swd.py:16-62.  dg_pyr_down: pyramid_down (:24-30) on `planes` = B*C images

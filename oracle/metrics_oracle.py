@@ -5,7 +5,8 @@ Restates, with numpy / stock torch CPU ops:
   * furthest point sampling + gather     utils/sampling/fps/furthest_point_sampling.cu:97-207, .py:84-93
   * Chamfer nearest-neighbour search      utils/metrics/distance/cd/chamfer_distance.cpp:41-66 (the extension's own CPU
                                           path `nnsearch`; the CUDA kernel computes the same quantity)
-  * COV / MMD / 1-NNA                     utils/metrics/cov_mmd_1nna.py:20-148
+  * approximate earth mover's distance    utils/metrics/distance/emd/earth_mover_distance.cu:28-190,218-262
+  * COV / MMD / 1-NNA                     utils/metrics/cov_mmd_1nna.py:12-148
   * JSD on the occupancy grid             utils/metrics/jsd.py:11-116
   * sliced Wasserstein distance           utils/metrics/swd.py:16-151 (random draws injected)
 
@@ -13,7 +14,7 @@ Parity pin:
   * JSD and SWD: utils/metrics/jsd.py and swd.py are plain torch and importable here; tests/golden/metrics.npz holds
     their outputs for seeded inputs (JSD: grid counters and the divergence; SWD: every score, with the reference's
     randperm / randn draws captured by replaying the generator) -> pinned.
-  * FPS, Chamfer, COV/MMD/1-NNA: the reference runs them through CUDA extensions that are JIT-compiled at import
+  * FPS, Chamfer, EMD, COV/MMD/1-NNA: the reference runs them through CUDA extensions that are JIT-compiled at import
     (`torch.utils.cpp_extension.load` of .cu files, nvcc absent here; cov_mmd_1nna.py imports them at module level), so
     none of it can be executed in this image -> PARITY UNPINNED against the reference; restated from the sources
     cited above, FPS including the launcher's tie-breaking order, and cross-checked against brute force in the tests.
@@ -89,6 +90,41 @@ def pairwise_cd(pcs_1, pcs_2):
     return chamfer_dir(pcs_1, pcs_2) + chamfer_dir(pcs_2, pcs_1).t()
 
 
+def emd_cost(x1, x2):
+    """approxmatch + matchcost of utils/metrics/distance/emd/earth_mover_distance.cu:28-190,218-262 for ONE pair
+    x1 [n,3], x2 [m,3] (float32): ten annealing levels exp(-4^j d^2), j = 7 .. -1, then 0; the cost is
+    sum_{k,l} match[l][k] * d^2(k,l), accumulated level by level (matchcost is linear in match)."""
+    x1, x2 = np.asarray(x1, np.float32), np.asarray(x2, np.float32)
+    n, m = x1.shape[0], x2.shape[0]
+    multiL, multiR = (1.0, float(n // m)) if n >= m else (float(m // n), 1.0)
+    remainL, remainR = np.full(n, multiL, np.float32), np.full(m, multiR, np.float32)
+    diff = x2[None, :, :] - x1[:, None, :]
+    d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1] + diff[..., 2] * diff[..., 2]).astype(np.float32)
+    cost = 0.0
+    for j in range(7, -3, -1):
+        level = np.float32(0.0) if j == -2 else np.float32(-(4.0 ** j))
+        E = np.exp(level * d2).astype(np.float32)                       # [n,m]
+        suml = np.float32(1e-9) + E @ remainR
+        ratioL = remainL / suml
+        sumr = (E.T @ ratioL) * remainR
+        consumption = np.minimum(remainR / (sumr + np.float32(1e-9)), np.float32(1.0))
+        ratioR = consumption * remainR
+        remainR = np.maximum(np.float32(0.0), remainR - sumr)
+        Wm = E * ratioL[:, None] * ratioR[None, :]
+        cost += float((Wm * d2).sum(dtype=np.float64))
+        remainL = np.maximum(np.float32(0.0), remainL - Wm.sum(axis=1))
+    return cost
+
+
+def pairwise_emd(pcs_1, pcs_2):
+    """_pairwise_distance(..., metrics=("emd",)) cov_mmd_1nna.py:25-52 with compute_emd :12-17 (cost / N)"""
+    out = torch.empty(len(pcs_1), len(pcs_2))
+    for i, a in enumerate(pcs_1):
+        for j, b in enumerate(pcs_2):
+            out[i, j] = emd_cost(a, b) / float(a.shape[0])
+    return out
+
+
 def cov_mmd(M_rg):
     """_compute_cov_mmd cov_mmd_1nna.py:55-66"""
     N_ref, N_gen = M_rg.shape
@@ -120,11 +156,14 @@ def nna(M_rr, M_rg, M_gg, k=1, sqrt=False):
     return s
 
 
-def compute_cov_mmd_1nna(pcs_gen, pcs_ref):
-    """compute_cov_mmd_1nna(pcs_gen, pcs_ref, batch, ("cd",)) cov_mmd_1nna.py:113-148 (result key names included)"""
-    M_rr, M_rg, M_gg = pairwise_cd(pcs_ref, pcs_ref), pairwise_cd(pcs_ref, pcs_gen), pairwise_cd(pcs_gen, pcs_gen)
-    res = {"{}-cd".format(k): v for k, v in cov_mmd(M_rg).items()}
-    res.update({"1-nn-{}-cd".format(k): v for k, v in nna(M_rr, M_rg, M_gg, k=1).items()})
+def compute_cov_mmd_1nna(pcs_gen, pcs_ref, metrics=("cd",)):
+    """compute_cov_mmd_1nna(pcs_gen, pcs_ref, batch, metrics) cov_mmd_1nna.py:113-148 (result key names included)"""
+    res = {}
+    for metric in metrics:
+        pw = {"cd": pairwise_cd, "emd": pairwise_emd}[metric]
+        M_rr, M_rg, M_gg = pw(pcs_ref, pcs_ref), pw(pcs_ref, pcs_gen), pw(pcs_gen, pcs_gen)
+        res.update({"{}-{}".format(k, metric): v for k, v in cov_mmd(M_rg).items()})
+        res.update({"1-nn-{}-{}".format(k, metric): v for k, v in nna(M_rr, M_rg, M_gg, k=1).items()})
     return res
 
 

@@ -83,7 +83,36 @@ def test_cov_mmd_1nna_matches_oracle():
     for k in want:
         assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, got[k], want[k])
     with pytest.raises(NotImplementedError):
-        compute_cov_mmd_1nna(torch.from_numpy(gen).to(DEV), torch.from_numpy(ref).to(DEV), 512, ("emd",))
+        compute_cov_mmd_1nna(torch.from_numpy(gen).to(DEV), torch.from_numpy(ref).to(DEV), 512, ("swd",))
+
+
+@pytest.mark.parametrize("n,m", [(64, 64), (200, 200), (96, 32), (50, 150)])
+def test_emd_matches_oracle(n, m):
+    """approxmatch + matchcost (earth_mover_distance.cu) fused: paired costs and the all-pairs matrix against the numpy
+    restatement; __expf against np.exp and fp32 sums in a different order -> 1e-3 relative"""
+    from dusty_gan_amd.utils.metrics import earth_mover_distance
+    from dusty_gan_amd.utils.metrics.distance import emd_distance_matrix
+    a = lidar_like_clouds(4, n, seed=n, drop=0.05)
+    b = lidar_like_clouds(4, m, seed=m + 7, drop=0.05) * 0.9
+    got = earth_mover_distance(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu()
+    want = torch.tensor([MO.emd_cost(a[i], b[i]) for i in range(4)])
+    assert float(((got - want).abs() / want.abs().clamp_min(1e-9)).max()) < 1e-3, (got, want)
+    if n == m:
+        M = emd_distance_matrix(torch.from_numpy(a[:3]).to(DEV), torch.from_numpy(b).to(DEV)).cpu()
+        assert M.shape == (3, 4) and rel_l2(M, MO.pairwise_emd(a[:3], b)) < 1e-3
+        self_cost = earth_mover_distance(torch.from_numpy(a).to(DEV), torch.from_numpy(a).to(DEV)).cpu()
+        assert float(self_cost.max()) < 1e-2 * float(want.min())  # a cloud matches itself at (almost) no cost
+
+
+def test_cov_mmd_1nna_emd_matches_oracle():
+    from dusty_gan_amd.utils.metrics import compute_cov_mmd_1nna
+    gen = lidar_like_clouds(7, 64, seed=11) * 0.8
+    ref = lidar_like_clouds(9, 64, seed=12)
+    got = compute_cov_mmd_1nna(torch.from_numpy(gen).to(DEV), torch.from_numpy(ref).to(DEV), 512, ("cd", "emd"), verbose=False)
+    want = MO.compute_cov_mmd_1nna(gen, ref, ("cd", "emd"))
+    assert set(got) == set(want) and len(got) == 24
+    for k in want:
+        assert abs(got[k] - want[k]) <= 2e-3 * max(1.0, abs(want[k])), (k, got[k], want[k])
 
 
 def test_jsd_matches_reference_golden():

@@ -275,6 +275,13 @@ def test_fps_and_chamfer_restatements():
             assert abs(float(L[i, j]) - tot / 9) < 1e-6
     M = MO.pairwise_cd(A, A)
     assert torch.allclose(M, M.t()) and float(M.diag().abs().max()) == 0.0
+    # EMD (approxmatch + matchcost): a cloud matches itself - in any point order - at zero cost; translating it by t
+    # costs n * |t|^2 once the matching is (nearly) one to one
+    pts = rng.normal(0, 0.3, (40, 3)).astype(np.float32)
+    assert MO.emd_cost(pts, pts) < 1e-6 and MO.emd_cost(pts, pts[::-1].copy()) < 1e-6
+    shift = np.float32([0.01, 0.0, 0.0])
+    assert abs(MO.emd_cost(pts, pts + shift) / (40 * 1e-4) - 1.0) < 0.05
+    assert MO.pairwise_emd(pts[None], (pts + shift)[None]).shape == (1, 1)
     # COV / MMD / 1-NNA on a hand-made matrix
     M_rg = torch.tensor([[0.1, 0.9, 0.8], [0.7, 0.2, 0.9]])
     r = MO.cov_mmd(M_rg)
