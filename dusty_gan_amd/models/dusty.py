@@ -21,6 +21,7 @@ class GumbelSigmoid(nn.Module):
                                       "configs (configs/model/dusty*_dcgan_eqlr.yaml: tau: 1)")
         self.tau, self.tau_max, self.hard, self.eps, self.pixelwise = tau, tau_max, hard, eps, pixelwise
         self.fixed_noise = None
+        self.fix_on_first_use = False  # utils.setup(fix_noise=True): what the reference's forward-pre-hook does
         self._rng = None
 
     def rng(self, device):
@@ -38,7 +39,12 @@ class GumbelSigmoid(nn.Module):
             shape = (-1, -1, -1) if self.pixelwise else (-1, -1, -1)
             return self.fixed_noise.to(device).expand(B, *shape).contiguous()
         shape = (B, 1, H, W) if self.pixelwise else (B, 1, 1, 1)
-        return self.rng(device).logistic_noise(shape, self.eps)
+        noise = self.rng(device).logistic_noise(shape, self.eps)
+        if self.fix_on_first_use:
+            # utils/__init__.py:141-149: `m.fixed_noise = m.logistic_noise(i[0])[[0]]` on the first call, reused after
+            self.fixed_noise = noise[[0]].clone()
+            return self.fixed_noise.expand(B, -1, -1, -1).contiguous()
+        return noise
 
     def forward(self, logits, threshold: float = 0.5):
         raise RuntimeError("GumbelSigmoid is fused into the generator head kernels; call the DUSty wrapper")

@@ -71,3 +71,24 @@ def load_config(overrides=(), config_dir=CONFIG_DIR):
     cfg.solver.lr.beta1 = float(cfg.solver.lr.beta1)
     cfg.solver.lr.beta2 = float(cfg.solver.lr.beta2)
     return cfg
+
+
+def load_config_file(path):
+    """A fully composed config (what Hydra dumps to .hydra/config.yaml and utils.setup reads, utils/__init__.py:122)."""
+    with open(path) as f:
+        cfg = Cfg.wrap(yaml.safe_load(f))
+    cfg.solver.lr.beta1 = float(cfg.solver.lr.beta1)
+    cfg.solver.lr.beta2 = float(cfg.solver.lr.beta2)
+    return cfg
+
+
+def dump_config(cfg, path):
+    """the inverse: write the composed tree as plain YAML"""
+    def plain(o):
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        return o
+    with open(path, "w") as f:
+        yaml.safe_dump(plain(cfg), f, sort_keys=False)  # key order matters: out_ch = {depth, confidence}

@@ -283,6 +283,25 @@ def test_checkpoint_roundtrip_and_generate(tmp_path):
     assert torch.isfinite(out["depth"]).all()
     with pytest.raises(RuntimeError):
         tr.G(torch.zeros(2, 8))  # CPU input: no fallback
+    # utils.setup (reference utils/__init__.py:116-160): the evaluation scripts' way back from a checkpoint
+    from dusty_gan_amd.utils import setup
+    from dusty_gan_amd.utils.config import dump_config
+    from dusty_gan_amd.utils.lidar import postprocess
+    cfg_path = str(tmp_path / "config.yaml")
+    dump_config(tr.cfg, cfg_path)
+    cfg, G, lidar, device = setup(path, cfg_path, ema=True, fix_noise=True)
+    assert device.type == "cuda" and cfg.dataset.shape == [32, 64] and not G.training
+    assert torch.equal(G.store.flat.cpu(), tr.G_ema.store.flat.cpu())
+    z = torch.randn(3, 8, device=device)
+    o1, o2 = G(z), None
+    o1 = {k: v.clone() for k, v in o1.items()}
+    o2 = G(z)
+    for k in o1:  # fix_noise: the Gumbel noise of the first call is reused, so the same latent gives the same scan
+        assert torch.equal(o1[k], o2[k]), k
+    m = [mod for mod in G.modules() if type(mod).__name__ == "GumbelSigmoid"]
+    assert len(m) == 2 and m[0].fixed_noise is not None and m[0].fixed_noise.shape == (1, 1, 32, 64)
+    out = postprocess(o2, lidar)
+    assert "points" in out and out["points"].shape == (3, 3, 32, 64)
 
 
 def test_path_length_regulariser_vs_oracle():
