@@ -81,7 +81,6 @@ PROTOTYPES = {
     "dg_gan_g_step": [_I, _P, _P, _I, _F, _P, _P, _P],
     "dg_mean_acc": [_P, _I, _P, _P],
     "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
-    "dg_proj_bwd_z": [_P, _I, _P, _I, _I, _L, _I, _F, _P, _P],
     "dg_pl_penalty": [_P, _I, _I, _F, _P, _P, _P, _P],
     "dg_head_post_bwd2": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _L, _F, _F, _P, _P, _P, _I, _P],
     "dg_scan_to_polar": [_P, _I, _I, _I, _I, _I, _I, _P, _D, _D, _F, _P, _P, _P, _P, _P],

@@ -267,39 +267,6 @@ __global__ void head_post_bwd2_kernel(const float* __restrict__ gout, const floa
   }
 }
 
-// dz[b][k] += scale * sum_n dp0[b][n] W[n][k]: the last link of d(sum x y)/dz through Proj (:282-287).  One workgroup
-// per slab of PZ_ROWS weight rows (read once, coalesced along k); dp0's slab sits in LDS; split-K by atomics.
-constexpr int PZ_ROWS = 256, PZ_BMAX = 32;
-template <typename TD, typename TW>
-__global__ __launch_bounds__(256) void proj_bwd_z_kernel(const TD* __restrict__ dp0, const TW* __restrict__ w, int B,
-                                                         long Np, int K, float scale, float* __restrict__ dz) {
-  __shared__ float s_d[PZ_BMAX][PZ_ROWS];
-  const long n0 = (long)blockIdx.x * PZ_ROWS;
-  const int rows = (int)min((long)PZ_ROWS, Np - n0);
-  for (int b0 = 0; b0 < B; b0 += PZ_BMAX) {
-    const int nb = min(PZ_BMAX, B - b0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb * PZ_ROWS; i += 256) {
-      const int b = i / PZ_ROWS, r = i % PZ_ROWS;
-      s_d[b][r] = r < rows ? (float)dp0[(long)(b0 + b) * Np + n0 + r] : 0.f;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 256) {
-      float acc[PZ_BMAX];
-#pragma unroll
-      for (int b = 0; b < PZ_BMAX; ++b) acc[b] = 0.f;
-      for (int r = 0; r < rows; ++r) {
-        const float wv = (float)w[(n0 + r) * K + k];
-#pragma unroll
-        for (int b = 0; b < PZ_BMAX; ++b) acc[b] += s_d[b][r] * wv;
-      }
-#pragma unroll
-      for (int b = 0; b < PZ_BMAX; ++b)
-        if (b < nb) atomicAdd(&dz[(long)(b0 + b) * K + k], acc[b] * scale);
-    }
-  }
-}
-
 // |J^T y| per sample, the running baseline and the penalty (:294-300), and v = w * d penalty / d dz, the direction of
 // the forward-over-reverse pass.  pl_ema (device scalar) is updated in place; acc[0] += baseline, acc[1] += penalty.
 // The baseline a = ema + 0.01 (mean l - ema) stays in the graph in the reference (lerp of a live mean), hence the
@@ -901,21 +868,6 @@ int dg_head_post_bwd2(const float* gout, const float* noise_pixel, const float* 
   head_post_bwd2_kernel<<<hb, 256, 0, (hipStream_t)s_>>>(gout, noise_pixel, noise_image, mask, ddepth, thead, arch,
                                                          1.f / tau, drop_const, B, HW, s_depth, s_conf, draw, dbias,
                                                          (bf16*)draw_pm, cp);
-  HIP_CHECK_RET(hipGetLastError());
-  return DG_OK;
-}
-
-int dg_proj_bwd_z(const void* dp0, int dp_dtype, const void* w, int w_dtype, int B, long Np, int K, float scale,
-                  float* dz, void* s_) {
-  if (!dp0 || !w || !dz || B <= 0 || Np <= 0 || K <= 0) return DG_EINVAL;
-  hipStream_t s = (hipStream_t)s_;
-  const unsigned grid = (unsigned)((Np + PZ_ROWS - 1) / PZ_ROWS);
-  if (dp_dtype == DG_BF16 && w_dtype == DG_BF16)
-    proj_bwd_z_kernel<bf16, bf16><<<grid, 256, 0, s>>>((const bf16*)dp0, (const bf16*)w, B, Np, K, scale, dz);
-  else if (dp_dtype == DG_F32 && w_dtype == DG_F32)
-    proj_bwd_z_kernel<float, float><<<grid, 256, 0, s>>>((const float*)dp0, (const float*)w, B, Np, K, scale, dz);
-  else
-    return DG_EUNSUPPORTED;
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

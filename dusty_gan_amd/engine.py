@@ -477,19 +477,30 @@ class GEngine:
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, dp[i], (4 * hc * wc * co, co, 1), dp[i - 1],
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
                    dbias=st.fptr(prev_b, g) if full else None, bias_mod=ci)
-        if full:
+        if full and second_of:
             self.proj_wgrad(st, dp[0], self.zT, B, True)        # z (x) tangent chain
             self.proj_wgrad(st, chain[2][0], self.vT, B, True)  # v (x) first-order chain
 
     def grad_z(self, st: ParamStore):
-        """d(sum x y)/dz [B,nz] fp32 from the data-only backward's dp[0] (Proj: a0 = lrelu(s z W^T + b))"""
+        """d(sum x y)/dz [B,nz] fp32 from the data-only backward's dp[0] (Proj: a0 = lrelu(s z W^T + b)):
+        dz^T [nz][B] = s * sum_n' W[n'][:] (x) dp0[:, n'] - a reduction over Proj's 131 072 output rows, i.e. the
+        weight-gradient GEMM shape (wmode 2: rows = "pixels") with W as the layer input and dp0^T, zero-padded to 64
+        columns, as the gradient; split-K on the MFMA kernel instead of a one-off VALU kernel."""
         c = self.cfg
         B = self.ws_B
         Np = c.h0 * c.w0 * c.ch[3]
-        dz = torch.zeros(B, c.nz, dtype=torch.float32, device=self.dp[0].device)
-        L.check(L.lib().dg_proj_bwd_z(L.ptr(self.dp[0]), self.ops.dt, st.sptr("proj_w"), self.ops.dt, B, Np, c.nz,
-                                      1.0 / math.sqrt(Np), L.ptr(dz), L.stream_ptr()), "dg_proj_bwd_z")
-        return dz
+        Bp = (B + 63) // 64 * 64
+        if getattr(self, "_dzT", None) is None or self._dzT.shape != (Np, Bp):
+            self._dzT = torch.zeros(Np, Bp, dtype=self.dtype, device=self.dp[0].device)
+            self._dzw = torch.empty(c.nz, Bp, dtype=torch.float32, device=self.dp[0].device)
+        self._dzT[:, :B].copy_(self.dp[0].view(B, Np).t())
+        self._dzw.zero_()
+        shadow = st.shadow[st.seg["proj_w"].off:st.seg["proj_w"].off + Np * c.nz]
+        # the kernel splits its reduction over (sample, row) units: present the Np rows as R "samples" of Np / R rows
+        R = 512 if Np % (512 * 64) == 0 else 1
+        self.ops.wgrad(2, 1, R, 1, Np // R, c.nz, Bp, shadow, ((Np // R) * c.nz, c.nz, 1), self._dzT,
+                       ((Np // R) * Bp, Bp, 1), L.ptr(self._dzw), 1.0 / math.sqrt(Np), accumulate=1)
+        return self._dzw[:, :B].t().contiguous()
 
     def tangent_forward(self, st: ParamStore, v):
         """Forward-mode derivative of the head pre-activations along the latent direction v [B,nz]: the generator with
@@ -519,10 +530,12 @@ class GEngine:
                (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR, out_dt=L.DG_F32,
                nscale=self.nscale)
 
-    def backward_second(self, st: ParamStore, y):
-        """the parameter gradient of <v, d(sum x y)/dz> (v folded into the tangents): accumulates into st.grad"""
+    def backward_second(self, st: ParamStore, y, proj_terms=True):
+        """the parameter gradient of <v, d(sum x y)/dz> (v folded into the tangents): accumulates into st.grad.
+        proj_terms=False leaves Proj.weight's two terms, dp2[0]^T z and dp[0]^T v, to the caller (who appends them to
+        the operand list of the fused optimizer / the all-gather)."""
         self._backward_chain(st, y, self.draw2, self.draw_pm2, self.dp2, acts=self.ta,
-                             chain=(self.draw, self.draw_pm, self.dp), second_of=True, thead=self.tout)
+                             chain=(self.draw, self.draw_pm, self.dp), second_of=proj_terms, thead=self.tout)
 
 
 class DEngine:

@@ -480,11 +480,10 @@ class Trainer:
         B = self.local_batch
         Gb, D = _backbone(self.G), self.D
         Gst, Dst = Gb.store, D.store
-        pl_on = "pl" in self.criterion  # its two extra gradient terms need Proj.weight's gradient materialised
-        self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 and not pl_on else ())
-        gather_proj = ((self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
-                       and not pl_on)
-        fuse_proj = (not gather_proj and not pl_on and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
+        pl_on = "pl" in self.criterion
+        self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
+        gather_proj = (self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
+        fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
                      and next(iter(Gst.seg)) == "proj_w" and Gst.seg["proj_w"].off == 0 and self._fuse_proj_ok
                      and self.optim_G.betas[0] == 0.0 and E.PROFILE is None)
         fuse_gathered = (gather_proj and self.dtype == torch.bfloat16 and Gst.seg["proj_w"].off == 0
@@ -520,7 +519,9 @@ class Trainer:
             mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj,
                                 join=not fuse_proj)
             if pl_on:
-                self._path_length(Gst, rand.get("pl"), B // 2, scal)
+                # (Proj.weight's two path-length terms follow its adversarial term: materialised here, or - when that
+                # gradient is formed inside the optimizer / from gathered operands - appended to its operand list below)
+                self._path_length(Gst, rand.get("pl"), B // 2, scal, proj_terms=not (gather_proj or fuse_proj))
         fused = None
         if gather_proj:
             # Proj.weight is 96 % of G's gradient bytes (268 MB fp32) and the last tensor backward produces.  It is a
@@ -528,13 +529,12 @@ class Trainer:
             # (z [B,nz] and dL/da0 [B,h0*w0*C], 8.4 MB per rank in bf16) and forms the GLOBAL-batch gradient locally:
             # same sum, 3.5x less xGMI traffic, and the 268 MB never cross a link.
             geng = self._mb[0]["geng"]
-            if self._gather is None or self._gather[0].numel() != self.world * geng.zT.numel():
-                self._gather = (geng.zT.new_empty(self.world * geng.zT.numel()),
-                                geng.dp[0].new_empty(self.world * geng.dp[0].numel()))
+            dp0, zT, nloc = self._proj_operands(geng, B)
+            if self._gather is None or self._gather[0].numel() != self.world * zT.numel():
+                self._gather = (zT.new_empty(self.world * zT.numel()), dp0.new_empty(self.world * dp0.numel()))
             zg, dg = self._gather
-            zT, dp0 = geng.zT, geng.dp[0]
             self._coll(lambda: (D_.all_gather_into(zg, zT), D_.all_gather_into(dg, dp0)))
-            nbg = self.world * B
+            nbg = self.world * nloc
             if fuse_gathered:
                 # ... and the global-batch gradient is not even written: the optimizer forms it tile by tile in the
                 # epilogue of the gradient GEMM (dg_adam_proj_fused -> MFMA path for nb > 64)
@@ -553,8 +553,9 @@ class Trainer:
                 geng = self._mb[0]["geng"]
                 c = geng.cfg
                 Np = c.h0 * c.w0 * c.ch[3]
-                fused = (geng.dp[0], geng.zT, L.dtype_code(self.dtype), B, Np, c.nz, 1.0 / math.sqrt(Np))
-                self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, geng.dp[0], geng.zT, B, False)
+                dp0, zT, nloc = self._proj_operands(geng, B)
+                fused = (dp0, zT, L.dtype_code(self.dtype), nloc, Np, c.nz, 1.0 / math.sqrt(Np))
+                self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, dp0, zT, nloc, False)
         # Adam + EMA fused (:312, :316); single-GPU bf16 runs also fold Proj.weight's gradient GEMM into the kernel
         ok = self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
                                shadow_dtype=self.dtype, fused_proj=fused)
@@ -567,7 +568,25 @@ class Trainer:
         self._mb = []
         return scal
 
-    def _path_length(self, Gst, inj, B_pl, scal):
+    def _proj_operands(self, geng, B):
+        """(gradient rows, input rows, count) whose product is Proj.weight's gradient: the adversarial pair and, with
+        the path-length term on, its two pairs (z_pl, tangent chain) and (v, first-order chain) - the three GEMMs share
+        the output, so they are ONE GEMM over the concatenated rows.  Static buffers (graph replay, all-gather)."""
+        if "pl" not in self.criterion:
+            return geng.dp[0], geng.zT, B
+        gp = self._geng_pl
+        Bp = gp.ws_B
+        n = B + 2 * Bp
+        if getattr(self, "_cat", None) is None or self._cat[0].numel() != n * geng.dp[0].numel() // B:
+            self._cat = (geng.dp[0].new_empty(n * geng.dp[0].numel() // B), geng.zT.new_empty(n * geng.zT.numel() // B))
+        d, z = self._cat
+        nd, nzv = geng.dp[0].numel(), geng.zT.numel()
+        d[:nd].copy_(geng.dp[0]); z[:nzv].copy_(geng.zT)
+        d[nd:nd + gp.dp2[0].numel()].copy_(gp.dp2[0]); z[nzv:nzv + gp.zT.numel()].copy_(gp.zT)
+        d[nd + gp.dp2[0].numel():].copy_(gp.dp[0]); z[nzv + gp.zT.numel():].copy_(gp.vT)
+        return d, z, n
+
+    def _path_length(self, Gst, inj, B_pl, scal, proj_terms=True):
         """Path-length regularisation (reference :268-306) for one micro-batch: accumulates
         d[w_pl * mean_b (|J_b^T y_b| - a)^2]/d theta into Gst.grad without autograd.  With v = d penalty / d(J^T y) held
         fixed, <v, J^T y> = <J v, y'(h) y>, so the parameter gradient is a forward-over-reverse pass: the reverse
@@ -598,7 +617,7 @@ class Trainer:
         L.check(lib.dg_pl_penalty(L.ptr(dz), B_pl, nz, w, L.ptr(self.pl_ema), L.ptr(v), L.ptr(scal) + 20, sp),
                 "dg_pl_penalty")                                # :294-303
         geng.tangent_forward(Gst, v)
-        geng.backward_second(Gst, yv)                           # the `loss_G.backward()` share of the penalty, :309
+        geng.backward_second(Gst, yv, proj_terms)               # the `loss_G.backward()` share of the penalty, :309
 
     def _scalar_keys(self):
         keys = ["loss/D/output/real", "loss/D/output/fake", "loss/D/adversarial"]

@@ -161,14 +161,11 @@ int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, f
 int dg_mean_acc(const float* x, int n, float* acc, void* stream);
 
 /* ---- path-length regularisation  trainers/dcgan_amp.py:268-306 (the parts that are not convolutions) ------------
- * The penalty needs d/dtheta of |d(sum x y)/dz|: a forward-over-reverse pass.  dg_proj_bwd_z finishes the reverse
- * pass (dz [B][K] fp32 += scale * dp0 [B][Np] W [Np][K]; dp0 = gradient w.r.t. Proj's pre-activation, W = the weight
- * shadow; dz zeroed by the caller).  dg_pl_penalty: lengths |dz_b|, the running baseline pl_ema (device scalar,
+ * The penalty needs d/dtheta of |d(sum x y)/dz|: a forward-over-reverse pass built from dg_conv / dg_wgrad (the
+ * reverse pass ends with dz^T = W^T dp0^T, a dg_wgrad of wmode 2) plus these two.  dg_pl_penalty: lengths |dz_b|, the running baseline pl_ema (device scalar,
  * updated: lerp(.., 0.01) :297), the penalty (:300) and v [B][K] = w * d penalty / d dz; acc[0] += baseline,
  * acc[1] += penalty.  dg_head_post_bwd2: tangent of dg_head_post_bwd along the head tangent `thead` [B,1+k,H,W] (the
  * Hessian of tanh / Gumbel straight-through maskout, models/dusty.py:77-91,107-127), same outputs as dg_head_post_bwd. */
-int dg_proj_bwd_z(const void* dp0, int dp_dtype, const void* w, int w_dtype, int B, long Np, int K, float scale,
-                  float* dz, void* stream);
 int dg_pl_penalty(const float* dz, int B, int K, float w, float* pl_ema, float* v, float* acc, void* stream);
 int dg_head_post_bwd2(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
                       const float* ddepth, const float* thead, int arch, float tau, float drop_const, int B, long HW,

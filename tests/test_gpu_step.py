@@ -322,6 +322,12 @@ def test_path_length_regulariser_vs_oracle():
     for k, v in ex["grad_G"].items():
         if v.numel() >= 1024:  # (a 2-element head-bias gradient is all bf16 slope-flip noise)
             assert _cos(gG[k], v) > 0.9, (k, _cos(gG[k], v))
+    # full-width latent grid (64x1024 -> Proj has 32 768 rows): d(sum x y)/dz goes through the split-K form of grad_z
+    _, _, resw = run_both("dusty1", (64, 1024), 64, 16, 128, 2, amp=False, steps=1, pl=2.0)
+    sc_ref, ex, synth, gD, gG, scal = resw[0]
+    assert abs(scal[6] - sc_ref["loss/G/path_length"]) <= 1e-3 * max(1.0, abs(sc_ref["loss/G/path_length"]))
+    for k, v in ex["grad_G"].items():
+        assert rel_l2(gG[k], v) < 2e-2 and _cos(gG[k], v) > 0.9999, (k, rel_l2(gG[k], v))
     # checkpoint carries the baseline; unknown weight keys still raise
     assert float(tr.state(1)["pl_ema"]) == float(tr.pl_ema)
 
