@@ -121,14 +121,14 @@ def test_two_ranks_segmented_graph_matches_eager():
     assert torch.equal(res[True][0]["G"], res[True][1]["G"])
 
 
-def fused_worker(rank, world, init_file, out_dir, fuse):
+def fused_worker(rank, world, init_file, out_dir, fuse, pl=0.0):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH"] = "0"
     os.environ["DUSTY_GAN_FUSE_PROJ"] = "1" if fuse else "0"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     torch.manual_seed(400)
     # nz = 128 and Np = 2 * 4 * 16 = 128: the smallest Proj the MFMA epilogue takes; global batch 2 x 40 = 80 > 64
-    tr = make_trainer("dusty1", True, (32, 64), 128, 4, 16, 40, amp=True)
+    tr = make_trainer("dusty1", True, (32, 64), 128, 4, 16, 40, amp=True, pl=pl)
     scal = [dict(tr.step(i).items()) for i in range(3)]
     used = tr.optim_G.regen_grad is not None  # set only while Proj.weight's gradient lives inside the optimizer kernel
     torch.save({"G": tr.G.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "V": tr.G.store.v.cpu(), "scal": scal,
@@ -137,14 +137,16 @@ def fused_worker(rank, world, init_file, out_dir, fuse):
     dist.destroy_process_group()
 
 
-def test_two_ranks_fused_proj_optimizer_matches_unfused():
+@pytest.mark.parametrize("pl", [0.0, 2.0])
+def test_two_ranks_fused_proj_optimizer_matches_unfused(pl):
     """world > 1, bf16: Proj.weight's global-batch gradient is formed from the all-gathered operands inside the optimizer
     (epilogue of the MFMA gradient GEMM) instead of being written and re-read; 3 iterations must train like the unfused
     sequence (same bf16 operands, same fp32 accumulation -> agreement far below bf16 resolution)."""
     res = {}
     for fuse in (True, False):
         with tempfile.TemporaryDirectory() as td:
-            mp.spawn(fused_worker, args=(2, os.path.join(td, "init"), td, fuse), nprocs=2, join=True)
+            # pl > 0: the path-length block appends its two operand pairs to what is all-gathered (3 x 40 rows per rank)
+            mp.spawn(fused_worker, args=(2, os.path.join(td, "init"), td, fuse, pl), nprocs=2, join=True)
             res[fuse] = [torch.load(os.path.join(td, f"f{int(fuse)}_r{r}.pt")) for r in range(2)]
     assert all(o["used"] for o in res[True]) and not any(o["used"] for o in res[False])
     for r in range(2):
