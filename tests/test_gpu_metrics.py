@@ -25,11 +25,12 @@ def lidar_like_clouds(B, n, seed, drop=0.15):
     return pts.astype(np.float32)
 
 
-@pytest.mark.parametrize("n,m", [(70, 20), (512, 64), (1000, 128), (4096, 512), (8192, 100)])
+@pytest.mark.parametrize("n,m", [(70, 20), (512, 64), (1000, 128), (4096, 512), (8192, 100),
+                                 (65536, 512)])  # last: a full 64x1024 scan to the validation size
 def test_fps_matches_oracle_indices(n, m):
     """index-exact furthest point sampling incl. the reference launcher's tie order and the origin-skip rule"""
     from dusty_gan_amd.utils.sampling import downsample_point_clouds, furthest_point_sampling
-    B = 3
+    B = 3 if n < 60000 else 1
     pts = lidar_like_clouds(B, n, seed=n + m)
     idx = furthest_point_sampling(torch.from_numpy(pts).to(DEV), m).cpu().numpy()
     sub = downsample_point_clouds(torch.from_numpy(pts).to(DEV), m).cpu().numpy()
