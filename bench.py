@@ -2,7 +2,8 @@
 """Benchmark of the dusty-gan training hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher - python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+     ... - or bare: with no WORLD_SIZE in the environment bench.py starts the N ranks itself and relays rank 0's line)
 
 One "step" = one `Trainer.step` (D update + G update + EMA, reference trainers/dcgan_amp.py:162-325) on synthetic
 64x1024 range images resident in HBM, 32 images per GPU (weak scaling).  Prints ONE JSON line on rank 0:
@@ -29,8 +30,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--arch", choices=["none", "dusty1", "dusty2"], default=None,
                     help="default: BASELINE configs[1] (dcgan_eqlr baseline) at N=1, configs[3] (dusty2) at N>1")
@@ -140,28 +141,71 @@ def cpu_baseline(args, arch):
                       f"fp32, stock torch CPU ops, {sum(times[1:]):.1f} s of CPU work"}
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, sorted): identifies the code a PMC collection was made on.  (The
+    GPU box has no .git, so a commit id cannot be checked there; the sources can.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "dusty_gan_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
-    collected from inside the process; profiles/README.md says how the file was made).  None if not measured."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    collected from inside the process; profiles/README.md says how the file is made: scripts/pmc_summary.py --traffic).
+    The file records the hash of the kernel sources it was collected on; a number from other sources is stale and is
+    reported as null, never copied."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
-            return round(json.load(f)[kernel]["bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+            d = json.load(f)
+        if d.get("kernel_source_sha") != kernel_source_sha():
+            return None, f"stale: collected on sources {d.get('kernel_source_sha')}, running {kernel_source_sha()}"
+        return round(d["kernels"][kernel]["bytes_per_launch"]), f"profiles/r02_pmc_traffic.json @ {d.get('git_sha', '?')}"
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"not collected ({type(e).__name__})"
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves (the
+    reference's train.py:185-186 does mp.spawn(main_worker, nprocs=ngpus)) and relay rank 0's JSON line.  Runs before
+    anything touches the GPU; the children are ordinary `torch.distributed.run` workers of this same file."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank per GPU over RCCL ("nccl" on ROCm).  DUSTY_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on
         # a single-GPU box (ranks share the device, buffers travel through the host) - a functional check, not a number.
         backend = os.environ.get("DUSTY_BENCH_BACKEND", "nccl")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            raise SystemExit(f"bench.py --gpus {world}: this node has {ndev} GPU(s); RCCL needs one device per rank "
+                             "(DUSTY_BENCH_BACKEND=gloo runs the ranks on shared devices as a functional check)")
+        local_rank = local_rank % max(ndev, 1)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -183,10 +227,15 @@ def main():
     if last is not None:
         _ = list(last.values())
     sync()
+    # per-step device times: one HIP event after every step on the launch stream (the replayed graph / the eager
+    # launches of a step run on torch's current stream, so consecutive events bracket exactly one step)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     prev = None
     for i in range(args.steps):
         cur = tr.step(i)
+        marks[i + 1].record()
         if prev is not None:
             _ = list(prev.values())  # read the previous step's scalars back while this step runs (one-step delay)
         prev = cur
@@ -200,6 +249,8 @@ def main():
     ms = 1e3 * dt / args.steps
     steps_s = args.steps / dt
     imgs = steps_s * args.batch * world
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    q = lambda f: round(per[min(len(per) - 1, int(f * len(per)))], 4)
 
     out = {"metric": "G+D train images/sec on 64x1024 LiDAR (steps/sec beside it)", "value": round(imgs, 2),
            "unit": "images/s", "steps_per_sec": round(steps_s, 3), "n_gpus": world, "steps": args.steps,
@@ -210,7 +261,16 @@ def main():
                                   f"R1 {'on' if args.gp > 0 else 'off'}, {'path-length reg on, ' if args.pl > 0 else ''}DiffAugment {'off' if args.no_augment else 'on'}, "
                                   "Adam+EMA, random-init weights",
                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+           "step_ms_device": {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90), "min": round(per[0], 4),
+                              "max": round(per[-1], 4), "note": "HIP events between consecutive steps, rank 0"},
+           "launch_mode": tr.launch_mode(),
            "scalars_last_step": {k: round(v, 5) for k, v in scal.items()}}
+    if world > 1:
+        out["distributed"] = {"backend": backend, "world_size": dist.get_world_size(),
+                              "devices_visible": torch.cuda.device_count()}
+        comm = tr.comm_profile(steps=3)
+        if comm:
+            out["distributed"]["exposed_ms_per_step"] = comm
     fl, f_g, f_d = flops_per_sample(args.shape, arch, args.gp)
     out["step_flops_fraction_of_mfma_peak"] = round(fl * args.batch * steps_s / 1e12 / PEAK_TFLOPS[args.precision], 4)
 
@@ -220,10 +280,12 @@ def main():
             name = max(fam, key=lambda k: fam[k]["ms"])
             f = fam[name]
             tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            traffic, src = pmc_traffic(name)
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 2),
                                "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_TFLOPS[args.precision], 4), "traffic": pmc_traffic(name),
-                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                               "frac": round(tf / PEAK_TFLOPS[args.precision], 4), "traffic": traffic,
+                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic_source": src, "kernel_source_sha": kernel_source_sha(),
                                "algorithmic_bytes_per_launch": round(f["bytes"] / f["n"]),
                                "launches": f["n"], "avg_launch_us": round(1e3 * f["ms"] / f["n"], 2)}
             out["kernel_families"] = {
@@ -233,7 +295,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, arch)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

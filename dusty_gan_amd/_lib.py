@@ -53,16 +53,24 @@ class DgWgrad(C.Structure):
     ]
 
 
+class DgConvPlan(C.Structure):
+    _fields_ = [("family", C.c_int), ("bm", C.c_int), ("bn", C.c_int), ("tiles", C.c_int), ("workgroups", C.c_int),
+                ("tiles_per_wg", C.c_int)]
+
+
 _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64
 
 # name -> argtypes (all return int except dg_version); mirrors include/dusty_gan_hip.h one to one
 PROTOTYPES = {
     "dg_conv": [C.POINTER(DgConv), _I, _P],
+    "dg_conv_ex": [C.POINTER(DgConv), _I, _I, _P],
+    "dg_conv_plan": [C.POINTER(DgConv), _I, _I, C.POINTER(DgConvPlan)],
     "dg_conv_mfma_supported": [C.POINTER(DgConv)],
     "dg_conv_kernel_choice": [C.POINTER(DgConv)],
     "dg_wgrad": [C.POINTER(DgWgrad), _I, _I, _P],
     "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_choice": [C.POINTER(DgWgrad)],
+    "dg_wgrad_kernel_variant": [C.POINTER(DgWgrad), _I],
     "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],

@@ -4,8 +4,8 @@
 #include <stdlib.h>
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
-int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream);
-int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream);
+int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
+int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
 int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, hipStream_t stream);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
@@ -20,23 +20,38 @@ extern "C" {
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
 // force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
-//        4 large-tile persistent MFMA kernel or error
-int dg_conv(const DgConv* p, int force, void* stream) {
+//        4 large-tile persistent MFMA kernel or error.  plan != NULL: describe the launch instead of making it.
+static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
   if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
   if (p->mode != MODE_GEMM && (p->Hc < 2 || p->Wc < 2)) return DG_EINVAL;
   if (p->epi == EPI_MASK && !p->aux) return DG_EINVAL;
   if (p->bias && p->bias_mod <= 0) return DG_EINVAL;
   if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
-  if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s) : DG_EUNSUPPORTED;
-  if (force == 4) return mfma_ok ? dg_conv_mfma_big_launch(p, s) : DG_EUNSUPPORTED;
-  if (force == 3) return thin_ok ? dg_conv_thin_launch(p, s) : DG_EUNSUPPORTED;
-  if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s);
-  if (force == 0 && thin_ok) return dg_conv_thin_launch(p, s);
+  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; }
+  if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (force == 4) return mfma_ok ? dg_conv_mfma_big_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
+  if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
+  if ((force == 3 || force == 0) && thin_ok) {
+    if (plan) { plan->family = 3; return DG_OK; }
+    return dg_conv_thin_launch(p, s);
+  }
+  if (plan) { plan->family = 1; return DG_OK; }
   return dg_conv_direct_launch(p, s);
+}
+
+int dg_conv(const DgConv* p, int force, void* stream) { return conv_dispatch(p, force, 0, (hipStream_t)stream, nullptr); }
+
+int dg_conv_ex(const DgConv* p, int force, int wg_cap, void* stream) {
+  return conv_dispatch(p, force, wg_cap, (hipStream_t)stream, nullptr);
+}
+
+int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan) {
+  if (!plan) return DG_EINVAL;
+  return conv_dispatch(p, force, wg_cap, nullptr, plan);
 }
 
 int dg_conv_kernel_choice(const DgConv* p) {  // 2 = MFMA, 3 = thin, 1 = direct (what force == 0 would pick)
@@ -51,12 +66,10 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
   const bool thin_ok = dg_wgrad_thin_supported(p);
-  // bf16 Down / Up layers: LDS-DMA ring version (wgrad_mfma_dma.hip); DG_WGRAD_DMA=0 keeps the register-staged kernel
-  static int use_dma = -1;
-  if (use_dma < 0) { const char* e = getenv("DG_WGRAD_DMA"); use_dma = e ? atoi(e) : 1; }
-  if (use_dma && (force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
+  // bf16 Down / Up layers: LDS-DMA ring version (wgrad_mfma_dma.hip); force == 6 asks for the register-staged kernel
+  if ((force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
     return dg_wgrad_mfma_dma_launch(p, accumulate, s);
-  if (force == 2) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
+  if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
   if (!accumulate) {
     const long n = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
@@ -65,6 +78,18 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   if (force == 3) return thin_ok ? dg_wgrad_thin_launch(p, s) : DG_EUNSUPPORTED;
   if (force == 0 && thin_ok) return dg_wgrad_thin_launch(p, s);
   return dg_wgrad_direct_launch(p, s);
+}
+
+// 5 = MFMA on the LDS-DMA ring (wgrad_mfma_dma.hip), 2 = register-staged MFMA, 3 = thin, 1 = direct: what `force` launches
+int dg_wgrad_kernel_variant(const DgWgrad* p, int force) {
+  const bool mfma_ok = dg_wgrad_mfma_supported(p);
+  if ((force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p)) return 5;
+  if (force == 2) return mfma_ok ? 2 : 0;
+  if (force == 0 && mfma_ok) return 2;
+  const bool thin_ok = dg_wgrad_thin_supported(p);
+  if (force == 3) return thin_ok ? 3 : 0;
+  if (force == 0 && thin_ok) return 3;
+  return 1;
 }
 
 int dg_wgrad_kernel_choice(const DgWgrad* p) {

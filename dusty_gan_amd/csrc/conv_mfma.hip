@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n,
 }
 
 template <typename T, int BM, int BN>
-static int launch_cfg(const ConvP* p, hipStream_t stream) {
+static int launch_cfg(const ConvP* p, hipStream_t stream, DgConvPlan* plan) {
   const int tiles_n = (p->N + BN - 1) / BN;
   int tiles_x = 1;
   long tiles_m;
@@ -334,6 +334,11 @@ static int launch_cfg(const ConvP* p, hipStream_t stream) {
   else tiles_m = (p->B + BM - 1) / BM;
   const long nwg = tiles_m * tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffffL) return DG_EINVAL;
+  if (plan) {
+    plan->family = 2; plan->bm = BM; plan->bn = BN; plan->tiles = (int)nwg; plan->workgroups = (int)nwg;
+    plan->tiles_per_wg = 1;
+    return DG_OK;
+  }
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
   static int var = -1;  // DG_CONV_VAR: 0 = 64-byte stages x 3, 1 = 64 x 4, 2 = 128 x 2
@@ -359,37 +364,56 @@ extern "C" int dg_conv_mfma_supported(const ConvP* p) {
   return 1;
 }
 
-int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream, int auto_rule);
-int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule);
+int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream, int auto_rule, int wg_cap, DgConvPlan* plan);
+int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule, int wg_cap, DgConvPlan* plan);
 
-int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream) {
+int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan);
+
+static int use_pp() {  // DG_CONV_PP=0: keep the lock-step persistent kernel for bf16 too (A/B runs of scripts/bench_conv.py)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DG_CONV_PP"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+// plan != NULL: fill it with what would be launched and launch nothing
+int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
   // layers that tile into 256-row M tiles go to the persistent large-tile kernel (conv_mfma_persist_impl.h);
   // DG_CONV_PERSIST=0 keeps everything on the one-tile-per-workgroup kernel below, =2 uses large tiles wherever
   // the geometry allows (A/B runs)
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("DG_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
+  if (persist && p->in_dtype == DG_BF16 && use_pp()) {
+    // bf16 layers with >= 256 tiles of 256 pixels: the ping-pong persistent kernel (conv_mfma_pp.hip)
+    const int rc = dg_conv_mfma_pp_launch(p, stream, persist == 1 ? 256 : 1, wg_cap, plan);
+    if (rc != DG_EUNSUPPORTED) return rc;
+  }
   if (persist) {
-    const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, persist == 1)
-                                          : dg_conv_mfma_persist_launch_f32(p, stream, persist == 1);
+    const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, persist == 1, wg_cap, plan)
+                                          : dg_conv_mfma_persist_launch_f32(p, stream, persist == 1, wg_cap, plan);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
   const bool m128 = p->mode == MODE_GEMM ? false : (p->Wc % 128 == 0);
   const bool n128 = p->N % 128 == 0;
   if (p->in_dtype == DG_BF16) {
-    if (m128 && n128) return launch_cfg<bf16, 128, 128>(p, stream);
-    if (m128) return launch_cfg<bf16, 128, 64>(p, stream);
-    if (n128) return launch_cfg<bf16, 64, 128>(p, stream);
-    return launch_cfg<bf16, 64, 64>(p, stream);
+    if (m128 && n128) return launch_cfg<bf16, 128, 128>(p, stream, plan);
+    if (m128) return launch_cfg<bf16, 128, 64>(p, stream, plan);
+    if (n128) return launch_cfg<bf16, 64, 128>(p, stream, plan);
+    return launch_cfg<bf16, 64, 64>(p, stream, plan);
   }
-  if (m128 && n128) return launch_cfg<float, 128, 128>(p, stream);
-  if (m128) return launch_cfg<float, 128, 64>(p, stream);
-  if (n128) return launch_cfg<float, 64, 128>(p, stream);
-  return launch_cfg<float, 64, 64>(p, stream);
+  if (m128 && n128) return launch_cfg<float, 128, 128>(p, stream, plan);
+  if (m128) return launch_cfg<float, 128, 64>(p, stream, plan);
+  if (n128) return launch_cfg<float, 64, 128>(p, stream, plan);
+  return launch_cfg<float, 64, 64>(p, stream, plan);
 }
 
 // large-tile persistent kernel wherever the geometry allows, else DG_EUNSUPPORTED (dg_conv force == 4; parity tests)
-int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream) {
+int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0) : dg_conv_mfma_persist_launch_f32(p, stream, 0);
+  if (p->in_dtype == DG_BF16 && use_pp()) {
+    const int rc = dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan);
+    if (rc != DG_EUNSUPPORTED) return rc;
+  }
+  return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0, wg_cap, plan)
+                                : dg_conv_mfma_persist_launch_f32(p, stream, 0, wg_cap, plan);
 }

@@ -1,6 +1,6 @@
 // fp32 (exact, v_mfma_f32_32x32x2_f32) instantiations of the persistent implicit-GEMM conv (conv_mfma_persist_impl.h)
 #include "conv_mfma_persist_impl.h"
 
-int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule) {
-  return persist::launch_dtype<float>(p, stream, auto_rule != 0);
+int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule, int wg_cap, DgConvPlan* plan) {
+  return persist::launch_dtype<float>(p, stream, auto_rule != 0, wg_cap, plan);
 }

@@ -477,7 +477,7 @@ bool make_geo(const ConvP* p, Geo& g) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int SB, int NS, int MODE>
-int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
+int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   Geo g = g0;
   static int resident = 0;                     // workgroups the device holds at once
   if (!resident) {
@@ -488,13 +488,19 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream) {
                                                                64 * WM * WN, 0));
     if (occ < 1) occ = 1;
     resident = occ * cus;
-    const char* e = getenv("DG_CONV_WGS");
-    if (e && atoi(e) > 0) resident = atoi(e);
   }
-  static int dbg = -1;
+  static int dbg = -1;  // DG_CONV_DBG: ablation builds of scripts/bench_conv.py (1 no DMA, 2 no MFMA, 4 no epilogue)
   if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
   g.dbg = dbg;
-  const int G = g.ntiles < resident ? g.ntiles : resident;
+  // wg_cap (dg_conv_ex): fewer workgroups than the device holds, i.e. longer tile chunks per workgroup (parity tests
+  // of the cross-tile ring on small problems)
+  const int cap = (wg_cap > 0 && wg_cap < resident) ? wg_cap : resident;
+  const int G = g.ntiles < cap ? g.ntiles : cap;
+  if (plan) {
+    plan->family = 4; plan->bm = BM; plan->bn = BN; plan->tiles = g.ntiles; plan->workgroups = G;
+    plan->tiles_per_wg = (g.ntiles + G - 1) / G;
+    return DG_OK;
+  }
   conv_kernel<T, BM, BN, WM, WN, SB, NS, MODE><<<(unsigned)G, 64 * WM * WN, 0, stream>>>(*p, g);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
@@ -525,7 +531,7 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
 }
 
 template <typename T>
-int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
+int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule, int wg_cap, DgConvPlan* plan) {
   Geo g;
   const int which = pick(p, g, auto_rule);
   if (which == 2) {
@@ -535,24 +541,24 @@ int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule) {
     if (sb128 < 0) { const char* e = getenv("DG_CONV_SB128"); sb128 = e ? atoi(e) : 1; }
     if constexpr (sizeof(T) == 2) {
       if (sb128 && p->K % 64 == 0)
-        return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream)
-                                  : launch<T, 256, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream);
+        return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream, wg_cap, plan)
+                                  : launch<T, 256, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream, wg_cap, plan);
     }
-    return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 64, 4, MODE_S2>(p, g, stream)
-                              : launch<T, 256, 128, 4, 2, 64, 4, MODE_UP>(p, g, stream);
+    return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 64, 4, MODE_S2>(p, g, stream, wg_cap, plan)
+                              : launch<T, 256, 128, 4, 2, 64, 4, MODE_UP>(p, g, stream, wg_cap, plan);
   }
   if (which == 4) {
     if constexpr (sizeof(T) == 2) {
       if (p->K % 64 == 0)
-        return p->mode == MODE_S2 ? launch<T, 128, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream)
-                                  : launch<T, 128, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream);
+        return p->mode == MODE_S2 ? launch<T, 128, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream, wg_cap, plan)
+                                  : launch<T, 128, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream, wg_cap, plan);
     }
   }
   if (which == 3) {
     if constexpr (sizeof(T) == 2) {
       if (p->K % 64 == 0)
-        return p->mode == MODE_S2 ? launch<T, 256, 64, 8, 1, 128, 3, MODE_S2>(p, g, stream)
-                                  : launch<T, 256, 64, 8, 1, 128, 3, MODE_UP>(p, g, stream);
+        return p->mode == MODE_S2 ? launch<T, 256, 64, 8, 1, 128, 3, MODE_S2>(p, g, stream, wg_cap, plan)
+                                  : launch<T, 256, 64, 8, 1, 128, 3, MODE_UP>(p, g, stream, wg_cap, plan);
     }
   }
   return DG_EUNSUPPORTED;

@@ -1,0 +1,430 @@
+// "Ping-pong" persistent implicit-GEMM conv on the matrix cores (gfx950, bf16): the kernel behind the fat layers of the
+// benchmark step.  Same passes as conv_mfma_persist_impl.h (Down forward / R1 tangent, Up forward, both backward-data
+// passes; reference: models/gans/dcgan_eqlr.py:19-26,75-82 with Pad / EqualLR / FusedLeakyReLU of models/ops/common.py
+// fused), same tile order, same LDS-DMA issue side - a different compute side.
+//
+// Why: ablation builds of the previous kernel (scripts/bench_conv.py, DG_CONV_DBG) showed its time to be the SUM of its
+// parts - skeleton (LDS fragment reads + barriers) 41 %, MFMA 22 %, DMA issue 19 %, epilogue 18 % - i.e. nothing
+// overlapped: its 8 waves run in lock step (one barrier per K step), so both waves of a SIMD read fragments, issue DMA
+// and feed the matrix pipe at the same moments.  Here the two waves of every SIMD are in OPPOSITE phases
+// (cdna_hip_programming.md §5 "8-phase" template; MI355X_MICROARCH.md "Two waves per SIMD" item 9):
+//
+//     wave group A (waves 0-3):  LOAD(t) | MFMA(t) | LOAD(t+1) | MFMA(t+1) | ...
+//     wave group B (waves 4-7):          | LOAD(t) | MFMA(t)   | LOAD(t+1) | ...        ( | = workgroup barrier )
+//
+//   LOAD(t): (epilogue of the finished tile, if any) ; all 16 fragment reads of K step t (ds_read_b128, 64 VGPRs) ;
+//            this wave's 6 LDS-DMA pieces of K step t+2 ; s_waitcnt {own pieces of t+1 landed, fragments in}
+//   MFMA(t): 32 x v_mfma_f32_16x16x32_bf16 straight from registers - no LDS, no waits.
+// Both groups run the same program; group B starts one barrier late.  Ring of 3 stages x 48 KB: stage t is read by A in
+// its LOAD(t) and by B one interval later; K step t+2 goes into the stage K step t-1 used, whose last reads retired (each
+// LOAD ends with lgkmcnt(0)) before the barrier in front of the interval that refills it.
+//
+// Accumulators are TRANSPOSED (weights as the A operand, pixels as B): a lane then holds 4 consecutive channels of one
+// pixel per 16 x 16 block, and with the weight rows of block j permuted (row 16g+4j+r feeds lane group g, register r)
+// 16 CONSECUTIVE channels of its pixel - the epilogue stores 16-byte pieces of the NHWC rows straight from registers:
+// no LDS transpose, no barrier, and it runs while the other group's MFMAs keep the matrix pipe busy.
+#include "conv_mfma_persist_impl.h"
+
+namespace pp {
+
+using persist::Geo;
+using persist::Tile;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define PP_WAIT(vm) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(vm) : "memory")
+
+template <int CTRL>
+__device__ __forceinline__ float row_add(float v) {  // v + (v of the lane CTRL selects inside the 16-lane row)
+  const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, s);
+}
+
+// MASK: the backward / tangent flavour (EPI_MASK: multiply by the saved activation's slope, optional bias-gradient sums,
+// no bias); otherwise EPI_LRELU / EPI_LINEAR with bias.  Two instantiations keep either epilogue's registers out of the
+// other (both in one kernel spilled past 256 VGPRs, and a scratch reload next to LDS-DMA costs a vmcnt(0) drain).
+template <int BN, int MODE, bool MASK>
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
+  constexpr int BM = 256, NWV = 8, WN = 2;
+  constexpr int SB = 128;                      // bytes of K per tile row and stage (64 bf16 channels)
+  constexpr int WC = BN / WN;                  // channels per wave
+  constexpr int TM = 4, TN = WC / 16;          // 16 x 16 blocks per wave: pixels x channels
+  constexpr int CPL = 4 * TN;                  // consecutive channels one lane ends up with
+  constexpr int STAGE = (BM + BN) * SB;
+  constexpr int NS = 3;
+  constexpr int IA = BM / 8 / NWV, IB = BN / 8 / NWV, IPT = IA + IB;
+  constexpr int NST = TM * CPL * 2 / 16;       // 16-byte stores per lane per tile
+  constexpr int NDB = 512;
+  constexpr int nW = MODE == MODE_S2 ? 4 : 2;
+  static_assert(IB >= 1 && NS * STAGE + 3 * NDB * 4 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + 3 * NDB * 4];
+
+  // ---- this workgroup's chunk of the tile order (XCD-aware, as the lock-step kernel: conv_mfma_persist_impl.h)
+  const int G = gridDim.x;
+  const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7;
+  const int gi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tq = g.ntiles / G, tr = g.ntiles % G;
+  const int t0 = gi * tq + (gi < tr ? gi : tr);
+  const int tcount = tq + (gi < tr ? 1 : 0);
+  if (tcount == 0) return;
+
+  const int tid = threadIdx.x;
+  const int KC = p.K / 64;
+  const int Ws = MODE == MODE_S2 ? 2 * p.Wc : p.Wc, cmul = MODE == MODE_S2 ? 2 : 1;
+  const int Wo = MODE == MODE_S2 ? p.Wc : 2 * p.Wc;
+  const int rows = MODE == MODE_S2 ? p.Hc : 2 * p.Hc;
+  const int tiles_n = g.tiles_n, tiles_x = g.tiles_x;
+
+  Tile first;
+  {
+    int mt = t0 / tiles_n;
+    first.nt = t0 % tiles_n;
+    first.px = 0;
+    first.xt = mt % tiles_x; mt /= tiles_x;
+    if (MODE == MODE_UP) { first.px = mt & 1; mt >>= 1; }
+    first.Y = mt % rows; first.bt = mt / rows;
+    first.nt = __builtin_amdgcn_readfirstlane(first.nt); first.xt = __builtin_amdgcn_readfirstlane(first.xt);
+    first.px = __builtin_amdgcn_readfirstlane(first.px); first.Y = __builtin_amdgcn_readfirstlane(first.Y);
+    first.bt = __builtin_amdgcn_readfirstlane(first.bt);
+  }
+
+  const bf16* in = (const bf16*)p.in;
+  const bf16* w = (const bf16*)p.w;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lrow = lane >> 3, pos = lane & 7;
+  auto swzA = [](int row) { return (row >> 1) & 7; };
+  auto swzB = [](int row) { return ((row >> 1) & 1) | (((row / CPL) & 3) << 1); };
+
+  // ---- issue side (K steps in tile order, two ahead of the compute side)
+  Tile ti = first;
+  int i_left = tcount;
+  unsigned long long hl = 0, hl_row;
+  int h_left = 0;
+  int nh_row = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl_row);
+  int it_j = 0, it_kc = 0;
+  unsigned voffA[IA], voffB[IB];
+  int colA[IA];
+  unsigned sampA[IA];
+  const char* sA = nullptr;
+  const char* sB = nullptr;
+#pragma unroll
+  for (int u = 0; u < IA; ++u) {
+    const int row = (wave + NWV * u) * 8 + lrow;
+    colA[u] = row & (g.SW - 1);
+    sampA[u] = (unsigned)((row >> g.lsw) * (int)p.in_sb * 2 + (pos ^ swzA(row)) * 16);
+  }
+#pragma unroll
+  for (int u = 0; u < IB; ++u) {
+    const int row = (wave + NWV * u) * 8 + lrow;
+    voffB[u] = (unsigned)(row * (int)p.w_sn * 2 + (pos ^ swzB(row)) * 16);
+  }
+  auto set_wtap = [&]() {
+    const int it_r = (int)(hl & 1023) >> 2, it_ky = (int)hl & 3;
+    int coff, kx;
+    if (MODE == MODE_S2) { coff = it_j - 1; kx = it_j; }
+    else if (ti.px == 0) { coff = it_j == 0 ? 0 : -1; kx = it_j == 0 ? 1 : 3; }
+    else { coff = it_j == 0 ? 1 : 0; kx = it_j == 0 ? 0 : 2; }
+    const int wt = it_ky * 4 + kx;
+    sB = (const char*)(w + (long)wt * p.w_st + (long)(ti.nt * BN) * p.w_sn);
+    sA = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb + (long)it_r * Ws * p.in_sp);
+#pragma unroll
+    for (int u = 0; u < IA; ++u) {
+      int c = cmul * (ti.xt * BM + colA[u]) + coff;
+      if (c < 0) c += Ws; else if (c >= Ws) c -= Ws;
+      voffA[u] = (unsigned)(c * (int)p.in_sp * 2) + sampA[u];
+    }
+  };
+  auto start_tile = [&]() { hl = hl_row; h_left = nh_row; it_j = 0; it_kc = 0; set_wtap(); };
+  start_tile();
+  auto advance = [&]() {
+    if (++it_kc < KC) return;
+    it_kc = 0;
+    if (++it_j < nW) { set_wtap(); return; }
+    it_j = 0;
+    hl >>= 10;
+    if (--h_left > 0) { set_wtap(); return; }
+    if (--i_left == 0) return;
+    if (persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows)) nh_row = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl_row);
+    start_tile();
+  };
+  auto issue_step = [&](int st) {              // this wave's IPT pieces of the next K step into stage st
+    unsigned char* base = lds + st * STAGE;
+    const unsigned k0b = (unsigned)it_kc * SB;
+    if (!(g.dbg & 1)) {
+#pragma unroll
+      for (int u = 0; u < IA; ++u) dma16(sA + k0b + voffA[u], base + (wave + NWV * u) * 1024);
+#pragma unroll
+      for (int u = 0; u < IB; ++u) dma16(sB + k0b + voffB[u], base + BM * SB + (wave + NWV * u) * 1024);
+    }
+    advance();
+  };
+
+  // ---- compute side constants
+  const int wm = wave >> 1, wn = wave & 1;
+  const int a16 = lane & 15, g4 = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // fragment addresses inside a stage: pixel rows (B operand) and permuted weight rows (A operand); k-step 1 = ^ 64
+  const unsigned pbase = (unsigned)((wm * 64 + a16) * SB + ((g4 ^ (a16 >> 1)) << 4));
+  const unsigned wrow = (unsigned)(wn * WC + (a16 >> 2) * CPL + (a16 & 3));
+  const unsigned wbase = (unsigned)((BM + wrow) * SB + ((g4 ^ (((a16 >> 1) & 1) | ((a16 >> 2) << 1))) << 4));
+
+  float* s_bias = (float*)(lds + NS * STAGE);
+  float* s_db = s_bias + NDB;
+  const unsigned sbias0 = lds0 + NS * STAGE, sdb0 = sbias0 + NDB * 4;
+  float* s_rs = s_db + NDB;                    // per-sample weights of the bias-gradient sums (B <= NDB)
+  const unsigned srs0 = sdb0 + NDB * 4;
+  const bool want_db = MASK && p.dbias != nullptr;
+  for (int i = tid; i < NDB; i += 64 * NWV) {
+    s_bias[i] = (!MASK && p.bias && i < p.N) ? p.bias[i % p.bias_mod] : 0.f;
+    s_db[i] = 0.f;
+    s_rs[i] = (p.rowscale && i < p.B) ? p.rowscale[i] : 1.f;
+  }
+  __syncthreads();
+
+  f32x4_t acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+  i32x4 fp[2][TM], fw[2][TN];                  // fragments of one whole K step
+
+  // ---- epilogue pieces
+  bf16* out = (bf16*)p.out;
+  const unsigned lane_coff = (unsigned)((wn * WC + g4 * CPL) * 2);  // this lane's first channel inside the N tile, bytes
+  unsigned pix_off[TM];                        // byte offset of this lane's pixel of block i from the tile base
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int trow = wm * 64 + i * 16 + a16;
+    const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
+    pix_off[i] = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2) + lane_coff;
+  }
+  auto tile_off = [&](const Tile& t) -> long {  // element offset of (sample group, row Y, first column, first channel)
+    const int n0 = t.xt * BM;
+    return (long)(t.bt * g.NSB) * p.out_sb + ((long)t.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + t.px)) * p.out_sp +
+           t.nt * BN;
+  };
+  // The leaky-relu mask source of a tile being finished (EPI_MASK) is fetched into the FRAGMENT registers of k-step 0
+  // (fp[0][i], fw[0][i]: 8 x 16 bytes, exactly one lane's 4 pixels x 32 bytes) once the last K step's first 16 MFMAs
+  // have read them: no extra registers, and the loads fly under the remaining 16 MFMAs and the barrier.
+  auto load_aux = [&](const Tile& t) {
+    const char* ab = (const char*)((const bf16*)p.aux + tile_off(t));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const char* src = ab + pix_off[i];
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fp[0][i]) : "v"(src) : "memory");
+      if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(fw[0][i]) : "v"(src) : "memory");
+    }
+  };
+  auto epilogue = [&](const Tile& t) {
+    char* ob = (char*)(out + tile_off(t));
+    if (MASK) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        asm volatile("" : "+v"(fp[0][i]));
+        if (NST / TM == 2) asm volatile("" : "+v"(fw[0][i]));
+      }
+    }
+    f32x4_t bias[TN];
+    float rs = 1.f;
+    if (want_db) {  // the wave's 64 pixels belong to one sample (SW >= 64): one per-sample weight per tile
+      const unsigned ra = srs0 + (unsigned)(t.bt * g.NSB + ((wm * 64) >> g.lsw)) * 4;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(rs) : "v"(ra) : "memory");
+    }
+    if (!MASK) {
+      const unsigned ba = sbias0 + (unsigned)(t.nt * BN * 4) + lane_coff * 2;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[j]) : "v"(ba), "n"(j * 16) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bias[j]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(rs));
+    }
+    i32x4 opk[TM][NST / TM];                   // packed outputs (kept for the bias-gradient sums: acc / aux are dead by then)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      alignas(16) bf16 o[CPL];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] * p.scale;
+          if (MASK) {
+            const bf16* av = (4 * j + r < 8) ? (const bf16*)&fp[0][i] : (const bf16*)&fw[0][i];
+            v *= ((float)av[(4 * j + r) & 7] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+          } else {
+            v += bias[j][r];
+            if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
+          }
+          o[4 * j + r] = (bf16)v;
+        }
+#pragma unroll
+      for (int h = 0; h < NST / TM; ++h) {
+        opk[i][h] = *(const i32x4*)&o[8 * h];
+        *(i32x4*)(ob + pix_off[i] + 16 * h) = opk[i][h];
+      }
+      __builtin_amdgcn_sched_barrier(0);       // one pixel block at a time: keeps the live ranges (and VGPRs) short
+    }
+    if (want_db) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) v += (float)((const bf16*)&opk[i][0])[c];
+        v = row_add<0xB1>(v);                  // quad_perm [1,0,3,2]
+        v = row_add<0x4E>(v);                  // quad_perm [2,3,0,1]
+        v = row_add<0x124>(v);                 // row_ror 4
+        v = row_add<0x128>(v);                 // row_ror 8
+        if (a16 == 0) {
+          const unsigned ad = sdb0 + (unsigned)(t.nt * BN * 4) + lane_coff * 2 + c * 4;
+          const float vv = v * rs;
+          asm volatile("ds_add_f32 %0, %1" ::"v"(ad), "v"(vv) : "memory");
+        }
+      }
+    }
+    zero_acc();
+  };
+
+  // ---- prologue: K steps 0 and 1 in flight, step 0 landed and published; group B starts one barrier late
+  int issued = 0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+    if (i_left > 0) { issue_step(d); ++issued; }
+  if (issued == 2) PP_WAIT(IPT); else PP_WAIT(0);
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();
+
+  Tile tc = first;
+  unsigned long long dummy;
+  int nh_c = persist::pack_htaps<MODE>(p.adj, tc.Y, p.Hc, dummy);
+  int st_c = 0, st_i = 2;                      // stage of the K step being loaded / stage refilled during it
+  bool pending = false;                        // a finished tile waits for its epilogue
+  Tile tdone = first;
+  for (int c = 0; c < tcount; ++c) {
+    const int nsteps = nh_c * nW * KC;
+    for (int s = 0; s < nsteps; ++s) {
+      // ================= LOAD(t)
+      const bool epi_now = pending;
+      if (pending) {
+        if (!(g.dbg & 4)) epilogue(tdone); else zero_acc();
+        pending = false;
+      }
+      {
+        const unsigned so = lds0 + (unsigned)st_c * STAGE;
+        const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          LDS_READ128(fp[0][i], pa0, i * 16 * SB);
+          LDS_READ128(fp[1][i], pa1, i * 16 * SB);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          LDS_READ128(fw[0][j], wa0, j * 4 * SB);
+          LDS_READ128(fw[1][j], wa1, j * 4 * SB);
+        }
+      }
+      const bool iss = i_left > 0;
+      if (iss) issue_step(st_i);
+      // own pieces of K step t+1 landed (everything but this interval's pieces and the epilogue's stores); fragments in
+      if (iss) { if (epi_now) PP_WAIT(IPT + NST); else PP_WAIT(IPT); }
+      else     { if (epi_now) PP_WAIT(NST); else PP_WAIT(0); }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ================= MFMA(t)
+      const bool last = s + 1 == nsteps;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (!(g.dbg & 2)) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[ks][j]),
+                                                                   __builtin_bit_cast(bf16x8, fp[ks][i]), acc[i][j], 0, 0, 0);
+        }
+        if (ks == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (MASK && last && !(g.dbg & 4)) load_aux(tc);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      st_c = st_c + 1 == NS ? 0 : st_c + 1;
+      st_i = st_i + 1 == NS ? 0 : st_i + 1;
+    }
+    pending = true;
+    tdone = tc;
+    if (persist::next_tile<MODE>(tc, tiles_n, tiles_x, rows)) nh_c = persist::pack_htaps<MODE>(p.adj, tc.Y, p.Hc, dummy);
+  }
+  if (pending && !(g.dbg & 4)) epilogue(tdone);
+  if (wave < 4) __builtin_amdgcn_s_barrier();  // pairs with group B's late start
+  if (want_db) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int n = tid; n < p.N; n += 64 * NWV) atomicAdd(&p.dbias[n % p.bias_mod], s_db[n]);
+  }
+}
+
+template <int BN, int MODE, bool MASK>
+int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
+  Geo g = g0;
+  static int resident = 0;
+  if (!resident) {
+    int dev = 0, cus = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    HIP_CHECK_RET(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    resident = cus;                            // 148 KB of LDS: one workgroup per CU
+  }
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+  g.dbg = dbg;
+  const int cap = (wg_cap > 0 && wg_cap < resident) ? wg_cap : resident;
+  const int G = g.ntiles < cap ? g.ntiles : cap;
+  if (plan) {
+    plan->family = 5; plan->bm = 256; plan->bn = BN; plan->tiles = g.ntiles; plan->workgroups = G;
+    plan->tiles_per_wg = (g.ntiles + G - 1) / G;
+    return DG_OK;
+  }
+  conv_pp_kernel<BN, MODE, MASK><<<(unsigned)G, 512, 0, stream>>>(*p, g);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+}  // namespace pp
+
+// bf16 layers that tile into 256-pixel x 128- (or 64-) channel tiles; DG_EUNSUPPORTED otherwise (the caller falls back
+// to the lock-step kernels).  min_tiles: the auto rule wants every CU busy.
+int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan) {
+  if (p->mode != MODE_S2 && p->mode != MODE_UP) return DG_EUNSUPPORTED;
+  if (p->in_dtype != DG_BF16 || p->out_dtype != DG_BF16 || p->w_dtype != DG_BF16) return DG_EUNSUPPORTED;
+  if (p->K % 64 != 0 || !p->ring || p->nscale) return DG_EUNSUPPORTED;
+  if (p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1) return DG_EUNSUPPORTED;
+  if (p->out_sp % 8 != 0 || p->in_sp % 8 != 0 || p->w_sn % 8 != 0) return DG_EUNSUPPORTED;   // 16-byte pieces
+  if (p->N > 512 || (p->bias && p->bias_mod < p->N && p->N % p->bias_mod != 0)) return DG_EUNSUPPORTED;
+  if (p->dbias && p->bias_mod < p->N) return DG_EUNSUPPORTED;
+  const bool mask = p->epi == EPI_MASK;
+  if (mask ? p->bias != nullptr : p->dbias != nullptr) return DG_EUNSUPPORTED;   // combinations no layer uses
+  if (p->rowscale && p->B > 512) return DG_EUNSUPPORTED;
+  persist::Geo g;
+  int bn = 0;
+  if (p->N % 128 == 0 && persist::make_geo<256, 128>(p, g) && g.SW >= 64 && g.ntiles >= min_tiles) bn = 128;
+  else if (p->N % 64 == 0 && persist::make_geo<256, 64>(p, g) && g.SW >= 64 && g.ntiles >= min_tiles) bn = 64;
+  if (!bn) return DG_EUNSUPPORTED;
+  const int sel = (bn == 128 ? 0 : 4) + (p->mode == MODE_UP ? 2 : 0) + (mask ? 1 : 0);
+  switch (sel) {
+    case 0: return pp::launch<128, MODE_S2, false>(p, g, stream, wg_cap, plan);
+    case 1: return pp::launch<128, MODE_S2, true>(p, g, stream, wg_cap, plan);
+    case 2: return pp::launch<128, MODE_UP, false>(p, g, stream, wg_cap, plan);
+    case 3: return pp::launch<128, MODE_UP, true>(p, g, stream, wg_cap, plan);
+    case 4: return pp::launch<64, MODE_S2, false>(p, g, stream, wg_cap, plan);
+    case 5: return pp::launch<64, MODE_S2, true>(p, g, stream, wg_cap, plan);
+    case 6: return pp::launch<64, MODE_UP, false>(p, g, stream, wg_cap, plan);
+    default: return pp::launch<64, MODE_UP, true>(p, g, stream, wg_cap, plan);
+  }
+}

@@ -18,6 +18,9 @@ ARCH_ID = {"none": 0, "dusty1": 1, "dusty2": 2}
 # bench.py sets this to a list to time every conv / wgrad launch with HIP events (kernel family, algorithmic FLOPs,
 # algorithmic bytes, start event, end event, shape tag).  None = no instrumentation (the normal path).
 PROFILE = None
+# tests / bench set this to a list to record what every conv / wgrad call launches: ("conv", DgConvPlan fields ..., tag)
+# or ("wgrad", variant, tag).  None = off.
+TRACE = None
 
 
 def _align(n, a=64):
@@ -197,6 +200,7 @@ class SideStream:
 
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
+    default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
 
     def __init__(self, dtype):
         self.lib = L.lib()
@@ -205,6 +209,7 @@ class Ops:
         self.es = 2 if dtype == torch.bfloat16 else 4
         # 0 auto (MFMA implicit GEMM where the shape allows), 1 direct VALU kernels only (cross-check runs)
         self.force = int(os.environ.get("DUSTY_GAN_FORCE_KERNEL", "0"))
+        self.wg_cap = Ops.default_wg_cap  # dg_conv_ex: cap on the persistent conv's workgroup count (0 = one residency wave)
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
@@ -231,8 +236,13 @@ class Ops:
         p.dbias, p.rowscale = dbias, L.ptr(rowscale)
         p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, (self.dt if w_dt is None else w_dt)
         p.nscale = L.ptr(nscale)
+        if TRACE is not None:
+            pl = L.DgConvPlan()
+            L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
+            TRACE.append(("conv", pl.family, pl.bm, pl.bn, pl.tiles, pl.workgroups, pl.tiles_per_wg,
+                          f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
         if PROFILE is None:
-            L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
+            L.check(self.lib.dg_conv_ex(C.byref(p), self.force, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
@@ -260,6 +270,9 @@ class Ops:
         p.g_sb, p.g_sp, p.g_sc = g_strides
         p.dw, p.scale, p.rowscale = dw_ptr, scale, L.ptr(rowscale)
         p.a_dtype, p.g_dtype = a_dt, g_dt
+        if TRACE is not None:
+            TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self.force),
+                          f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
         if PROFILE is None:
             L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
             return
@@ -367,11 +380,16 @@ class GEngine:
         self.ops.wgrad(2, 1, 1, 1, nb, Np, c.nz, dp0, (0, Np, 1), zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
                        1.0 / math.sqrt(Np), accumulate=int(accumulate))
 
-    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, join=True, data_only=False):
+    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, join=True, data_only=False,
+                 chain_first=False, after_chain=None, after_up1=None):
         """ddepth [B,1,H,W] fp32 = dLoss/d(output depth).  Accumulates every G parameter gradient into st.grad
         (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309).  data_only: just the backward-data chain
         (self.draw, self.dp[3..0] = gradients w.r.t. the pre-activations), no parameter gradient is touched - the
-        first half of the path-length regulariser's d(sum x y)/dz."""
+        first half of the path-length regulariser's d(sum x y)/dz.
+        chain_first (data-parallel runs): the whole backward-data chain first - after it dp[0], Proj's gradient operand,
+        and every bias gradient are final (`after_chain()`: the trainer starts the operand all-gather) - then the weight
+        gradients largest first (`after_up1()`: the bucket that holds 75 % of the remaining gradient bytes is final), so
+        both exchanges run beside the remaining weight-gradient kernels.  Same kernels, same results."""
         if data_only:
             return self._backward_chain(st, ddepth, self.draw, self.draw_pm, self.dp, acts=None, chain=None,
                                         second_of=None)
@@ -387,41 +405,62 @@ class GEngine:
                                      self.HW, s_depth, s_conf, L.ptr(self.draw), st.fptr("head_b", st.grad),
                                      L.ptr(self.draw_pm), self.cp, sp),
                 "dg_head_post_bwd")
-        hc, wc = self.grid[3]
         pl = (c.nheads * self.HW, 1, self.HW)
-        # head weight gradient and backward-data (gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad)
-        if self.draw_pm is not None:  # bf16: the pixel-major copy feeds the two thin MFMA kernels
-            cp = self.cp
+        pm = self.draw_pm is not None  # bf16: the pixel-major copy of the head gradient feeds the two thin MFMA kernels
+        cp = self.cp
+        hsrc, hstr, hkw_w, hkw_c = ((self.draw_pm, (self.HW * cp, cp, 1), {}, {}) if pm else
+                                    (self.draw, pl, {"g_dt": L.DG_F32}, {"in_dt": L.DG_F32}))
+
+        def head_wgrad():
+            hc, wc = self.grid[3]
             with SideStream.fork():
-                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw_pm,
-                        (self.HW * cp, cp, 1), st.fptr("head_w", st.grad), 1.0)
-            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw_pm, (self.HW * cp, cp, 1), self.dp[3],
+                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), hsrc, hstr,
+                        st.fptr("head_w", st.grad), 1.0, **hkw_w)
+
+        def head_bwd_data():  # gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad
+            hc, wc = self.grid[3]
+            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], hsrc, hstr, self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
-                   dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3])
-        else:
-            with SideStream.fork():
-                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.draw, pl,
-                        st.fptr("head_w", st.grad), 1.0, g_dt=L.DG_F32)
-            o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], self.draw, pl, self.dp[3],
-                   (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
-                   dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], in_dt=L.DG_F32)
-        for i in (3, 2, 1):
+                   dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], **hkw_c)
+
+        def up_wgrad(i):
             hc, wc = self.grid[i - 1]
             ci, co = chs[i - 1], chs[i]
-            s = 1.0 / math.sqrt(co * 16)
             with SideStream.fork():
                 o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
-                        (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), s)
+                        (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), 1.0 / math.sqrt(co * 16))
+
+        def up_bwd_data(i):
+            hc, wc = self.grid[i - 1]
+            ci, co = chs[i - 1], chs[i]
             prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, self.dp[i], (4 * hc * wc * co, co, 1), self.dp[i - 1],
-                   (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
+                   (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), 1.0 / math.sqrt(co * 16), L.EPI_MASK, aux=self.a[i - 1],
                    dbias=st.fptr(prev_b, st.grad), bias_mod=ci)
+
+        if chain_first:
+            head_bwd_data()
+            for i in (3, 2, 1):
+                up_bwd_data(i)
+            if after_chain is not None:
+                after_chain()
+            up_wgrad(1)
+            if after_up1 is not None:
+                after_up1()
+            up_wgrad(2)
+            up_wgrad(3)
+            head_wgrad()
+        else:
+            head_wgrad()
+            head_bwd_data()
+            for i in (3, 2, 1):
+                up_wgrad(i)
+                up_bwd_data(i)
         if not skip_proj:
             with SideStream.fork():
                 self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
         if join:  # join=False: the caller joins after work that does not need the weight gradients (fused Proj Adam)
             SideStream.join()
-
 
     # ------------------------------------------------------------------ path-length regulariser (trainers/dcgan_amp.py:268-306)
     def _backward_chain(self, st, ddepth, draw, draw_pm, dp, acts, chain, second_of, thead=None):
@@ -620,11 +659,11 @@ class DEngine:
         L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")
 
-    def wgrad(self, st, a_slot, g_slot, n, rowscale):
-        """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot+b]) for the four Down layers."""
+    def wgrad(self, st, a_slot, g_slot, n, rowscale, layers=(1, 2, 3, 4)):
+        """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot+b]) for the Down layers in `layers`."""
         c, o = self.cfg, self.ops
         with SideStream.fork():
-            for i in range(1, 5):
+            for i in layers:
                 hc, wc = self.grid[i]
                 ci, co = self.chs[i - 1], self.chs[i]
                 o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],

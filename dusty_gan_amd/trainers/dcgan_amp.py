@@ -16,6 +16,7 @@ What differs underneath:
 import math
 import os.path as osp
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import torch
 import torch.distributed as dist
@@ -41,41 +42,26 @@ def _rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-class LazyScalars(dict):
-    """dict[str,float] whose values are read back from the device on first access (one D2H copy per step instead
-    of the reference's 5-7 blocking `.item()` calls, trainers/dcgan_amp.py:319-323)."""
+class LazyScalars(Mapping):
+    """Read-only mapping str -> float whose values are read back from the device on first access (one D2H copy per
+    step instead of the reference's 5-7 blocking `.item()` calls, trainers/dcgan_amp.py:319-323).  Every accessor
+    (`[]`, get, items, keys, values, iteration, ==, dict(x)) resolves first; it is deliberately NOT a dict subclass:
+    dict's C fast paths (json.dumps, dict.update, copy) would see an empty table before the read-back."""
 
     def __init__(self, keys, dev_tensor):
-        super().__init__()
-        self._keys, self._dev, self._done = list(keys), dev_tensor, False
+        self._keys, self._dev, self._vals = list(keys), dev_tensor, None
 
     def _resolve(self):
-        if not self._done:
-            vals = self._dev.tolist()
-            for k, v in zip(self._keys, vals):
-                dict.__setitem__(self, k, v)
-            self._done = True
+        if self._vals is None:
+            self._vals = dict(zip(self._keys, self._dev.tolist()))
             self._dev = None
+        return self._vals
 
     def __getitem__(self, k):
-        self._resolve()
-        return dict.__getitem__(self, k)
-
-    def items(self):
-        self._resolve()
-        return dict.items(self)
-
-    def keys(self):
-        self._resolve()
-        return dict.keys(self)
-
-    def values(self):
-        self._resolve()
-        return dict.values(self)
+        return self._resolve()[k]
 
     def __iter__(self):
-        self._resolve()
-        return dict.__iter__(self)
+        return iter(self._keys)
 
     def __len__(self):
         return len(self._keys)
@@ -83,9 +69,13 @@ class LazyScalars(dict):
     def __contains__(self, k):
         return k in self._keys
 
+    def copy(self):
+        return dict(self._resolve())
+
+    as_dict = copy
+
     def __repr__(self):
-        self._resolve()
-        return dict.__repr__(self)
+        return repr(self._resolve())
 
 
 class FlatAdam:
@@ -320,7 +310,8 @@ class Trainer:
         self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
         self._graph, self._eager_steps = None, 0
         self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
-        self._force_seg = os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"  # debug: split the graph at world == 1 too
+        self._force_seg = os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"  # one process runs the multi-rank schedule
+        self._works, self._comm_events = {}, None
         self._fuse_proj_ok = os.environ.get("DUSTY_GAN_FUSE_PROJ", "1") != "0"
 
     # ------------------------------------------------------------------ helpers
@@ -370,11 +361,24 @@ class Trainer:
                          "noise": None if not pl.get("noise") else {k: f(v) for k, v in pl["noise"].items()}}
         return out
 
-    def _coll(self, fn):
+    def _coll(self, fn, name=None):
         """Run a collective (or any host-side call that cannot be captured) at this point of the launch sequence.
         Eager: call it.  While the step is being captured for replay: close the current hipGraph segment, remember
         `fn`, open the next segment - the replay alternates graph launches and these calls in the same order.
-        `fn` must only touch tensors whose storage is the same on every step (flat buffers, preallocated outputs)."""
+        `fn` must only touch tensors whose storage is the same on every step (flat buffers, preallocated outputs).
+        With `self._comm_events` set (Trainer.comm_profile) HIP events on the launch stream bracket the call: their
+        distance is the time the compute stream spent blocked on it, i.e. the EXPOSED communication time."""
+        if name is not None:
+            inner = fn
+
+            def fn():
+                if self._comm_events is None:
+                    return inner()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                inner()
+                e1.record()
+                self._comm_events.append((name, e0, e1))
         if self._cap is None:
             fn()
             return
@@ -382,26 +386,59 @@ class Trainer:
         self._cap.append(fn)
         self._cap_open()
 
+    def _comm_issue(self, key, fn):
+        """Start a collective WITHOUT making the compute stream wait for it (async_op=True: RCCL runs it on its own
+        stream behind everything issued so far); `_comm_wait(key)` is where its result is first needed."""
+        def issue():
+            self._works[key] = fn()
+        self._coll(issue, name=None)
+
+    def _comm_wait(self, *keys):
+        def wait():
+            for k in keys:
+                w = self._works.pop(k, None)
+                if w is not None:
+                    w.wait()  # nccl: the current stream waits (no host block); gloo: host wait
+        self._coll(wait, name="wait " + "+".join(keys))
+
     def _cap_open(self):
+        import os
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while this thread captures
-        ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self.world > 1 else "global")
+        pool = None if os.environ.get("DUSTY_DBG_POOLS") == "separate" else self._cap_pool
+        ctx = torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if self.world > 1 else "global")
         ctx.__enter__()
         self._cap_cur = (g, ctx)
 
     def _cap_close(self):
+        import warnings
         g, ctx = self._cap_cur
-        ctx.__exit__(None, None, None)
-        self._cap.append(g)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            ctx.__exit__(None, None, None)
+        # two host-side calls in a row (issue of one bucket, wait for both) leave an empty segment between them: drop it
+        if not any("is empty" in str(w.message) for w in caught):
+            self._cap.append(g)
         self._cap_cur = None
+
+    def _bucketed(self):
+        """multi-rank schedule (also with DUSTY_GAN_FORCE_SEG=1 in one process): bucketed, overlapped exchanges"""
+        return (self.world > 1 or self._force_seg) and self.n_acc == 1
 
     def _allreduce(self, store):
         """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
         if self.world > 1:
-            self._coll(lambda: D_.allreduce_grads(store.grad))
+            self._coll(lambda: D_.allreduce_grads(store.grad), name="all-reduce grads")
         elif self._force_seg:
             self._coll(lambda: None)
         return 1.0 / self.world
+
+    def _allreduce_async(self, key, buf):
+        """issue half of a bucketed gradient exchange (`_comm_wait(key)` completes it)"""
+        if self.world > 1:
+            self._comm_issue(key, lambda: D_.allreduce_grads(buf, async_op=True)[0])
+        elif self._force_seg:
+            self._coll(lambda: None)
 
     # ------------------------------------------------------------------ D phase (reference :171-238)
     def optimize_D(self, reals=None, rands=None):
@@ -426,7 +463,7 @@ class Trainer:
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
         scal = torch.zeros(7, dtype=torch.float32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        for j, sync in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
+        for j in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
             if reals is not None:
                 x_real, m_real = reals[j]
             else:
@@ -446,13 +483,19 @@ class Trainer:
             L.check(lib.dg_gan_d_step(self.gan_code, float(self.criterion["gan"].smoothing), L.ptr(y),
                                       L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs), L.ptr(scal),
                                       Dst.fptr("final_b", Dst.grad), sp), "dg_gan_d_step")
+            # data-parallel runs (one micro-batch): the gradient exchange is cut into two buckets at d4_w (73 % of D's
+            # bytes live in [d4_w, end)) and the weight gradients are formed last layer first, so the large bucket
+            # travels while the three smaller layers' gradients are still being computed
+            bucketed = self._bucketed()
+            cut = Dst.seg["d4_w"].off
             if gp > 0:
                 deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
-                # (side stream) weight gradients of the real (weighted by dLoss/dy_real) + fake halves, beside the
-                # rest of the R1 chain
-                deng.wgrad(Dst, 0, 0, 2 * B, rs)
-                deng.final_wgrad(Dst, 0, 2 * B, dy)
                 g = torch.empty(B, 1, self.H, self.W, **f32)
+                if not bucketed:
+                    # (side stream) weight gradients of the real (weighted by dLoss/dy_real) + fake halves, beside the
+                    # rest of the R1 chain
+                    deng.wgrad(Dst, 0, 0, 2 * B, rs)
+                    deng.final_wgrad(Dst, 0, 2 * B, dy)
                 deng.backward_input(Dst, 0, B, g)
                 ssq = torch.empty(B, **f32)
                 L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
@@ -461,15 +504,37 @@ class Trainer:
                 vg = torch.empty_like(g)
                 L.check(lib.dg_scale(L.ptr(g), gp / self.n_acc / B, g.numel(), L.ptr(vg), sp), "dg_scale")
                 deng.forward(Dst, vg, 2 * B, tangent_of=0)
-                deng.wgrad(Dst, 2 * B, 0, B, None)      # tangent (x) real chain
-                deng.final_wgrad(Dst, 2 * B, B, None)
+                if not bucketed:
+                    deng.wgrad(Dst, 2 * B, 0, B, None)      # tangent (x) real chain
+                    deng.final_wgrad(Dst, 2 * B, B, None)
+                else:
+                    for layers in ((4,), (3, 2, 1)):
+                        deng.wgrad(Dst, 0, 0, 2 * B, rs, layers=layers)
+                        deng.wgrad(Dst, 2 * B, 0, B, None, layers=layers)
+                        if layers == (4,):
+                            deng.final_wgrad(Dst, 0, 2 * B, dy)
+                            deng.final_wgrad(Dst, 2 * B, B, None)
+                            E.SideStream.join()
+                            self._allreduce_async("D.hi", Dst.grad[cut:])
             else:
                 deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
-                deng.wgrad(Dst, 0, 0, 2 * B, None)
-                deng.final_wgrad(Dst, 0, 2 * B, dy)
+                if not bucketed:
+                    deng.wgrad(Dst, 0, 0, 2 * B, None)
+                    deng.final_wgrad(Dst, 0, 2 * B, dy)
+                else:
+                    deng.wgrad(Dst, 0, 0, 2 * B, None, layers=(4,))
+                    deng.final_wgrad(Dst, 0, 2 * B, dy)
+                    E.SideStream.join()
+                    self._allreduce_async("D.hi", Dst.grad[cut:])
+                    deng.wgrad(Dst, 0, 0, 2 * B, None, layers=(3, 2, 1))
             E.SideStream.join()
             self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
-        gscale = self._allreduce(Dst)
+        if self._bucketed():
+            self._allreduce_async("D.lo", Dst.grad[:Dst.seg["d4_w"].off])
+            self._comm_wait("D.hi", "D.lo")
+            gscale = 1.0 / self.world
+        else:
+            gscale = self._allreduce(Dst)
         self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype)  # :238
         self._dev_scal = scal
         return scal
@@ -494,7 +559,7 @@ class Trainer:
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         f32 = dict(dtype=torch.float32, device=self.device)
         scal = self._dev_scal
-        for j, sync in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
+        for j in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
             mb = self._mb[j]
             rand = mb["rand"]
             # :255/:259 A(real) and D(real) feed only the relativistic losses (loss.py:76-85); the other metrics'
@@ -516,8 +581,20 @@ class Trainer:
             dx = torch.empty(B, 1, self.H, self.W, **f32)
             deng.backward_input(Dst, 0, B, dx)
             ddepth = self.A.backward(dx, rand["aug"][3])
-            mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj,
-                                join=not fuse_proj)
+            overlap = gather_proj and not pl_on  # (the path-length block adds to every gradient after this pass)
+            if overlap:
+                geng = mb["geng"]
+                zg, dg = self._gather_bufs(geng, B)
+                hi0, hi1 = Gst.seg["proj_b"].off, Gst.seg["up2_w"].off
+                geng.backward(
+                    Gst, ddepth, skip_proj=True, chain_first=True,
+                    after_chain=lambda: self._comm_issue("G.gather", lambda: D_.Works(
+                        [D_.all_gather_into(zg, geng.zT, async_op=True), D_.all_gather_into(dg, geng.dp[0], async_op=True)])),
+                    after_up1=lambda: self._allreduce_async("G.hi", Gst.grad[hi0:hi1]))
+                self._allreduce_async("G.lo", Gst.grad[hi1:])
+            else:
+                mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj,
+                                    join=not fuse_proj)
             if pl_on:
                 # (Proj.weight's two path-length terms follow its adversarial term: materialised here, or - when that
                 # gradient is formed inside the optimizer / from gathered operands - appended to its operand list below)
@@ -529,11 +606,17 @@ class Trainer:
             # (z [B,nz] and dL/da0 [B,h0*w0*C], 8.4 MB per rank in bf16) and forms the GLOBAL-batch gradient locally:
             # same sum, 3.5x less xGMI traffic, and the 268 MB never cross a link.
             geng = self._mb[0]["geng"]
-            dp0, zT, nloc = self._proj_operands(geng, B)
-            if self._gather is None or self._gather[0].numel() != self.world * zT.numel():
-                self._gather = (zT.new_empty(self.world * zT.numel()), dp0.new_empty(self.world * dp0.numel()))
-            zg, dg = self._gather
-            self._coll(lambda: (D_.all_gather_into(zg, zT), D_.all_gather_into(dg, dp0)))
+            if not pl_on:
+                # started inside the backward pass (right after the data chain / the largest weight gradient)
+                zg, dg = self._gather_bufs(geng, B)
+                nloc = B
+                self._comm_wait("G.gather")
+            else:
+                dp0, zT, nloc = self._proj_operands(geng, B)
+                if self._gather is None or self._gather[0].numel() != self.world * zT.numel():
+                    self._gather = (zT.new_empty(self.world * zT.numel()), dp0.new_empty(self.world * dp0.numel()))
+                zg, dg = self._gather
+                self._coll(lambda: (D_.all_gather_into(zg, zT), D_.all_gather_into(dg, dp0)), name="all-gather Proj operands")
             nbg = self.world * nloc
             if fuse_gathered:
                 # ... and the global-batch gradient is not even written: the optimizer forms it tile by tile in the
@@ -544,8 +627,11 @@ class Trainer:
                 self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, dg, zg, nbg, False)
             else:
                 geng.proj_wgrad(Gst, dg, zg, nbg)
-            tail = Gst.grad[Gst.seg["proj_b"].off:]
-            self._coll(lambda: D_.allreduce_grads(tail))
+            if not pl_on:
+                self._comm_wait("G.hi", "G.lo")
+            else:
+                tail = Gst.grad[Gst.seg["proj_b"].off:]
+                self._coll(lambda: D_.allreduce_grads(tail), name="all-reduce G tail")
             gscale = 1.0 / self.world
         else:
             gscale = self._allreduce(Gst)
@@ -567,6 +653,33 @@ class Trainer:
                               shadow_dtype=self.dtype)
         self._mb = []
         return scal
+
+    def _gather_bufs(self, geng, B):
+        """static all-gather destinations for Proj's gradient operands (z rows, dL/da0 rows) of the global batch"""
+        n = self.world * geng.zT.numel()
+        if self._gather is None or self._gather[0].numel() != n:
+            self._gather = (geng.zT.new_empty(n), geng.dp[0].new_empty(self.world * geng.dp[0].numel()))
+        return self._gather
+
+    def launch_mode(self):
+        """how `step` is being launched (bench.py reports it)"""
+        if self._graph is None:
+            return "eager launches"
+        n = sum(isinstance(g, torch.cuda.CUDAGraph) for g in self._graph)
+        return "one hipGraph per step" if n == 1 else f"{n} hipGraph segments per step, collectives between them"
+
+    def comm_profile(self, steps=3):
+        """Exposed communication time per step [ms] by collective: HIP events on the launch stream around every
+        host-side collective / wait of `steps` further steps (after the timed region of bench.py)."""
+        self._comm_events = []
+        for i in range(steps):
+            self.step(i)
+        torch.cuda.synchronize()
+        ev, self._comm_events = self._comm_events, None
+        out = {}
+        for name, e0, e1 in ev:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1) / steps
+        return {k: round(v, 4) for k, v in out.items()}
 
     def _proj_operands(self, geng, B):
         """(gradient rows, input rows, count) whose product is Proj.weight's gradient: the adversarial pair and, with
@@ -644,11 +757,9 @@ class Trainer:
     def _graph_eligible(self, reals, rands):
         import os
         from .. import engine as E
-        # world > 1: the segmented replay (collectives between hipGraph segments) is opt-in (DUSTY_GAN_GRAPH_DDP=1).  It
-        # matches the eager launches in tests/test_gpu_ddp.py, but two gloo ranks sharing one GPU at the benchmark's
-        # size produced garbage after a host-side stream synchronize in some runs (scripts/debug_ddp_graph.py) and the
-        # RCCL configuration cannot be validated on a one-GPU box, so multi-rank runs launch eagerly by default.
-        if self.world > 1 and os.environ.get("DUSTY_GAN_GRAPH_DDP", "0") != "1":
+        # world > 1: the step is replayed as hipGraph segments with the collectives issued between them (eager launches
+        # cost more host time than the kernels take); DUSTY_GAN_GRAPH_DDP=0 falls back to eager launches
+        if self.world > 1 and os.environ.get("DUSTY_GAN_GRAPH_DDP", "1") == "0":
             return False
         # the replay copies each batch into static device buffers, so the loader must yield fixed-shape device batches
         return (reals is None and rands is None and self.use_graph and E.PROFILE is None
@@ -706,6 +817,9 @@ class Trainer:
                 item()
         self.optim_D.step_count += 1
         self.optim_G.step_count += 1
+        # the replayed Adam+EMA kernel rewrote G_ema's master through raw pointers: its low-precision / transposed
+        # shadows (built lazily, only when G_ema is evaluated) are stale now
+        _backbone(self.G_ema).store._seen_version = -1
         return self._g_out.clone()
 
     def step(self, i=0, reals=None, rands=None):
@@ -767,7 +881,8 @@ class Trainer:
             data["real-3d"].append(inv_to_xyz(x_real))
         N = sum(t.shape[0] for t in data["real-2d"])
         for _ in range(0, N, self.local_batch):
-            x_fake = self.G_ema(latent=self.sample_latents(self.local_batch))["depth"]
+            # (the generator returns views of its persistent workspace: keep a copy, not the view)
+            x_fake = self.G_ema(latent=self.sample_latents(self.local_batch))["depth"].clone()
             data["fake-2d"].append(x_fake)
             data["fake-3d"].append(inv_to_xyz(x_fake))
         for key in data:

@@ -22,6 +22,12 @@ class DiffAugment(nn.Module):
         for k in self.policy:
             if k not in L.POLICY_BITS:
                 raise KeyError(k)  # same failure mode as AUGMENT_FNS[p] in the reference
+        # the fused kernel applies the stages in the reference's shipped order (solver/nsgan_eqlr.yaml:34-39); the
+        # reference iterates the list as given (diff_augment.py:124-131) and contrast's per-sample mean does not commute
+        # with translation / cutout, so another order would silently compute something else
+        order = [k for k in DEFAULT_POLICY if k in self.policy]
+        if [k for k in self.policy if k in DEFAULT_POLICY] != order or len(set(self.policy)) != len(self.policy):
+            raise NotImplementedError(f"DiffAugment policy order {self.policy}: the kernel applies {order}")
         if p != 1.0:
             raise NotImplementedError("DiffAugment probability p != 1 (the reference trainer always uses p=1)")
         self.p = p

@@ -69,16 +69,29 @@ def all_gather_cat(t):
     return out.view(t.dtype)
 
 
-def all_gather_into(out, t):
+def all_gather_into(out, t, async_op=False):
     """all-gather of a flat device tensor into the preallocated `out` (world * t.numel() elements, same dtype); the
-    storage of `out` is reused on every step so the consumers can sit inside a captured hipGraph"""
+    storage of `out` is reused on every step so the consumers can sit inside a captured hipGraph.  async_op: returns the
+    work handle (the caller waits where the result is first needed) instead of blocking the stream."""
     w = world_size()
     raw = t.contiguous().view(torch.uint8)
     dst = out.view(torch.uint8)
+    work = None
     if w == 1:
         dst.copy_(raw)
     elif dist.get_backend() == "nccl":
-        dist.all_gather_into_tensor(dst, raw)
+        work = dist.all_gather_into_tensor(dst, raw, async_op=async_op)
     else:
-        dist.all_gather(list(dst.view(w, -1).unbind(0)), raw)
-    return out
+        work = dist.all_gather(list(dst.view(w, -1).unbind(0)), raw, async_op=async_op)
+    return work if async_op else out
+
+
+class Works:
+    """several work handles waited as one"""
+
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()

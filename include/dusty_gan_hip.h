@@ -90,6 +90,20 @@ typedef struct DgWgrad {
  * persistent MFMA kernel or error (what 0 / 2 pick for layers that fill the chip with such tiles).
  */
 int dg_conv(const DgConv* p, int force, void* stream);
+/* What a dg_conv call launches (introspection for the parity tests and the benchmark: which kernel family / tile ran,
+ * and how many tiles each persistent workgroup walks).  family: 1 direct, 2 one-tile-per-workgroup MFMA, 3 thin,
+ * 4 persistent large-tile MFMA (lock step: fp32, small layers), 5 persistent ping-pong MFMA (bf16 fat layers).  dg_conv_ex = dg_conv with a cap on the persistent kernel's workgroup count
+ * (wg_cap <= 0: one residency wave of the device); dg_conv_plan fills `plan` for the same arguments and launches
+ * nothing. */
+typedef struct DgConvPlan {
+  int family;
+  int bm, bn;        /* output tile (pixels x channels), 0 for the non-MFMA kernels */
+  int tiles;         /* tiles of the launch */
+  int workgroups;    /* grid size */
+  int tiles_per_wg;  /* most tiles any workgroup walks */
+} DgConvPlan;
+int dg_conv_ex(const DgConv* p, int force, int wg_cap, void* stream);
+int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan);
 int dg_conv_mfma_supported(const DgConv* p);
 int dg_conv_kernel_choice(const DgConv* p);   /* what force == 0 launches: 2 MFMA, 3 thin, 1 direct */
 
@@ -98,6 +112,9 @@ int dg_conv_kernel_choice(const DgConv* p);   /* what force == 0 launches: 2 MFM
 int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream);
 int dg_wgrad_mfma_supported(const DgWgrad* p);
 int dg_wgrad_kernel_choice(const DgWgrad* p);
+/* which kernel `force` launches: 5 MFMA on the LDS-DMA ring (bf16 Down/Up layers), 2 register-staged MFMA (also
+ * force == 6), 3 thin, 1 direct, 0 unsupported */
+int dg_wgrad_kernel_variant(const DgWgrad* p, int force);
 
 /* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* stream);

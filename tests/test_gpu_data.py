@@ -188,7 +188,16 @@ def test_trainer_trains_from_scan_files(tmp_path):
         s = tr.step(i)
         assert all(np.isfinite(v) for v in s.values()), (i, dict(s.items()))
     assert tr._graph is not None
+    # G_ema keeps changing under graph replays (the fused Adam+EMA kernel writes its master through raw pointers): an
+    # evaluation after further replays must see the new weights, and match an fp32 evaluation of the master
+    first = tr.generate(ema=True)["depth_orig"].clone()
+    for i in range(6, 9):
+        tr.step(i)
     out = tr.generate(ema=True)
+    assert not torch.equal(first, out["depth_orig"])
+    Ge = {k: v.detach().cpu().clone() for k, v in tr.G_ema.state_dict().items()}
+    ref = O.generator_backbone(Ge, tr.fixed_noise.cpu())  # depth_orig = tanh(depth head): no Gumbel noise involved
+    assert float((out["depth_orig"].cpu() - ((ref["depth"] + 1) / 2).clamp(0, 1)).abs().max()) < 1e-4
     assert out["points"].shape == (4, 3, 32, 64) and torch.isfinite(out["points"]).all()
     assert out["normals"].shape == (4, 3, 32, 64) and 0.0 <= float(out["normals"].min()) <= float(out["normals"].max()) <= 1.0
     assert float(out["depth"].min()) >= 0.0 and float(out["depth"].max()) <= 1.0
@@ -214,6 +223,11 @@ def test_validation_end_to_end(tmp_path):
     N = 7
     assert len(tr.val_dataset) == N and len(tr.val_loader) == 2  # drop_last=False: 4 + 3
     assert data["real-2d"].shape == (N, 1, 32, 64) and data["fake-3d"].shape == (N, 96, 3)
+    # N = 7 > local batch 4: the second generated batch must not be a second copy of the first (the generator returns
+    # views of one workspace; validation() has to keep copies)
+    f2 = data["fake-2d"]
+    assert f2.shape == (N, 1, 32, 64) and not torch.equal(f2[:3], f2[4:7])
+    assert len({float(f2[i].sum()) for i in range(N)}) == N
     want_keys = {"swd-16", "swd-32", "swd-mean", "jsd", "mmd-cd", "mmd-sample-cd", "cov-cd"} | {
         f"1-nn-{k}-cd" for k in ("tp", "fp", "fn", "tn", "precision", "recall", "accuracy_t", "accuracy_f", "accuracy")}
     assert set(scores) == want_keys and all(np.isfinite(v) for v in scores.values())

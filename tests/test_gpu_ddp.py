@@ -87,14 +87,22 @@ def test_two_ranks_on_one_gpu_match_single_process():
     assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
 
 
-def graph_worker(rank, world, init_file, out_dir, use_graph):
+def graph_worker(rank, world, init_file, out_dir, use_graph, full=False):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH"] = "1" if use_graph else "0"
-    os.environ["DUSTY_GAN_GRAPH_DDP"] = "1"  # the segmented replay is opt-in for world > 1
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     torch.manual_seed(300)  # same seed on both ranks: same initial nets, same device RNG streams
-    tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
-    scal = [dict(tr.step(i).items()) for i in range(5)]
+    if full:  # the benchmark's nets and image size, bf16, 8 images per rank
+        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8, amp=True)
+    else:
+        tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
+    scal = []
+    for i in range(6 if full else 5):
+        s = tr.step(i)
+        if full and i % 2 == 1:
+            torch.cuda.synchronize()  # host-side synchronisation between replays (bench.py's sync / barrier pattern)
+            dist.barrier()
+        scal.append(dict(s.items()))
     segs = 0 if tr._graph is None else sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
     torch.save({"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": scal,
                 "segs": segs}, os.path.join(out_dir, f"g{int(use_graph)}_r{rank}.pt"))
@@ -102,23 +110,54 @@ def graph_worker(rank, world, init_file, out_dir, use_graph):
     dist.destroy_process_group()
 
 
-def test_two_ranks_segmented_graph_matches_eager():
-    """world > 1 (opt-in, DUSTY_GAN_GRAPH_DDP=1): the step is replayed as hipGraph segments with the collectives (D gradient all-reduce, Proj operand
-    gather, G tail all-reduce) called between them; 5 iterations must train exactly like the eager launch sequence."""
+@pytest.mark.parametrize("full", [False, True], ids=["tiny-fp32", "64x1024-bf16-B8"])
+def test_two_ranks_segmented_graph_matches_eager(full):
+    """world > 1 (the default there): the step is replayed as hipGraph segments with the collectives (two D gradient
+    buckets, Proj operand gather, two G gradient buckets; issued asynchronously, waited where their result is needed)
+    called between them; the iterations must train like the eager launch sequence.  `full`: at the benchmark's network
+    and image size with host-side synchronisation between replays (the configuration round 1 saw garbage in)."""
     res = {}
     for use_graph in (True, False):
         with tempfile.TemporaryDirectory() as td:
-            mp.spawn(graph_worker, args=(2, os.path.join(td, "init"), td, use_graph), nprocs=2, join=True)
+            mp.spawn(graph_worker, args=(2, os.path.join(td, "init"), td, use_graph, full), nprocs=2, join=True)
             res[use_graph] = [torch.load(os.path.join(td, f"g{int(use_graph)}_r{r}.pt")) for r in range(2)]
-    assert res[True][0]["segs"] == 4 and res[False][0]["segs"] == 0  # 3 collective points -> 4 graph segments
+    assert res[True][0]["segs"] >= 4 and res[False][0]["segs"] == 0  # collective points split the graph
     for r in range(2):
         a, b = res[True][r], res[False][r]
         for k in ("G", "D", "E"):
-            assert rel_l2(a[k], b[k]) < 1e-5, k
+            # bf16 / full size: atomics reorder sums and Adam (beta1 = 0) turns a sign change of a rounding-noise gradient
+            # into a 2 lr step: bounded per element, tiny over a tensor; garbage would be O(1)
+            assert rel_l2(a[k], b[k]) < (2e-3 if full else 1e-5), (k, rel_l2(a[k], b[k]))
+            if full:  # (step k of Adam can move an element by up to ~sqrt(k) lr while v-hat is young: 6 steps < 0.05)
+                assert float((a[k] - b[k]).abs().max()) <= 0.05, k
         for x, y in zip(a["scal"], b["scal"]):
             for k in x:
-                assert abs(x[k] - y[k]) < 1e-4 * max(1.0, abs(y[k])), k
+                assert abs(x[k] - y[k]) < (3e-2 if full else 1e-4) * max(1.0, abs(y[k])), (k, x[k], y[k])
     assert torch.equal(res[True][0]["G"], res[True][1]["G"])
+
+
+def test_forced_segments_single_process_match_one_graph(monkeypatch):
+    """DUSTY_GAN_FORCE_SEG=1: one process runs the multi-rank schedule (bucket order, chain-first G backward, operand
+    gather, graph segments) with degenerate collectives - it must train like the single-graph replay at the benchmark's
+    size, bf16."""
+    from tests.test_gpu_step import make_trainer
+
+    def run(seg):
+        monkeypatch.setenv("DUSTY_GAN_FORCE_SEG", "1" if seg else "0")
+        torch.manual_seed(77)
+        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
+        sc = [dict(tr.step(i).items()) for i in range(5)]
+        segs = sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
+        return tr, sc, segs
+    a, sa, na = run(True)
+    b, sb, nb = run(False)
+    assert na >= 4 and nb == 1
+    for net in ("G", "D", "G_ema"):
+        fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
+        assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb))
+    for x, y in zip(sa, sb):
+        for k in x:
+            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
 def fused_worker(rank, world, init_file, out_dir, fuse, pl=0.0):
@@ -160,3 +199,26 @@ def test_two_ranks_fused_proj_optimizer_matches_unfused(pl):
             for k in x:
                 assert abs(x[k] - y[k]) < 5e-3 * max(1.0, abs(y[k])), (k, x[k], y[k])
     assert torch.equal(res[True][0]["G"], res[True][1]["G"])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (the reference's train.py:185-186
+    mp.spawn) and prints ONE JSON line with n_gpus = 2; gloo lets both ranks share this box's one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DUSTY_BENCH_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3",
+                          "--batch", "4", "--shape", "64", "256", "--no-cpu-baseline"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
+    assert "segments" in out["launch_mode"]
+    assert set(out["distributed"]["exposed_ms_per_step"]) >= {"wait D.hi+D.lo", "wait G.gather", "wait G.hi+G.lo"}
+    assert out["step_ms_device"]["p50"] > 0

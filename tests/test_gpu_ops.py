@@ -471,7 +471,10 @@ def test_nsgan_step_kernels_match_plain_ones(L):
 
 @pytest.mark.parametrize("nb,Np,K", [(4, 200, 8), (32, 1000, 512), (64, 130, 256),
                                      # larger (all-gathered) batches: the optimizer runs as the epilogue of the MFMA GEMM
-                                     (64, 1024, 512), (128, 256, 128), (256, 384, 512), (100, 128, 256), (6, 128, 128)])
+                                     (64, 1024, 512), (128, 256, 128), (256, 384, 512), (100, 128, 256), (6, 128, 128),
+                                     # the timed shapes: Proj.weight of the 64x1024 nets (Np = 4*64*512) at the per-GPU
+                                     # batch and at the all-gathered batch of an 8-GPU run
+                                     (32, 131072, 512), (256, 131072, 512)])
 def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
     """dg_adam_proj_fused (Proj.weight's gradient GEMM inside the optimizer kernel) against the oracle's Adam applied to
     the explicitly formed gradient wscale * dp0^T z of the same bf16 operands, incl. EMA, bf16 shadow, device step."""
