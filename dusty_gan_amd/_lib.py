@@ -105,6 +105,7 @@ PROTOTYPES = {
     "dg_extract_patches": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "dg_sample_sum": [_P, _I, _L, _I, _P, _P],
     "dg_scale": [_P, _F, _L, _P, _P],
+    "dg_zero": [_P, _L, _P],
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dg_cast": [_P, _P, _I, _L, _P],
     "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
@@ -176,6 +177,14 @@ def ptr(t):
 def stream_ptr():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def zero_(t):
+    """t.zero_() as a kernel of this library (fp32 tensors; see dg_zero in include/dusty_gan_hip.h)"""
+    import torch
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    check(lib().dg_zero(t.data_ptr(), t.numel(), stream_ptr()), "dg_zero")
+    return t
 
 
 def policy_mask(policy):

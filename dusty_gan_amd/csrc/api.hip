@@ -67,13 +67,15 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
   const bool thin_ok = dg_wgrad_thin_supported(p);
   // bf16 Down / Up layers: LDS-DMA ring version (wgrad_mfma_dma.hip); force == 6 asks for the register-staged kernel
-  if ((force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
+  static int use_dma = -1;  // DG_WGRAD_DMA=0: debugging aid (scripts/debug_seg_sync3.sh)
+  if (use_dma < 0) { const char* e = getenv("DG_WGRAD_DMA"); use_dma = e ? atoi(e) : 1; }
+  if (use_dma && (force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
     return dg_wgrad_mfma_dma_launch(p, accumulate, s);
   if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
   if (!accumulate) {
     const long n = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
-    HIP_CHECK_RET(hipMemsetAsync(p->dw, 0, sizeof(float) * n, s));
+    { const int zrc = dg_zero_f32(p->dw, n, s); if (zrc) return zrc; }
   }
   if (force == 3) return thin_ok ? dg_wgrad_thin_launch(p, s) : DG_EUNSUPPORTED;
   if (force == 0 && thin_ok) return dg_wgrad_thin_launch(p, s);
@@ -91,6 +93,8 @@ int dg_wgrad_kernel_variant(const DgWgrad* p, int force) {
   if (force == 0 && thin_ok) return 3;
   return 1;
 }
+
+int dg_zero(float* p, long n, void* stream) { return p ? dg_zero_f32(p, n, (hipStream_t)stream) : DG_EINVAL; }
 
 int dg_wgrad_kernel_choice(const DgWgrad* p) {
   if (dg_wgrad_mfma_supported(p)) return 2;

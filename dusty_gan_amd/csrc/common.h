@@ -121,6 +121,13 @@ __host__ __device__ inline void dg_wgrad1d(int wmode, int circ, int m, int Nc, i
   }
 }
 
+// Zero-fill as a KERNEL launch.  hipMemsetAsync is not used anywhere in this library: captured into a hipGraph its small
+// fills (32-byte per-sample accumulators) came back wrong on ROCm 7.2 / gfx950 in the replay that follows a host-side
+// hipStreamSynchronize - the accumulators kept garbage, DiffAugment's contrast mean blew up and the step trained on
+// 1e24-sized images (scripts/debug_seg_sync5.py; tests/test_gpu_step.py::test_graph_replay_survives_host_sync).  A kernel
+// node carries its arguments by value and replays correctly.
+int dg_zero_f32(float* p, long n, hipStream_t s);
+
 // Parameter blocks are part of the C ABI: include/dusty_gan_hip.h
 typedef DgConv ConvP;
 typedef DgWgrad WgradP;

@@ -406,7 +406,7 @@ int dg_chamfer_dir(const float* A, int Na, int n, const float* Bc, int Nb, int m
   if (wpc > 2) wpc = (wpc + 3) / 4 * 4;         // 1, 2 or whole workgroups
   const int gy = wpc >= 4 ? Na : (Na + 4 / wpc - 1) / (4 / wpc);
   const int gz = wpc >= 4 ? wpc / 4 : 1;
-  if (wpc > 1) HIP_CHECK_RET(hipMemsetAsync(L, 0, sizeof(float) * (size_t)Na * Nb, s));
+  if (wpc > 1) { const int zrc = dg_zero_f32(L, (long)Na * Nb, s); if (zrc) return zrc; }
   // TB clouds of B per workgroup: long enough to amortise the A registers, short enough for >= ~8 workgroups per CU
   int TB = 32;
   while (TB > 1 && (long)((Nb + TB - 1) / TB) * gy * gz < 2048) TB >>= 1;

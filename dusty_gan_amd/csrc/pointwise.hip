@@ -652,6 +652,20 @@ __global__ void logistic_noise_kernel(const float* __restrict__ u1, const float*
 // ----------------------------------------------------------------------------------------------------------
 static inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
+__global__ void dg_zero_kernel(float* __restrict__ p, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+
+int dg_zero_f32(float* p, long n, hipStream_t s) {
+  if (n <= 0) return DG_OK;
+  unsigned g = nblk(n);
+  if (g > 2048) g = 2048;
+  dg_zero_kernel<<<g, 256, 0, s>>>(p, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 extern "C" {
 
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* s_) {
@@ -675,7 +689,7 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
                  void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  HIP_CHECK_RET(hipMemsetAsync(y, 0, sizeof(float) * B, s));
+  { const int zrc = dg_zero_f32(y, B, s); if (zrc) return zrc; }
   unsigned slabs = nblk(n, 256 * 16);
   if (slabs > 32) slabs = 32;
   if (slabs < 1) slabs = 1;
@@ -731,7 +745,7 @@ int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* n
 
 int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  HIP_CHECK_RET(hipMemsetAsync(out, 0, sizeof(float) * B, s));
+  { const int zrc = dg_zero_f32(out, B, s); if (zrc) return zrc; }
   unsigned gx = nblk(n, 256 * 8);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
@@ -771,7 +785,7 @@ int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const in
   hipStream_t s = (hipStream_t)s_;
   const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
   if (policy & 4) {
-    HIP_CHECK_RET(hipMemsetAsync(gsum, 0, sizeof(float) * B, s));
+    { const int zrc = dg_zero_f32(gsum, B, s); if (zrc) return zrc; }
     unsigned gxn = nblk((long)H * W, 256 * 8);
     if (gxn > 64) gxn = 64;
     diffaug_bwd_sum_kernel<<<dim3(gxn, B), 256, 0, s>>>(a, gy, gsum);

@@ -533,7 +533,7 @@ class GEngine:
             self._dzT = torch.zeros(Np, Bp, dtype=self.dtype, device=self.dp[0].device)
             self._dzw = torch.empty(c.nz, Bp, dtype=torch.float32, device=self.dp[0].device)
         self._dzT[:, :B].copy_(self.dp[0].view(B, Np).t())
-        self._dzw.zero_()
+        L.zero_(self._dzw)
         shadow = st.shadow[st.seg["proj_w"].off:st.seg["proj_w"].off + Np * c.nz]
         # the kernel splits its reduction over (sample, row) units: present the Np rows as R "samples" of Np / R rows
         R = 512 if Np % (512 * 64) == 0 else 1

@@ -144,16 +144,16 @@ class FlatAdam:
         gradient is written with plain stores when there is a single micro-batch), which need no memset"""
         st = self.store
         if not skip:
-            st.grad.zero_()
+            L.zero_(st.grad)
             return
         cuts = sorted((st.seg[k].off, st.seg[k].off + st.seg[k].numel) for k in skip)
         pos = 0
         for a, b in cuts:
             if a > pos:
-                st.grad[pos:a].zero_()
+                L.zero_(st.grad[pos:a])
             pos = b
         if pos < st.n:
-            st.grad[pos:].zero_()
+            L.zero_(st.grad[pos:])
 
     def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None):
         """fused_proj = (dp0, zT, op_dtype, nb, Np, K, wscale): the first segment of the store is Proj.weight [Np][K] and
@@ -461,7 +461,7 @@ class Trainer:
         self._mb = []
         dev = self.device
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
-        scal = torch.zeros(7, dtype=torch.float32, device=dev)
+        scal = L.zero_(torch.empty(7, dtype=torch.float32, device=dev))
         f32 = dict(dtype=torch.float32, device=dev)
         for j in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
             if reals is not None:

@@ -251,6 +251,9 @@ int dg_extract_patches(const float* img, int B, int C, int H, int W, int ph, int
 /* ---- small reductions / helpers --------------------------------------------------------------------------- */
 int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */
 int dg_scale(const float* x, float a, long n, float* y, void* stream);
+/* p[0..n) = 0 as a kernel launch (optim.zero_grad, trainers/dcgan_amp.py:177,246, and the step's accumulators).  The
+ * library never uses hipMemsetAsync: its small fills replayed wrong from a hipGraph after a host-side synchronize. */
+int dg_zero(float* p, long n, void* stream);
 
 /* ---- optim.Adam.step + ema_inplace  trainers/dcgan_amp.py:116-125,238,312,316 and :30-35 ------------------ */
 int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema, void* shadow, int shadow_dtype,

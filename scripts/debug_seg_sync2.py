@@ -5,7 +5,7 @@ import torch
 from tests.test_gpu_step import make_trainer
 mode = os.environ.get("DBG_SYNC", "device")
 torch.manual_seed(300)
-tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8, amp=True)
+tr = make_trainer("none", True, (64, 1024), 512, 64, 512, int(os.environ.get("DBG_B", "8")), amp=os.environ.get("DBG_FP32") is None)
 
 def pools():
     segs = torch.cuda.memory_snapshot()

@@ -354,3 +354,22 @@ def test_graph_replay_matches_eager_launches(monkeypatch, gan_mode):
     for x, y in zip(sa, sb):
         for k in x:
             assert abs(x[k] - y[k]) < 1e-4 * max(1.0, abs(y[k])), k
+
+
+def test_graph_replay_survives_host_sync():
+    """A host-side stream synchronize between two replays of the captured step must not change what the next replay
+    computes.  Round 1 / 2 finding: with hipMemsetAsync nodes in the graph (the 32-byte per-sample accumulators of
+    DiffAugment's contrast mean, R1's |g|^2 sums, the logits) the replay after an explicit synchronize left garbage in
+    those accumulators - 1e24-sized augmented images, garbage losses, a silently corrupted run ("garbage after a
+    host-side synchronize" in the round-1 notes).  The library now zero-fills with a kernel (csrc/common.h)."""
+    torch.manual_seed(300)
+    tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8, amp=True)
+    for i in range(8):
+        s = tr.step(i)
+        if i % 2 == 1:
+            torch.cuda.current_stream().synchronize()
+        if i == 5:
+            torch.cuda.synchronize()
+        vals = list(s.values())
+        assert all(abs(v) < 50.0 for v in vals), (i, vals)
+    assert tr._graph is not None
