@@ -10,6 +10,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdustygan_hip.so")
+if os.environ.get("DUSTY_GAN_LIB_DIAG") == "1":  # kernel-development aid: `make -C csrc diag` (ablation switches, stamps)
+    LIB_PATH = os.path.join(CSRC, "libdustygan_hip_diag.so")
 
 DG_OK, DG_EINVAL, DG_EUNSUPPORTED, DG_EHIP = 0, 1, 2, 3
 DG_F32, DG_BF16 = 0, 1

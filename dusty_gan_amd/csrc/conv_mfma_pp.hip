@@ -34,6 +34,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define PP_WAIT(vm) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(vm) : "memory")
 
+// Diagnostics are compiled in only with -DDG_PP_DIAG (make DIAG=1): every runtime check in the K-step loop costs issue
+// slots the loop does not have (the LOAD half is instruction-issue bound: ~6-7 cycles per instruction beside the partner
+// wave's MFMAs).  With it, DG_CONV_DBG bits work as in the lock-step kernel (1 no DMA, 2 no MFMA, 4 no epilogue) and
+// DG_CONV_DBG & 8 adds shader-clock stamps around the segments of a K step, summed per wave and
+// written over the first bytes of the OUTPUT by workgroup 0 (scripts/bench_conv.py prints them; the output is garbage)
+__device__ __forceinline__ unsigned long long pp_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float row_add(float v) {  // v + (v of the lane CTRL selects inside the 16-lane row)
   const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
@@ -95,22 +108,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   auto swzA = [](int row) { return (row >> 1) & 7; };
   auto swzB = [](int row) { return ((row >> 1) & 1) | (((row / CPL) & 3) << 1); };
 
-  // ---- issue side (K steps in tile order, two ahead of the compute side)
-  Tile ti = first;
-  int i_left = tcount;
-  unsigned long long hl = 0, hl_row;
-  int h_left = 0;
-  int nh_row = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl_row);
-  int it_j = 0, it_kc = 0;
-  unsigned voffA[IA], voffB[IB];
-  int colA[IA];
-  unsigned sampA[IA];
-  const char* sA = nullptr;
-  const char* sB = nullptr;
+  // ---- issue side: an explicit loop nest (tile, H tap, W tap, 64-channel chunk) drives the kernel; the compute side
+  //      follows two K steps behind and only counts steps.  (A first version advanced a state machine once per K step:
+  //      ~450 instructions per step, most of them scalar bookkeeping and branches - the ablation build without DMA, MFMA
+  //      and epilogue still took 56 % of the full kernel's time.)
+  unsigned voffA[IA], voffB[IB];               // per-lane byte offsets (A: per tile and W tap, B: constant)
+  int colA[IA];                                // tile-row column inside its sample segment
+  unsigned sampA[IA];                          // byte offset of the row's sample inside the sample group + swizzled chunk
 #pragma unroll
   for (int u = 0; u < IA; ++u) {
     const int row = (wave + NWV * u) * 8 + lrow;
-    colA[u] = row & (g.SW - 1);
+    colA[u] = cmul * (row & (g.SW - 1));
     sampA[u] = (unsigned)((row >> g.lsw) * (int)p.in_sb * 2 + (pos ^ swzA(row)) * 16);
   }
 #pragma unroll
@@ -118,46 +126,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     const int row = (wave + NWV * u) * 8 + lrow;
     voffB[u] = (unsigned)(row * (int)p.w_sn * 2 + (pos ^ swzB(row)) * 16);
   }
-  auto set_wtap = [&]() {
-    const int it_r = (int)(hl & 1023) >> 2, it_ky = (int)hl & 3;
-    int coff, kx;
-    if (MODE == MODE_S2) { coff = it_j - 1; kx = it_j; }
-    else if (ti.px == 0) { coff = it_j == 0 ? 0 : -1; kx = it_j == 0 ? 1 : 3; }
-    else { coff = it_j == 0 ? 1 : 0; kx = it_j == 0 ? 0 : 2; }
-    const int wt = it_ky * 4 + kx;
-    sB = (const char*)(w + (long)wt * p.w_st + (long)(ti.nt * BN) * p.w_sn);
-    sA = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb + (long)it_r * Ws * p.in_sp);
-#pragma unroll
-    for (int u = 0; u < IA; ++u) {
-      int c = cmul * (ti.xt * BM + colA[u]) + coff;
-      if (c < 0) c += Ws; else if (c >= Ws) c -= Ws;
-      voffA[u] = (unsigned)(c * (int)p.in_sp * 2) + sampA[u];
-    }
-  };
-  auto start_tile = [&]() { hl = hl_row; h_left = nh_row; it_j = 0; it_kc = 0; set_wtap(); };
-  start_tile();
-  auto advance = [&]() {
-    if (++it_kc < KC) return;
-    it_kc = 0;
-    if (++it_j < nW) { set_wtap(); return; }
-    it_j = 0;
-    hl >>= 10;
-    if (--h_left > 0) { set_wtap(); return; }
-    if (--i_left == 0) return;
-    if (persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows)) nh_row = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl_row);
-    start_tile();
-  };
-  auto issue_step = [&](int st) {              // this wave's IPT pieces of the next K step into stage st
-    unsigned char* base = lds + st * STAGE;
-    const unsigned k0b = (unsigned)it_kc * SB;
-    if (!(g.dbg & 1)) {
-#pragma unroll
-      for (int u = 0; u < IA; ++u) dma16(sA + k0b + voffA[u], base + (wave + NWV * u) * 1024);
-#pragma unroll
-      for (int u = 0; u < IB; ++u) dma16(sB + k0b + voffB[u], base + BM * SB + (wave + NWV * u) * 1024);
-    }
-    advance();
-  };
+  const char* sA_k = nullptr;                  // wave-uniform bases of the K step being issued
+  const char* sB_k = nullptr;
+  const unsigned dst_wave = (unsigned)wave * 1024u;
 
   // ---- compute side constants
   const int wm = wave >> 1, wn = wave & 1;
@@ -182,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   __syncthreads();
 
   f32x4_t acc[TM][TN];
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -201,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
     pix_off[i] = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2) + lane_coff;
   }
-  auto tile_off = [&](const Tile& t) -> long {  // element offset of (sample group, row Y, first column, first channel)
+  auto tile_off = [&](const Tile& t) __attribute__((always_inline)) -> long {  // element offset of (sample group, row Y, first column, first channel)
     const int n0 = t.xt * BM;
     return (long)(t.bt * g.NSB) * p.out_sb + ((long)t.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + t.px)) * p.out_sp +
            t.nt * BN;
@@ -209,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // The leaky-relu mask source of a tile being finished (EPI_MASK) is fetched into the FRAGMENT registers of k-step 0
   // (fp[0][i], fw[0][i]: 8 x 16 bytes, exactly one lane's 4 pixels x 32 bytes) once the last K step's first 16 MFMAs
   // have read them: no extra registers, and the loads fly under the remaining 16 MFMAs and the barrier.
-  auto load_aux = [&](const Tile& t) {
+  auto load_aux = [&](const Tile& t) __attribute__((always_inline)) {
     const char* ab = (const char*)((const bf16*)p.aux + tile_off(t));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -218,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(fw[0][i]) : "v"(src) : "memory");
     }
   };
-  auto epilogue = [&](const Tile& t) {
+  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
     char* ob = (char*)(out + tile_off(t));
     if (MASK) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,28 +217,37 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       asm volatile("" : "+v"(rs));
     }
+    // (no pointers into fp / fw / acc anywhere below: an address-taken register array ends up in scratch memory)
     i32x4 opk[TM][NST / TM];                   // packed outputs (kept for the bias-gradient sums: acc / aux are dead by then)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      alignas(16) bf16 o[CPL];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] * p.scale;
-          if (MASK) {
-            const bf16* av = (4 * j + r < 8) ? (const bf16*)&fp[0][i] : (const bf16*)&fw[0][i];
-            v *= ((float)av[(4 * j + r) & 7] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
-          } else {
-            v += bias[j][r];
-            if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
-          }
-          o[4 * j + r] = (bf16)v;
-        }
 #pragma unroll
       for (int h = 0; h < NST / TM; ++h) {
-        opk[i][h] = *(const i32x4*)&o[8 * h];
-        *(i32x4*)(ob + pix_off[i] + 16 * h) = opk[i][h];
+        const i32x4 ax = h == 0 ? fp[0][i] : fw[0][i];   // mask source of channels 8h .. 8h+7 (MASK only)
+        i32x4 pk;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {                 // two channels per 32-bit word
+          float v2[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int c = 8 * h + 2 * e2 + q, j = c >> 2, r = c & 3;
+            float v = acc[i][j][r] * p.scale;
+            if (MASK) {
+              const unsigned w32 = (unsigned)ax[e2];
+              const float a = __builtin_bit_cast(float, q ? (w32 & 0xffff0000u) : (w32 << 16));
+              v *= (a > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+            } else {
+              v += bias[j][r];
+              if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
+            }
+            v2[q] = v;
+          }
+          const unsigned lo = __builtin_bit_cast(unsigned short, (bf16)v2[0]);
+          const unsigned hi = __builtin_bit_cast(unsigned short, (bf16)v2[1]);
+          pk[e2] = (int)(lo | (hi << 16));
+        }
+        opk[i][h] = pk;
+        *(i32x4*)(ob + pix_off[i] + 16 * h) = pk;
       }
       __builtin_amdgcn_sched_barrier(0);       // one pixel block at a time: keeps the live ranges (and VGPRs) short
     }
@@ -276,7 +256,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       for (int c = 0; c < CPL; ++c) {
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) v += (float)((const bf16*)&opk[i][0])[c];
+        for (int i = 0; i < TM; ++i) {
+          const unsigned w32 = (unsigned)opk[i][c >> 3][(c & 7) >> 1];
+          v += __builtin_bit_cast(float, (c & 1) ? (w32 & 0xffff0000u) : (w32 << 16));
+        }
         v = row_add<0xB1>(v);                  // quad_perm [1,0,3,2]
         v = row_add<0x4E>(v);                  // quad_perm [2,3,0,1]
         v = row_add<0x124>(v);                 // row_ror 4
@@ -291,56 +274,68 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     zero_acc();
   };
 
-  // ---- prologue: K steps 0 and 1 in flight, step 0 landed and published; group B starts one barrier late
-  int issued = 0;
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-    if (i_left > 0) { issue_step(d); ++issued; }
-  if (issued == 2) PP_WAIT(IPT); else PP_WAIT(0);
-  __builtin_amdgcn_s_barrier();
-  if (wave >= 4) __builtin_amdgcn_s_barrier();
-
-  Tile tc = first;
-  unsigned long long dummy;
-  int nh_c = persist::pack_htaps<MODE>(p.adj, tc.Y, p.Hc, dummy);
-  int st_c = 0, st_i = 2;                      // stage of the K step being loaded / stage refilled during it
+  // ---- main loop
+  if (wave >= 4) __builtin_amdgcn_s_barrier(); // group B runs one barrier behind group A
+  int warm = 2;                                // the compute side starts with the third step
+  int c_rem = 0, nsteps_q = 0;                 // K steps left in the compute side's tile / steps of the tile issued last
+  unsigned so_c = 0, so_i = 0;                 // LDS offset of the stage being read / refilled
   bool pending = false;                        // a finished tile waits for its epilogue
-  Tile tdone = first;
-  for (int c = 0; c < tcount; ++c) {
-    const int nsteps = nh_c * nW * KC;
-    for (int s = 0; s < nsteps; ++s) {
-      // ================= LOAD(t)
-      const bool epi_now = pending;
+  Tile tc = first, tdone = first;
+
+  // one K step: LOAD half (epilogue of a finished tile, fragment reads of the compute step, DMA of the issue step, waits)
+  // | barrier | MFMA half | barrier
+  // (always_inline: a lambda left as a call keeps the captured register arrays - acc, fp, fw - in scratch memory)
+#ifdef DG_PP_DIAG
+  const int dbg = g.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+  const bool stamps = (dbg & 8) != 0;
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};  // LOAD work, LOAD waits, barrier 1, MFMA half, barrier 2, between steps
+  unsigned long long tend = 0;
+  auto step = [&](const bool iss) __attribute__((always_inline)) {
+    const bool comp = warm == 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    if (stamps) { t0 = pp_stamp(); if (tend) tsum[5] += t0 - tend; }
+    if (comp) {
       if (pending) {
-        if (!(g.dbg & 4)) epilogue(tdone); else zero_acc();
+        if (!(dbg & 4)) epilogue(tdone); else zero_acc();
         pending = false;
       }
-      {
-        const unsigned so = lds0 + (unsigned)st_c * STAGE;
-        const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
+      const unsigned so = lds0 + so_c;
+      const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          LDS_READ128(fp[0][i], pa0, i * 16 * SB);
-          LDS_READ128(fp[1][i], pa1, i * 16 * SB);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          LDS_READ128(fw[0][j], wa0, j * 4 * SB);
-          LDS_READ128(fw[1][j], wa1, j * 4 * SB);
-        }
+      for (int i = 0; i < TM; ++i) {
+        LDS_READ128(fp[0][i], pa0, i * 16 * SB);
+        LDS_READ128(fp[1][i], pa1, i * 16 * SB);
       }
-      const bool iss = i_left > 0;
-      if (iss) issue_step(st_i);
-      // own pieces of K step t+1 landed (everything but this interval's pieces and the epilogue's stores); fragments in
-      if (iss) { if (epi_now) PP_WAIT(IPT + NST); else PP_WAIT(IPT); }
-      else     { if (epi_now) PP_WAIT(NST); else PP_WAIT(0); }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ================= MFMA(t)
-      const bool last = s + 1 == nsteps;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        LDS_READ128(fw[0][j], wa0, j * 4 * SB);
+        LDS_READ128(fw[1][j], wa1, j * 4 * SB);
+      }
+    }
+    if (iss && !(dbg & 1)) {
+      unsigned char* base = lds + so_i + dst_wave;
+#pragma unroll
+      for (int u = 0; u < IA; ++u) dma16(sA_k + voffA[u], base + NWV * u * 1024);
+#pragma unroll
+      for (int u = 0; u < IB; ++u) dma16(sB_k + voffB[u], base + BM * SB + NWV * u * 1024);
+    }
+    if (stamps) t1 = pp_stamp();
+    // own pieces of the PREVIOUS issue step landed (everything but this step's pieces and the epilogue's stores), and
+    // the fragments are in
+    // (the stores of an epilogue that ran in this half are waited for too - once per tile, they are mostly retired)
+    if (iss) PP_WAIT(IPT); else PP_WAIT(0);
+    if (stamps) t2 = pp_stamp();
+    __builtin_amdgcn_s_barrier();
+    if (stamps) t3 = pp_stamp();
+    __builtin_amdgcn_sched_barrier(0);
+    if (comp) {
+      const bool last = c_rem == 1;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if (!(g.dbg & 2)) {
+        if (!(dbg & 2)) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -350,19 +345,73 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
         }
         if (ks == 0) {
           __builtin_amdgcn_sched_barrier(0);
-          if (MASK && last && !(g.dbg & 4)) load_aux(tc);
+          if (MASK && last && !(dbg & 4)) load_aux(tc);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      st_c = st_c + 1 == NS ? 0 : st_c + 1;
-      st_i = st_i + 1 == NS ? 0 : st_i + 1;
+      if (last) {
+        pending = true;
+        tdone = tc;
+        persist::next_tile<MODE>(tc, tiles_n, tiles_x, rows);
+        c_rem = nsteps_q;
+      } else {
+        --c_rem;
+      }
+      so_c = so_c + STAGE == NS * STAGE ? 0u : so_c + STAGE;
+    } else {
+      --warm;
     }
-    pending = true;
-    tdone = tc;
-    if (persist::next_tile<MODE>(tc, tiles_n, tiles_x, rows)) nh_c = persist::pack_htaps<MODE>(p.adj, tc.Y, p.Hc, dummy);
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamps) t4 = pp_stamp();
+    __builtin_amdgcn_s_barrier();
+    if (stamps) {
+      t5 = pp_stamp();
+      tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
+      tend = t5;
+    }
+    so_i = so_i + STAGE == NS * STAGE ? 0u : so_i + STAGE;
+  };
+
+  const unsigned spb = (unsigned)p.in_sp * 2u;   // bytes per input pixel (< 2^24)
+  const long tap_b = (long)p.w_st * 2;           // bytes per weight tap
+  Tile ti = first;
+  for (int c = 0; c < tcount; ++c) {
+    unsigned long long hl;
+    const int nh = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl);
+    nsteps_q = nh * nW * KC;
+    if (c == 0) c_rem = nsteps_q;
+    const char* in_t = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb);
+    const char* w_t = (const char*)(w + (long)(ti.nt * BN) * p.w_sn);
+    const int x0 = cmul * ti.xt * BM;
+    for (int h = 0; h < nh; ++h) {
+      const int it_r = (int)(hl & 1023) >> 2, it_ky = (int)hl & 3;
+      hl >>= 10;
+      const char* sA_row = in_t + (long)it_r * Ws * p.in_sp * 2;
+      for (int j = 0; j < nW; ++j) {
+        int coff, kx;
+        if (MODE == MODE_S2) { coff = j - 1; kx = j; }
+        else if (ti.px == 0) { coff = j == 0 ? 0 : -1; kx = j == 0 ? 1 : 3; }
+        else { coff = j == 0 ? 1 : 0; kx = j == 0 ? 0 : 2; }
+        const char* sB_row = w_t + (long)(it_ky * 4 + kx) * tap_b;
+#pragma unroll
+        for (int u = 0; u < IA; ++u)             // circular columns: Ws is a power of two (checked by the launcher)
+          voffA[u] = __umul24((unsigned)((x0 + colA[u] + coff) & (Ws - 1)), spb) + sampA[u];
+        for (int kc = 0; kc < KC; ++kc) {
+          sA_k = sA_row + kc * SB;
+          sB_k = sB_row + kc * SB;
+          step(true);
+        }
+      }
+    }
+    persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows);
   }
-  if (pending && !(g.dbg & 4)) epilogue(tdone);
+  step(false);
+  step(false);
+  if (pending && !(dbg & 4)) epilogue(tdone);
+  if (stamps && blockIdx.x == 0 && lane == 0) {
+    float* sink = (float*)p.out + wave * 8;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = 0; k < 6; ++k) sink[k] = (float)tsum[k];
+  }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // pairs with group B's late start
   if (want_db) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -408,6 +457,8 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
   if (p->out_sp % 8 != 0 || p->in_sp % 8 != 0 || p->w_sn % 8 != 0) return DG_EUNSUPPORTED;   // 16-byte pieces
   if (p->N > 512 || (p->bias && p->bias_mod < p->N && p->N % p->bias_mod != 0)) return DG_EUNSUPPORTED;
   if (p->dbias && p->bias_mod < p->N) return DG_EUNSUPPORTED;
+  const int Ws = p->mode == MODE_S2 ? 2 * p->Wc : p->Wc;
+  if ((Ws & (Ws - 1)) != 0 || p->in_sp * 2 >= (1 << 24)) return DG_EUNSUPPORTED;  // column wrap by mask, 24-bit multiply
   const bool mask = p->epi == EPI_MASK;
   if (mask ? p->bias != nullptr : p->dbias != nullptr) return DG_EUNSUPPORTED;   // combinations no layer uses
   if (p->rowscale && p->B > 512) return DG_EUNSUPPORTED;

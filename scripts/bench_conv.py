@@ -68,6 +68,12 @@ for name, mode, adj, Hc, Wc, K, N, bm in CONV:
     tot_ms += ms
     tot_fl += fl
     print(f"{name:10s} B{n:3d} {Hc:2d}x{Wc:3d} K{K:3d} N{N:3d}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TFLOP/s")
+    if int(os.environ.get("DG_CONV_DBG", "0")) & 8:  # cycle stamps of workgroup 0 (waves 0 and 4), see conv_mfma_pp.hip
+        st = out[:128].view(torch.float32).tolist()
+        for wv, v in ((f"wave{k}", st[8 * k:8 * k + 6]) for k in (0, 4)):
+            tot = sum(v) or 1.0
+            print(f"    {wv}: cycles load {v[0]:.0f} ({100 * v[0] / tot:.0f}%) wait {v[1]:.0f} ({100 * v[1] / tot:.0f}%) bar1 {v[2]:.0f} "
+                  f"({100 * v[2] / tot:.0f}%) mfma {v[3]:.0f} ({100 * v[3] / tot:.0f}%) bar2 {v[4]:.0f} ({100 * v[4] / tot:.0f}%) gap {v[5]:.0f} ({100 * v[5] / tot:.0f}%) total {tot:.0f}")
 print(f"conv total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
 
 o.force = 2
