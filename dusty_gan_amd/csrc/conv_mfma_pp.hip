@@ -302,25 +302,41 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
         if (!(dbg & 4)) epilogue(tdone); else zero_acc();
         pending = false;
       }
+    }
+    // The wave's 6 LDS-DMA pieces are accepted at the texture path's rate (64 B/clk per CU: a 1 KiB piece every ~15
+    // cycles, i.e. every ~60 for each of the four waves issuing), the 16 fragment reads at the LDS's (256 B/clk: ~16
+    // cycles per read with four waves reading).  Issued back to back the two take 360 + 256 cycles of the half that
+    // decides the step time; alternated - reads while the next piece waits for the texture path - they overlap.
+    {
       const unsigned so = lds0 + so_c;
       const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
+      unsigned char* dst = lds + so_i + dst_wave;
+      auto piece = [&](int q) __attribute__((always_inline)) {
+        if (!iss || (dbg & 1)) return;
+        if (q < IA) dma16(sA_k + voffA[q], dst + NWV * q * 1024);
+        else dma16(sB_k + voffB[q - IA], dst + BM * SB + NWV * (q - IA) * 1024);
+      };
+      constexpr int NR = 2 * TM + 2 * TN;      // fragment reads
+      if (comp) {
+        int q = 0;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        LDS_READ128(fp[0][i], pa0, i * 16 * SB);
-        LDS_READ128(fp[1][i], pa1, i * 16 * SB);
+        for (int r = 0; r < NR; ++r) {
+          // one piece after every NR / IPT reads, the first one up front
+          if (q < IPT && r * IPT >= q * NR) { piece(q); ++q; }
+          if (r < 2 * TM) {
+            const int i = r >> 1;
+            if (r & 1) LDS_READ128(fp[1][i], pa1, i * 16 * SB); else LDS_READ128(fp[0][i], pa0, i * 16 * SB);
+          } else {
+            const int j = (r - 2 * TM) >> 1;
+            if (r & 1) LDS_READ128(fw[1][j], wa1, j * 4 * SB); else LDS_READ128(fw[0][j], wa0, j * 4 * SB);
+          }
+        }
+#pragma unroll
+        for (; q < IPT; ++q) piece(q);
+      } else {
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) piece(q);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        LDS_READ128(fw[0][j], wa0, j * 4 * SB);
-        LDS_READ128(fw[1][j], wa1, j * 4 * SB);
-      }
-    }
-    if (iss && !(dbg & 1)) {
-      unsigned char* base = lds + so_i + dst_wave;
-#pragma unroll
-      for (int u = 0; u < IA; ++u) dma16(sA_k + voffA[u], base + NWV * u * 1024);
-#pragma unroll
-      for (int u = 0; u < IB; ++u) dma16(sB_k + voffB[u], base + BM * SB + NWV * u * 1024);
     }
     if (stamps) t1 = pp_stamp();
     // own pieces of the PREVIOUS issue step landed (everything but this step's pieces and the epilogue's stores), and
