@@ -25,6 +25,8 @@
 // no LDS transpose, no barrier, and it runs while the other group's MFMAs keep the matrix pipe busy.
 #include "conv_mfma_persist_impl.h"
 
+#include <type_traits>
+
 namespace pp {
 
 using persist::Geo;
@@ -108,12 +110,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   auto swzA = [](int row) { return (row >> 1) & 7; };
   auto swzB = [](int row) { return ((row >> 1) & 1) | (((row / CPL) & 3) << 1); };
 
-  // ---- issue side: an explicit loop nest (tile, H tap, W tap, 64-channel chunk) drives the kernel; the compute side
-  //      follows two K steps behind and only counts steps.  (A first version advanced a state machine once per K step:
-  //      ~450 instructions per step, most of them scalar bookkeeping and branches - the ablation build without DMA, MFMA
-  //      and epilogue still took 56 % of the full kernel's time.)
-  unsigned voffA[IA], voffB[IB];               // per-lane byte offsets (A: per tile and W tap, B: constant)
-  int colA[IA];                                // tile-row column inside its sample segment
+  // ---- issue side.  K steps of a tile run (H tap, 64-channel chunk, W tap) with the nW W taps INNERMOST and unrolled:
+  //      consecutive steps then differ by a per-lane column shift (precomputed per tile: voffA[tap]) and the weight tap
+  //      only, the compute side - two steps behind - meets its tile boundary at FIXED positions of the unrolled group
+  //      (last step at position 1 of a tile's first group, epilogue in front of position 2 % nW), and a K step costs
+  //      ~25 scalar instructions.  (A state machine advanced once per K step cost ~80 scalar instructions and 16
+  //      branches per step - SQ_INSTS_SALU was 2.4x SQ_INSTS_MFMA - and the instruction issue of the LOAD half, not the
+  //      LDS, the texture path or the matrix pipe, bounded the kernel.)
+  unsigned voffA[nW][IA], voffB[IB];           // per-lane byte offsets (A: per tile and W tap, B: constant)
+  int colA[IA];                                // (stride-scaled) tile-row column inside its sample segment
   unsigned sampA[IA];                          // byte offset of the row's sample inside the sample group + swizzled chunk
 #pragma unroll
   for (int u = 0; u < IA; ++u) {
@@ -126,8 +131,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     const int row = (wave + NWV * u) * 8 + lrow;
     voffB[u] = (unsigned)(row * (int)p.w_sn * 2 + (pos ^ swzB(row)) * 16);
   }
-  const char* sA_k = nullptr;                  // wave-uniform bases of the K step being issued
-  const char* sB_k = nullptr;
   const unsigned dst_wave = (unsigned)wave * 1024u;
 
   // ---- compute side constants
@@ -275,16 +278,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   };
 
   // ---- main loop
-  if (wave >= 4) __builtin_amdgcn_s_barrier(); // group B runs one barrier behind group A
-  int warm = 2;                                // the compute side starts with the third step
-  int c_rem = 0, nsteps_q = 0;                 // K steps left in the compute side's tile / steps of the tile issued last
-  unsigned so_c = 0, so_i = 0;                 // LDS offset of the stage being read / refilled
-  bool pending = false;                        // a finished tile waits for its epilogue
-  Tile tc = first, tdone = first;
-
-  // one K step: LOAD half (epilogue of a finished tile, fragment reads of the compute step, DMA of the issue step, waits)
-  // | barrier | MFMA half | barrier
-  // (always_inline: a lambda left as a call keeps the captured register arrays - acc, fp, fw - in scratch memory)
 #ifdef DG_PP_DIAG
   const int dbg = g.dbg;
 #else
@@ -293,136 +286,147 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const bool stamps = (dbg & 8) != 0;
   unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};  // LOAD work, LOAD waits, barrier 1, MFMA half, barrier 2, between steps
   unsigned long long tend = 0;
-  auto step = [&](const bool iss) __attribute__((always_inline)) {
-    const bool comp = warm == 0;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-    if (stamps) { t0 = pp_stamp(); if (tend) tsum[5] += t0 - tend; }
-    if (comp) {
-      if (pending) {
-        if (!(dbg & 4)) epilogue(tdone); else zero_acc();
+
+  if (wave >= 4) __builtin_amdgcn_s_barrier(); // group B runs one barrier behind group A
+  unsigned so_c = STAGE, so_i = 0;             // LDS offset of the stage read / refilled (compute = issue - 2 = issue + 1 mod 3)
+  bool pending = false;                        // a finished tile waits for its epilogue
+  bool warm = true;                            // the very first group: no compute step behind positions 0 and 1
+  Tile tprev = first;                          // the tile the compute side is finishing / has finished
+  const char* sA_k = nullptr;                  // wave-uniform bases of the (H tap, channel chunk) being issued
+  const char* sB_k = nullptr;
+  const long tap_b = (long)p.w_st * 2;         // bytes per weight tap
+  const unsigned spb = (unsigned)p.in_sp * 2u; // bytes per input pixel (< 2^24)
+
+  // one LDS-DMA piece: wave-uniform 64-bit base + per-lane 32-bit offset -> LDS at M0 (written in the same statement;
+  // nothing else in this kernel uses M0)
+  auto dma_s = [&](unsigned voff, const char* sbase, unsigned ldsaddr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
+  };
+
+  // One group = the nW W taps of one (H tap, channel chunk): nW K steps, each
+  //   LOAD half (epilogue of a finished tile; fragment reads of the compute step alternated with the DMA of the issue
+  //   step; waits) | barrier | MFMA half | barrier
+  // first: the group opens a tile (or is the drain group after the last one), so positions 0 and 1 still compute the
+  // previous tile.  kx0 / kxs: W taps of the group are kx0 + j * kxs.
+  auto group = [&](auto iss_tag, const bool first, const int kx0, const int kxs) __attribute__((always_inline)) {
+    constexpr bool ISS = decltype(iss_tag)::value;
+#pragma unroll
+    for (int j = 0; j < nW; ++j) {
+      if (!ISS && j >= 2) {                      // drain: nothing left to compute, keep the barrier count
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        continue;
+      }
+      unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+      if (stamps) { t0 = pp_stamp(); if (tend) tsum[5] += t0 - tend; }
+      const bool comp = j >= 2 || !(first && warm);            // runtime only at positions 0 and 1
+      const bool last = j == 1 && first && !warm;              // the compute step closes the previous tile
+      if (j == 2 % nW && pending) {
+        if (!(dbg & 4)) epilogue(tprev); else zero_acc();
         pending = false;
       }
-    }
-    // The wave's 6 LDS-DMA pieces are accepted at the texture path's rate (64 B/clk per CU: a 1 KiB piece every ~15
-    // cycles, i.e. every ~60 for each of the four waves issuing), the 16 fragment reads at the LDS's (256 B/clk: ~16
-    // cycles per read with four waves reading).  Issued back to back the two take 360 + 256 cycles of the half that
-    // decides the step time; alternated - reads while the next piece waits for the texture path - they overlap.
-    {
-      const unsigned so = lds0 + so_c;
-      const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
-      unsigned char* dst = lds + so_i + dst_wave;
-      auto piece = [&](int q) __attribute__((always_inline)) {
-        if (!iss || (dbg & 1)) return;
-        if (q < IA) dma16(sA_k + voffA[q], dst + NWV * q * 1024);
-        else dma16(sB_k + voffB[q - IA], dst + BM * SB + NWV * (q - IA) * 1024);
-      };
-      constexpr int NR = 2 * TM + 2 * TN;      // fragment reads
-      if (comp) {
-        int q = 0;
-#pragma unroll
+      {
+        const unsigned so = lds0 + so_c;
+        const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
+        const unsigned dst = lds0 + so_i + dst_wave;
+        const char* sB_j = sB_k + (long)(kx0 + j * kxs) * tap_b;
+        auto piece = [&](int q) __attribute__((always_inline)) {
+          if (!ISS || (dbg & 1)) return;
+          if (q < IA) dma_s(voffA[j][q], sA_k, dst + NWV * q * 1024);
+          else dma_s(voffB[q - IA], sB_j, dst + BM * SB + NWV * (q - IA) * 1024);
+        };
+        constexpr int NR = 2 * TM + 2 * TN;      // fragment reads (unconditional: behind positions 0 and 1 of the very
+        int q = 0;                               // first group they fetch bytes nobody uses - cheaper than a second
+#pragma unroll                                   // register set for a conditionally written fragment)
         for (int r = 0; r < NR; ++r) {
-          // one piece after every NR / IPT reads, the first one up front
-          if (q < IPT && r * IPT >= q * NR) { piece(q); ++q; }
+          if (q < IPT && r * IPT >= q * NR) { piece(q); ++q; }   // a piece after every NR / IPT reads
+          if (dbg & 16) continue;
           if (r < 2 * TM) {
             const int i = r >> 1;
             if (r & 1) LDS_READ128(fp[1][i], pa1, i * 16 * SB); else LDS_READ128(fp[0][i], pa0, i * 16 * SB);
           } else {
-            const int j = (r - 2 * TM) >> 1;
-            if (r & 1) LDS_READ128(fw[1][j], wa1, j * 4 * SB); else LDS_READ128(fw[0][j], wa0, j * 4 * SB);
+            const int jj = (r - 2 * TM) >> 1;
+            if (r & 1) LDS_READ128(fw[1][jj], wa1, jj * 4 * SB); else LDS_READ128(fw[0][jj], wa0, jj * 4 * SB);
           }
         }
 #pragma unroll
         for (; q < IPT; ++q) piece(q);
-      } else {
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) piece(q);
       }
-    }
-    if (stamps) t1 = pp_stamp();
-    // own pieces of the PREVIOUS issue step landed (everything but this step's pieces and the epilogue's stores), and
-    // the fragments are in
-    // (the stores of an epilogue that ran in this half are waited for too - once per tile, they are mostly retired)
-    if (iss) PP_WAIT(IPT); else PP_WAIT(0);
-    if (stamps) t2 = pp_stamp();
-    __builtin_amdgcn_s_barrier();
-    if (stamps) t3 = pp_stamp();
-    __builtin_amdgcn_sched_barrier(0);
-    if (comp) {
-      const bool last = c_rem == 1;
+      if (stamps) t1 = pp_stamp();
+      // own pieces of the PREVIOUS issue step landed (everything but this step's pieces; the stores of an epilogue that
+      // ran in this half are waited for too - once per tile, mostly retired), and the fragments are in
+      if (ISS) PP_WAIT(IPT); else PP_WAIT(0);
+      if (stamps) t2 = pp_stamp();
+      __builtin_amdgcn_s_barrier();
+      if (stamps) t3 = pp_stamp();
+      __builtin_amdgcn_sched_barrier(0);
+      if (comp) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (!(dbg & 2)) {
+        for (int ks = 0; ks < 2; ++ks) {
+          if (!(dbg & 2)) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[ks][j]),
-                                                                   __builtin_bit_cast(bf16x8, fp[ks][i]), acc[i][j], 0, 0, 0);
+              for (int jj = 0; jj < TN; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[ks][jj]),
+                                                                      __builtin_bit_cast(bf16x8, fp[ks][i]), acc[i][jj], 0, 0, 0);
+          }
+          if (ks == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (MASK && last && !(dbg & 4)) load_aux(tprev);
+          }
         }
-        if (ks == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (MASK && last && !(dbg & 4)) load_aux(tc);
-        }
-      }
-      if (last) {
-        pending = true;
-        tdone = tc;
-        persist::next_tile<MODE>(tc, tiles_n, tiles_x, rows);
-        c_rem = nsteps_q;
+        if (last) pending = true;
+        so_c = so_c + STAGE == NS * STAGE ? 0u : so_c + STAGE;
       } else {
-        --c_rem;
+        so_c = so_c + STAGE == NS * STAGE ? 0u : so_c + STAGE;
       }
-      so_c = so_c + STAGE == NS * STAGE ? 0u : so_c + STAGE;
-    } else {
-      --warm;
+      __builtin_amdgcn_sched_barrier(0);
+      if (stamps) t4 = pp_stamp();
+      __builtin_amdgcn_s_barrier();
+      if (stamps) {
+        t5 = pp_stamp();
+        tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
+        tend = t5;
+      }
+      so_i = so_i + STAGE == NS * STAGE ? 0u : so_i + STAGE;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamps) t4 = pp_stamp();
-    __builtin_amdgcn_s_barrier();
-    if (stamps) {
-      t5 = pp_stamp();
-      tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
-      tend = t5;
-    }
-    so_i = so_i + STAGE == NS * STAGE ? 0u : so_i + STAGE;
   };
 
-  const unsigned spb = (unsigned)p.in_sp * 2u;   // bytes per input pixel (< 2^24)
-  const long tap_b = (long)p.w_st * 2;           // bytes per weight tap
   Tile ti = first;
   for (int c = 0; c < tcount; ++c) {
     unsigned long long hl;
     const int nh = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl);
-    nsteps_q = nh * nW * KC;
-    if (c == 0) c_rem = nsteps_q;
     const char* in_t = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb);
     const char* w_t = (const char*)(w + (long)(ti.nt * BN) * p.w_sn);
     const int x0 = cmul * ti.xt * BM;
+    // W taps of this tile: S2 kx = 0..3 at column offsets -1..2; UP (column parity px) kx = 1,3 at 0,-1 or kx = 0,2 at 1,0
+    const int kx0 = MODE == MODE_S2 ? 0 : (ti.px == 0 ? 1 : 0), kxs = MODE == MODE_S2 ? 1 : 2;
+#pragma unroll
+    for (int j = 0; j < nW; ++j) {
+      const int coff = MODE == MODE_S2 ? j - 1 : (ti.px == 0 ? -j : 1 - j);
+#pragma unroll
+      for (int u = 0; u < IA; ++u)               // circular columns: Ws is a power of two (checked by the launcher)
+        voffA[j][u] = __umul24((unsigned)((x0 + colA[u] + coff) & (Ws - 1)), spb) + sampA[u];
+    }
+    bool firstg = true;
     for (int h = 0; h < nh; ++h) {
       const int it_r = (int)(hl & 1023) >> 2, it_ky = (int)hl & 3;
       hl >>= 10;
-      const char* sA_row = in_t + (long)it_r * Ws * p.in_sp * 2;
-      for (int j = 0; j < nW; ++j) {
-        int coff, kx;
-        if (MODE == MODE_S2) { coff = j - 1; kx = j; }
-        else if (ti.px == 0) { coff = j == 0 ? 0 : -1; kx = j == 0 ? 1 : 3; }
-        else { coff = j == 0 ? 1 : 0; kx = j == 0 ? 0 : 2; }
-        const char* sB_row = w_t + (long)(it_ky * 4 + kx) * tap_b;
-#pragma unroll
-        for (int u = 0; u < IA; ++u)             // circular columns: Ws is a power of two (checked by the launcher)
-          voffA[u] = __umul24((unsigned)((x0 + colA[u] + coff) & (Ws - 1)), spb) + sampA[u];
-        for (int kc = 0; kc < KC; ++kc) {
-          sA_k = sA_row + kc * SB;
-          sB_k = sB_row + kc * SB;
-          step(true);
-        }
+      const char* sA_row = in_t + (long)it_r * Ws * spb;
+      const char* sB_row = w_t + (long)(it_ky * 4) * tap_b;
+      for (int kc = 0; kc < KC; ++kc) {
+        sA_k = sA_row + kc * SB;
+        sB_k = sB_row + kc * SB;
+        group(std::true_type{}, firstg, kx0, kxs);
+        if (firstg) { firstg = false; warm = false; }
       }
     }
+    tprev = ti;
     persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows);
   }
-  step(false);
-  step(false);
-  if (pending && !(dbg & 4)) epilogue(tdone);
+  group(std::false_type{}, true, 0, 0);
+  if (pending && !(dbg & 4)) epilogue(tprev);
   if (stamps && blockIdx.x == 0 && lane == 0) {
     float* sink = (float*)p.out + wave * 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

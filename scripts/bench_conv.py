@@ -4,7 +4,7 @@ import math
 import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from dusty_gan_amd import _lib as L
@@ -76,6 +76,8 @@ for name, mode, adj, Hc, Wc, K, N, bm in CONV:
                   f"({100 * v[2] / tot:.0f}%) mfma {v[3]:.0f} ({100 * v[3] / tot:.0f}%) bar2 {v[4]:.0f} ({100 * v[4] / tot:.0f}%) gap {v[5]:.0f} ({100 * v[5] / tot:.0f}%) total {tot:.0f}")
 print(f"conv total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
 
+if len(sys.argv) > 3 and sys.argv[3] == "convonly":
+    sys.exit(0)
 o.force = 2
 tot_ms, tot_fl = 0.0, 0.0
 for name, wmode, Hc, Wc, Ci, Co, bm in WGRAD:
