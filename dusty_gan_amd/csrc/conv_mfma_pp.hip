@@ -36,10 +36,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define PP_WAIT(vm) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(vm) : "memory")
 
-// Diagnostics are compiled in only with -DDG_PP_DIAG (make DIAG=1): every runtime check in the K-step loop costs issue
+// Diagnostics are compiled in only with -DDG_PP_DIAG=<bits> (make diag DIAGBITS=<bits>, default 8): every runtime check in the K-step loop costs issue
 // slots the loop does not have (the LOAD half is instruction-issue bound: ~6-7 cycles per instruction beside the partner
-// wave's MFMAs).  With it, DG_CONV_DBG bits work as in the lock-step kernel (1 no DMA, 2 no MFMA, 4 no epilogue) and
-// DG_CONV_DBG & 8 adds shader-clock stamps around the segments of a K step, summed per wave and
+// wave's MFMAs).  Bits as in the lock-step kernel's DG_CONV_DBG (1 no DMA, 2 no MFMA, 4 no epilogue, 16 no
+// fragment reads); 8 adds shader-clock stamps around the segments of a K step, summed per wave and
 // written over the first bytes of the OUTPUT by workgroup 0 (scripts/bench_conv.py prints them; the output is garbage)
 __device__ __forceinline__ unsigned long long pp_stamp() {
   unsigned long long t;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 
   // ---- main loop
 #ifdef DG_PP_DIAG
-  const int dbg = g.dbg;
+  constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
 #else
   constexpr int dbg = 0;
 #endif
