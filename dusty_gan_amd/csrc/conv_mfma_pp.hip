@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const unsigned srs0 = sdb0 + NDB * 4;
   const bool want_db = MASK && p.dbias != nullptr;
   for (int i = tid; i < NDB; i += 64 * NWV) {
-    s_bias[i] = (!MASK && p.bias && i < p.N) ? p.bias[i % p.bias_mod] : 0.f;
+    s_bias[i] = (!MASK && p.bias && i < p.N) ? p.bias[i % p.bias_mod] * (p.epi == EPI_LRELU ? SQRT2 : 1.f) : 0.f;
     s_db[i] = 0.f;
     s_rs[i] = (p.rowscale && i < p.B) ? p.rowscale[i] : 1.f;
   }
@@ -192,6 +192,24 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(fw[0][i]) : "v"(src) : "memory");
     }
   };
+  // Bias-gradient sums (EPI_MASK with dbias): per lane 4 TN channel sums over its pixels, weighted per sample, of the
+  // fp32 values BEFORE rounding; reduced over the 16 pixel lanes and added to the LDS accumulators once per tile.
+  // (Keeping the sums in registers across the tiles of a workgroup - one N tile - cost 16 persistent VGPRs and measured
+  // 5-10 % slower on the MODE_UP layers.)
+  auto flush_db = [&](float (&dbacc)[CPL], int nt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      float v = dbacc[c];
+      v = row_add<0xB1>(v);                    // quad_perm [1,0,3,2]
+      v = row_add<0x4E>(v);                    // quad_perm [2,3,0,1]
+      v = row_add<0x124>(v);                   // row_ror 4
+      v = row_add<0x128>(v);                   // row_ror 8
+      if (a16 == 0) {
+        const unsigned ad = sdb0 + (unsigned)(nt * BN * 4) + lane_coff * 2 + c * 4;
+        asm volatile("ds_add_f32 %0, %1" ::"v"(ad), "v"(v) : "memory");
+      }
+    }
+  };
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
     char* ob = (char*)(out + tile_off(t));
     if (MASK) {
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       }
     }
     f32x4_t bias[TN];
-    float rs = 1.f;
+    float rs = 0.f;
     if (want_db) {  // the wave's 64 pixels belong to one sample (SW >= 64): one per-sample weight per tile
       const unsigned ra = srs0 + (unsigned)(t.bt * g.NSB + ((wm * 64) >> g.lsw)) * 4;
       asm volatile("ds_read_b32 %0, %1" : "=v"(rs) : "v"(ra) : "memory");
@@ -221,7 +239,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       asm volatile("" : "+v"(rs));
     }
     // (no pointers into fp / fw / acc anywhere below: an address-taken register array ends up in scratch memory)
-    i32x4 opk[TM][NST / TM];                   // packed outputs (kept for the bias-gradient sums: acc / aux are dead by then)
+    // MASK:  out = acc * (aux > 0 ? scale sqrt2 : 0.2 scale sqrt2)          unpack, compare, select, multiply
+    // else:  out = lrelu(acc * scale' + bias') with sqrt2 folded into scale' and the staged bias (lrelu commutes with a
+    //        positive factor): fma, multiply, max
+    float dbacc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dbacc[c] = 0.f;
+    const float c_pos = p.scale * SQRT2, c_neg = p.scale * (LRELU_SLOPE * SQRT2);
+    const float c_lin = p.epi == EPI_LRELU ? c_pos : p.scale;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -234,14 +259,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const int c = 8 * h + 2 * e2 + q, j = c >> 2, r = c & 3;
-            float v = acc[i][j][r] * p.scale;
+            float v;
             if (MASK) {
               const unsigned w32 = (unsigned)ax[e2];
               const float a = __builtin_bit_cast(float, q ? (w32 & 0xffff0000u) : (w32 << 16));
-              v *= (a > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+              v = acc[i][j][r] * (a > 0.f ? c_pos : c_neg);
+              dbacc[c] = fmaf(v, rs, dbacc[c]);     // (rs = 0 without dbias: no branch per element)
             } else {
-              v += bias[j][r];
-              if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
+              v = fmaf(acc[i][j][r], c_lin, bias[j][r]);
+              if (p.epi == EPI_LRELU) v = fmaxf(v, LRELU_SLOPE * v);
             }
             v2[q] = v;
           }
@@ -249,31 +275,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           const unsigned hi = __builtin_bit_cast(unsigned short, (bf16)v2[1]);
           pk[e2] = (int)(lo | (hi << 16));
         }
-        opk[i][h] = pk;
         *(i32x4*)(ob + pix_off[i] + 16 * h) = pk;
       }
       __builtin_amdgcn_sched_barrier(0);       // one pixel block at a time: keeps the live ranges (and VGPRs) short
     }
-    if (want_db) {
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const unsigned w32 = (unsigned)opk[i][c >> 3][(c & 7) >> 1];
-          v += __builtin_bit_cast(float, (c & 1) ? (w32 & 0xffff0000u) : (w32 << 16));
-        }
-        v = row_add<0xB1>(v);                  // quad_perm [1,0,3,2]
-        v = row_add<0x4E>(v);                  // quad_perm [2,3,0,1]
-        v = row_add<0x124>(v);                 // row_ror 4
-        v = row_add<0x128>(v);                 // row_ror 8
-        if (a16 == 0) {
-          const unsigned ad = sdb0 + (unsigned)(t.nt * BN * 4) + lane_coff * 2 + c * 4;
-          const float vv = v * rs;
-          asm volatile("ds_add_f32 %0, %1" ::"v"(ad), "v"(vv) : "memory");
-        }
-      }
-    }
+    if (want_db) flush_db(dbacc, t.nt);
     zero_acc();
   };
 

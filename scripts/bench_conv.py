@@ -45,6 +45,8 @@ def timeit(fn, iters=10):
 
 
 tot_ms, tot_fl = 0.0, 0.0
+if len(sys.argv) > 3 and sys.argv[3] == "wgradonly":
+    CONV = []
 for name, mode, adj, Hc, Wc, K, N, bm in CONV:
     n = B * bm
     if mode == L.MODE_S2:
@@ -74,7 +76,8 @@ for name, mode, adj, Hc, Wc, K, N, bm in CONV:
             tot = sum(v) or 1.0
             print(f"    {wv}: cycles load {v[0]:.0f} ({100 * v[0] / tot:.0f}%) wait {v[1]:.0f} ({100 * v[1] / tot:.0f}%) bar1 {v[2]:.0f} "
                   f"({100 * v[2] / tot:.0f}%) mfma {v[3]:.0f} ({100 * v[3] / tot:.0f}%) bar2 {v[4]:.0f} ({100 * v[4] / tot:.0f}%) gap {v[5]:.0f} ({100 * v[5] / tot:.0f}%) total {tot:.0f}")
-print(f"conv total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+if CONV:
+    print(f"conv total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
 
 if len(sys.argv) > 3 and sys.argv[3] == "convonly":
     sys.exit(0)
