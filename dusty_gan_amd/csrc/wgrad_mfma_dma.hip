@@ -16,6 +16,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -39,7 +41,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   constexpr int RA = BM * 2, RG = BN * 2;                 // LDS row bytes (one pixel)
   constexpr int STA = BKP * RA, STG = BKP * RG, STAGE = STA + STG;
   constexpr int PA = STA / 1024 / 4, PG = STG / 1024 / 4;  // DMA pieces per wave per stage
-  constexpr int IPT = PA + PG;
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(PA >= 1 && PG >= 1, "tile too small for the piece distribution");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   const long units = (long)p.B * p.Hc;
   const long u0 = units * bz / gridDim.z, u1 = units * (bz + 1) / gridDim.z;
   const int cpr = p.Wc / BKP;                             // chunks per row
-  const long nchunks = (u1 - u0) * cpr;
+  const long nchunks64 = (u1 - u0) * cpr;
   const int Wa = WMODE == 0 ? 2 * p.Wc : p.Wc;
   const int Wg = WMODE == 1 ? 2 * p.Wc : p.Wc;
   const bf16* A = (const bf16*)p.a;
@@ -68,51 +69,68 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
 
   // ---- DMA side.  Piece = 1 KiB = 64 lanes x 16 B = (1024 / row bytes) whole rows; lane -> (row in piece, chunk);
   //      the chunk's 64-byte group is XORed with the row (256-byte rows: row & 3; 128-byte rows: (row >> 1) & 1).
+  //      All loop state is 32-bit and advanced incrementally (the first version divided 64-bit unit indices per chunk
+  //      and rebuilt 64-bit addresses per piece: SQ_INSTS_SALU was 8.8x, SQ_INSTS_VALU 7.8x SQ_INSTS_MFMA, the matrix
+  //      pipe 27 % busy); a piece is one saddr-form LDS-DMA: wave-uniform row base + per-lane 32-bit offset.
   constexpr int CA = RA / 16, CG = RG / 16;               // 16-byte chunks per row
   constexpr int RPA = 64 / CA, RPG = 64 / CG;             // rows per piece
   auto swz = [](int row, int rowbytes) { return rowbytes == 256 ? (row & 3) : ((row >> 1) & 1); };
-  int rowA[PA], chA[PA], rowG[PG], chG[PG];
+  int rowA[PA], rowG[PG];
+  unsigned chA[PA], chG[PG];                              // byte offset of the lane's (swizzled) chunk inside its pixel
 #pragma unroll
   for (int v = 0; v < PA; ++v) {
     const int r = (wave + 4 * v) * RPA + lane / CA, c = lane % CA;
     rowA[v] = r;
-    chA[v] = ((((c >> 2) ^ swz(r, RA)) << 2) | (c & 3)) * 8;   // source element offset inside the pixel's channels
+    chA[v] = (unsigned)(((((c >> 2) ^ swz(r, RA)) << 2) | (c & 3)) * 16);
   }
 #pragma unroll
   for (int v = 0; v < PG; ++v) {
     const int r = (wave + 4 * v) * RPG + lane / CG, c = lane % CG;
     rowG[v] = r;
-    chG[v] = ((((c >> 2) ^ swz(r, RG)) << 2) | (c & 3)) * 8;
+    chG[v] = (unsigned)(((((c >> 2) ^ swz(r, RG)) << 2) | (c & 3)) * 16);
   }
-  long iu = u0;                                           // issue position (unit, chunk in row)
-  int ixc = 0;
-  const bf16* abase = A;
-  const bf16* gbase = G;
-  auto set_unit = [&](long u) {
-    const int b = (int)(u / p.Hc), m = (int)(u % p.Hc);
+  const unsigned aspb = (unsigned)asp * 2u, gspb = (unsigned)gsp * 2u;   // bytes per pixel (< 2^24)
+  const int da = WMODE == 0 ? kx - 1 : (kx == 0 ? 1 : (kx == 3 ? -1 : 0));  // column shift of the tap on the A grid
+  const int dg = WMODE == 1 ? ((kx == 0 || kx == 2) ? 1 : 0) : 0;        // column parity of the tap on the G grid
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto dma_s = [&](unsigned voff, const char* sbase, unsigned ldsaddr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
+  };
+  const int nchunks = (int)nchunks64;
+  int ib = (int)(u0 / p.Hc), im = (int)(u0 % p.Hc), ixc = 0;   // issue position: sample, coarse row, chunk in row
+  const char* abase = nullptr;
+  const char* gbase = nullptr;
+  auto set_unit = [&](int b, int m) __attribute__((always_inline)) {
     int rowa, rowg;
     dg_wgrad1d(WMODE, 0, m, p.Hc, ky, rowa, rowg);
-    abase = A + (long)b * p.a_sb + (long)rowa * Wa * p.a_sp + ci0;
-    gbase = G + (long)b * p.g_sb + (long)rowg * Wg * p.g_sp + co0;
+    // (readfirstlane: the "s" operands of the DMA statement must be provably wave-uniform)
+    auto uni = [](const bf16* q) __attribute__((always_inline)) {
+      const unsigned long long v = (unsigned long long)q;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return (const char*)(((unsigned long long)hi << 32) | lo);
+    };
+    abase = uni(A + (long)b * p.a_sb + (long)rowa * Wa * asp + ci0);
+    gbase = uni(G + (long)b * p.g_sb + (long)rowg * Wg * gsp + co0);
   };
-  set_unit(iu);
-  auto issue = [&](int st) {
-    unsigned char* base = lds + st * STAGE;
+  set_unit(ib, im);
+  auto issue = [&](unsigned st_off) __attribute__((always_inline)) {
+    const unsigned base = lds0 + st_off + (unsigned)wave * 1024u;
+    const int x0 = ixc * BKP;
 #pragma unroll
-    for (int v = 0; v < PA; ++v) {
-      const int x = ixc * BKP + rowA[v];
-      int ca;
-      if (WMODE == 0) { ca = 2 * x + kx - 1; if (ca < 0) ca += Wa; else if (ca >= Wa) ca -= Wa; }
-      else { ca = x + (kx == 0 ? 1 : (kx == 3 ? -1 : 0)); if (ca < 0) ca += Wa; else if (ca >= Wa) ca -= Wa; }
-      dma16(abase + (unsigned)(ca * asp + chA[v]), base + (wave + 4 * v) * 1024);
+    for (int v = 0; v < PA; ++v) {                          // circular columns: Wa is a power of two (launcher check)
+      const unsigned ca = (unsigned)(((WMODE == 0 ? 2 : 1) * (x0 + rowA[v]) + da) & (Wa - 1));
+      dma_s(__umul24(ca, aspb) + chA[v], abase, base + 4 * v * 1024);
     }
 #pragma unroll
     for (int v = 0; v < PG; ++v) {
-      const int x = ixc * BKP + rowG[v];
-      const int cg = WMODE == 1 ? 2 * x + ((kx == 0 || kx == 2) ? 1 : 0) : x;
-      dma16(gbase + (unsigned)(cg * gsp + chG[v]), base + STA + (wave + 4 * v) * 1024);
+      const unsigned cg = (unsigned)((WMODE == 1 ? 2 : 1) * (x0 + rowG[v]) + dg);
+      dma_s(__umul24(cg, gspb) + chG[v], gbase, base + STA + 4 * v * 1024);
     }
-    if (++ixc == cpr) { ixc = 0; ++iu; if (iu < u1) set_unit(iu); }
+    if (++ixc == cpr) {
+      ixc = 0;
+      if (++im == p.Hc) { im = 0; ++ib; }
+      set_unit(ib, im);                                     // (one unit past the end at the very last chunk: never used)
+    }
   };
 
   // ---- read side: lane -> (row block q, column quad pp) inside its 16-lane group; group -> (k half, column block)
@@ -120,7 +138,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   const int lr = lane & 31, lh = lane >> 5;
   const int g16 = lane >> 4, i16 = lane & 15;
   const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   unsigned offA[TM], offG[TN];                            // byte offset of this lane's lo read at kq = 0, stage 0
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -141,78 +158,85 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  int cb_s = (int)(u0 / p.Hc), cm = (int)(u0 % p.Hc), cxc = 0;   // compute position (sample for the per-sample weight)
   float cur_rs = 1.f;
   if (p.rowscale && nchunks > 0) {
-    cur_rs = p.rowscale[(int)(u0 / p.Hc)];
+    cur_rs = p.rowscale[cb_s];
     if (fabsf(cur_rs) < 1e-30f) cur_rs = cur_rs < 0.f ? -1e-30f : 1e-30f;
   }
 
-  // ---- ring: chunk s lives in stage s % NS; at the top of chunk s wait until it landed (NS-2 younger chunks may
-  //      still fly), barrier (everyone's share landed, everyone finished reading stage (s-1) % NS), refill that
-  //      stage with chunk s + NS - 1, compute chunk s
-  long issued = 0;
-  for (; issued < NS - 1 && issued < nchunks; ++issued) issue((int)(issued % NS));
-  long cu = u0;
-  int cxc = 0;
-  for (long s = 0; s < nchunks; ++s) {
-    const long younger = issued - 1 - s;
-    if (younger <= 0) DG_WAITV(0);
-    else if (younger == 1) DG_WAITV(IPT);
-    else DG_WAITV(2 * IPT);
+  // ---- ring of NS = 2 stages: chunk s lives in stage s & 1; at the top of chunk s wait until it landed, barrier
+  //      (everyone's share landed, everyone finished reading the other stage), refill the other stage with chunk s + 1,
+  //      compute chunk s
+  if (nchunks > 0) issue(0);
+  unsigned so = 0;                                          // LDS offset of the stage being computed
+  for (int s = 0; s < nchunks; ++s) {
+    DG_WAITV(0);
     __builtin_amdgcn_s_barrier();
-    if (issued < nchunks) { issue((int)(issued % NS)); ++issued; }
-    const unsigned so = (unsigned)((s % NS) * STAGE);
+    if (s + 1 < nchunks) issue(so ^ (unsigned)STAGE);
     // the reads of k-step kq+1 are issued before the MFMAs of kq (two fragment sets, counted lgkmcnt)
     i32x2 alo[2][TM], ahi[2][TM], glo[2][TN], ghi[2][TN];
-    auto read_set = [&](int set, int kq) {
+    unsigned ra[TM], rg[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        TR16(alo[set][i], offA[i] + so + kq * 16 * RA, 0);
-        TR16(ahi[set][i], offA[i] + so + kq * 16 * RA, 4 * RA);
-      }
+    for (int i = 0; i < TM; ++i) ra[i] = offA[i] + so;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        TR16(glo[set][j], offG[j] + so + kq * 16 * RG, 0);
-        TR16(ghi[set][j], offG[j] + so + kq * 16 * RG, 4 * RG);
-      }
-    };
-    read_set(0, 0);
-#pragma unroll
-    for (int kq = 0; kq < BKP / 16; ++kq) {
-      if (kq + 1 < BKP / 16) {
-        read_set((kq + 1) & 1, kq + 1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+    for (int j = 0; j < TN; ++j) rg[j] = offG[j] + so;
+#define DG_READ_SET(kq)                                            \
+  do {                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {               \
+      TR16(alo[(kq) & 1][i], ra[i], (kq) * 16 * RA);               \
+      TR16(ahi[(kq) & 1][i], ra[i], (kq) * 16 * RA + 4 * RA);      \
+    }                                                              \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {               \
+      TR16(glo[(kq) & 1][j], rg[j], (kq) * 16 * RG);               \
+      TR16(ghi[(kq) & 1][j], rg[j], (kq) * 16 * RG + 4 * RG);      \
+    }                                                              \
+  } while (0)
+    auto mfmas = [&](int set) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const i32x4 fa = {alo[kq & 1][i][0], alo[kq & 1][i][1], ahi[kq & 1][i][0], ahi[kq & 1][i][1]};
-          const i32x4 fg = {glo[kq & 1][j][0], glo[kq & 1][j][1], ghi[kq & 1][j][0], ghi[kq & 1][j][1]};
+          const i32x4 fa = {alo[set][i][0], alo[set][i][1], ahi[set][i][0], ahi[set][i][1]};
+          const i32x4 fg = {glo[set][j][0], glo[set][j][1], ghi[set][j][0], ghi[set][j][1]};
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fg),
                                                               acc[i][j], 0, 0, 0);
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    static_assert(BKP / 16 == 4, "four k-steps per chunk");
+    DG_READ_SET(0);
+    DG_READ_SET(1);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+    mfmas(0);
+    DG_READ_SET(2);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+    mfmas(1);
+    DG_READ_SET(3);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+    mfmas(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mfmas(1);
+    so ^= (unsigned)STAGE;
     // per-sample weights: running sum kept divided by the current sample's weight (wgrad_mfma.hip)
-    const int cur_b = (int)(cu / p.Hc);
-    if (++cxc == cpr) { cxc = 0; ++cu; }
-    if (p.rowscale && s + 1 < nchunks) {
-      const int next_b = (int)(cu / p.Hc);
-      if (next_b != cur_b) {
-        float rn = p.rowscale[next_b];
-        if (fabsf(rn) < 1e-30f) rn = rn < 0.f ? -1e-30f : 1e-30f;
-        const float ratio = cur_rs / rn;
-        cur_rs = rn;
+    if (++cxc == cpr) {
+      cxc = 0;
+      if (++cm == p.Hc) {
+        cm = 0;
+        ++cb_s;
+        if (p.rowscale && s + 1 < nchunks) {
+          float rn = p.rowscale[cb_s];
+          if (fabsf(rn) < 1e-30f) rn = rn < 0.f ? -1e-30f : 1e-30f;
+          const float ratio = cur_rs / rn;
+          cur_rs = rn;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] *= ratio;
+            for (int j = 0; j < TN; ++j) acc[i][j] *= ratio;
+        }
       }
     }
   }
@@ -259,6 +283,9 @@ int dg_wgrad_mfma_dma_supported(const WgradP* p) {
   if (!p->ring || p->a_sc != 1 || p->g_sc != 1) return 0;
   if (p->Ci % 64 != 0 || p->Co % 64 != 0 || p->Wc % BKP != 0 || p->Hc < 2) return 0;
   if (p->a_sp % 8 != 0 || p->g_sp % 8 != 0) return 0;      // 16-byte DMA granules
+  if ((p->Wc & (p->Wc - 1)) != 0) return 0;                // circular column wrap by mask
+  if (p->a_sp * 2 >= (1 << 24) || p->g_sp * 2 >= (1 << 24)) return 0;  // 24-bit offset multiply
+  if ((long)p->B * p->Hc * (p->Wc / BKP) > 0x7fffffffL) return 0;
   return 1;
 }
 
