@@ -1,0 +1,60 @@
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes of the eager training step (one with --pmc FETCH_SIZE, one
+with --pmc WRITE_SIZE; TCC has too few slots for both).  usage:
+    python scripts/pmc_traffic.py out.json <fetch counter_collection.csv> <write counter_collection.csv>
+Units: KB; FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md "HBM"); Infinity
+Cache hits are included.  The file records the hash of the kernel sources it was collected on (bench.py refuses a
+number from other sources) and the kernel symbols behind each family."""
+import collections
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha  # noqa: E402
+
+FAMILIES = {  # bench.py family name -> substrings of the kernel symbols it covers
+    "conv_mfma_kernel": ("conv_pp_kernel", "persist11conv_kernel", "conv_mfma_kernel"),
+    "wgrad_mfma_kernel": ("wgrad_dma_kernel",),
+    "adam_ema_kernel": ("adam_ema_kernel", "adam_proj_fused_kernel", "wgrad_mfma_kernelIDF16bLi128ELi128ELb1"),
+}
+
+
+def load(path, counter):
+    tot, n, names = collections.Counter(), collections.Counter(), collections.defaultdict(set)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            for fam, subs in FAMILIES.items():
+                if any(s in r["Kernel_Name"] for s in subs):
+                    tot[fam] += float(r["Counter_Value"])
+                    n[fam] += 1
+                    names[fam].add(r["Kernel_Name"][:120])
+    return tot, n, names
+
+
+def main():
+    out, fetch_csv, write_csv = sys.argv[1:4]
+    fk, fn, names = load(fetch_csv, "FETCH_SIZE")
+    wk, wn, _ = load(write_csv, "WRITE_SIZE")
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        sha = ""
+    res = {"_note": __doc__.strip().split("usage")[0].strip() + " bytes_per_launch = (2*FETCH_KB + WRITE_KB)*1024 / launches.",
+           "kernel_source_sha": kernel_source_sha(), "git_sha": sha or "(collected on the GPU box: no .git there)", "kernels": {}}
+    for fam in FAMILIES:
+        if fn[fam] == 0:
+            continue
+        assert fn[fam] == wn[fam], (fam, fn[fam], wn[fam])
+        res["kernels"][fam] = {"fetch_kb_raw": fk[fam], "write_kb": wk[fam], "launches": fn[fam],
+                               "bytes_per_launch": (2 * fk[fam] + wk[fam]) * 1024 / fn[fam], "symbols": sorted(names[fam])}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: round(v["bytes_per_launch"]) for k, v in res["kernels"].items()}))
+
+
+if __name__ == "__main__":
+    main()
