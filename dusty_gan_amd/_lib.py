@@ -10,8 +10,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdustygan_hip.so")
-if os.environ.get("DUSTY_GAN_LIB_DIAG") == "1":  # kernel-development aid: `make -C csrc diag` (ablation switches, stamps)
-    LIB_PATH = os.path.join(CSRC, "libdustygan_hip_diag.so")
+if os.environ.get("DUSTY_GAN_LIB_DIAG"):  # kernel-development aid: `make -C csrc diag` (ablation switches, stamps);
+    _d = os.environ["DUSTY_GAN_LIB_DIAG"]  # "1" or the suffix of a renamed copy (libdustygan_hip_diag<suffix>.so)
+    LIB_PATH = os.path.join(CSRC, "libdustygan_hip_diag%s.so" % ("" if _d == "1" else _d))
 
 DG_OK, DG_EINVAL, DG_EUNSUPPORTED, DG_EHIP = 0, 1, 2, 3
 DG_F32, DG_BF16 = 0, 1

@@ -12,8 +12,8 @@
 //     wave group A (waves 0-3):  LOAD(t) | MFMA(t) | LOAD(t+1) | MFMA(t+1) | ...
 //     wave group B (waves 4-7):          | LOAD(t) | MFMA(t)   | LOAD(t+1) | ...        ( | = workgroup barrier )
 //
-//   LOAD(t): (epilogue of the finished tile, if any) ; all 16 fragment reads of K step t (ds_read_b128, 64 VGPRs) ;
-//            this wave's 6 LDS-DMA pieces of K step t+2 ; s_waitcnt {own pieces of t+1 landed, fragments in}
+//   LOAD(t): all 16 fragment reads of K step t (ds_read_b128, 64 VGPRs) ; this wave's 6 LDS-DMA pieces of K step t+2 ;
+//            s_waitcnt {own pieces of t+1 landed, fragments in} ; (epilogue of the finished tile, if any)
 //   MFMA(t): 32 x v_mfma_f32_16x16x32_bf16 straight from registers - no LDS, no waits.
 // Both groups run the same program; group B starts one barrier late.  Ring of 3 stages x 48 KB: stage t is read by A in
 // its LOAD(t) and by B one interval later; K step t+2 goes into the stage K step t-1 used, whose last reads retired (each
@@ -39,7 +39,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // Diagnostics are compiled in only with -DDG_PP_DIAG=<bits> (make diag DIAGBITS=<bits>, default 8): every runtime check in the K-step loop costs issue
 // slots the loop does not have (the LOAD half is instruction-issue bound: ~6-7 cycles per instruction beside the partner
 // wave's MFMAs).  Bits as in the lock-step kernel's DG_CONV_DBG (1 no DMA, 2 no MFMA, 4 no epilogue, 16 no
-// fragment reads); 8 adds shader-clock stamps around the segments of a K step, summed per wave and
+// fragment reads, 32 half of the pixel-tile DMA, 64 no mask-source loads, 128 no output stores); 8 adds shader-clock stamps around the segments of a K step, summed per wave and
 // written over the first bytes of the OUTPUT by workgroup 0 (scripts/bench_conv.py prints them; the output is garbage)
 __device__ __forceinline__ unsigned long long pp_stamp() {
   unsigned long long t;
@@ -73,6 +73,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int nW = MODE == MODE_S2 ? 4 : 2;
   static_assert(IB >= 1 && NS * STAGE + 3 * NDB * 4 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + 3 * NDB * 4];
+#ifdef DG_PP_DIAG
+  constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
+#else
+  constexpr int dbg = 0;
+#endif
 
   // ---- this workgroup's chunk of the tile order (XCD-aware, as the lock-step kernel: conv_mfma_persist_impl.h)
   const int G = gridDim.x;
@@ -180,16 +185,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     return (long)(t.bt * g.NSB) * p.out_sb + ((long)t.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + t.px)) * p.out_sp +
            t.nt * BN;
   };
-  // The leaky-relu mask source of a tile being finished (EPI_MASK) is fetched into the FRAGMENT registers of k-step 0
-  // (fp[0][i], fw[0][i]: 8 x 16 bytes, exactly one lane's 4 pixels x 32 bytes) once the last K step's first 16 MFMAs
-  // have read them: no extra registers, and the loads fly under the remaining 16 MFMAs and the barrier.
+  // The leaky-relu mask source of a tile being finished (EPI_MASK) is fetched during the tile's last MFMA half into
+  // registers of its own (one lane's 4 pixels x 16 TN bytes); the epilogue runs at the END of the next LOAD half, behind that
+  // half's ordinary wait - which, counting in order, covers these loads too (they were issued before the half's
+  // pieces).  (Round-2 finding: with the mask source aliased onto fragment registers the epilogue had to run FIRST in
+  // the half behind a vmcnt(0), i.e. drain every LDS-DMA piece in flight once per tile - the EPI_MASK layers stayed at
+  // 720-740 TFLOP/s while the others reached 830-1150.)
+  i32x4 axr[MASK ? NST : 1];
   auto load_aux = [&](const Tile& t) __attribute__((always_inline)) {
     const char* ab = (const char*)((const bf16*)p.aux + tile_off(t));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const char* src = ab + pix_off[i];
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fp[0][i]) : "v"(src) : "memory");
-      if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(fw[0][i]) : "v"(src) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(axr[(NST / TM) * i]) : "v"(src) : "memory");
+      if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(axr[2 * i + 1]) : "v"(src) : "memory");
     }
   };
   // Bias-gradient sums (EPI_MASK with dbias): per lane 4 TN channel sums over its pixels, weighted per sample, of the
@@ -197,28 +206,27 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // (Keeping the sums in registers across the tiles of a workgroup - one N tile - cost 16 persistent VGPRs and measured
   // 5-10 % slower on the MODE_UP layers.)
   auto flush_db = [&](float (&dbacc)[CPL], int nt) __attribute__((always_inline)) {
+    // stage by stage over all CPL channels (independent DPP chains fill each other's hazard slots), then ONE predicated
+    // block of LDS adds (a branch per channel cost 8-16 exec save/restores per tile)
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      float v = dbacc[c];
-      v = row_add<0xB1>(v);                    // quad_perm [1,0,3,2]
-      v = row_add<0x4E>(v);                    // quad_perm [2,3,0,1]
-      v = row_add<0x124>(v);                   // row_ror 4
-      v = row_add<0x128>(v);                   // row_ror 8
-      if (a16 == 0) {
-        const unsigned ad = sdb0 + (unsigned)(nt * BN * 4) + lane_coff * 2 + c * 4;
-        asm volatile("ds_add_f32 %0, %1" ::"v"(ad), "v"(v) : "memory");
-      }
+    for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0xB1>(dbacc[c]);    // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0x4E>(dbacc[c]);    // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0x124>(dbacc[c]);   // row_ror 4
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0x128>(dbacc[c]);   // row_ror 8
+    if (a16 == 0) {
+      const unsigned ad = sdb0 + (unsigned)(nt * BN * 4) + lane_coff * 2;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(ad), "v"(dbacc[c]), "n"(c * 4) : "memory");
     }
   };
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
     char* ob = (char*)(out + tile_off(t));
-    if (MASK) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MASK) {                                // (the caller's wait covered the loads: pin the uses behind it)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        asm volatile("" : "+v"(fp[0][i]));
-        if (NST / TM == 2) asm volatile("" : "+v"(fw[0][i]));
-      }
+      for (int i = 0; i < NST; ++i) asm volatile("" : "+v"(axr[i]));
     }
     f32x4_t bias[TN];
     float rs = 0.f;
@@ -245,13 +253,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     float dbacc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dbacc[c] = 0.f;
-    const float c_pos = p.scale * SQRT2, c_neg = p.scale * (LRELU_SLOPE * SQRT2);
+    float c_pos = p.scale * SQRT2, c_neg = p.scale * (LRELU_SLOPE * SQRT2);
+    asm volatile("" : "+v"(c_pos), "+v"(c_neg));   // (opaque: else the select is made between constants and every
+                                                   //  element pays a second multiply by the scale)
     const float c_lin = p.epi == EPI_LRELU ? c_pos : p.scale;
+    const float slope = p.epi == EPI_LRELU ? LRELU_SLOPE : 1.f;          // max(v, 1 v) = v: no select per element
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int h = 0; h < NST / TM; ++h) {
-        const i32x4 ax = h == 0 ? fp[0][i] : fw[0][i];   // mask source of channels 8h .. 8h+7 (MASK only)
+        const i32x4 ax = axr[MASK ? (NST / TM) * i + h : 0];   // mask source of channels 8h .. 8h+7 (MASK only)
         i32x4 pk;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {                 // two channels per 32-bit word
@@ -261,21 +272,23 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
             const int c = 8 * h + 2 * e2 + q, j = c >> 2, r = c & 3;
             float v;
             if (MASK) {
-              const unsigned w32 = (unsigned)ax[e2];
-              const float a = __builtin_bit_cast(float, q ? (w32 & 0xffff0000u) : (w32 << 16));
-              v = acc[i][j][r] * (a > 0.f ? c_pos : c_neg);
+              // bf16 a > 0  <=>  its 16 bits as a signed integer > 0: the halves are compared in place (low half: 16-bit
+              // compare of the word's low bits, high half: the word above 0xffff), no unpacking
+              const int w32 = ax[e2];
+              const bool posv = q ? w32 > 0xffff : (short)w32 > 0;
+              v = acc[i][j][r] * (posv ? c_pos : c_neg);
               dbacc[c] = fmaf(v, rs, dbacc[c]);     // (rs = 0 without dbias: no branch per element)
             } else {
               v = fmaf(acc[i][j][r], c_lin, bias[j][r]);
-              if (p.epi == EPI_LRELU) v = fmaxf(v, LRELU_SLOPE * v);
+              v = fmaxf(v, slope * v);
             }
             v2[q] = v;
           }
-          const unsigned lo = __builtin_bit_cast(unsigned short, (bf16)v2[0]);
-          const unsigned hi = __builtin_bit_cast(unsigned short, (bf16)v2[1]);
-          pk[e2] = (int)(lo | (hi << 16));
+          unsigned pw;                                   // both halves in one conversion (RNE, as (bf16)v)
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw) : "v"(v2[0]), "v"(v2[1]));
+          pk[e2] = (int)pw;
         }
-        *(i32x4*)(ob + pix_off[i] + 16 * h) = pk;
+        if (!(dbg & 128)) *(i32x4*)(ob + pix_off[i] + 16 * h) = pk; else asm volatile("" ::"v"(pk));
       }
       __builtin_amdgcn_sched_barrier(0);       // one pixel block at a time: keeps the live ranges (and VGPRs) short
     }
@@ -284,11 +297,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   };
 
   // ---- main loop
-#ifdef DG_PP_DIAG
-  constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
-#else
-  constexpr int dbg = 0;
-#endif
   const bool stamps = (dbg & 8) != 0;
   unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};  // LOAD work, LOAD waits, barrier 1, MFMA half, barrier 2, between steps
   unsigned long long tend = 0;
@@ -327,10 +335,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       if (stamps) { t0 = pp_stamp(); if (tend) tsum[5] += t0 - tend; }
       const bool comp = j >= 2 || !(first && warm);            // runtime only at positions 0 and 1
       const bool last = j == 1 && first && !warm;              // the compute step closes the previous tile
-      if (j == 2 % nW && pending) {
-        if (!(dbg & 4)) epilogue(tprev); else zero_acc();
-        pending = false;
-      }
       {
         const unsigned so = lds0 + so_c;
         const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
         const char* sB_j = sB_k + (long)(kx0 + j * kxs) * tap_b;
         auto piece = [&](int q) __attribute__((always_inline)) {
           if (!ISS || (dbg & 1)) return;
+          if ((dbg & 32) && q >= IA / 2 && q < IA) return;       // what-if: half the pixel-tile traffic (shared W taps)
           if (q < IA) dma_s(voffA[j][q], sA_k, dst + NWV * q * 1024);
           else dma_s(voffB[q - IA], sB_j, dst + BM * SB + NWV * (q - IA) * 1024);
         };
@@ -362,6 +367,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       // own pieces of the PREVIOUS issue step landed (everything but this step's pieces; the stores of an epilogue that
       // ran in this half are waited for too - once per tile, mostly retired), and the fragments are in
       if (ISS) PP_WAIT(IPT); else PP_WAIT(0);
+      if (j == 2 % nW && pending) {              // the finished tile's epilogue: behind the wait (mask source landed),
+        if (!(dbg & 4)) epilogue(tprev); else zero_acc();   // in front of the MFMA half that restarts the accumulators
+        pending = false;
+      }
       if (stamps) t2 = pp_stamp();
       __builtin_amdgcn_s_barrier();
       if (stamps) t3 = pp_stamp();
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           }
           if (ks == 0) {
             __builtin_amdgcn_sched_barrier(0);
-            if (MASK && last && !(dbg & 4)) load_aux(tprev);
+            if (MASK && last && !(dbg & (4 | 64))) load_aux(tprev);
           }
         }
         if (last) pending = true;
@@ -432,7 +441,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows);
   }
   group(std::false_type{}, true, 0, 0);
-  if (pending && !(dbg & 4)) epilogue(tprev);
+  if (pending && !(dbg & 4)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    epilogue(tprev);
+  }
   if (stamps && blockIdx.x == 0 && lane == 0) {
     float* sink = (float*)p.out + wave * 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

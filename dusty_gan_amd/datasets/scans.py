@@ -179,6 +179,7 @@ class ScanLoader:
         self.copy_stream = torch.cuda.Stream(self.device)
         self.slots = [_Slot(self.B, *self.scan_shape, self.device) for _ in range(max(1, prefetch) + 1)]
         self.epoch = 0
+        self.skip = 0  # batches of the NEXT epoch to pass over without reading (checkpoint resume: Trainer._restore_position)
 
     def __len__(self):
         n = len(sampler_indices(len(self.dataset), self.world, self.rank, shuffle=False))
@@ -221,7 +222,11 @@ class ScanLoader:
         rng = np.random.default_rng([self.seed, self.rank, self.epoch])
         self.epoch += 1
         ds = self.dataset
-        pending, nxt = deque(), 0
+        pending, nxt = deque(), min(self.skip, len(batches))
+        for _ in range(nxt):  # resumed mid-epoch: keep the flip stream aligned with an uninterrupted run
+            if ds.flip:
+                rng.random(self.B)
+        self.skip = 0
         free = deque(self.slots)
         while nxt < len(batches) and free:
             s = free.popleft()

@@ -265,9 +265,10 @@ class Trainer:
         else:
             from ..datasets import ScanLoader, define_dataset
             self.dataset = define_dataset(self.cfg.dataset, phase="train")  # NotImplementedError for unknown names
-            self.loader = cycle(ScanLoader(self.dataset, self.local_batch, self.device, world=_world(), rank=_rank(),
+            self._scan_loader = ScanLoader(self.dataset, self.local_batch, self.device, world=_world(), rank=_rank(),
                                            num_workers=int(local_cfg["num_workers"] if isinstance(local_cfg, dict)
-                                                           else local_cfg.num_workers)))
+                                                           else local_cfg.num_workers))
+            self.loader = cycle(self._scan_loader)
 
         # losses (reference :104-113)
         self.loss_weight = dict(self.cfg.solver.loss)
@@ -288,8 +289,11 @@ class Trainer:
 
         # resume (reference :134-144)
         self.start_iteration = 0
+        self.batches_drawn = 0
+        resume_extra = None
         if self.cfg.resume is not None:
-            sd = torch.load(self.cfg.resume, map_location="cpu")
+            sd = torch.load(self.cfg.resume, map_location="cpu", weights_only=False)
+            resume_extra = sd.get("resume_state")
             self.start_iteration = sd["step"] // self.cfg.solver.batch_size
             self.G.load_state_dict(sd["G"])
             self.D.load_state_dict(sd["D"])
@@ -302,6 +306,8 @@ class Trainer:
         self.n_acc = int(self.cfg.solver.num_accumulation)
         self.rng = Philox(torch.initial_seed() + 7919 * _rank(), self.device, stream_id=1)
         self.fixed_noise = self.sample_latents(self.local_batch)
+        if resume_extra is not None:
+            self._restore_position(resume_extra)
         self._geng = None
         self._pending = None
         self._dev_scal = None
@@ -318,6 +324,10 @@ class Trainer:
     def sample_latents(self, B):
         """reference :151-152"""
         return self.rng.normal(B * self.cfg.model.gen.in_ch).view(B, self.cfg.model.gen.in_ch)
+
+    def _next_batch(self):
+        self.batches_drawn += 1
+        return next(self.loader)
 
     def fetch_reals(self, raw_batch):
         """reference :154-160"""
@@ -467,7 +477,7 @@ class Trainer:
             if reals is not None:
                 x_real, m_real = reals[j]
             else:
-                x_real, m_real = self.fetch_reals(next(self.loader))
+                x_real, m_real = self.fetch_reals(self._next_batch())
             rand = self._prep_rand(rands[j] if rands is not None else None, B)
             synth = gengs[j].forward(Gst, rand["z"], rand["noise"], training=True)  # :195 (graph kept = workspaces)
             xcat = torch.empty(2 * B, 1, self.H, self.W, **f32)
@@ -770,7 +780,7 @@ class Trainer:
         step cost ~5 ms of Python/ctypes time when issued one by one, more than the kernels themselves; captured once
         they replay from one host call.  Everything that changes between steps lives in device memory (Philox
         counters, Adam step counts, the input batch in a static buffer), so replays draw fresh randomness."""
-        batch = next(self.loader)
+        batch = self._next_batch()
         if self._graph is None:
             if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
                 self._eager_steps += 1
@@ -898,7 +908,46 @@ class Trainer:
             return OrderedDict((k, v.detach().cpu().contiguous()) for k, v in m.state_dict().items())
         return {"step": step, "G": sd(self.G), "D": sd(self.D), "G_ema": sd(self.G_ema),
                 "optim_G": self.optim_G.state_dict(), "optim_D": self.optim_D.state_dict(),
-                "pl_ema": self.pl_ema.detach().cpu().reshape(()) if "pl" in self.criterion else None}
+                "pl_ema": self.pl_ema.detach().cpu().reshape(()) if "pl" in self.criterion else None,
+                # what the reference's checkpoint omits: without it a resumed run draws other latents,
+                # augmentations and batches than the uninterrupted one.  An extra key: the reference's loaders ignore it.
+                "resume_state": self._position()}
+
+    def _position(self):
+        """Philox streams (seed, stream id, counter) of the trainer and of DiffAugment, the fixed evaluation latents and
+        the number of batches drawn from the loader, per rank"""
+        def ph(r):
+            return None if r is None else {"seed": r.seed, "stream_id": r.stream_id, "offset": r.offset}
+        return {"rank": _rank(), "world": self.world, "rng": ph(self.rng), "augment_rng": ph(self.A._rng),
+                "fixed_noise": self.fixed_noise.detach().cpu(), "batches_drawn": self.batches_drawn}
+
+    def _restore_position(self, st):
+        from ..utils.rng import Philox
+        if int(st.get("world", 1)) != self.world or int(st.get("rank", 0)) != _rank():
+            import warnings
+            warnings.warn("checkpoint position belongs to another rank layout; random streams restart")
+            return
+
+        def mk(d):
+            r = Philox(d["seed"], self.device, stream_id=d["stream_id"])
+            r.ctr.fill_(int(d["offset"]))
+            return r
+        self.rng = mk(st["rng"])
+        if st.get("augment_rng") is not None:
+            self.A._rng = mk(st["augment_rng"])
+        self.fixed_noise = st["fixed_noise"].to(self.device)
+        # the loader: same epoch, same position inside it
+        n = int(st["batches_drawn"])
+        self.batches_drawn = n
+        src = getattr(self, "dataset", None)
+        from ..datasets.scans import ScanLoader
+        inner = getattr(self, "_scan_loader", None)
+        if isinstance(inner, ScanLoader):
+            per = len(inner)
+            inner.epoch, inner.skip = n // per, n % per
+        elif isinstance(src, SyntheticLiDAR):
+            for _ in range(n % len(src)):
+                next(self.loader)
 
     def save_models(self, suffix, step, directory="models"):
         """reference :395-409 (same keys, reference-shaped tensors)"""

@@ -64,7 +64,7 @@ for name, mode, adj, Hc, Wc, K, N, bm in CONV:
     def run():
         o.conv(mode, adj, True, n, Hc, Wc, K, N, x, (hin * win * K, K, 1), out, (ho * wo * N, N, 1), w.data_ptr(),
                0.01, epi, bias=None if adj else bias.data_ptr(), bias_mod=N, aux=aux if adj else None,
-               dbias=db.data_ptr() if adj else None)
+               dbias=db.data_ptr() if (adj and not os.environ.get('BENCH_NO_DB')) else None)
     ms = timeit(run)
     fl = 2.0 * n * ho * wo * N * K * taps
     tot_ms += ms

@@ -270,7 +270,8 @@ def test_checkpoint_roundtrip_and_generate(tmp_path):
     assert all(np.isfinite(v) for v in s.values())
     path = tr.save_models("0000000002", 2, directory=str(tmp_path))
     sd = torch.load(path, map_location="cpu")
-    assert set(sd.keys()) == {"step", "G", "D", "G_ema", "optim_G", "optim_D", "pl_ema"}
+    # the reference's keys (trainers/dcgan_amp.py:395-409) + the position record it omits
+    assert set(sd.keys()) == {"step", "G", "D", "G_ema", "optim_G", "optim_D", "pl_ema", "resume_state"}
     assert sd["G"]["backbone.3.1.module.weight"].shape == (8, 4, 4, 4)  # ConvTranspose2d layout (Cin,Cout,4,4)
     assert sd["D"]["1.1.module.weight"].shape == (4, 2, 4, 4)            # Conv2d layout (Cout,Cin,4,4)
     tr2 = make_trainer("dusty2", True, (32, 64), 8, 4, 16, 2)
@@ -373,3 +374,65 @@ def test_graph_replay_survives_host_sync():
         vals = list(s.values())
         assert all(abs(v) < 50.0 for v in vals), (i, vals)
     assert tr._graph is not None
+
+
+@pytest.mark.parametrize("arch", ["dusty2", "none"])
+def test_resume_continues_like_the_uninterrupted_run(tmp_path, arch):
+    """cfg.resume (reference :134-144) + the position record: 3 steps, checkpoint, a NEW trainer resumed from it, 3 more
+    steps == 6 uninterrupted steps - same latents, Gumbel noise, augmentation draws and batches (Philox counters and
+    loader position restored), same Adam step counts.  fp32.  The yardstick is the run-to-run noise of the uninterrupted
+    run itself (split-K atomics reorder sums; Adam with beta1 = 0 turns the sign of a rounding-noise gradient into a
+    2 lr difference; the hard Gumbel threshold of the dusty archs turns a last-bit logit difference into a flipped
+    pixel): the resumed run must be as close to the uninterrupted one as a second uninterrupted run is (x5 + 1e-5), and
+    a checkpoint WITHOUT the position record (the reference's format: randomness re-drawn, loader restarted) must not be
+    - the control that shows the yardstick can tell the two apart."""
+    from dusty_gan_amd.trainers.dcgan_amp import Trainer
+    from dusty_gan_amd.utils.config import load_config
+
+    def cfg(resume=None):
+        model = {"none": "dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
+        ov = [f"model={model}", "dataset=synthetic", "dataset.shape=[32,64]", "model.gen.in_ch=8", "model.gen.ch_base=4",
+              "model.gen.ch_max=16", "model.dis.ch_base=4", "model.dis.ch_max=16", "solver.batch_size=4",
+              "enable_amp=false", "dataset.pool=3"]
+        c = load_config(ov)
+        c.resume = resume
+        return c
+    lc = {"gpu": 0, "ngpus": 1, "batch_size": 4, "num_workers": 0}
+
+    def params(t):
+        return torch.cat([getattr(t, net).store.flat.cpu() for net in ("G", "D", "G_ema")])
+    torch.manual_seed(11)
+    a = Trainer(cfg(), lc)
+    sa = [dict(a.step(i).items()) for i in range(6)]
+    torch.manual_seed(11)
+    a2 = Trainer(cfg(), lc)
+    for i in range(6):
+        a2.step(i)
+    noise = rel_l2(params(a2), params(a))
+    torch.manual_seed(11)
+    b = Trainer(cfg(), lc)
+    for i in range(3):
+        b.step(i)
+    path = b.save_models("mid", 3 * 4, directory=str(tmp_path))
+    torch.manual_seed(999)  # the resumed process has another torch seed: everything must come from the checkpoint
+    c = Trainer(cfg(resume=path), lc)
+    assert c.start_iteration == 3 and c.optim_G.step_count == 3 and c.batches_drawn == 3
+    assert torch.equal(c.fixed_noise.cpu(), a.fixed_noise.cpu())
+    sc = [dict(c.step(i).items()) for i in range(3, 6)]
+    bound = 5 * noise + 1e-5
+    assert rel_l2(params(c), params(a)) <= bound, (rel_l2(params(c), params(a)), noise)
+    if arch == "none":  # (the dusty archs' scalars carry the flipped pixels of the hard threshold)
+        for x, y in zip(sc, sa[3:]):
+            for k in y:
+                assert abs(x[k] - y[k]) <= 1e-4 * max(1.0, abs(y[k])), (k, x[k], y[k])
+    # control: the same checkpoint without the position record
+    sd = torch.load(path, weights_only=False)
+    sd.pop("resume_state")
+    path2 = str(tmp_path / "no_position.pth")
+    torch.save(sd, path2)
+    torch.manual_seed(999)
+    d = Trainer(cfg(resume=path2), lc)
+    for i in range(3, 6):
+        d.step(i)
+    assert rel_l2(params(d), params(a)) > 4 * bound, (rel_l2(params(d), params(a)), bound)
+    assert c.rng.offset == a.rng.offset and c.A._rng.offset == a.A._rng.offset

@@ -311,3 +311,42 @@ def test_swd_oracle_matches_reference():
     for k, v in got.items():
         assert abs(v - float(g[f"swd/score/{k}"])) < 1e-6, k
     assert MO.swd_patch_counts(32, 64, 2) == [26 * 58, 10 * 26]
+
+
+def test_chamfer_oracle_pinned_by_the_reference_nnsearch():
+    """oracle/metrics_oracle.py `chamfer_dir` against the reference's OWN nearest-neighbour search: `nnsearch` of
+    utils/metrics/distance/cd/chamfer_distance.cpp:39-66, compiled from the reference's source file by
+    oracle/Makefile.ref into oracle/_ref/libref_cd.so (built by __graft_entry__.build() where /root/reference exists;
+    the .so travels to the GPU box).  Ragged sizes, duplicate points (first index wins on ties), one-point clouds."""
+    import ctypes
+    import os
+    from oracle import metrics_oracle as MO
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_cd.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_cd.so not built (make -f oracle/Makefile.ref needs /root/reference)")
+    lib = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+
+    def ref_nnsearch(x1, x2):  # x1 [b,n,3], x2 [b,m,3] -> dist [b,n], idx [b,n]
+        x1, x2 = np.ascontiguousarray(x1, np.float32), np.ascontiguousarray(x2, np.float32)
+        b, n, m = x1.shape[0], x1.shape[1], x2.shape[1]
+        dist, idx = np.zeros((b, n), np.float32), np.zeros((b, n), np.int32)
+        lib.ref_cd_nnsearch(b, n, m, x1.ctypes.data_as(vp), x2.ctypes.data_as(vp), dist.ctypes.data_as(vp), idx.ctypes.data_as(vp))
+        return dist, idx
+    rng = np.random.default_rng(3)
+    for Na, n, Nb, m in ((3, 17, 4, 9), (2, 1, 2, 5), (5, 64, 5, 64), (1, 200, 3, 33)):
+        A = rng.standard_normal((Na, n, 3)).astype(np.float32)
+        B = rng.standard_normal((Nb, m, 3)).astype(np.float32)
+        B[:, -1] = B[:, 0]  # duplicate points: ties
+        L = MO.chamfer_dir(A, B).numpy()
+        for i in range(Na):
+            for j in range(Nb):
+                d, _ = ref_nnsearch(A[i][None], B[j][None])
+                assert abs(L[i, j] - d.mean()) <= 1e-6 * max(1.0, abs(d.mean())), (i, j)
+        # compute_cd of cov_mmd_1nna.py:20-22 = dl.mean + dr.mean
+        if Na == Nb:
+            M = MO.pairwise_cd(A, B).numpy()
+            for i in range(Na):
+                dl, _ = ref_nnsearch(A[i][None], B[i][None])
+                dr, _ = ref_nnsearch(B[i][None], A[i][None])
+                assert abs(M[i, i] - (dl.mean() + dr.mean())) <= 1e-6 * max(1.0, abs(M[i, i]))
