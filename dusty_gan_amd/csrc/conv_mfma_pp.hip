@@ -65,14 +65,21 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int WC = BN / WN;                  // channels per wave
   constexpr int TM = 4, TN = WC / 16;          // 16 x 16 blocks per wave: pixels x channels
   constexpr int CPL = 4 * TN;                  // consecutive channels one lane ends up with
-  constexpr int STAGE = (BM + BN) * SB;
-  constexpr int NS = 3;
-  constexpr int IA = BM / 8 / NWV, IB = BN / 8 / NWV, IPT = IA + IB;
+  // One ring stage = one PAIR of K steps: the two W taps of a pair read the SAME input pixels one column apart, so
+  // the pair shares one pixel image of SW + 1 columns per sample segment (<= 260 rows, 33 pieces of 8 rows) and owns
+  // two weight tiles.  (With one 256-row pixel tile per K step the LDS-DMA of the pixels was issued and written twice:
+  // a what-if build that dropped half of those pieces ran the layer set 11 % faster.)
+  constexpr int IMG_ROWS = 264;
+  constexpr int AIMG = IMG_ROWS * SB;
+  constexpr int BT = BN * SB;
+  constexpr int PSTAGE = AIMG + 2 * BT;
+  constexpr int NPS = 2;
+  constexpr int IA = 4, IB = BN / 8 / NWV;     // pieces per wave: image (+ piece 32: wave 0), one weight tile
   constexpr int NST = TM * CPL * 2 / 16;       // 16-byte stores per lane per tile
   constexpr int NDB = 512;
-  constexpr int nW = MODE == MODE_S2 ? 4 : 2;
-  static_assert(IB >= 1 && NS * STAGE + 3 * NDB * 4 <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + 3 * NDB * 4];
+  constexpr int NPAIR = MODE == MODE_S2 ? 2 : 1;   // pairs per (H tap, 64-channel chunk)
+  static_assert(IB >= 1 && NPS * PSTAGE + 3 * NDB * 4 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NPS * PSTAGE + 3 * NDB * 4];
 #ifdef DG_PP_DIAG
   constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
 #else
@@ -112,24 +119,35 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const bf16* w = (const bf16*)p.w;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lrow = lane >> 3, pos = lane & 7;
-  auto swzA = [](int row) { return (row >> 1) & 7; };
+  // 16-byte chunk c of image row r lives at chunk c ^ swzA(r).  The fragment reads of the two taps start at rows r and
+  // r + 1 of segments pitched SW + 1 rows, i.e. at ANY row offset: ((r >> 1) & 3) << 1 keeps the four 16-lane groups of
+  // ds_read_b128 conflict-free for every offset (exhaustive check over the linear maps of the row bits; the previous
+  // (r >> 1) & 7 is conflict-free for even offsets only).
+  auto swzA = [](int row) { return ((row >> 1) & 3) << 1; };
   auto swzB = [](int row) { return ((row >> 1) & 1) | (((row / CPL) & 3) << 1); };
 
-  // ---- issue side.  K steps of a tile run (H tap, 64-channel chunk, W tap) with the nW W taps INNERMOST and unrolled:
-  //      consecutive steps then differ by a per-lane column shift (precomputed per tile: voffA[tap]) and the weight tap
-  //      only, the compute side - two steps behind - meets its tile boundary at FIXED positions of the unrolled group
-  //      (last step at position 1 of a tile's first group, epilogue in front of position 2 % nW), and a K step costs
-  //      ~25 scalar instructions.  (A state machine advanced once per K step cost ~80 scalar instructions and 16
-  //      branches per step - SQ_INSTS_SALU was 2.4x SQ_INSTS_MFMA - and the instruction issue of the LOAD half, not the
-  //      LDS, the texture path or the matrix pipe, bounded the kernel.)
-  unsigned voffA[nW][IA], voffB[IB];           // per-lane byte offsets (A: per tile and W tap, B: constant)
-  int colA[IA];                                // (stride-scaled) tile-row column inside its sample segment
-  unsigned sampA[IA];                          // byte offset of the row's sample inside the sample group + swizzled chunk
+  // ---- issue side.  K steps of a tile run (H tap, 64-channel chunk, pair, tap of the pair).  A pair's image row m of
+  //      segment s holds input column cmul (x_seg + m) + cb (circular), cb = -1 / 0 for the odd / even stride-2 pair
+  //      and -1 / 0 for column parity 0 / 1 of MODE_UP; tap t of the pair reads image rows m + t:
+  //        MODE_S2 pair 0: kx 0, 2 (columns 2x - 1, 2x + 1)   pair 1: kx 1, 3 (columns 2x, 2x + 2)
+  //        MODE_UP px 0:   kx 3, 1 (columns x - 1, x)         px 1:   kx 2, 0 (columns x, x + 1)
+  //      The per-lane source offsets change with the tile only (voffA[pair][piece]); a K step costs ~20 scalar
+  //      instructions.  (A state machine advanced once per K step cost ~80 and 16 branches - SQ_INSTS_SALU was 2.4x
+  //      SQ_INSTS_MFMA - and the instruction issue of the LOAD half, not the LDS, the texture path or the matrix
+  //      pipe, bounded the kernel.)
+  unsigned voffA[NPAIR][IA + 1], voffB[IB];    // per-lane byte offsets (image: per tile and pair, weights: constant)
+  int colA[IA + 1];                            // (stride-scaled) image column inside its sample segment
+  unsigned sampA[IA + 1];                      // byte offset of the row's sample inside the sample group + swizzled chunk
+  {
+    const int pitch = g.SW + 1;
 #pragma unroll
-  for (int u = 0; u < IA; ++u) {
-    const int row = (wave + NWV * u) * 8 + lrow;
-    colA[u] = cmul * (row & (g.SW - 1));
-    sampA[u] = (unsigned)((row >> g.lsw) * (int)p.in_sb * 2 + (pos ^ swzA(row)) * 16);
+    for (int u = 0; u <= IA; ++u) {
+      const int m = (u < IA ? (wave + NWV * u) : 32) * 8 + lrow;
+      int seg = m / pitch, c = m - seg * pitch;
+      if (seg >= g.NSB) { seg = 0; c = 0; }    // pad rows of the last piece: any valid address
+      colA[u] = cmul * c;
+      sampA[u] = (unsigned)(seg * (int)p.in_sb * 2 + (pos ^ swzA(m)) * 16);
+    }
   }
 #pragma unroll
   for (int u = 0; u < IB; ++u) {
@@ -142,14 +160,23 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int a16 = lane & 15, g4 = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  // fragment addresses inside a stage: pixel rows (B operand) and permuted weight rows (A operand); k-step 1 = ^ 64
-  const unsigned pbase = (unsigned)((wm * 64 + a16) * SB + ((g4 ^ (a16 >> 1)) << 4));
+  // fragment addresses inside a pair stage: image rows of tap 0 / tap 1 (B operand) and permuted weight rows (A
+  // operand); k-step 1 = ^ 64.  The wave's 64 tile rows lie in one sample segment (SW >= 64).
+  unsigned pbase[2];
+  {
+    const int rowbase = ((wm * 64) >> g.lsw) * (g.SW + 1) + ((wm * 64) & (g.SW - 1));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = rowbase + a16 + t;
+      pbase[t] = (unsigned)(r * SB + ((g4 ^ swzA(r)) << 4));
+    }
+  }
   const unsigned wrow = (unsigned)(wn * WC + (a16 >> 2) * CPL + (a16 & 3));
-  const unsigned wbase = (unsigned)((BM + wrow) * SB + ((g4 ^ (((a16 >> 1) & 1) | ((a16 >> 2) << 1))) << 4));
+  const unsigned wbase = (unsigned)(AIMG + wrow * SB + ((g4 ^ (((a16 >> 1) & 1) | ((a16 >> 2) << 1))) << 4));
 
-  float* s_bias = (float*)(lds + NS * STAGE);
+  float* s_bias = (float*)(lds + NPS * PSTAGE);
   float* s_db = s_bias + NDB;
-  const unsigned sbias0 = lds0 + NS * STAGE, sdb0 = sbias0 + NDB * 4;
+  const unsigned sbias0 = lds0 + NPS * PSTAGE, sdb0 = sbias0 + NDB * 4;
   float* s_rs = s_db + NDB;                    // per-sample weights of the bias-gradient sums (B <= NDB)
   const unsigned srs0 = sdb0 + NDB * 4;
   const bool want_db = MASK && p.dbias != nullptr;
@@ -302,55 +329,65 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   unsigned long long tend = 0;
 
   if (wave >= 4) __builtin_amdgcn_s_barrier(); // group B runs one barrier behind group A
-  unsigned so_c = STAGE, so_i = 0;             // LDS offset of the stage read / refilled (compute = issue - 2 = issue + 1 mod 3)
+  unsigned so_c = PSTAGE, so_i = 0;            // LDS offsets of the pair stage read / refilled (two stages, swapped per pair)
   bool pending = false;                        // a finished tile waits for its epilogue
-  bool warm = true;                            // the very first group: no compute step behind positions 0 and 1
+  bool warm = true;                            // the very first pair: nothing to compute yet
   Tile tprev = first;                          // the tile the compute side is finishing / has finished
-  const char* sA_k = nullptr;                  // wave-uniform bases of the (H tap, channel chunk) being issued
-  const char* sB_k = nullptr;
   const long tap_b = (long)p.w_st * 2;         // bytes per weight tap
   const unsigned spb = (unsigned)p.in_sp * 2u; // bytes per input pixel (< 2^24)
 
-  // one LDS-DMA piece: wave-uniform 64-bit base + per-lane 32-bit offset -> LDS at M0 (written in the same statement;
-  // nothing else in this kernel uses M0)
-  auto dma_s = [&](unsigned voff, const char* sbase, unsigned ldsaddr) __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
+  // one LDS-DMA piece: wave-uniform 64-bit base + per-lane 32-bit offset -> LDS at M0 = stage base + constant (written in
+  // the same statement; nothing else in this kernel uses M0)
+  auto dma_s = [&](unsigned voff, const char* sbase, unsigned ldsbase, auto off_tag) __attribute__((always_inline)) {
+    constexpr int OFF = decltype(off_tag)::value;
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 ::"s"(ldsbase), "v"(voff), "s"(sbase), "n"(OFF) : "memory", "scc");
   };
 
-  // One group = the nW W taps of one (H tap, channel chunk): nW K steps, each
-  //   LOAD half (epilogue of a finished tile; fragment reads of the compute step alternated with the DMA of the issue
-  //   step; waits) | barrier | MFMA half | barrier
-  // first: the group opens a tile (or is the drain group after the last one), so positions 0 and 1 still compute the
-  // previous tile.  kx0 / kxs: W taps of the group are kx0 + j * kxs.
-  auto group = [&](auto iss_tag, const bool first, const int kx0, const int kxs) __attribute__((always_inline)) {
+  // One pair = two K steps (the two W taps that share a pixel image), each
+  //   LOAD half (fragment reads of the compute step alternated with the step's DMA; waits; epilogue of a finished
+  //   tile) | barrier | MFMA half | barrier
+  // The compute side runs ONE PAIR behind the issue side: while pair q is issued into one stage, pair q - 1 is read
+  // from the other.  Tap 0's LOAD half issues the whole image and the weight tile of tap 0, tap 1's the weight tile of
+  // tap 1; each LOAD half ends with "everything but this half's pieces has landed", so the image and tile 0 have a full
+  // interval to land before the stage is read and tile 1 one and a half.  A stage is refilled one pair after its last
+  // read (each LOAD half ends with lgkmcnt(0) in front of a barrier).
+  // first: the pair opens a tile (or is the drain pair after the last one): its compute steps close the previous tile.
+  auto pair_iter = [&](auto iss_tag, const bool first, const int pi, const char* sA, const char* sB0, const char* sB1)
+      __attribute__((always_inline)) {
     constexpr bool ISS = decltype(iss_tag)::value;
-#pragma unroll
-    for (int j = 0; j < nW; ++j) {
-      if (!ISS && j >= 2) {                      // drain: nothing left to compute, keep the barrier count
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        continue;
-      }
+    const bool comp = !warm;
+    auto step = [&](auto t_tag) __attribute__((always_inline)) {
+      constexpr int t = decltype(t_tag)::value;
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
       if (stamps) { t0 = pp_stamp(); if (tend) tsum[5] += t0 - tend; }
-      const bool comp = j >= 2 || !(first && warm);            // runtime only at positions 0 and 1
-      const bool last = j == 1 && first && !warm;              // the compute step closes the previous tile
+      const bool last = t == 1 && first && !warm;             // the compute step closes the previous tile
       {
         const unsigned so = lds0 + so_c;
-        const unsigned pa0 = so + pbase, pa1 = so + (pbase ^ 64u), wa0 = so + wbase, wa1 = so + (wbase ^ 64u);
+        const unsigned pa0 = so + pbase[t], pa1 = so + (pbase[t] ^ 64u);
+        const unsigned wa0 = so + wbase + t * BT, wa1 = so + ((wbase ^ 64u) + t * BT);
         const unsigned dst = lds0 + so_i + dst_wave;
-        const char* sB_j = sB_k + (long)(kx0 + j * kxs) * tap_b;
-        auto piece = [&](int q) __attribute__((always_inline)) {
+        constexpr int NP = t == 0 ? IA + IB : IB;   // pieces of this half (wave 0: + the image's 33rd piece, issued first)
+        auto piece = [&](auto q_tag) __attribute__((always_inline)) {
+          constexpr int q = decltype(q_tag)::value;
           if (!ISS || (dbg & 1)) return;
-          if ((dbg & 32) && q >= IA / 2 && q < IA) return;       // what-if: half the pixel-tile traffic (shared W taps)
-          if (q < IA) dma_s(voffA[j][q], sA_k, dst + NWV * q * 1024);
-          else dma_s(voffB[q - IA], sB_j, dst + BM * SB + NWV * (q - IA) * 1024);
+          if constexpr (t == 0 && q < IA) dma_s(voffA[pi][q], sA, dst, std::integral_constant<int, NWV * q * 1024>{});
+          else if constexpr (t == 0) dma_s(voffB[q - IA], sB0, dst, std::integral_constant<int, AIMG + NWV * (q - IA) * 1024>{});
+          else dma_s(voffB[q], sB1, dst, std::integral_constant<int, AIMG + BT + NWV * q * 1024>{});
         };
-        constexpr int NR = 2 * TM + 2 * TN;      // fragment reads (unconditional: behind positions 0 and 1 of the very
-        int q = 0;                               // first group they fetch bytes nobody uses - cheaper than a second
-#pragma unroll                                   // register set for a conditionally written fragment)
+        if (ISS && t == 0 && wave == 0 && !(dbg & 1))
+          dma_s(voffA[pi][IA], sA, lds0 + so_i, std::integral_constant<int, 32 * 1024>{});
+        constexpr int NR = 2 * TM + 2 * TN;      // fragment reads (unconditional: in the very first pair they fetch bytes
+        int q = 0;                               // nobody uses - cheaper than a second register set for a conditionally
+                                                 // written fragment)
+        auto pieces_upto = [&](int r) __attribute__((always_inline)) {   // a piece after every NR / NP reads
+#define PP_PIECE(Q) if constexpr (Q < NP) { if (q == Q && r * NP >= Q * NR) { piece(std::integral_constant<int, Q>{}); ++q; } }
+          PP_PIECE(0) PP_PIECE(1) PP_PIECE(2) PP_PIECE(3) PP_PIECE(4) PP_PIECE(5) PP_PIECE(6) PP_PIECE(7)
+#undef PP_PIECE
+        };
+#pragma unroll
         for (int r = 0; r < NR; ++r) {
-          if (q < IPT && r * IPT >= q * NR) { piece(q); ++q; }   // a piece after every NR / IPT reads
+          pieces_upto(r);
           if (dbg & 16) continue;
           if (r < 2 * TM) {
             const int i = r >> 1;
@@ -360,15 +397,24 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
             if (r & 1) LDS_READ128(fw[1][jj], wa1, jj * 4 * SB); else LDS_READ128(fw[0][jj], wa0, jj * 4 * SB);
           }
         }
-#pragma unroll
-        for (; q < IPT; ++q) piece(q);
+        pieces_upto(1 << 20);
+        pieces_upto(1 << 20);
       }
       if (stamps) t1 = pp_stamp();
-      // own pieces of the PREVIOUS issue step landed (everything but this step's pieces; the stores of an epilogue that
-      // ran in this half are waited for too - once per tile, mostly retired), and the fragments are in
-      if (ISS) PP_WAIT(IPT); else PP_WAIT(0);
-      if (j == 2 % nW && pending) {              // the finished tile's epilogue: behind the wait (mask source landed),
-        if (!(dbg & 4)) epilogue(tprev); else zero_acc();   // in front of the MFMA half that restarts the accumulators
+      // everything but this half's pieces has landed (the stores of an epilogue that ran one half earlier are waited
+      // for too - once per tile, mostly retired), and the fragments are in
+      if (!ISS) PP_WAIT(0);
+      else if (t == 0) { if (wave == 0) PP_WAIT(IA + IB + 1); else PP_WAIT(IA + IB); }
+      else PP_WAIT(IB);
+      if (t == 0 && pending) {                   // the finished tile's epilogue: behind the wait (mask source landed),
+        if (!(dbg & 4)) epilogue(tprev);         // in front of the MFMA half that restarts the accumulators
+        else {                                   // (ablation: keep the MFMAs alive without their consumer)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) asm volatile("" ::"v"(acc[i][jj]));
+          zero_acc();
+        }
         pending = false;
       }
       if (stamps) t2 = pp_stamp();
@@ -392,9 +438,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           }
         }
         if (last) pending = true;
-        so_c = so_c + STAGE == NS * STAGE ? 0u : so_c + STAGE;
-      } else {
-        so_c = so_c + STAGE == NS * STAGE ? 0u : so_c + STAGE;
       }
       __builtin_amdgcn_sched_barrier(0);
       if (stamps) t4 = pp_stamp();
@@ -404,8 +447,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
         tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
         tend = t5;
       }
-      so_i = so_i + STAGE == NS * STAGE ? 0u : so_i + STAGE;
-    }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    const unsigned sw_ = so_c; so_c = so_i; so_i = sw_;
   };
 
   Tile ti = first;
@@ -415,15 +460,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     const char* in_t = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb);
     const char* w_t = (const char*)(w + (long)(ti.nt * BN) * p.w_sn);
     const int x0 = cmul * ti.xt * BM;
-    // W taps of this tile: S2 kx = 0..3 at column offsets -1..2; UP (column parity px) kx = 1,3 at 0,-1 or kx = 0,2 at 1,0
-    const int kx0 = MODE == MODE_S2 ? 0 : (ti.px == 0 ? 1 : 0), kxs = MODE == MODE_S2 ? 1 : 2;
 #pragma unroll
-    for (int j = 0; j < nW; ++j) {
-      const int coff = MODE == MODE_S2 ? j - 1 : (ti.px == 0 ? -j : 1 - j);
+    for (int pi = 0; pi < NPAIR; ++pi) {
+      const int cb = MODE == MODE_S2 ? pi - 1 : (ti.px == 0 ? -1 : 0);
 #pragma unroll
-      for (int u = 0; u < IA; ++u)               // circular columns: Ws is a power of two (checked by the launcher)
-        voffA[j][u] = __umul24((unsigned)((x0 + colA[u] + coff) & (Ws - 1)), spb) + sampA[u];
+      for (int u = 0; u <= IA; ++u)              // circular columns: Ws is a power of two (checked by the launcher)
+        voffA[pi][u] = __umul24((unsigned)((x0 + colA[u] + cb) & (Ws - 1)), spb) + sampA[u];
     }
+    // weight taps of the pair's two K steps (see the table at the issue side)
+    const int kxa = MODE == MODE_S2 ? 0 : (ti.px == 0 ? 3 : 2), kxb = MODE == MODE_S2 ? 2 : (ti.px == 0 ? 1 : 0);
     bool firstg = true;
     for (int h = 0; h < nh; ++h) {
       const int it_r = (int)(hl & 1023) >> 2, it_ky = (int)hl & 3;
@@ -431,16 +476,19 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       const char* sA_row = in_t + (long)it_r * Ws * spb;
       const char* sB_row = w_t + (long)(it_ky * 4) * tap_b;
       for (int kc = 0; kc < KC; ++kc) {
-        sA_k = sA_row + kc * SB;
-        sB_k = sB_row + kc * SB;
-        group(std::true_type{}, firstg, kx0, kxs);
-        if (firstg) { firstg = false; warm = false; }
+        const char* sA_k = sA_row + kc * SB;
+        const char* sB_k = sB_row + kc * SB;
+#pragma unroll
+        for (int pi = 0; pi < NPAIR; ++pi) {
+          pair_iter(std::true_type{}, firstg, pi, sA_k, sB_k + (long)(kxa + pi) * tap_b, sB_k + (long)(kxb + pi) * tap_b);
+          if (firstg) { firstg = false; warm = false; }
+        }
       }
     }
     tprev = ti;
     persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows);
   }
-  group(std::false_type{}, true, 0, 0);
+  pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr);
   if (pending && !(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epilogue(tprev);
