@@ -78,8 +78,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int NST = TM * CPL * 2 / 16;       // 16-byte stores per lane per tile
   constexpr int NDB = 512;
   constexpr int NPAIR = MODE == MODE_S2 ? 2 : 1;   // pairs per (H tap, 64-channel chunk)
-  static_assert(IB >= 1 && NPS * PSTAGE + 3 * NDB * 4 <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NPS * PSTAGE + 3 * NDB * 4];
+  constexpr int SCR = 16 * WC * 2;             // per-wave transpose strip of the epilogue: 16 pixels x the wave's channels
+  static_assert(IB >= 1 && NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR];
 #ifdef DG_PP_DIAG
   constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
 #else
@@ -200,13 +201,34 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // ---- epilogue pieces
   bf16* out = (bf16*)p.out;
   const unsigned lane_coff = (unsigned)((wn * WC + g4 * CPL) * 2);  // this lane's first channel inside the N tile, bytes
-  unsigned pix_off[TM];                        // byte offset of this lane's pixel of block i from the tile base
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int trow = wm * 64 + i * 16 + a16;
+  const long px_b = (long)(MODE == MODE_S2 ? 1 : 2) * p.out_sp * 2;   // bytes between consecutive tile rows of a segment
+  unsigned pix_off;                            // byte offset of this lane's pixel of block row 0 from the tile base
+  {
+    const int trow = wm * 64 + a16;
     const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
-    pix_off[i] = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2) + lane_coff;
+    pix_off = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2) + lane_coff;
   }
+  // Output stores go through a wave-private LDS strip, one 16-pixel block row at a time: a lane owns 16 B pieces of 16
+  // DIFFERENT pixels' rows (stride out_sp), so a store straight from the accumulator layout touched 64 cache lines per
+  // instruction, 16-32 B each - ablation: those stores were half of the epilogue's cost and the epilogue a quarter of
+  // the kernel.  Through the strip a store instruction writes whole 128 B (64 B: N tile 64) runs of 8 (16) pixels.
+  constexpr int CH = WC / 8;                   // 16-byte chunks per pixel in the strip (8 or 4)
+  constexpr int RPB = 64 / CH;                 // pixels per store instruction
+  constexpr int NRD = 16 / RPB;                // store instructions per block row (== NST / TM)
+  static_assert(NRD == NST / TM, "strip geometry");
+  auto swzS = [](int px) { return CH == 8 ? (px & 7) : ((px >> 1) & 3); };
+  const unsigned scr0 = lds0 + NPS * PSTAGE + 3 * NDB * 4 + (unsigned)wave * SCR;
+  // (block row i / second store h: wave-uniform steps from one per-lane offset - the wave's 64 tile rows lie in one segment)
+  const unsigned scr_w = scr0 + (unsigned)(a16 * (CH * 16) + (((g4 * NRD) ^ swzS(a16)) << 4));   // chunk h: ^ (h << 4)
+  unsigned scr_r, st_off;
+  {
+    const int pr = lane / CH, c = lane % CH;
+    scr_r = scr0 + (unsigned)(pr * (CH * 16) + ((c ^ swzS(pr)) << 4));                            // store h: + h * 1024
+    const int trow = wm * 64 + pr;
+    const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
+    st_off = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2 + (wn * WC) * 2 + c * 16);
+  }
+  static_assert(NRD == 1 || RPB * CH * 16 == 1024, "strip read offset");
   auto tile_off = [&](const Tile& t) __attribute__((always_inline)) -> long {  // element offset of (sample group, row Y, first column, first channel)
     const int n0 = t.xt * BM;
     return (long)(t.bt * g.NSB) * p.out_sb + ((long)t.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + t.px)) * p.out_sp +
@@ -222,10 +244,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   auto load_aux = [&](const Tile& t) __attribute__((always_inline)) {
     const char* ab = (const char*)((const bf16*)p.aux + tile_off(t));
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const char* src = ab + pix_off[i];
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(axr[(NST / TM) * i]) : "v"(src) : "memory");
-      if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(axr[2 * i + 1]) : "v"(src) : "memory");
+    for (int i = 0; i < TM; ++i) {             // wave-uniform base of block row i + the lane's 32-bit offset
+      const char* src = ab + (long)(i * 16) * px_b;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(axr[(NST / TM) * i]) : "v"(pix_off), "s"(src) : "memory");
+      if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(axr[2 * i + 1]) : "v"(pix_off), "s"(src) : "memory");
     }
   };
   // Bias-gradient sums (EPI_MASK with dbias): per lane 4 TN channel sums over its pixels, weighted per sample, of the
@@ -285,8 +307,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
                                                    //  element pays a second multiply by the scale)
     const float c_lin = p.epi == EPI_LRELU ? c_pos : p.scale;
     const float slope = p.epi == EPI_LRELU ? LRELU_SLOPE : 1.f;          // max(v, 1 v) = v: no select per element
+    i32x4 rd[NRD];                               // block row i - 1, read back pixel-major, waiting for its stores
+    auto store_row = [&](int i) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < NRD; ++h) {
+        asm volatile("" : "+v"(rd[h]));
+        char* dstp = ob + (long)(i * 16 + h * RPB) * px_b + st_off;
+        if (!(dbg & 128)) *(i32x4*)dstp = rd[h]; else asm volatile("" ::"v"(rd[h]));
+      }
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      // strip: the chunks of block row i are written as they are made, read back pixel-major, and stored after the
+      // arithmetic of block row i + 1 (which runs under the read latency)
 #pragma unroll
       for (int h = 0; h < NST / TM; ++h) {
         const i32x4 ax = axr[MASK ? (NST / TM) * i + h : 0];   // mask source of channels 8h .. 8h+7 (MASK only)
@@ -315,10 +349,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw) : "v"(v2[0]), "v"(v2[1]));
           pk[e2] = (int)pw;
         }
-        if (!(dbg & 128)) *(i32x4*)(ob + pix_off[i] + 16 * h) = pk; else asm volatile("" ::"v"(pk));
+        if (h == 0 && i > 0) store_row(i - 1);           // (its reads were issued a block row of arithmetic ago)
+        asm volatile("ds_write_b128 %0, %1" ::"v"(scr_w ^ (unsigned)(h << 4)), "v"(pk) : "memory");
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < NRD; ++h)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rd[h]) : "v"(scr_r), "n"(h * 1024) : "memory");
       __builtin_amdgcn_sched_barrier(0);       // one pixel block at a time: keeps the live ranges (and VGPRs) short
     }
+    store_row(TM - 1);
     if (want_db) flush_db(dbacc, t.nt);
     zero_acc();
   };
