@@ -1,11 +1,10 @@
 // extern "C" dispatchers of the conv-like passes (include/dusty_gan_hip.h).
 #include "common.h"
 
-#include <stdlib.h>
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
-int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
+int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
 int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, hipStream_t stream);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
@@ -20,7 +19,8 @@ extern "C" {
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
 // force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
-//        4 large-tile persistent MFMA kernel or error.  plan != NULL: describe the launch instead of making it.
+//        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error.
+//        plan != NULL: describe the launch instead of making it.
 static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
   if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
@@ -32,7 +32,7 @@ static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, 
   const bool thin_ok = dg_conv_thin_supported(p);
   if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; }
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
-  if (force == 4) return mfma_ok ? dg_conv_mfma_big_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (force == 4 || force == 5) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {
@@ -67,9 +67,7 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
   const bool thin_ok = dg_wgrad_thin_supported(p);
   // bf16 Down / Up layers: LDS-DMA ring version (wgrad_mfma_dma.hip); force == 6 asks for the register-staged kernel
-  static int use_dma = -1;  // DG_WGRAD_DMA=0: debugging aid (scripts/debug_seg_sync3.sh)
-  if (use_dma < 0) { const char* e = getenv("DG_WGRAD_DMA"); use_dma = e ? atoi(e) : 1; }
-  if (use_dma && (force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
+  if ((force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
     return dg_wgrad_mfma_dma_launch(p, accumulate, s);
   if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);

@@ -339,13 +339,8 @@ static int launch_cfg(const ConvP* p, hipStream_t stream, DgConvPlan* plan) {
     plan->tiles_per_wg = 1;
     return DG_OK;
   }
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-  static int var = -1;  // DG_CONV_VAR: 0 = 64-byte stages x 3, 1 = 64 x 4, 2 = 128 x 2
-  if (var < 0) { const char* e = getenv("DG_CONV_VAR"); var = e ? atoi(e) : 2; }
-  if (var == 1) conv_mfma_kernel<T, BM, BN, 64, 4><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, dbg);
-  else if (var == 2) conv_mfma_kernel<T, BM, BN, 128, 2><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, dbg);
-  else conv_mfma_kernel<T, BM, BN, 64, 3><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, dbg);
+  // 128-byte stages x 2 (64-byte stages x 3 / x 4 measured slower on every layer and are not instantiated)
+  conv_mfma_kernel<T, BM, BN, 128, 2><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, 0);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -369,28 +364,19 @@ int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto
 
 int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan);
 
-static int use_pp() {  // DG_CONV_PP=0: keep the lock-step persistent kernel for bf16 too (A/B runs of scripts/bench_conv.py)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DG_CONV_PP"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
-// plan != NULL: fill it with what would be launched and launch nothing
+// plan != NULL: fill it with what would be launched and launch nothing.
+// Auto rule: bf16 layers with >= 256 tiles of 256 pixels -> ping-pong persistent kernel (conv_mfma_pp.hip, family 5);
+// layers the lock-step persistent kernel tiles with every CU busy -> that one (conv_mfma_persist_impl.h, family 4: fp32,
+// 128 x 128 tiles); everything else -> one tile per workgroup (below, family 2).
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  // layers that tile into 256-row M tiles go to the persistent large-tile kernel (conv_mfma_persist_impl.h);
-  // DG_CONV_PERSIST=0 keeps everything on the one-tile-per-workgroup kernel below, =2 uses large tiles wherever
-  // the geometry allows (A/B runs)
-  static int persist = -1;
-  if (persist < 0) { const char* e = getenv("DG_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
-  if (persist && p->in_dtype == DG_BF16 && use_pp()) {
-    // bf16 layers with >= 256 tiles of 256 pixels: the ping-pong persistent kernel (conv_mfma_pp.hip)
-    const int rc = dg_conv_mfma_pp_launch(p, stream, persist == 1 ? 256 : 1, wg_cap, plan);
+  if (p->in_dtype == DG_BF16) {
+    const int rc = dg_conv_mfma_pp_launch(p, stream, 256, wg_cap, plan);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
-  if (persist) {
-    const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, persist == 1, wg_cap, plan)
-                                          : dg_conv_mfma_persist_launch_f32(p, stream, persist == 1, wg_cap, plan);
+  {
+    const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 1, wg_cap, plan)
+                                          : dg_conv_mfma_persist_launch_f32(p, stream, 1, wg_cap, plan);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
   const bool m128 = p->mode == MODE_GEMM ? false : (p->Wc % 128 == 0);
@@ -407,13 +393,11 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
   return launch_cfg<float, 64, 64>(p, stream, plan);
 }
 
-// large-tile persistent kernel wherever the geometry allows, else DG_EUNSUPPORTED (dg_conv force == 4; parity tests)
-int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
+// a persistent large-tile kernel wherever its geometry allows, else DG_EUNSUPPORTED (parity tests of either family on
+// small problems): dg_conv force == 4 -> the lock-step kernel, force == 5 -> the ping-pong kernel
+int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  if (p->in_dtype == DG_BF16 && use_pp()) {
-    const int rc = dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan);
-    if (rc != DG_EUNSUPPORTED) return rc;
-  }
+  if (family == 5) return p->in_dtype == DG_BF16 ? dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan) : DG_EUNSUPPORTED;
   return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0, wg_cap, plan)
                                 : dg_conv_mfma_persist_launch_f32(p, stream, 0, wg_cap, plan);
 }

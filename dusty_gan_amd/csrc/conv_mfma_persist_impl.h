@@ -489,9 +489,7 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
     if (occ < 1) occ = 1;
     resident = occ * cus;
   }
-  static int dbg = -1;  // DG_CONV_DBG: ablation builds of scripts/bench_conv.py (1 no DMA, 2 no MFMA, 4 no epilogue)
-  if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-  g.dbg = dbg;
+  g.dbg = 0;  // (ablation bits of the kernel-development builds: 1 no DMA, 2 no MFMA, 4 no epilogue)
   // wg_cap (dg_conv_ex): fewer workgroups than the device holds, i.e. longer tile chunks per workgroup (parity tests
   // of the cross-tile ring on small problems)
   const int cap = (wg_cap > 0 && wg_cap < resident) ? wg_cap : resident;
@@ -524,9 +522,7 @@ inline int pick(const ConvP* p, Geo& g, bool auto_rule) {
   if (p->N == 64 && (!auto_rule || p->epi == EPI_MASK) && make_geo<256, 64>(p, g) && g.ntiles >= min_tiles) return 3;
   // layers with too few 256-row tiles (the 4 x 64 maps at batch 32): 128 x 128 tiles on 8 waves of 32 x 64, built from
   // two samples' row segments where the map is 64 wide (Up1 backward-data -13 %, Down4 forward at B = 32 -10 %)
-  static int t128 = -1;  // DG_CONV_T128=0 switches it off (A/B runs)
-  if (t128 < 0) { const char* e = getenv("DG_CONV_T128"); t128 = e ? atoi(e) : 1; }
-  if (t128 && make_geo<128, 128>(p, g) && g.ntiles >= min_tiles) return 4;
+  if (make_geo<128, 128>(p, g) && g.ntiles >= min_tiles) return 4;
   return 0;
 }
 
@@ -536,11 +532,9 @@ int launch_dtype(const ConvP* p, hipStream_t stream, bool auto_rule, int wg_cap,
   const int which = pick(p, g, auto_rule);
   if (which == 2) {
     // bf16: 128-byte stages x 3 (one barrier per 64 channels, 8-row epilogue strips to fit the LDS) measured 8-12 %
-    // faster than 64 x 4 on every layer of this tile; DG_CONV_SB128=0 switches back (A/B runs)
-    static int sb128 = -1;
-    if (sb128 < 0) { const char* e = getenv("DG_CONV_SB128"); sb128 = e ? atoi(e) : 1; }
+    // faster than 64 x 4 on every layer of this tile
     if constexpr (sizeof(T) == 2) {
-      if (sb128 && p->K % 64 == 0)
+      if (p->K % 64 == 0)
         return p->mode == MODE_S2 ? launch<T, 256, 128, 4, 2, 128, 3, MODE_S2>(p, g, stream, wg_cap, plan)
                                   : launch<T, 256, 128, 4, 2, 128, 3, MODE_UP>(p, g, stream, wg_cap, plan);
     }

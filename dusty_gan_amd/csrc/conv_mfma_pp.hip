@@ -556,9 +556,7 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
     HIP_CHECK_RET(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     resident = cus;                            // 148 KB of LDS: one workgroup per CU
   }
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("DG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-  g.dbg = dbg;
+  g.dbg = 0;
   const int cap = (wg_cap > 0 && wg_cap < resident) ? wg_cap : resident;
   const int G = g.ntiles < cap ? g.ntiles : cap;
   if (plan) {

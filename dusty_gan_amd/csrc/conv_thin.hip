@@ -643,175 +643,6 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The same operation as a column walker with an LDS-DMA row ring.  thin_up_mfma_kernel above reads every input row
-// three times (once per neighbouring output row pair) through registers, one load -> MFMA -> store chain at a time:
-// it sits at a third of the HBM roof.  Here a workgroup owns one 64-pixel column tile of one sample and walks DOWN the
-// rows: each input row tile (66 pixels x 128 B) is fetched ONCE, by LDS-DMA, UR_PF rows ahead of its use, into a ring
-// of UR_NS row slots; the 3 x 3 tap window of output row pair m is slots m, m+1, m+2.
-//   * DMA pieces are lane-linear (1 KB per wave instruction), so bank conflicts are avoided by swizzling the SOURCE:
-//     LDS chunk j of pixel c holds channel chunk j ^ ((c >> 1) & 7); readers undo it.
-//   * LDS reads are inline asm (hipcc drains vmcnt(0) before any LDS access it can see after a DMA) and the arrival of
-//     row m+1 is a COUNTED wait: vmcnt retires in order, and after the pieces of row m+1 this wave has issued at least
-//     2 pieces for each of the UR_PF - 1 younger rows and 2 stores for each completed step since.
-constexpr int UR_NS = 8, UR_PF = 5;            // UR_NS = UR_PF + 3
-constexpr int UR_SLOT = 9 * 1024;              // 66 px x 128 B = 8448 B, rounded up to whole DMA pieces
-constexpr int UR_LDS_BYTES = UR_NS * UR_SLOT + 2 * 18 * 1024;  // ring + the two edge-row fragment classes
-#define UR_LDS_READ128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory")
-
-__global__ __launch_bounds__(256) void thin_up_ring_kernel(ConvP p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int N = p.N, Wc = p.Wc, Hc = p.Hc;
-  const int nwg = gridDim.x, id = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;     // neighbouring column tiles (shared halo) on one XCD
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-  const int tiles = Wc / TU_PX;
-  const int b = logical / tiles, n0 = (logical % tiles) * TU_PX;
-  const bf16* in = (const bf16*)p.in + (long)b * p.in_sb;
-  const int col = lane & 15, kg = lane >> 4;
-
-  // DMA geometry of this lane: pieces wave, wave + 4 (all lanes) and piece 8 (wave 0, lanes 0..15)
-  long soff[3];
-  bool sok[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int pos = (k * 4 + wave) * 64 + lane;             // 16-byte chunk index inside the row slot
-    const int c = pos >> 3, j = pos & 7;
-    sok[k] = k < 2 || (wave == 0 && c < TU_PX + 2);
-    int cc = n0 - 1 + (c < TU_PX + 2 ? c : 0);
-    if (cc < 0) cc += Wc; else if (cc >= Wc) cc -= Wc;
-    soff[k] = (long)cc * p.in_sp + (j ^ ((c >> 1) & 7)) * 8;
-  }
-  auto issue_row = [&](int rr) {                            // rr in [-1, ...): input row rr, clamped (zero weights outside)
-    const int r = rr < 0 ? 0 : (rr >= Hc ? Hc - 1 : rr);
-    unsigned char* slot = ring + ((rr + 1) % UR_NS) * UR_SLOT;
-    const bf16* src = in + (long)r * Wc * p.in_sp;
-    dma16(src + soff[0], slot + wave * 1024);
-    dma16(src + soff[1], slot + (4 + wave) * 1024);
-    if (wave == 0) {
-      if (sok[2]) dma16(src + soff[2], slot + 8 * 1024);
-    }
-  };
-  // reader geometry: pixel xl + d, channel chunks kg and kg + 4 (swizzled)
-  const int xl = wave * 16 + col;
-  unsigned roff[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const int c = xl + d;
-    roff[d] = (unsigned)(c * 128 + ((kg ^ ((c >> 1) & 7)) * 16));
-  }
-  const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-
-  // per-lane epilogue constants, loaded BEFORE the ring starts: a vector load inside the loop would make the
-  // compiler wait for it - and, vmcnt being in-order, for the freshly issued DMA row in front of it
-  float sc_h[2], bias_h[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int q = 2 * kg + h, n = q < 2 * N ? q % N : 0;
-    sc_h[h] = p.nscale ? p.scale * p.nscale[n] : p.scale;
-    bias_h[h] = p.bias ? p.bias[n % p.bias_mod] : 0.f;
-  }
-  // Weight fragments: the interior class lives in registers for the whole walk; the first / last row classes are
-  // parked in LDS behind the ring and read (inline asm) only in those two steps.  No global load may sit inside the
-  // walk: hipcc would drain vmcnt(0) - i.e. the whole DMA ring - in front of its first use, every iteration.
-  unsigned char* edge_frags = ring + UR_NS * UR_SLOT;      // [2][18][64 lanes][16 B]
-  for (int i = tid; i < 2 * 18 * 64; i += 256)
-    *(uint4*)(edge_frags + i * 16) = *(const uint4*)(g_up_frag + (18 * 64 + i) * 16);   // classes 1 and 2
-  tw_bf16x8 fa[18];
-#pragma unroll
-  for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(g_up_frag + ((0 * 18 + f) * 64 + lane) * 16);
-  __syncthreads();
-  const unsigned edge_base = ring_base + (unsigned)(UR_NS * UR_SLOT) + (unsigned)lane * 16u;
-  for (int rr = -1; rr <= UR_PF; ++rr) issue_row(rr);      // rows -1 .. UR_PF in flight
-  for (int m = 0; m < Hc; ++m) {
-    // row m+1 has landed when at most (UR_PF - 1) * 2 + min(m, UR_PF) * 2 younger operations are outstanding
-#ifdef UR_DEBUG_DRAIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    switch (99) {
-#else
-    switch (m < UR_PF ? m : UR_PF) {
-#endif
-      case 0: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-    }
-    __builtin_amdgcn_s_barrier();                           // everyone's pieces of row m+1; everyone done with row m-2
-    issue_row(m + 1 + UR_PF);                               // always (clamped rows at the tail keep the counts uniform)
-    tw_bf16x8 fb[18];
-    auto read_row = [&](int rr) {
-      const unsigned sb = ring_base + (unsigned)(((m + rr) % UR_NS) * UR_SLOT);
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        UR_LDS_READ128(fb[(rr * 3 + d) * 2 + 0], sb + roff[d]);
-        UR_LDS_READ128(fb[(rr * 3 + d) * 2 + 1], sb + (roff[d] ^ 64u));
-      }
-    };
-    // The compiler treats the asm outputs as ready the moment the ds_read is issued and is free to schedule the MFMAs
-    // (pure register operations) above a bare s_waitcnt.  So every fragment is tied to an empty volatile asm that
-    // follows the wait which covers it: its consumers cannot move above that.
-    tw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (m == 0 || m == Hc - 1) {                            // edge rows: their weight fragments come from LDS too
-      tw_bf16x8 fe[18];
-      const unsigned eb = edge_base + (m == 0 ? 0u : 18u * 1024u);
-      read_row(0); read_row(1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      read_row(2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int f = 0; f < 9; ++f) UR_LDS_READ128(fe[f], eb + (unsigned)f * 1024u);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int f = 9; f < 18; ++f) UR_LDS_READ128(fe[f], eb + (unsigned)f * 1024u);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int f = 0; f < 18; ++f) { asm volatile("" : "+v"(fb[f])); asm volatile("" : "+v"(fe[f])); }
-#pragma unroll
-      for (int f = 0; f < 18; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fe[f], fb[f], acc, 0, 0, 0);
-    } else {
-      // interior rows: LDS reads of row r+1 / r+2 run under the MFMAs of row r (lgkmcnt is a 4-bit, in-order counter:
-      // never more than 12 reads outstanding)
-      read_row(0); read_row(1);
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-#pragma unroll
-      for (int f = 0; f < 6; ++f) asm volatile("" : "+v"(fb[f]));
-      read_row(2);
-#pragma unroll
-      for (int f = 0; f < 6; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb[f], acc, 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-#pragma unroll
-      for (int f = 6; f < 12; ++f) asm volatile("" : "+v"(fb[f]));
-#pragma unroll
-      for (int f = 6; f < 12; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb[f], acc, 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int f = 12; f < 18; ++f) asm volatile("" : "+v"(fb[f]));
-#pragma unroll
-      for (int f = 12; f < 18; ++f) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb[f], acc, 0, 0, 0);
-    }
-    const int x = n0 + xl;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = 2 * kg + h;
-      if (q >= 2 * N) continue;
-      const int py = q / N, n = q % N;
-      const float v0 = acc[2 * h] * sc_h[h] + bias_h[h], v1 = acc[2 * h + 1] * sc_h[h] + bias_h[h];
-      const long o = (long)b * p.out_sb + ((long)(2 * m + py) * (2 * Wc) + 2 * x) * p.out_sp + (long)n * p.out_sn;
-      if (p.out_dtype == DG_F32 && p.out_sp == 1) {
-        *(float2*)((float*)p.out + o) = make_float2(v0, v1);
-      } else {
-        dg_st(p.out, o, p.out_dtype, v0);
-        dg_st(p.out, o + p.out_sp, p.out_dtype, v1);
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail's clamped DMA rows must not outlive the workgroup's LDS
-}
-
 int dg_conv_up_mfma_supported(const ConvP* p) {
   if (p->mode != MODE_UP || !p->ring) return 0;
   if (p->in_dtype != DG_BF16 || p->w_dtype != DG_BF16) return 0;
@@ -824,20 +655,9 @@ int dg_conv_up_mfma_supported(const ConvP* p) {
 int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_up_mfma_supported(p)) return DG_EUNSUPPORTED;
   thin_up_prep_kernel<<<dim3(36, 3), 256, 0, s>>>(*p);
-  // opt-in (DG_UP_RING=1): parity-green (tests/test_gpu_thin.py under that switch) but within box-to-box noise of the
-  // row kernel on the whole step (3.51 vs 3.53 ms), so the simpler kernel stays the default
-  static const int ring = [] { const char* e = getenv("DG_UP_RING"); return e ? atoi(e) : 0; }();
-  if (ring) {
-    static bool opted = false;
-    if (!opted) {
-      HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_up_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        UR_LDS_BYTES));
-      opted = true;
-    }
-    thin_up_ring_kernel<<<(unsigned)((long)p->B * (p->Wc / TU_PX)), 256, UR_LDS_BYTES, s>>>(*p);
-  } else {
-    thin_up_mfma_kernel<<<(unsigned)((long)p->B * p->Hc), 256, 0, s>>>(*p);
-  }
+  // (a column-walker variant with an LDS-DMA row ring that fetched every input row once instead of three times measured
+  //  within noise of this kernel on the step - 0.277 vs 0.282 ms for the family - and was removed in round 2)
+  thin_up_mfma_kernel<<<(unsigned)((long)p->B * p->Hc), 256, 0, s>>>(*p);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1161,9 +981,7 @@ int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
   const int tiles_x = p->Wc / 32;
   const long ntiles = (long)p->B * p->Hc * tiles_x;
   long blocks = (ntiles + 3) / 4;
-  static long cap = 0;
-  // 2 blocks per CU: the per-wave weight preload amortises over more tiles (DG_S2_BLOCKS overrides)
-  if (!cap) { const char* e = getenv("DG_S2_BLOCKS"); cap = e ? atol(e) : 512; }
+  const long cap = 512;  // 2 blocks per CU: the per-wave weight preload amortises over more tiles
   if (blocks > cap) blocks = cap;
   if (p->in_sp == 2) thin_s2_mfma_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
   else thin_s2_mfma_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);

@@ -459,10 +459,9 @@ int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_
   const bool valu_ok = nb <= 64 && nb % 2 == 0 && K % 4 == 0 && K / 4 <= 256 && 256 % (K / 4) == 0 && lds <= 64 * 1024;
   // The MFMA gradient GEMM with the optimizer as its epilogue takes every batch size when Np and K are multiples of 128
   // and measured 6 % faster than the LDS-resident VALU kernel even at nb = 32 (scripts/bench_proj_adam.py: 311 vs
-  // 331 us); DG_PROJ_ADAM_MFMA=0 keeps the VALU kernel wherever it applies (A/B switch).
-  static const int use_mfma = [] { const char* e = getenv("DG_PROJ_ADAM_MFMA"); return e ? atoi(e) : 1; }();
+  // 331 us); the VALU kernel takes the shapes the GEMM does not tile.
   const bool mfma_ok = Np % 128 == 0 && K % 128 == 0;
-  if (!valu_ok || (use_mfma && mfma_ok)) {
+  if (!valu_ok || mfma_ok) {
     // (wgrad_mfma.hip; also the only fused path for nb > 64, i.e. the all-gathered global batch of a multi-GPU run);
     // shapes neither kernel takes -> DG_EUNSUPPORTED -> caller's unfused path
     WgradP w{};

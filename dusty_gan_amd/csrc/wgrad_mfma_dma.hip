@@ -11,7 +11,11 @@
 //   * LDS rows are unpadded (DMA pieces are lane-linear); the 4-row x 64-byte footprint of a transposing read is
 //     spread over the banks by an XOR swizzle of the 64-byte column group with the row (applied on the DMA source
 //     address, undone in the read address, which only depends on the lane);
-//   * transposing reads are inline asm (a compiler-visible LDS read behind an in-flight DMA drains vmcnt(0)).
+//   * transposing reads are inline asm (a compiler-visible LDS read behind an in-flight DMA drains vmcnt(0));
+//   * a workgroup owns a PAIR of W taps (kx, kx + 2): both read the same G pixels and A pixels one column apart, so a
+//     chunk is one G tile + one A image of 64 + 1 pixels, the G fragments feed both taps' MFMAs, and the LDS - which
+//     bounded the one-tap version (fragment reads ~50 % + DMA writes ~50 % of its bandwidth at 40 % MFMA use) - moves
+//     half the DMA bytes and three quarters of the fragment bytes per flop.
 #include "common.h"
 
 #include <stdlib.h>
@@ -36,11 +40,12 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 #define DG_WAITV(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define TR16(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 
-template <int WMODE, int BM, int BN>
+// NT = W taps per workgroup: 1, or 2 = the pair (kx, kx + 2) on one G tile and one A image of 64 + 1 pixels
+template <int WMODE, int BM, int BN, int NT>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n, int accumulate) {
   constexpr int RA = BM * 2, RG = BN * 2;                 // LDS row bytes (one pixel)
-  constexpr int STA = BKP * RA, STG = BKP * RG, STAGE = STA + STG;
-  constexpr int PA = STA / 1024 / 4, PG = STG / 1024 / 4;  // DMA pieces per wave per stage
+  constexpr int STA = BKP * RA + (NT == 2 ? 1024 : 0), STG = BKP * RG, STAGE = STA + STG;   // pair: 64 + 1 pixels (one more piece of rows)
+  constexpr int PA = BKP * RA / 1024 / 4, PG = STG / 1024 / 4;  // DMA pieces per wave per stage (+ the A image's last piece: wave 0)
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(PA >= 1 && PG >= 1, "tile too small for the piece distribution");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
   const int ct = bx % tiles_n, mt = bx / tiles_n;
   const int ci0 = mt * BM, co0 = ct * BN;
-  const int tap = by, ky = tap >> 2, kx = tap & 3;
+  const int ky = NT == 2 ? by >> 1 : by >> 2, kxp = NT == 2 ? by & 1 : by & 3;   // pair: kx = kxp and kxp + 2; single: kx = kxp
   const long units = (long)p.B * p.Hc;
   const long u0 = units * bz / gridDim.z, u1 = units * (bz + 1) / gridDim.z;
   const int cpr = p.Wc / BKP;                             // chunks per row
@@ -89,9 +94,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
     rowG[v] = r;
     chG[v] = (unsigned)(((((c >> 2) ^ swz(r, RG)) << 2) | (c & 3)) * 16);
   }
+  const int rowX = BKP + lane / CA;                       // the image's last piece (rows 64 ..): wave 0
+  const unsigned chX = (unsigned)((((((lane % CA) >> 2) ^ swz(rowX, RA)) << 2) | (lane % CA & 3)) * 16);
   const unsigned aspb = (unsigned)asp * 2u, gspb = (unsigned)gsp * 2u;   // bytes per pixel (< 2^24)
-  const int da = WMODE == 0 ? kx - 1 : (kx == 0 ? 1 : (kx == 3 ? -1 : 0));  // column shift of the tap on the A grid
-  const int dg = WMODE == 1 ? ((kx == 0 || kx == 2) ? 1 : 0) : 0;        // column parity of the tap on the G grid
+  // A image row m of a chunk starting at coarse column x0 holds A-grid column amul (x0 + m) + da; the pair's taps read
+  // image rows r + 0 and r + 1 for chunk pixel r:
+  //   wmode 0 (Down): columns 2x + kx - 1:  kx = kxp -> row r, kx = kxp + 2 -> row r + 1;         da = kxp - 1
+  //   wmode 1 (Up):   columns x + d(kx), d = +1, 0, 0, -1:  pair 0: kx 2 -> r, kx 0 -> r + 1 (da = 0);
+  //                                                         pair 1: kx 3 -> r, kx 1 -> r + 1 (da = -1)
+  //   single tap kx: image row r holds the tap's own column (Down: 2x + kx - 1; Up: x + d(kx))
+  const int da = NT == 2 ? (WMODE == 0 ? kxp - 1 : -kxp)
+                         : (WMODE == 0 ? kxp - 1 : (kxp == 0 ? 1 : (kxp == 3 ? -1 : 0)));
+  const int kx_s0 = NT == 2 ? (WMODE == 0 ? kxp : kxp + 2) : kxp, kx_s1 = WMODE == 0 ? kxp + 2 : kxp;
+  const int dg = WMODE == 1 ? (NT == 2 ? 1 - kxp : ((kxp == 0 || kxp == 2) ? 1 : 0)) : 0;   // column parity on the G grid
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   auto dma_s = [&](unsigned voff, const char* sbase, unsigned ldsaddr) __attribute__((always_inline)) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
@@ -121,6 +136,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
       const unsigned ca = (unsigned)(((WMODE == 0 ? 2 : 1) * (x0 + rowA[v]) + da) & (Wa - 1));
       dma_s(__umul24(ca, aspb) + chA[v], abase, base + 4 * v * 1024);
     }
+    if (NT == 2 && wave == 0) {
+      const unsigned ca = (unsigned)(((WMODE == 0 ? 2 : 1) * (x0 + rowX) + da) & (Wa - 1));
+      dma_s(__umul24(ca, aspb) + chX, abase, lds0 + st_off + 4 * PA * 1024);
+    }
 #pragma unroll
     for (int v = 0; v < PG; ++v) {
       const unsigned cg = (unsigned)((WMODE == 1 ? 2 : 1) * (x0 + rowG[v]) + dg);
@@ -138,25 +157,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   const int lr = lane & 31, lh = lane >> 5;
   const int g16 = lane >> 4, i16 = lane & 15;
   const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3;
-  unsigned offA[TM], offG[TN];                            // byte offset of this lane's lo read at kq = 0, stage 0
+  unsigned offA[NT][TM], offG[TN];                         // byte offset of this lane's lo read at kq = 0, stage 0 (A: per tap)
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int colb = (wm * (BM / 2) + i * 32 + 16 * cb + 4 * pp) * 2;
-    offA[i] = lds0 + (8 * kh + q) * RA + ((((colb >> 6) ^ swz(q, RA)) << 6) | (colb & 63));
-  }
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int colb = (wm * (BM / 2) + i * 32 + 16 * cb + 4 * pp) * 2;
+      offA[t][i] = lds0 + (8 * kh + q + t) * RA + ((((colb >> 6) ^ swz(q + t, RA)) << 6) | (colb & 63));
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int colb = (wn * (BN / 2) + j * 32 + 16 * cb + 4 * pp) * 2;
     offG[j] = lds0 + STA + (8 * kh + q) * RG + ((((colb >> 6) ^ swz(q, RG)) << 6) | (colb & 63));
   }
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[NT][TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
 
   int cb_s = (int)(u0 / p.Hc), cm = (int)(u0 % p.Hc), cxc = 0;   // compute position (sample for the per-sample weight)
   float cur_rs = 1.f;
@@ -175,17 +198,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
     __builtin_amdgcn_s_barrier();
     if (s + 1 < nchunks) issue(so ^ (unsigned)STAGE);
     // the reads of k-step kq+1 are issued before the MFMAs of kq (two fragment sets, counted lgkmcnt)
-    i32x2 alo[2][TM], ahi[2][TM], glo[2][TN], ghi[2][TN];
-    unsigned ra[TM], rg[TN];
+    i32x2 alo[2][NT][TM], ahi[2][NT][TM], glo[2][TN], ghi[2][TN];   // [set][tap][..]
+    unsigned ra[NT][TM], rg[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) ra[i] = offA[i] + so;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ra[t][i] = offA[t][i] + so;
 #pragma unroll
     for (int j = 0; j < TN; ++j) rg[j] = offG[j] + so;
 #define DG_READ_SET(kq)                                            \
   do {                                                             \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                 \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {               \
-      TR16(alo[(kq) & 1][i], ra[i], (kq) * 16 * RA);               \
-      TR16(ahi[(kq) & 1][i], ra[i], (kq) * 16 * RA + 4 * RA);      \
+      TR16(alo[(kq) & 1][t][i], ra[t][i], (kq) * 16 * RA);         \
+      TR16(ahi[(kq) & 1][t][i], ra[t][i], (kq) * 16 * RA + 4 * RA);\
     }                                                              \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {               \
       TR16(glo[(kq) & 1][j], rg[j], (kq) * 16 * RG);               \
@@ -196,27 +222,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) {
+        const i32x4 fg = {glo[set][j][0], glo[set][j][1], ghi[set][j][0], ghi[set][j][1]};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const i32x4 fa = {alo[set][i][0], alo[set][i][1], ahi[set][i][0], ahi[set][i][1]};
-          const i32x4 fg = {glo[set][j][0], glo[set][j][1], ghi[set][j][0], ghi[set][j][1]};
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fg),
-                                                              acc[i][j], 0, 0, 0);
-        }
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const i32x4 fa = {alo[set][t][i][0], alo[set][t][i][1], ahi[set][t][i][0], ahi[set][t][i][1]};
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
+                                                                   __builtin_bit_cast(bf16x8, fg), acc[t][i][j], 0, 0, 0);
+          }
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
     static_assert(BKP / 16 == 4, "four k-steps per chunk");
     DG_READ_SET(0);
     DG_READ_SET(1);
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT * TM + TN)) : "memory");
     mfmas(0);
     DG_READ_SET(2);
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT * TM + TN)) : "memory");
     mfmas(1);
     DG_READ_SET(3);
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM + TN)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT * TM + TN)) : "memory");
     mfmas(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     mfmas(1);
@@ -233,44 +262,61 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
           const float ratio = cur_rs / rn;
           cur_rs = rn;
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] *= ratio;
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[t][i][j] *= ratio;
         }
       }
     }
   }
 
   // D layout: col = lane & 31 (co), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (ci)
-  float* dw = p.dw + (long)tap * p.Ci * p.Co;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int t = 0; t < NT; ++t) {
+    float* dw = p.dw + (long)(ky * 4 + (t == 0 ? kx_s0 : kx_s1)) * p.Ci * p.Co;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ci = ci0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int co = co0 + wn * (BN / 2) + j * 32 + lr;
-        const float v = acc[i][j][e] * (p.scale * cur_rs);
-        float* dst = dw + (long)ci * p.Co + co;
-        if (accumulate) atomicAdd(dst, v);
-        else *dst = v;
-      }
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = ci0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const int co = co0 + wn * (BN / 2) + j * 32 + lr;
+          const float v = acc[t][i][j][e] * (p.scale * cur_rs);
+          float* dst = dw + (long)ci * p.Co + co;
+          if (accumulate) atomicAdd(dst, v);
+          else *dst = v;
+        }
+  }
 }
 
 template <int WMODE, int BM, int BN>
 int launch_dma(const WgradP* p, int accumulate, hipStream_t stream) {
   const int tiles_m = p->Ci / BM, tiles_n = p->Co / BN;
   const long units = (long)p->B * p->Hc;
-  const long tiles = (long)tiles_m * tiles_n * 16;
-  long split = 1;
-  if (accumulate) {
-    split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
-    if (split > units) split = units;
-    if (split < 1) split = 1;
+  auto split_for = [&](long tiles) {
+    long split = 1;
+    if (accumulate) {
+      split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
+      if (split > units) split = units;
+      if (split < 1) split = 1;
+    }
+    return split;
+  };
+  // Tap pairs halve the DMA bytes and the (tile, tap) workgroups, so the same workgroup count needs twice the K split -
+  // twice the partial tiles to add atomically - and each workgroup's pixel range halves.  Measured (scripts/bench_conv.py):
+  // Down2 at batch 64 +16 % (64 chunks per workgroup), Up3 equal, the layers left with <= 32 chunks per workgroup
+  // 5-25 % slower.  So: pairs where a workgroup still walks >= 48 chunks.
+  const long split2 = split_for((long)tiles_m * tiles_n * 8);
+  if (accumulate && units / split2 * (p->Wc / BKP) >= 48) {
+    dim3 grid((unsigned)(tiles_m * tiles_n), 8u, (unsigned)split2);
+    wgrad_dma_kernel<WMODE, BM, BN, 2><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+  } else {
+    dim3 grid((unsigned)(tiles_m * tiles_n), 16u, (unsigned)split_for((long)tiles_m * tiles_n * 16));
+    wgrad_dma_kernel<WMODE, BM, BN, 1><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   }
-  dim3 grid((unsigned)(tiles_m * tiles_n), 16u, (unsigned)split);
-  wgrad_dma_kernel<WMODE, BM, BN><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

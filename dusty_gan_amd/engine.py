@@ -164,40 +164,6 @@ class NetCfg:
             raise NotImplementedError("discriminator in_ch != 1 (the range-image path is single channel)")
 
 
-class SideStream:
-    """Second HIP stream for the weight-gradient kernels.  A layer's weight gradient and the backward-data pass that
-    continues the chain read the same tensors and write disjoint ones, and nothing consumes a weight gradient before
-    the optimizer - so the (latency-bound) wgrad kernels run beside the chain instead of between its links.  Inside a
-    hipGraph capture the fork / join events become graph edges.  Opt-in (`DUSTY_GAN_SIDE_STREAM=1`): it was worth ~1 %
-    while the weight-gradient kernel was latency-bound; with the LDS-DMA version (wgrad_mfma_dma.hip) both streams
-    compete for the same DMA / LDS path and the step is 1.3 % FASTER on one stream (same-box A/B, 3.77 vs 3.82 ms)."""
-    enabled = os.environ.get("DUSTY_GAN_SIDE_STREAM", "0") == "1"
-    _streams = {}
-    _dirty = set()
-
-    @classmethod
-    def fork(cls):
-        """context manager: work issued inside runs on the side stream, after everything issued so far"""
-        dev = torch.cuda.current_device()
-        if not cls.enabled or PROFILE is not None:
-            import contextlib
-            return contextlib.nullcontext()
-        side = cls._streams.get(dev)
-        if side is None:
-            side = cls._streams[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        cls._dirty.add(dev)
-        return torch.cuda.stream(side)
-
-    @classmethod
-    def join(cls):
-        """the current stream waits for everything issued to the side stream"""
-        dev = torch.cuda.current_device()
-        if dev in cls._dirty:
-            torch.cuda.current_stream().wait_stream(cls._streams[dev])
-            cls._dirty.discard(dev)
-
-
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
     default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
@@ -207,8 +173,8 @@ class Ops:
         self.dtype = dtype
         self.dt = L.dtype_code(dtype)
         self.es = 2 if dtype == torch.bfloat16 else 4
-        # 0 auto (MFMA implicit GEMM where the shape allows), 1 direct VALU kernels only (cross-check runs)
-        self.force = int(os.environ.get("DUSTY_GAN_FORCE_KERNEL", "0"))
+        # dg_conv / dg_wgrad `force` (0 auto; the parity tests set 1 direct, 2 MFMA, 3 thin, 4 / 5 persistent kernels)
+        self.force = 0
         self.wg_cap = Ops.default_wg_cap  # dg_conv_ex: cap on the persistent conv's workgroup count (0 = one residency wave)
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
@@ -380,7 +346,7 @@ class GEngine:
         self.ops.wgrad(2, 1, 1, 1, nb, Np, c.nz, dp0, (0, Np, 1), zT, (0, c.nz, 1), st.fptr("proj_w", st.grad),
                        1.0 / math.sqrt(Np), accumulate=int(accumulate))
 
-    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, join=True, data_only=False,
+    def backward(self, st: ParamStore, ddepth, accumulate_proj=False, skip_proj=False, data_only=False,
                  chain_first=False, after_chain=None, after_up1=None):
         """ddepth [B,1,H,W] fp32 = dLoss/d(output depth).  Accumulates every G parameter gradient into st.grad
         (the autograd work of loss_G.backward(), trainers/dcgan_amp.py:309).  data_only: just the backward-data chain
@@ -413,9 +379,8 @@ class GEngine:
 
         def head_wgrad():
             hc, wc = self.grid[3]
-            with SideStream.fork():
-                o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), hsrc, hstr,
-                        st.fptr("head_w", st.grad), 1.0, **hkw_w)
+            o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), hsrc, hstr,
+                    st.fptr("head_w", st.grad), 1.0, **hkw_w)
 
         def head_bwd_data():  # gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad
             hc, wc = self.grid[3]
@@ -426,9 +391,8 @@ class GEngine:
         def up_wgrad(i):
             hc, wc = self.grid[i - 1]
             ci, co = chs[i - 1], chs[i]
-            with SideStream.fork():
-                o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
-                        (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), 1.0 / math.sqrt(co * 16))
+            o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
+                    (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), 1.0 / math.sqrt(co * 16))
 
         def up_bwd_data(i):
             hc, wc = self.grid[i - 1]
@@ -457,10 +421,7 @@ class GEngine:
                 up_wgrad(i)
                 up_bwd_data(i)
         if not skip_proj:
-            with SideStream.fork():
-                self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
-        if join:  # join=False: the caller joins after work that does not need the weight gradients (fused Proj Adam)
-            SideStream.join()
+            self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
 
     # ------------------------------------------------------------------ path-length regulariser (trainers/dcgan_amp.py:268-306)
     def _backward_chain(self, st, ddepth, draw, draw_pm, dp, acts, chain, second_of, thead=None):
@@ -662,18 +623,16 @@ class DEngine:
     def wgrad(self, st, a_slot, g_slot, n, rowscale, layers=(1, 2, 3, 4)):
         """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot+b]) for the Down layers in `layers`."""
         c, o = self.cfg, self.ops
-        with SideStream.fork():
-            for i in layers:
-                hc, wc = self.grid[i]
-                ci, co = self.chs[i - 1], self.chs[i]
-                o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
-                        (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
-                        a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i])
+        for i in layers:
+            hc, wc = self.grid[i]
+            ci, co = self.chs[i - 1], self.chs[i]
+            o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
+                    (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
+                    a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i])
 
     def final_wgrad(self, st, slot, n, coef):
         """dwf += s_f * sum_b coef[b] * h4[slot+b]"""
         o, lib = self.ops, L.lib()
         nf = self.per[4]
-        with SideStream.fork():
-            L.check(lib.dg_batch_wsum(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n,
-                                      nf, st.fptr("final_w", st.grad), L.stream_ptr()), "dg_batch_wsum")
+        L.check(lib.dg_batch_wsum(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n,
+                                  nf, st.fptr("final_w", st.grad), L.stream_ptr()), "dg_batch_wsum")

@@ -172,17 +172,14 @@ class FlatAdam:
         if fused_proj is not None:
             dp0, zT, op_dt, nb, Np, K, wscale = fused_proj
             if self.betas[0] != 0.0:
-                E.SideStream.join()
                 return False
             rc = lib.dg_adam_proj_fused(L.ptr(st.flat), L.ptr(st.v), ema_ptr, L.ptr(st.shadow), sdt, L.ptr(dp0), L.ptr(zT),
                                         op_dt, nb, Np, K, wscale, gscale, self.lr, self.betas[1], self.eps,
                                         L.ptr(self._step_dev), ema_decay, L.stream_ptr())
             if rc == L.DG_EUNSUPPORTED:
-                E.SideStream.join()
                 return False
             L.check(rc, "dg_adam_proj_fused")
             off = Np * K
-        E.SideStream.join()  # the remaining segments need the weight gradients still running on the side stream
         self.step_count += 1
         self._last_gscale = gscale
         # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
@@ -415,8 +412,7 @@ class Trainer:
         import os
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while this thread captures
-        pool = None if os.environ.get("DUSTY_DBG_POOLS") == "separate" else self._cap_pool
-        ctx = torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if self.world > 1 else "global")
+        ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self.world > 1 else "global")
         ctx.__enter__()
         self._cap_cur = (g, ctx)
 
@@ -524,7 +520,6 @@ class Trainer:
                         if layers == (4,):
                             deng.final_wgrad(Dst, 0, 2 * B, dy)
                             deng.final_wgrad(Dst, 2 * B, B, None)
-                            E.SideStream.join()
                             self._allreduce_async("D.hi", Dst.grad[cut:])
             else:
                 deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
@@ -534,10 +529,8 @@ class Trainer:
                 else:
                     deng.wgrad(Dst, 0, 0, 2 * B, None, layers=(4,))
                     deng.final_wgrad(Dst, 0, 2 * B, dy)
-                    E.SideStream.join()
                     self._allreduce_async("D.hi", Dst.grad[cut:])
                     deng.wgrad(Dst, 0, 0, 2 * B, None, layers=(3, 2, 1))
-            E.SideStream.join()
             self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
         if self._bucketed():
             self._allreduce_async("D.lo", Dst.grad[:Dst.seg["d4_w"].off])
@@ -603,8 +596,7 @@ class Trainer:
                     after_up1=lambda: self._allreduce_async("G.hi", Gst.grad[hi0:hi1]))
                 self._allreduce_async("G.lo", Gst.grad[hi1:])
             else:
-                mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj,
-                                    join=not fuse_proj)
+                mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj)
             if pl_on:
                 # (Proj.weight's two path-length terms follow its adversarial term: materialised here, or - when that
                 # gradient is formed inside the optimizer / from gathered operands - appended to its operand list below)

@@ -86,8 +86,9 @@ typedef struct DgWgrad {
  *   their autograd backward-data passes (loss.backward() at trainers/dcgan_amp.py:235,309 and
  *   torch.autograd.grad(create_graph=True) at :218-223), and the R1 tangent pass (double backward, :229-235).
  * force: 0 = pick (MFMA implicit GEMM when the shape allows, else the thin LDS/VALU kernel for <=4-channel sides,
- * else the general direct kernel), 1 = direct, 2 = MFMA or error, 3 = thin or error, 4 = the large-tile (256-row)
- * persistent MFMA kernel or error (what 0 / 2 pick for layers that fill the chip with such tiles).
+ * else the general direct kernel), 1 = direct, 2 = MFMA or error, 3 = thin or error, 4 / 5 = a persistent large-tile
+ * MFMA kernel or error (4 the lock-step one, 5 the bf16 ping-pong one; what 0 / 2 pick for layers that fill the chip
+ * with such tiles - the forced forms let parity tests run either family on small problems).
  */
 int dg_conv(const DgConv* p, int force, void* stream);
 /* What a dg_conv call launches (introspection for the parity tests and the benchmark: which kernel family / tile ran,

@@ -74,7 +74,7 @@ def pack_up(w):  # ConvTranspose2d weight (Ci,Co,4,4) -> fwd [16][co][ci], bwd [
     return fwd, bwd
 
 
-CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct, 2 = MFMA, 4 = large-tile persistent MFMA kernel
+CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct, 2 = MFMA, 4 / 5 = lock-step / ping-pong persistent kernel
     (6, 4, 8, 16, 2, True, torch.float32, 1),
     (6, 4, 8, 16, 2, False, torch.float32, 1),
     (5, 3, 4, 6, 3, True, torch.float32, 1),
@@ -88,6 +88,11 @@ CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct, 2 = MFMA,
     (128, 128, 2, 512, 1, True, torch.bfloat16, 4),
     (128, 256, 4, 64, 8, True, torch.bfloat16, 4),
     (64, 128, 2, 256, 1, True, torch.bfloat16, 4),   # backward-data: 256 x 64 tiles (8 waves of 32 x 64)
+    # the ping-pong kernel (bf16; what the benchmark's fat layers run) on the same geometries
+    (256, 128, 4, 128, 2, True, torch.bfloat16, 5),
+    (128, 128, 2, 512, 1, True, torch.bfloat16, 5),
+    (128, 256, 4, 64, 8, True, torch.bfloat16, 5),
+    (64, 128, 2, 256, 1, True, torch.bfloat16, 5),   # backward-data: 256 x 64 tiles
 ]
 
 
@@ -127,7 +132,7 @@ def test_down_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     # weight gradient
     from dusty_gan_amd.engine import Ops
     o = Ops(dtype)
-    o.force = 2 if force == 4 else force
+    o.force = 2 if force in (4, 5) else force
     xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
     dw = torch.zeros(16, Ci, Co, device=DEV)
     o.wgrad(0, ring, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw.data_ptr(), s)
@@ -175,7 +180,7 @@ def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     assert rel_l2(db, ref_dx.sum(dim=[0, 2, 3])) < (tol if dtype == torch.float32 else 5e-2)
     from dusty_gan_amd.engine import Ops
     o = Ops(dtype)
-    o.force = 2 if force == 4 else force
+    o.force = 2 if force in (4, 5) else force
     xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
     dw = torch.zeros(16, Ci, Co, device=DEV)
     o.wgrad(1, ring, B, H, W, Ci, Co, xd, (H * W * Ci, Ci, 1), ed, (4 * H * W * Co, Co, 1), dw.data_ptr(), s)

@@ -36,26 +36,28 @@ def _persist(trace):
 # all three tile shapes (256 x 128, 256 x 64, 128 x 128), both modes, adj 0 / 1, bias-gradient sums with per-sample
 # weights, uneven chunk lengths (tile count not a multiple of the workgroup count)
 MULTI = [
-    (128, 256, 4, 128, 8, torch.bfloat16, 5),    # 256 x 128 tiles from 2 samples' row segments
-    (256, 128, 4, 128, 8, torch.bfloat16, 3),
-    (128, 128, 4, 512, 4, torch.bfloat16, 7),    # two x tiles per row
-    (128, 256, 4, 64, 16, torch.bfloat16, 4),    # 4 samples' row segments per tile
-    (128, 256, 4, 64, 14, torch.bfloat16, 6),    # 14 % 4 != 0: 128 x 128 tiles from 2 samples' row segments
-    (64, 128, 4, 256, 4, torch.bfloat16, 5),     # 64-channel side: 256 x 64 tiles in the backward-data passes
-    (128, 256, 4, 64, 16, torch.float32, 3),     # fp32 instance (64-byte stages x 4)
-    (128, 128, 4, 256, 8, torch.float32, 5),
+    (128, 256, 4, 128, 8, torch.bfloat16, 5, 5),    # 256 x 128 tiles from 2 samples' row segments
+    (256, 128, 4, 128, 8, torch.bfloat16, 3, 5),
+    (128, 128, 4, 512, 4, torch.bfloat16, 7, 5),    # two x tiles per row
+    (128, 256, 4, 64, 16, torch.bfloat16, 4, 5),    # 4 samples' row segments per tile
+    (64, 128, 4, 256, 4, torch.bfloat16, 5, 5),     # 64-channel side: 256 x 64 tiles in the backward-data passes
+    (128, 256, 4, 128, 8, torch.bfloat16, 5, 4),    # the lock-step kernel on the same geometries
+    (128, 256, 4, 64, 14, torch.bfloat16, 6, 4),    # 14 % 4 != 0: 128 x 128 tiles from 2 samples' row segments
+    (64, 128, 4, 256, 4, torch.bfloat16, 5, 4),
+    (128, 256, 4, 64, 16, torch.float32, 3, 4),     # fp32 instance (64-byte stages x 4)
+    (128, 128, 4, 256, 8, torch.float32, 5, 4),
 ]
 
 
-@pytest.mark.parametrize("Ci,Co,H,W,B,dtype,cap", MULTI)
+@pytest.mark.parametrize("Ci,Co,H,W,B,dtype,cap,family", MULTI)
 @pytest.mark.parametrize("which", ["down", "up"])
-def test_persistent_conv_several_tiles_per_workgroup(monkeypatch, trace, which, Ci, Co, H, W, B, dtype, cap):
+def test_persistent_conv_several_tiles_per_workgroup(monkeypatch, trace, which, Ci, Co, H, W, B, dtype, cap, family):
     from dusty_gan_amd.engine import Ops
     monkeypatch.setattr(Ops, "default_wg_cap", cap)
     from dusty_gan_amd import _lib as L
     fn = OPS.test_down_fwd_bwd_wgrad if which == "down" else OPS.test_up_fwd_bwd_wgrad
-    fn(L, Ci, Co, H, W, B, True, dtype, 4)
-    pc = _persist(trace)
+    fn(L, Ci, Co, H, W, B, True, dtype, family)
+    pc = [t for t in trace if t[0] == "conv" and t[1] == family]   # dg_conv force 4 / 5 -> plan family 4 / 5
     assert len(pc) == 2, trace                      # forward + backward-data both on the persistent kernel
     for t in pc:
         assert t[5] <= cap and t[6] >= 4, t         # workgroups <= cap, >= 4 tiles per workgroup
