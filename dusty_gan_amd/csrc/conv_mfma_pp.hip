@@ -78,7 +78,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int NST = TM * CPL * 2 / 16;       // 16-byte stores per lane per tile
   constexpr int NDB = 512;
   constexpr int NPAIR = MODE == MODE_S2 ? 2 : 1;   // pairs per (H tap, 64-channel chunk)
-  constexpr int SCR = 16 * WC * 2;             // per-wave transpose strip of the epilogue: 16 pixels x the wave's channels
+  constexpr bool STRIP = BN == 128;            // output stores through a per-wave LDS transpose strip (below)
+  constexpr int SCR = STRIP ? 16 * WC * 2 : 0; // 16 pixels x the wave's channels
   static_assert(IB >= 1 && NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR];
 #ifdef DG_PP_DIAG
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // Output stores go through a wave-private LDS strip, one 16-pixel block row at a time: a lane owns 16 B pieces of 16
   // DIFFERENT pixels' rows (stride out_sp), so a store straight from the accumulator layout touched 64 cache lines per
   // instruction, 16-32 B each - ablation: those stores were half of the epilogue's cost and the epilogue a quarter of
-  // the kernel.  Through the strip a store instruction writes whole 128 B (64 B: N tile 64) runs of 8 (16) pixels.
+  // the kernel.  Through the strip a store instruction writes whole 128 B runs of 8 pixels.  (N tile 64: a lane owns ONE
+  // 16 B piece per pixel and the four lanes of a pixel already cover a 64 B run - all of the pixel this wave has - so
+  // the strip would only add its LDS round trips: direct stores.)
   constexpr int CH = WC / 8;                   // 16-byte chunks per pixel in the strip (8 or 4)
   constexpr int RPB = 64 / CH;                 // pixels per store instruction
   constexpr int NRD = 16 / RPB;                // store instructions per block row (== NST / TM)
@@ -349,16 +352,23 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw) : "v"(v2[0]), "v"(v2[1]));
           pk[e2] = (int)pw;
         }
+        if (!STRIP) {                                    // N tile 64: the four lanes of a pixel already write one 64 B run
+          char* dstp = ob + (long)(i * 16) * px_b + pix_off;
+          if (!(dbg & 128)) *(i32x4*)dstp = pk; else asm volatile("" ::"v"(pk));
+          continue;
+        }
         if (h == 0 && i > 0) store_row(i - 1);           // (its reads were issued a block row of arithmetic ago)
         asm volatile("ds_write_b128 %0, %1" ::"v"(scr_w ^ (unsigned)(h << 4)), "v"(pk) : "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (STRIP) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int h = 0; h < NRD; ++h)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rd[h]) : "v"(scr_r), "n"(h * 1024) : "memory");
+        for (int h = 0; h < NRD; ++h)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rd[h]) : "v"(scr_r), "n"(h * 1024) : "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);       // one pixel block at a time: keeps the live ranges (and VGPRs) short
     }
-    store_row(TM - 1);
+    if (STRIP) store_row(TM - 1);
     if (want_db) flush_db(dbacc, t.nt);
     zero_acc();
   };
