@@ -77,6 +77,7 @@ PROTOTYPES = {
     "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
+    "dg_final_fwd_acc": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
     "dg_final_bwd_data": [_P, _I, _P, _P, _P, _F, _I, _L, _I, _P, _P, _P],
     "dg_batch_wsum": [_P, _I, _P, _F, _I, _L, _P, _P],
     "dg_head_post_fwd": [_P, _P, _P, _I, _I, _F, _F, _I, _L, _P, _P, _P],
@@ -84,6 +85,8 @@ PROTOTYPES = {
     "dg_logistic_noise": [_P, _P, _F, _L, _P, _P],
     "dg_diffaug_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_diffaug_fwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_diffaug_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_nsgan_d": [_P, _P, _I, _F, _P, _P, _P, _P],
     "dg_nsgan_g": [_P, _I, _F, _P, _P, _P],
     "dg_nsgan_d_step": [_P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
@@ -107,6 +110,7 @@ PROTOTYPES = {
     "dg_pyr_up_sub": [_P, _P, _L, _I, _I, _P],
     "dg_extract_patches": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "dg_sample_sum": [_P, _I, _L, _I, _P, _P],
+    "dg_sample_sum_acc": [_P, _I, _L, _I, _P, _P],
     "dg_scale": [_P, _F, _L, _P, _P],
     "dg_zero": [_P, _L, _P],
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],
@@ -188,6 +192,34 @@ def zero_(t):
     assert t.dtype == torch.float32 and t.is_contiguous()
     check(lib().dg_zero(t.data_ptr(), t.numel(), stream_ptr()), "dg_zero")
     return t
+
+
+class AccArena:
+    """Small fp32 accumulators that must start at zero (per-sample sums, logits, the logged scalars), carved from ONE
+    buffer that one kernel zero-fills at the start of a training step - instead of one ~5 us zero-fill node per
+    accumulator (11 per step).  `take(n)` hands out a slice that has been zero since the last `begin()` and is handed
+    out once; None when the arena is not in use or exhausted (the caller then uses the self-zeroing entry point)."""
+    SIZE = 8192
+    buf, pos = None, 0
+
+    @classmethod
+    def begin(cls, device):
+        import torch
+        if cls.buf is None or cls.buf.device != torch.device(device):
+            cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
+        zero_(cls.buf)
+        cls.pos = 0
+
+    @classmethod
+    def take(cls, n, device=None):
+        import torch
+        if cls.buf is None or (device is not None and cls.buf.device != torch.device(device)):
+            return None
+        a = (cls.pos + 15) // 16 * 16          # 64-byte slices
+        if a + n > cls.SIZE:
+            return None
+        cls.pos = a + n
+        return cls.buf[a:a + n]
 
 
 def policy_mask(policy):

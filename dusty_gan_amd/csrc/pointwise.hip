@@ -2,6 +2,37 @@
 // DiffAugment, NSGAN losses, fetch_reals and small reductions.  Images are fp32 [B,1,H,W]; feature maps are T.
 #include "common.h"
 
+// 16-byte loads / stores of feature-map elements as floats: V = 8 bf16 or 4 fp32 per access
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+    const uint4 r = *(const uint4*)p;
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = __builtin_bit_cast(float, w[k] << 16);
+      v[2 * k + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      w[k] = (unsigned)__builtin_bit_cast(unsigned short, (bf16)v[2 * k]) |
+             ((unsigned)__builtin_bit_cast(unsigned short, (bf16)v[2 * k + 1]) << 16);
+    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+template <> struct Vec16<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 r = *(const float4*)p;
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
 // ----------------------------------------------------------------------------------------------------------
 // BlurVH (models/ops/common.py:74-88): x [B,H,W] fp32 -> h0 [B,H,W,2] (ch0 = vertical [1,2,1]/4 with reflect rows,
 // ch1 = horizontal [1,2,1]/4 with circular / reflect columns).
@@ -50,6 +81,94 @@ __global__ void blur_bwd_kernel(const T* __restrict__ d, float* __restrict__ dx,
   dx[idx] = v + h;
 }
 
+// Four pixels per thread (W % 4 == 0): 16-byte loads of the three rows, one 16-byte (bf16) / two (fp32) stores; the same
+// expressions as the scalar kernels above, which remain for other widths.
+template <typename T>
+__global__ __launch_bounds__(256) void blur_fwd4_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H,
+                                                        int W, int ring) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // quad index
+  const int W4 = W >> 2;
+  if (q >= (long)B * H * W4) return;
+  const int x0 = (int)(q % W4) * 4, y = (int)((q / W4) % H);
+  const long base = (q / W4 - y) * W;                            // b*H*W
+  const int yu = y == 0 ? 1 : y - 1, yd = y == H - 1 ? H - 2 : y + 1;
+  const float* rc = x + base + (long)y * W;
+  const float4 c4 = *(const float4*)(rc + x0);
+  const float4 u4 = *(const float4*)(x + base + (long)yu * W + x0);
+  const float4 d4 = *(const float4*)(x + base + (long)yd * W + x0);
+  int xl = x0 - 1, xr = x0 + 4;
+  if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
+  else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
+  const float c[6] = {rc[xl], c4.x, c4.y, c4.z, c4.w, rc[xr]};
+  const float u[4] = {u4.x, u4.y, u4.z, u4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = 0.25f * u[k] + 0.5f * c[k + 1] + 0.25f * d[k];
+    o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
+  }
+  T* op = out + (base + (long)y * W + x0) * 2;
+  if constexpr (sizeof(T) == 2) {
+    Vec16<bf16>::store((bf16*)op, o);
+  } else {
+    *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+    *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d, float* __restrict__ dx, int B, int H,
+                                                        int W, int ring) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W4 = W >> 2;
+  if (q >= (long)B * H * W4) return;
+  const int x0 = (int)(q % W4) * 4, y = (int)((q / W4) % H);
+  const long base = (q / W4 - y) * W;
+  auto row8 = [&](int yy, float (&v)[8]) {                      // (ch0, ch1) of pixels x0 .. x0+3 of row yy
+    const T* p = d + (base + (long)yy * W + x0) * 2;
+    if constexpr (sizeof(T) == 2) {
+      Vec16<bf16>::load((const bf16*)p, v);
+    } else {
+      const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+  };
+  auto D1 = [&](int yy, int xq) { return (float)d[(base + (long)yy * W + xq) * 2 + 1]; };
+  float m[8];
+  row8(y, m);
+  float v[4], h[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = 0.5f * m[2 * k];
+  if (y > 0) { float t[8]; row8(y - 1, t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+  if (y < H - 1) { float t[8]; row8(y + 1, t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+  if (y == 1) { float t[8]; row8(0, t);          // row 0 read x[1] as its reflected upper neighbour
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+  if (y == H - 2) { float t[8]; row8(H - 1, t);  // row H-1 read x[H-2] as its reflected lower neighbour
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int xx = x0 + k;
+    h[k] = 0.5f * m[2 * k + 1];
+    const bool hasl = k > 0, hasr = k < 3;       // neighbours inside the quad come from registers
+    if (ring) {
+      h[k] += 0.25f * (hasl ? m[2 * k - 1] : D1(y, xx == 0 ? W - 1 : xx - 1)) +
+              0.25f * (hasr ? m[2 * k + 3] : D1(y, xx == W - 1 ? 0 : xx + 1));
+    } else {
+      if (xx > 0) h[k] += 0.25f * (hasl ? m[2 * k - 1] : D1(y, xx - 1));
+      if (xx < W - 1) h[k] += 0.25f * (hasr ? m[2 * k + 3] : D1(y, xx + 1));
+      if (xx == 1) h[k] += 0.25f * D1(y, 0);
+      if (xx == W - 2) h[k] += 0.25f * D1(y, W - 1);
+    }
+  }
+  *(float4*)(dx + base + (long)y * W + x0) = make_float4(v[0] + h[0], v[1] + h[1], v[2] + h[2], v[3] + h[3]);
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // Final EqualLR(Conv2d(C,1,(h0,w0))) (models/gans/dcgan_eqlr.py:95): y[b] = scale * <d4[b], wf> + bias.
 template <typename T>
@@ -58,6 +177,28 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const T* __restrict__ d4
                                                         float* __restrict__ y) {
   // grid = (slabs, B): each block reduces one slab of one sample and adds it to y[b] (zeroed by the launcher);
   // slab 0 also adds the bias.  One block per sample left 7/8 of the chip idle (0.18 ms per call at B = 64).
+  // 16-byte accesses (n % V == 0, checked by the launcher; else the scalar kernel below).
+  __shared__ float red[16];
+  constexpr int V = Vec16<T>::V;
+  const int b = blockIdx.y;
+  const T* row = d4 + (long)b * n;
+  float acc = 0.f;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (long)gridDim.x * blockDim.x * V) {
+    float a[V];
+    Vec16<T>::load(row + i, a);
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+      const float4 w4 = *(const float4*)(wf + i + k);
+      acc += a[k] * w4.x + a[k + 1] * w4.y + a[k + 2] * w4.z + a[k + 3] * w4.w;
+    }
+  }
+  const float s = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(&y[b], s * scale + ((bias && blockIdx.x == 0) ? bias[0] : 0.f));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void final_fwd_scalar_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
+                                                               const float* __restrict__ bias, float scale, long n,
+                                                               float* __restrict__ y) {
   __shared__ float red[16];
   const int b = blockIdx.y;
   const T* row = d4 + (long)b * n;
@@ -69,13 +210,52 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const T* __restrict__ d4
 }
 
 // dd4[b][i] = up[b] * scale * wf[i] * lrelu'(d4[b][i]) * sqrt2 ; dbias4[i % C] += rowscale[b] * dd4[b][i]
+// A block owns 64 V consecutive elements; its four waves split the samples (wave w: b = w, w + 4, ...), a lane owns V
+// consecutive elements (V consecutive channels: C % V == 0): 16-byte loads and stores, four samples in flight per
+// element tile, the waves' bias-gradient partials meet in LDS and leave as ONE atomic per element per block.  (One
+// element per thread over all samples in turn: 2-byte accesses, 15 us for 34 MB.)
 template <typename T>
 __global__ __launch_bounds__(256) void final_bwd_data_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
                                                              const float* __restrict__ up,
                                                              const float* __restrict__ rowscale, float scale, int B,
                                                              long n, int C, T* __restrict__ dd4,
                                                              float* __restrict__ dbias) {
-  // grid.x covers n in chunks of blockDim; each thread loops over the batch so its channel (i % C) is fixed
+  constexpr int V = Vec16<T>::V;
+  __shared__ float part[4][64 * V];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * 64 + lane) * V;
+  float w[V], db[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { w[k] = i < n ? wf[i + k] * scale : 0.f; db[k] = 0.f; }
+  if (i < n) {
+#pragma unroll 4
+    for (int b = wave; b < B; b += 4) {
+      float a[V], g[V];
+      Vec16<T>::load(d4 + (long)b * n + i, a);
+      const float u = up ? up[b] : 1.f, rs = rowscale ? rowscale[b] : 1.f;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        g[k] = u * w[k] * (a[k] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+        db[k] += rs * g[k];
+      }
+      Vec16<T>::store(dd4 + (long)b * n + i, g);
+    }
+  }
+  if (!dbias) return;
+#pragma unroll
+  for (int k = 0; k < V; ++k) part[wave][lane * V + k] = db[k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * V; e += 256) {
+    const long ie = (long)blockIdx.x * 64 * V + e;
+    if (ie < n) atomicAdd(&dbias[ie % C], part[0][e] + part[1][e] + part[2][e] + part[3][e]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void final_bwd_data_scalar_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
+                                                                    const float* __restrict__ up,
+                                                                    const float* __restrict__ rowscale, float scale,
+                                                                    int B, long n, int C, T* __restrict__ dd4,
+                                                                    float* __restrict__ dbias) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float w = wf[i] * scale;
@@ -89,10 +269,39 @@ __global__ __launch_bounds__(256) void final_bwd_data_kernel(const T* __restrict
   if (dbias) atomicAdd(&dbias[i % C], db);
 }
 
-// out[i] += scale * sum_b coef[b] * src[b][i]   (coef null -> 1)
+// out[i] += scale * sum_b coef[b] * src[b][i]   (coef null -> 1).  Vector form: a block owns 64 V consecutive elements,
+// its four waves split the samples, partials meet in LDS, plain read-modify-write of out (no atomics).
 template <typename T>
-__global__ void batch_wsum_kernel(const T* __restrict__ src, const float* __restrict__ coef, float scale, int B,
-                                  long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void batch_wsum_kernel(const T* __restrict__ src, const float* __restrict__ coef,
+                                                         float scale, int B, long n, float* __restrict__ out) {
+  constexpr int V = Vec16<T>::V;
+  __shared__ float part[4][64 * V];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * 64 + lane) * V;
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int b = wave; b < B; b += 4) {
+      float a[V];
+      Vec16<T>::load(src + (long)b * n + i, a);
+      const float c = coef ? coef[b] : 1.f;
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += c * a[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) part[wave][lane * V + k] = acc[k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * V; e += 256) {
+    const long ie = (long)blockIdx.x * 64 * V + e;
+    if (ie < n) out[ie] += (part[0][e] + part[1][e] + part[2][e] + part[3][e]) * scale;
+  }
+}
+template <typename T>
+__global__ void batch_wsum_scalar_kernel(const T* __restrict__ src, const float* __restrict__ coef, float scale, int B,
+                                         long n, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float acc = 0.f;
@@ -317,9 +526,16 @@ __global__ __launch_bounds__(256) void sample_sum_kernel(const float* __restrict
   const int b = blockIdx.y;
   const float* row = x + (long)b * n;
   float acc = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float v = row[i];
-    acc += sq ? v * v : v;
+  if ((n & 3) == 0 && (((size_t)row) & 15) == 0) {             // 16-byte loads
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+      const float4 v = *(const float4*)(row + i);
+      acc += sq ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : v.x + v.y + v.z + v.w;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const float v = row[i];
+      acc += sq ? v * v : v;
+    }
   }
   const float s = dg_block_sum(acc, red);
   if (threadIdx.x == 0) atomicAdd(&out[b], s);
@@ -671,7 +887,10 @@ extern "C" {
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
-  if (dtype == DG_BF16) blur_fwd_kernel<bf16><<<nblk(n), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
+  if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)x & 15) == 0 && ((size_t)out & 15) == 0) {
+    if (dtype == DG_BF16) blur_fwd4_kernel<bf16><<<nblk(n / 4), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
+    else blur_fwd4_kernel<float><<<nblk(n / 4), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
+  } else if (dtype == DG_BF16) blur_fwd_kernel<bf16><<<nblk(n), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
   else blur_fwd_kernel<float><<<nblk(n), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
@@ -680,32 +899,66 @@ int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int r
 int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ring, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
-  if (dtype == DG_BF16) blur_bwd_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
+  if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)d & 15) == 0 && ((size_t)dx & 15) == 0) {
+    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<nblk(n / 4), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
+    else blur_bwd4_kernel<float><<<nblk(n / 4), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
+  } else if (dtype == DG_BF16) blur_bwd_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
   else blur_bwd_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+static inline bool vec_ok(const void* p, long n, int dtype) {
+  const int V = dtype == DG_BF16 ? 8 : 4;
+  return n % V == 0 && ((size_t)p & 15) == 0;
+}
+
+static int final_fwd_impl(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
+                          bool zero, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (zero) { const int zrc = dg_zero_f32(y, B, s); if (zrc) return zrc; }
+  const bool vec = vec_ok(d4, n, dtype) && ((size_t)wf & 15) == 0;
+  const int V = vec ? (dtype == DG_BF16 ? 8 : 4) : 1;
+  unsigned slabs = nblk(n, 256 * 4 * V);
+  if (slabs > 32) slabs = 32;
+  if (slabs < 1) slabs = 1;
+  if (vec) {
+    if (dtype == DG_BF16) final_fwd_kernel<bf16><<<dim3(slabs, B), 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
+    else final_fwd_kernel<float><<<dim3(slabs, B), 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
+  } else {
+    if (dtype == DG_BF16) final_fwd_scalar_kernel<bf16><<<dim3(slabs, B), 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
+    else final_fwd_scalar_kernel<float><<<dim3(slabs, B), 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
 
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
                  void* s_) {
-  hipStream_t s = (hipStream_t)s_;
-  { const int zrc = dg_zero_f32(y, B, s); if (zrc) return zrc; }
-  unsigned slabs = nblk(n, 256 * 16);
-  if (slabs > 32) slabs = 32;
-  if (slabs < 1) slabs = 1;
-  if (dtype == DG_BF16) final_fwd_kernel<bf16><<<dim3(slabs, B), 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
-  else final_fwd_kernel<float><<<dim3(slabs, B), 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
-  HIP_CHECK_RET(hipGetLastError());
-  return DG_OK;
+  return final_fwd_impl(d4, dtype, wf, bias, scale, B, n, y, true, s_);
+}
+// `_acc` forms: the small fp32 accumulator the kernel adds into (y / out / xsum / gsum) was zeroed by the CALLER - a step
+// that carves all of them from one buffer zero-fills once instead of once per call (each fill is a ~5 us graph node)
+int dg_final_fwd_acc(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
+                     void* s_) {
+  return final_fwd_impl(d4, dtype, wf, bias, scale, B, n, y, false, s_);
 }
 
 int dg_final_bwd_data(const void* d4, int dtype, const float* wf, const float* up, const float* rowscale, float scale,
                       int B, long n, int C, void* dd4, float* dbias, void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  if (dtype == DG_BF16)
-    final_bwd_data_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d4, wf, up, rowscale, scale, B, n, C, (bf16*)dd4, dbias);
-  else
-    final_bwd_data_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d4, wf, up, rowscale, scale, B, n, C, (float*)dd4, dbias);
+  const int V = dtype == DG_BF16 ? 8 : 4;
+  if (vec_ok(d4, n, dtype) && vec_ok(dd4, n, dtype) && C % V == 0) {
+    const unsigned grid = nblk(n / V, 64);
+    if (dtype == DG_BF16)
+      final_bwd_data_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)d4, wf, up, rowscale, scale, B, n, C, (bf16*)dd4, dbias);
+    else
+      final_bwd_data_kernel<float><<<grid, 256, 0, s>>>((const float*)d4, wf, up, rowscale, scale, B, n, C, (float*)dd4, dbias);
+  } else if (dtype == DG_BF16) {
+    final_bwd_data_scalar_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d4, wf, up, rowscale, scale, B, n, C, (bf16*)dd4, dbias);
+  } else {
+    final_bwd_data_scalar_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d4, wf, up, rowscale, scale, B, n, C, (float*)dd4, dbias);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -713,8 +966,16 @@ int dg_final_bwd_data(const void* d4, int dtype, const float* wf, const float* u
 int dg_batch_wsum(const void* src, int dtype, const float* coef, float scale, int B, long n, float* out,
                   void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  if (dtype == DG_BF16) batch_wsum_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)src, coef, scale, B, n, out);
-  else batch_wsum_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)src, coef, scale, B, n, out);
+  const int V = dtype == DG_BF16 ? 8 : 4;
+  if (vec_ok(src, n, dtype)) {
+    const unsigned grid = nblk(n / V, 64);
+    if (dtype == DG_BF16) batch_wsum_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)src, coef, scale, B, n, out);
+    else batch_wsum_kernel<float><<<grid, 256, 0, s>>>((const float*)src, coef, scale, B, n, out);
+  } else if (dtype == DG_BF16) {
+    batch_wsum_scalar_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)src, coef, scale, B, n, out);
+  } else {
+    batch_wsum_scalar_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)src, coef, scale, B, n, out);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -743,15 +1004,22 @@ int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* n
   return DG_OK;
 }
 
-int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* s_) {
+static int sample_sum_impl(const float* x, int B, long n, int sq, float* out, bool zero, void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  { const int zrc = dg_zero_f32(out, B, s); if (zrc) return zrc; }
+  if (zero) { const int zrc = dg_zero_f32(out, B, s); if (zrc) return zrc; }
   unsigned gx = nblk(n, 256 * 8);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
   sample_sum_kernel<<<dim3(gx, B), 256, 0, s>>>(x, n, sq, out);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+
+int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* s_) {
+  return sample_sum_impl(x, B, n, sq, out, true, s_);
+}
+int dg_sample_sum_acc(const float* x, int B, long n, int sq, float* out, void* s_) {
+  return sample_sum_impl(x, B, n, sq, out, false, s_);
 }
 
 static AugP make_aug(const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
@@ -765,13 +1033,13 @@ static AugP make_aug(const float* u_b, const float* u_c, const int* t_h, const i
 }
 
 // xsum: [B] workspace (per-sample sum of x), y: [B,H,W]
-int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
-                   const int* o_x, const int* o_y, int policy, int B, int H, int W, float* xsum, float* y,
-                   void* s_) {
+static int diffaug_fwd_impl(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                            const int* o_x, const int* o_y, int policy, int B, int H, int W, float* xsum, float* y,
+                            bool zero, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
   if (policy & 4) {
-    const int rc = dg_sample_sum(x, B, (long)H * W, 0, xsum, s);
+    const int rc = sample_sum_impl(x, B, (long)H * W, 0, xsum, zero, s);
     if (rc) return rc;
   }
   diffaug_fwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, x, xsum, y);
@@ -779,13 +1047,24 @@ int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int
   return DG_OK;
 }
 
-int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
-                   const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
+int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                   const int* o_x, const int* o_y, int policy, int B, int H, int W, float* xsum, float* y,
                    void* s_) {
+  return diffaug_fwd_impl(x, u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W, xsum, y, true, s_);
+}
+int dg_diffaug_fwd_acc(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                       const int* o_x, const int* o_y, int policy, int B, int H, int W, float* xsum, float* y,
+                       void* s_) {
+  return diffaug_fwd_impl(x, u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W, xsum, y, false, s_);
+}
+
+static int diffaug_bwd_impl(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                            const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
+                            bool zero, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
   if (policy & 4) {
-    { const int zrc = dg_zero_f32(gsum, B, s); if (zrc) return zrc; }
+    if (zero) { const int zrc = dg_zero_f32(gsum, B, s); if (zrc) return zrc; }
     unsigned gxn = nblk((long)H * W, 256 * 8);
     if (gxn > 64) gxn = 64;
     diffaug_bwd_sum_kernel<<<dim3(gxn, B), 256, 0, s>>>(a, gy, gsum);
@@ -793,6 +1072,16 @@ int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const in
   diffaug_bwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, gy, gsum, gx);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                   const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
+                   void* s_) {
+  return diffaug_bwd_impl(gy, u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W, gsum, gx, true, s_);
+}
+int dg_diffaug_bwd_acc(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                       const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
+                       void* s_) {
+  return diffaug_bwd_impl(gy, u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W, gsum, gx, false, s_);
 }
 
 int dg_nsgan_d(const float* y_real, const float* y_fake, int B, float w_gan, float* dy_real, float* dy_fake,

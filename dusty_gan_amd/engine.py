@@ -581,6 +581,11 @@ class DEngine:
                    aux_off=(tangent_of or 0) * self.per[i])
         if tangent_of is None:
             nf = self.per[4]
+            y = L.AccArena.take(n, self.y.device)  # logits: a pre-zeroed slice of the step's arena while a step runs
+            if y is not None:
+                L.check(lib.dg_final_fwd_acc(L.ptr(self.h[4]) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
+                                             1.0 / math.sqrt(nf), n, nf, L.ptr(y), sp), "dg_final_fwd_acc")
+                return y
             L.check(lib.dg_final_fwd(L.ptr(self.h[4]) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
                                      1.0 / math.sqrt(nf), n, nf, L.ptr(self.y) + 4 * slot, sp), "dg_final_fwd")
         return self.y[slot:slot + n]

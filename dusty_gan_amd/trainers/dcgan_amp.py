@@ -467,7 +467,9 @@ class Trainer:
         self._mb = []
         dev = self.device
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
-        scal = L.zero_(torch.empty(7, dtype=torch.float32, device=dev))
+        # every small accumulator of the step (these scalars, per-sample sums, logits) comes zeroed out of ONE arena
+        L.AccArena.begin(dev)
+        scal = L.AccArena.take(16, dev)[:7]
         f32 = dict(dtype=torch.float32, device=dev)
         for j in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
             if reals is not None:
@@ -503,8 +505,12 @@ class Trainer:
                     deng.wgrad(Dst, 0, 0, 2 * B, rs)
                     deng.final_wgrad(Dst, 0, 2 * B, dy)
                 deng.backward_input(Dst, 0, B, g)
-                ssq = torch.empty(B, **f32)
-                L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
+                ssq = L.AccArena.take(B, dev)
+                if ssq is not None:
+                    L.check(lib.dg_sample_sum_acc(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum_acc")
+                else:
+                    ssq = torch.empty(B, **f32)
+                    L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
                 L.check(lib.dg_mean_acc(L.ptr(ssq), B, L.ptr(scal) + 12, sp), "dg_mean_acc")  # :229
                 # R1 double backward: tangent v = d(gp/2 * mean_b |g_b|^2)/dg = (gp/B) g, pushed forward through D
                 vg = torch.empty_like(g)

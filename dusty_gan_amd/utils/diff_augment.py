@@ -94,10 +94,12 @@ class DiffAugment(nn.Module):
         x = x.contiguous()
         if out is None:
             out = torch.empty_like(x)
-        ws = torch.empty(B, dtype=torch.float32, device=x.device)
+        ws = L.AccArena.take(B, x.device)     # per-sample sums: a pre-zeroed slice of the step's arena, if a step is running
+        fn = L.lib().dg_diffaug_fwd_acc if ws is not None else L.lib().dg_diffaug_fwd
+        if ws is None:
+            ws = torch.empty(B, dtype=torch.float32, device=x.device)
         args, keep = self._args(rp, B, x.device)
-        L.check(L.lib().dg_diffaug_fwd(L.ptr(x), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()),
-                "dg_diffaug_fwd")
+        L.check(fn(L.ptr(x), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()), "dg_diffaug_fwd")
         return out
 
     def backward(self, gy, rp, out=None):
@@ -106,10 +108,12 @@ class DiffAugment(nn.Module):
         gy = gy.contiguous()
         if out is None:
             out = torch.empty_like(gy)
-        ws = torch.empty(B, dtype=torch.float32, device=gy.device)
+        ws = L.AccArena.take(B, gy.device)
+        fn = L.lib().dg_diffaug_bwd_acc if ws is not None else L.lib().dg_diffaug_bwd
+        if ws is None:
+            ws = torch.empty(B, dtype=torch.float32, device=gy.device)
         args, keep = self._args(rp, B, gy.device)
-        L.check(L.lib().dg_diffaug_bwd(L.ptr(gy), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()),
-                "dg_diffaug_bwd")
+        L.check(fn(L.ptr(gy), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()), "dg_diffaug_bwd")
         return out
 
     def forward(self, x):

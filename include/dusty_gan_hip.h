@@ -124,6 +124,11 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
 /* ---- final EqualLR(Conv2d(C,1,(h0,w0)))  models/gans/dcgan_eqlr.py:95 ------------------------------------ */
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
                  void* stream);
+/* `_acc` forms (dg_final_fwd_acc, dg_sample_sum_acc, dg_diffaug_fwd_acc, dg_diffaug_bwd_acc): the fp32 accumulator the
+ * call adds into (y / out / xsum / gsum) was zeroed by the CALLER - a step that carves all of them from one buffer zero-fills
+ * once per step instead of once per call */
+int dg_final_fwd_acc(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
+                 void* stream);
 /* dd4[b] = up[b]*scale*wf*lrelu'(d4[b])*sqrt2 ; dbias4[i%C] += rowscale[b]*dd4[b][i] */
 int dg_final_bwd_data(const void* d4, int dtype, const float* wf, const float* up, const float* rowscale, float scale,
                       int B, long n, int C, void* dd4, float* dbias, void* stream);
@@ -147,7 +152,11 @@ int dg_logistic_noise(const float* u1, const float* u2, float eps, long n, float
 /* policy bits: 1 brightness, 2 saturation, 4 contrast, 8 translation, 16 cutout; per-sample draws are arguments */
 int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
                    const int* o_y, int policy, int B, int H, int W, float* xsum_ws, float* y, void* stream);
+int dg_diffaug_fwd_acc(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                   const int* o_y, int policy, int B, int H, int W, float* xsum_ws, float* y, void* stream);
 int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                   const int* o_y, int policy, int B, int H, int W, float* gsum_ws, float* gx, void* stream);
+int dg_diffaug_bwd_acc(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
                    const int* o_y, int policy, int B, int H, int W, float* gsum_ws, float* gx, void* stream);
 
 /* ---- GANLoss(nsgan)  models/loss.py:39-41,68-69 + gradient w.r.t. the logits ----------------------------- */
@@ -251,6 +260,8 @@ int dg_extract_patches(const float* img, int B, int C, int H, int W, int ph, int
 
 /* ---- small reductions / helpers --------------------------------------------------------------------------- */
 int dg_sample_sum(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */
+int dg_scale(const float* x, float a, long n, float* y, void* stream);
+int dg_sample_sum_acc(const float* x, int B, long n, int sq, float* out, void* stream); /* out[b] = sum x or x^2 */
 int dg_scale(const float* x, float a, long n, float* y, void* stream);
 /* p[0..n) = 0 as a kernel launch (optim.zero_grad, trainers/dcgan_amp.py:177,246, and the step's accumulators).  The
  * library never uses hipMemsetAsync: its small fills replayed wrong from a hipGraph after a host-side synchronize. */

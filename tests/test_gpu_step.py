@@ -380,12 +380,12 @@ def test_graph_replay_survives_host_sync():
 def test_resume_continues_like_the_uninterrupted_run(tmp_path, arch):
     """cfg.resume (reference :134-144) + the position record: 3 steps, checkpoint, a NEW trainer resumed from it, 3 more
     steps == 6 uninterrupted steps - same latents, Gumbel noise, augmentation draws and batches (Philox counters and
-    loader position restored), same Adam step counts.  fp32.  The yardstick is the run-to-run noise of the uninterrupted
-    run itself (split-K atomics reorder sums; Adam with beta1 = 0 turns the sign of a rounding-noise gradient into a
-    2 lr difference; the hard Gumbel threshold of the dusty archs turns a last-bit logit difference into a flipped
-    pixel): the resumed run must be as close to the uninterrupted one as a second uninterrupted run is (x5 + 1e-5), and
-    a checkpoint WITHOUT the position record (the reference's format: randomness re-drawn, loader restarted) must not be
-    - the control that shows the yardstick can tell the two apart."""
+    loader position restored), same Adam step counts.  fp32.  Measured (scripts/resume_noise.py, relative L2 over all
+    parameters of G, D and G_ema after the six steps): two uninterrupted runs differ by ~1e-8 (split-K atomics), the
+    dusty archs in some runs by 1.4e-4 (a last-bit logit difference flips one pixel of the hard Gumbel threshold); the
+    resumed run sits in the same two clusters; the same checkpoint WITHOUT the position record (the reference's format:
+    randomness re-drawn, loader restarted) lands 3.5e-3 - 4.1e-3 away.  Bounds: resumed <= 5e-4, control >= 2e-3 - the
+    control shows the bound can tell the two apart."""
     from dusty_gan_amd.trainers.dcgan_amp import Trainer
     from dusty_gan_amd.utils.config import load_config
 
@@ -405,11 +405,6 @@ def test_resume_continues_like_the_uninterrupted_run(tmp_path, arch):
     a = Trainer(cfg(), lc)
     sa = [dict(a.step(i).items()) for i in range(6)]
     torch.manual_seed(11)
-    a2 = Trainer(cfg(), lc)
-    for i in range(6):
-        a2.step(i)
-    noise = rel_l2(params(a2), params(a))
-    torch.manual_seed(11)
     b = Trainer(cfg(), lc)
     for i in range(3):
         b.step(i)
@@ -419,8 +414,7 @@ def test_resume_continues_like_the_uninterrupted_run(tmp_path, arch):
     assert c.start_iteration == 3 and c.optim_G.step_count == 3 and c.batches_drawn == 3
     assert torch.equal(c.fixed_noise.cpu(), a.fixed_noise.cpu())
     sc = [dict(c.step(i).items()) for i in range(3, 6)]
-    bound = 5 * noise + 1e-5
-    assert rel_l2(params(c), params(a)) <= bound, (rel_l2(params(c), params(a)), noise)
+    assert rel_l2(params(c), params(a)) <= 5e-4, rel_l2(params(c), params(a))
     if arch == "none":  # (the dusty archs' scalars carry the flipped pixels of the hard threshold)
         for x, y in zip(sc, sa[3:]):
             for k in y:
@@ -434,5 +428,5 @@ def test_resume_continues_like_the_uninterrupted_run(tmp_path, arch):
     d = Trainer(cfg(resume=path2), lc)
     for i in range(3, 6):
         d.step(i)
-    assert rel_l2(params(d), params(a)) > 4 * bound, (rel_l2(params(d), params(a)), bound)
+    assert rel_l2(params(d), params(a)) >= 2e-3, rel_l2(params(d), params(a))
     assert c.rng.offset == a.rng.offset and c.A._rng.offset == a.A._rng.offset
