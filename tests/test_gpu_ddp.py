@@ -191,9 +191,10 @@ def test_two_ranks_fused_proj_optimizer_matches_unfused(pl):
     for r in range(2):
         a, b = res[True][r], res[False][r]
         # not bit-equal: the split-K atomics of the other weight gradients reorder fp32 sums from run to run, and a
-        # last-bit difference can flip a bf16 rounding of the next step's shadows; a wrong kernel would be O(1) off
-        assert rel_l2(a["G"], b["G"]) < 1e-4, rel_l2(a["G"], b["G"])
-        assert rel_l2(a["E"], b["E"]) < 1e-4, rel_l2(a["E"], b["E"])
+        # last-bit difference can flip a bf16 rounding of the next step's shadows or one pixel of the hard Gumbel
+        # threshold (runs cluster at ~1e-8 and ~1.4e-4, scripts/resume_noise.py); a wrong kernel would be O(1) off
+        assert rel_l2(a["G"], b["G"]) < 5e-4, rel_l2(a["G"], b["G"])
+        assert rel_l2(a["E"], b["E"]) < 5e-4, rel_l2(a["E"], b["E"])
         assert rel_l2(a["V"], b["V"]) < 5e-3, rel_l2(a["V"], b["V"])
         for x, y in zip(a["scal"], b["scal"]):
             for k in x:
