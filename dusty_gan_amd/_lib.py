@@ -76,16 +76,19 @@ PROTOTYPES = {
     "dg_wgrad_kernel_variant": [C.POINTER(DgWgrad), _I],
     "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "dg_blur_bwd_r1": [_P, _I, _P, _F, _P, _I, _I, _I, _I, _P],
     "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
     "dg_final_fwd_acc": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
     "dg_final_bwd_data": [_P, _I, _P, _P, _P, _F, _I, _L, _I, _P, _P, _P],
     "dg_batch_wsum": [_P, _I, _P, _F, _I, _L, _P, _P],
     "dg_head_post_fwd": [_P, _P, _P, _I, _I, _F, _F, _I, _L, _P, _P, _P],
+    "dg_head_post_fwd_sum": [_P, _P, _P, _I, _I, _F, _F, _I, _L, _P, _P, _P, _P],
     "dg_head_post_bwd": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _L, _F, _F, _P, _P, _P, _I, _P],
     "dg_logistic_noise": [_P, _P, _F, _L, _P, _P],
     "dg_diffaug_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_fwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_diffaug_fwd_pre": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_nsgan_d": [_P, _P, _I, _F, _P, _P, _P, _P],
     "dg_nsgan_g": [_P, _I, _F, _P, _P, _P],
@@ -95,6 +98,7 @@ PROTOTYPES = {
     "dg_gan_g_step": [_I, _P, _P, _I, _F, _P, _P, _P],
     "dg_mean_acc": [_P, _I, _P, _P],
     "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
+    "dg_fetch_reals_sum": [_P, _P, _F, _F, _F, _I, _L, _P, _P, _P],
     "dg_pl_penalty": [_P, _I, _I, _F, _P, _P, _P, _P],
     "dg_head_post_bwd2": [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _L, _F, _F, _P, _P, _P, _I, _P],
     "dg_scan_to_polar": [_P, _I, _I, _I, _I, _I, _I, _P, _D, _D, _F, _P, _P, _P, _P, _P],
@@ -121,6 +125,7 @@ PROTOTYPES = {
     "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
     "dg_counter_add": [_P, _U64, _P],
+    "dg_counter_add_multi": [_P, _P, _I, _P],
     "dg_philox_fill_dev": [_U64, _U64, _P, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw_dev": [_U64, _U64, _P, _I, _I, _I, _P, _P, _P],
     "dg_adam_ema_step_dev": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _P, _F, _P],
@@ -200,7 +205,7 @@ class AccArena:
     accumulator (11 per step).  `take(n)` hands out a slice that has been zero since the last `begin()` and is handed
     out once; None when the arena is not in use or exhausted (the caller then uses the self-zeroing entry point)."""
     SIZE = 8192
-    buf, pos = None, 0
+    buf, pos, epoch = None, 0, 0               # epoch: counts begin() calls (a slice is only meaningful within its epoch)
 
     @classmethod
     def begin(cls, device):
@@ -209,6 +214,7 @@ class AccArena:
             cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
         zero_(cls.buf)
         cls.pos = 0
+        cls.epoch += 1
 
     @classmethod
     def take(cls, n, device=None):
@@ -220,6 +226,48 @@ class AccArena:
             return None
         cls.pos = a + n
         return cls.buf[a:a + n]
+
+
+class Counters:
+    """Device counters (Philox offsets, Adam step counts) are advanced behind their consumers.  The advances of a step are
+    queued here and applied by ONE kernel at the end of the step (`flush`); anything that reads a counter with a queued
+    advance - the next draw from the same generator, `Philox.offset`, the next optimizer step - flushes first."""
+    pending = {}
+
+    @classmethod
+    def add(cls, t, n):
+        e = cls.pending.setdefault(t.data_ptr(), [t, 0])
+        e[1] += int(n)
+
+    @classmethod
+    def flush_if(cls, t):
+        if t is not None and t.data_ptr() in cls.pending:
+            cls.flush()
+
+    @classmethod
+    def flush(cls):
+        import ctypes as C
+        items = list(cls.pending.values())
+        cls.pending.clear()
+        for i in range(0, len(items), 8):
+            chunk = items[i:i + 8]
+            ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t, _ in chunk])
+            dels = (C.c_uint64 * len(chunk))(*[d for _, d in chunk])
+            check(lib().dg_counter_add_multi(ptrs, dels, len(chunk), stream_ptr()), "dg_counter_add_multi")
+
+
+def tag_sums(t, sums):
+    """remember on an image tensor the per-sample sums its producer kernel accumulated (DiffAugment's contrast reads them
+    instead of making its own pass) - valid while the arena epoch lasts and the tensor is not rewritten"""
+    t._dg_sums = (sums, AccArena.epoch, t._version)
+    return t
+
+
+def tagged_sums(t):
+    tag = getattr(t, "_dg_sums", None)
+    if tag is None or tag[1] != AccArena.epoch or tag[2] != t._version:
+        return None
+    return tag[0]
 
 
 def policy_mask(policy):

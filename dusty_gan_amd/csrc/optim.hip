@@ -295,6 +295,10 @@ __global__ void aug_draw_kernel(uint64_t seed, uint64_t stream, uint64_t offset,
 __global__ void counter_add_kernel(unsigned long long* c, unsigned long long delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
 }
+struct CounterAdds { unsigned long long* c[8]; unsigned long long d[8]; int k; };
+__global__ void counter_add_multi_kernel(CounterAdds a) {
+  if (blockIdx.x == 0 && threadIdx.x < a.k) *a.c[threadIdx.x] += a.d[threadIdx.x];
+}
 __global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
                                        int kind, float lo, float hi, int ilo, int ihi, long n, void* __restrict__ out) {
   const uint64_t offset = *offp;
@@ -406,6 +410,23 @@ int dg_aug_draw(uint64_t seed, uint64_t stream, uint64_t offset, int B, int H, i
 
 int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* s_) {
   counter_add_kernel<<<1, 64, 0, (hipStream_t)s_>>>(counter, delta);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// k <= 8 DISTINCT counters advanced by one launch (a step's Philox offsets and Adam step counts, queued by the caller
+// behind their consumers: one graph node instead of one per counter)
+int dg_counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, void* s_) {
+  if (k < 1 || k > 8 || !counters || !deltas) return DG_EINVAL;
+  CounterAdds a{};
+  for (int i = 0; i < k; ++i) {
+    if (!counters[i]) return DG_EINVAL;
+    for (int j = 0; j < i; ++j)
+      if (counters[j] == counters[i]) return DG_EINVAL;
+    a.c[i] = counters[i]; a.d[i] = deltas[i];
+  }
+  a.k = k;
+  counter_add_multi_kernel<<<1, 64, 0, (hipStream_t)s_>>>(a);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

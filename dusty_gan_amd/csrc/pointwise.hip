@@ -116,12 +116,20 @@ __global__ __launch_bounds__(256) void blur_fwd4_kernel(const float* __restrict_
   }
 }
 
+// ssq != nullptr (R1): dx = oscale * g and ssq[b] += sum of g^2 over the sample, g = the adjoint's result - the R1
+// penalty's per-sample |g|^2 and its tangent v = (gp / B) g in the pass that makes g (H W a multiple of 1024: a block
+// lies inside one sample).
 template <typename T>
 __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d, float* __restrict__ dx, int B, int H,
-                                                        int W, int ring) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                        int W, int ring, float oscale, float* __restrict__ ssq, int qchunk) {
+  __shared__ float red[16];
   const int W4 = W >> 2;
-  if (q >= (long)B * H * W4) return;
+  float ssacc = 0.f;
+  // ssq: a block walks `qchunk` consecutive quads of one sample (one atomic per block); else one quad per thread
+  const long qbase = ssq ? (long)blockIdx.x * qchunk : (long)blockIdx.x * blockDim.x;
+  const long qend = ssq ? qbase + qchunk : qbase + blockDim.x;
+  for (long q = qbase + threadIdx.x; q < qend; q += blockDim.x) {
+  if (q >= (long)B * H * W4) break;             // (never taken when ssq is set: the grid is exact)
   const int x0 = (int)(q % W4) * 4, y = (int)((q / W4) % H);
   const long base = (q / W4 - y) * W;
   auto row8 = [&](int yy, float (&v)[8]) {                      // (ch0, ch1) of pixels x0 .. x0+3 of row yy
@@ -166,7 +174,14 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
       if (xx == W - 2) h[k] += 0.25f * D1(y, W - 1);
     }
   }
-  *(float4*)(dx + base + (long)y * W + x0) = make_float4(v[0] + h[0], v[1] + h[1], v[2] + h[2], v[3] + h[3]);
+  const float g0 = v[0] + h[0], g1 = v[1] + h[1], g2 = v[2] + h[2], g3 = v[3] + h[3];
+  *(float4*)(dx + base + (long)y * W + x0) = make_float4(oscale * g0, oscale * g1, oscale * g2, oscale * g3);
+  ssacc += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
+  }
+  if (ssq) {
+    const float sblk = dg_block_sum(ssacc, red);
+    if (threadIdx.x == 0) atomicAdd(&ssq[qbase / ((long)H * W4)], sblk);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -313,19 +328,20 @@ __global__ void batch_wsum_scalar_kernel(const T* __restrict__ src, const float*
 // Head post-processing: Generator.forward's tanh (models/gans/dcgan_eqlr.py:71) + DUSty maskout
 // (models/dusty.py:77-91, 107-127).  gout [B,1+k,H,W] planar fp32: ch0 raw depth -> tanh in place (depth_orig),
 // ch1.. confidence logits (kept).  arch: 0 none, 1 dusty1, 2 dusty2.  noise_pixel [B,H,W], noise_image [B].
-__global__ void head_post_fwd_kernel(float* __restrict__ gout, const float* __restrict__ noise_pixel,
-                                     const float* __restrict__ noise_image, int arch, int training, float inv_tau,
-                                     float drop_const, int B, long HW, float* __restrict__ mask,
-                                     float* __restrict__ depth) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * HW) return;
+// dsum != nullptr: dsum[b] += sum of depth[b] - the per-sample sum DiffAugment's contrast needs of its input, produced where
+// the image is produced.  A block then owns `chunk` consecutive pixels of ONE sample (HW % chunk == 0) and issues one atomic:
+// with one block per 256 pixels the 8192 atomics on 32 addresses cost 80 us (round 1 met the same in head_post_bwd).
+__device__ __forceinline__ float head_post_px(float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                              const float* __restrict__ noise_image, int arch, int training,
+                                              float inv_tau, float drop_const, long HW, float* __restrict__ mask,
+                                              long idx) {
   const int b = (int)(idx / HW);
   const long p = idx - (long)b * HW;
   const int nch = 1 + (arch == 0 ? 0 : arch);
   float* g = gout + (long)b * nch * HW + p;
   const float t = tanhf(g[0]);
   g[0] = t;
-  if (arch == 0) { depth[idx] = t; return; }
+  if (arch == 0) return t;
   const float sp = 1.f / (1.f + __expf(-(g[HW] + noise_pixel[idx]) * inv_tau));
   const float mp = sp > 0.5f ? 1.f : 0.f;
   float m = mp;
@@ -343,7 +359,28 @@ __global__ void head_post_fwd_kernel(float* __restrict__ gout, const float* __re
     mask[(long)b * 2 * HW + HW + p] = mi;
     m = mp * mi;
   }
-  depth[idx] = m * t + (1.f - m) * drop_const;
+  return m * t + (1.f - m) * drop_const;
+}
+__global__ __launch_bounds__(256) void head_post_fwd_kernel(float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                     const float* __restrict__ noise_image, int arch, int training, float inv_tau,
+                                     float drop_const, int B, long HW, float* __restrict__ mask,
+                                     float* __restrict__ depth, float* __restrict__ dsum, int chunk) {
+  __shared__ float red[16];
+  if (!dsum) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)B * HW)
+      depth[idx] = head_post_px(gout, noise_pixel, noise_image, arch, training, inv_tau, drop_const, HW, mask, idx);
+    return;
+  }
+  const long i0 = (long)blockIdx.x * chunk;
+  float acc = 0.f;
+  for (long idx = i0 + threadIdx.x; idx < i0 + chunk; idx += blockDim.x) {
+    const float dv = head_post_px(gout, noise_pixel, noise_image, arch, training, inv_tau, drop_const, HW, mask, idx);
+    depth[idx] = dv;
+    acc += dv;
+  }
+  const float sblk = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(&dsum[i0 / HW], sblk);
 }
 
 // Backward of the above: ddepth [B,H,W] -> draw [B,1+k,H,W] planar (gradient w.r.t. the head conv outputs).
@@ -840,16 +877,33 @@ __global__ __launch_bounds__(256) void mean_acc_kernel(const float* __restrict__
 }
 
 // fetch_reals (trainers/dcgan_amp.py:154-160; utils/lidar.py:31-36; utils/__init__.py:70-73)
-__global__ void fetch_reals_kernel(const float* __restrict__ pol, const float* __restrict__ mask, float min_d,
-                                   float max_d, float drop_const, long n, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float depth = pol[i] * (max_d - min_d) + min_d;
+__device__ __forceinline__ float fetch_real_px(float pol, float m, float min_d, float max_d, float drop_const) {
+  const float depth = pol * (max_d - min_d) + min_d;
   const float disp = 1.f / depth;
   float inv = (disp - 1.f / max_d) / (1.f / min_d - 1.f / max_d);
   inv = inv * 2.f - 1.f;
-  const float m = mask[i];
-  out[i] = m * inv + (1.f - m) * drop_const;
+  return m * inv + (1.f - m) * drop_const;
+}
+// xsum != nullptr: per-sample sums of the result, one atomic per block of `chunk` pixels (see head_post_fwd_kernel)
+__global__ __launch_bounds__(256) void fetch_reals_kernel(const float* __restrict__ pol, const float* __restrict__ mask,
+                                                          float min_d, float max_d, float drop_const, long n,
+                                                          float* __restrict__ out, float* __restrict__ xsum, long HW,
+                                                          int chunk) {
+  __shared__ float red[16];
+  if (!xsum) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fetch_real_px(pol[i], mask[i], min_d, max_d, drop_const);
+    return;
+  }
+  const long i0 = (long)blockIdx.x * chunk;
+  float acc = 0.f;
+  for (long i = i0 + threadIdx.x; i < i0 + chunk; i += blockDim.x) {
+    const float v = fetch_real_px(pol[i], mask[i], min_d, max_d, drop_const);
+    out[i] = v;
+    acc += v;
+  }
+  const float sblk = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(&xsum[i0 / HW], sblk);
 }
 
 // y = a * x
@@ -867,6 +921,13 @@ __global__ void logistic_noise_kernel(const float* __restrict__ u1, const float*
 
 // ----------------------------------------------------------------------------------------------------------
 static inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+// pixels per block of the kernels that also sum their output per sample: the largest power-of-two multiple of 256 that
+// divides HW, at most 4096 (one atomic per block: 16 per 64x1024 sample)
+static int sum_chunk(long HW) {
+  int c = 256;
+  while (c < 4096 && HW % (2 * c) == 0) c *= 2;
+  return c;
+}
 
 __global__ void dg_zero_kernel(float* __restrict__ p, long n) {
   const long stride = (long)gridDim.x * blockDim.x;
@@ -900,8 +961,8 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
   if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)d & 15) == 0 && ((size_t)dx & 15) == 0) {
-    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<nblk(n / 4), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
-    else blur_bwd4_kernel<float><<<nblk(n / 4), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
+    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<nblk(n / 4), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, 1.f, nullptr, 256);
+    else blur_bwd4_kernel<float><<<nblk(n / 4), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, 1.f, nullptr, 256);
   } else if (dtype == DG_BF16) blur_bwd_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
   else blur_bwd_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
   HIP_CHECK_RET(hipGetLastError());
@@ -929,6 +990,21 @@ static int final_fwd_impl(const void* d4, int dtype, const float* wf, const floa
     if (dtype == DG_BF16) final_fwd_scalar_kernel<bf16><<<dim3(slabs, B), 256, 0, s>>>((const bf16*)d4, wf, bias, scale, n, y);
     else final_fwd_scalar_kernel<float><<<dim3(slabs, B), 256, 0, s>>>((const float*)d4, wf, bias, scale, n, y);
   }
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// BlurVH adjoint for the R1 chain: dx = oscale * g, ssq[b] += |g_b|^2 (ssq zeroed by the caller); DG_EUNSUPPORTED unless
+// W % 4 == 0 and H W % 1024 == 0 (the caller then runs dg_blur_bwd + dg_sample_sum + dg_scale)
+int dg_blur_bwd_r1(const void* d, int dtype, float* dx, float oscale, float* ssq, int B, int H, int W, int ring, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!ssq) return DG_EINVAL;
+  const long n = (long)B * H * W;
+  if (W % 4 != 0 || W < 8 || H < 2 || ((long)H * W) % 1024 != 0 || ((size_t)d & 15) != 0 || ((size_t)dx & 15) != 0)
+    return DG_EUNSUPPORTED;
+  const int qchunk = sum_chunk((long)H * W / 4) > 1024 ? 1024 : sum_chunk((long)H * W / 4);   // quads per block
+  if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<nblk(n / 4, qchunk), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, oscale, ssq, qchunk);
+  else blur_bwd4_kernel<float><<<nblk(n / 4, qchunk), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, oscale, ssq, qchunk);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -980,14 +1056,27 @@ int dg_batch_wsum(const void* src, int dtype, const float* coef, float scale, in
   return DG_OK;
 }
 
-int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
-                     float tau, float drop_const, int B, long HW, float* mask, float* depth, void* s_) {
+static int head_post_fwd_impl(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
+                              float tau, float drop_const, int B, long HW, float* mask, float* depth, float* dsum, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (arch < 0 || arch > 2) return DG_EINVAL;
-  head_post_fwd_kernel<<<nblk((long)B * HW), 256, 0, s>>>(gout, noise_pixel, noise_image, arch, training, 1.f / tau,
-                                                           drop_const, B, HW, mask, depth);
+  if (dsum && HW % 256 != 0) return DG_EUNSUPPORTED;
+  const int chunk = dsum ? sum_chunk(HW) : 256;
+  head_post_fwd_kernel<<<nblk((long)B * HW, chunk), 256, 0, s>>>(gout, noise_pixel, noise_image, arch, training, 1.f / tau,
+                                                                  drop_const, B, HW, mask, depth, dsum, chunk);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
+                     float tau, float drop_const, int B, long HW, float* mask, float* depth, void* s_) {
+  return head_post_fwd_impl(gout, noise_pixel, noise_image, arch, training, tau, drop_const, B, HW, mask, depth, nullptr, s_);
+}
+// ... + dsum[b] += sum of depth[b] (dsum zeroed by the caller; HW % 256 == 0 or DG_EUNSUPPORTED): the per-sample sums
+// that dg_diffaug_fwd_pre takes instead of making its own pass over the image
+int dg_head_post_fwd_sum(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
+                         float tau, float drop_const, int B, long HW, float* mask, float* depth, float* dsum, void* s_) {
+  if (!dsum) return DG_EINVAL;
+  return head_post_fwd_impl(gout, noise_pixel, noise_image, arch, training, tau, drop_const, B, HW, mask, depth, dsum, s_);
 }
 
 int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
@@ -1058,6 +1147,17 @@ int dg_diffaug_fwd_acc(const float* x, const float* u_b, const float* u_c, const
   return diffaug_fwd_impl(x, u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W, xsum, y, false, s_);
 }
 
+// xsum already holds the per-sample sums of x (dg_fetch_reals_sum / dg_head_post_fwd_sum): no pass of its own
+int dg_diffaug_fwd_pre(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                       const int* o_x, const int* o_y, int policy, int B, int H, int W, const float* xsum, float* y,
+                       void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
+  diffaug_fwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, x, xsum, y);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 static int diffaug_bwd_impl(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
                             const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
                             bool zero, void* s_) {
@@ -1102,7 +1202,19 @@ int dg_nsgan_g(const float* y_fake, int B, float w_gan, float* dy, float* scal, 
 int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,
                    float* out, void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  fetch_reals_kernel<<<nblk(n), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, n, out);
+  fetch_reals_kernel<<<nblk(n), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, n, out, nullptr, 1, 256);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+// ... + xsum[b] += sum of out[b] over its HW pixels (xsum zeroed by the caller; HW % 256 == 0 or DG_EUNSUPPORTED)
+int dg_fetch_reals_sum(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, int B,
+                       long HW, float* out, float* xsum, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!xsum) return DG_EINVAL;
+  if (HW % 256 != 0) return DG_EUNSUPPORTED;
+  const int chunk = sum_chunk(HW);
+  fetch_reals_kernel<<<nblk((long)B * HW, chunk), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, (long)B * HW, out,
+                                                                xsum, HW, chunk);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

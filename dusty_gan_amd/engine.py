@@ -326,10 +326,15 @@ class GEngine:
             self.noise_image = noise["image"].contiguous().float() if (arch == 2 and training) else None
             if arch == 2 and training and self.noise_image is None:
                 raise ValueError("dusty2 in training mode needs image-level noise")
-        L.check(lib.dg_head_post_fwd(L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
-                                     L.ptr(self.noise_image) if arch == 2 and training else None, arch,
-                                     int(training), c.tau, c.drop_const, B, self.HW, L.ptr(self.mask),
-                                     L.ptr(self.depth), sp), "dg_head_post_fwd")
+        sums = L.AccArena.take(B, self.depth.device) if self.HW % 256 == 0 else None
+        hp_args = (L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
+                   L.ptr(self.noise_image) if arch == 2 and training else None, arch, int(training), c.tau, c.drop_const, B,
+                   self.HW, L.ptr(self.mask), L.ptr(self.depth))
+        if sums is not None:  # per-sample sums of the depth image in the same pass (DiffAugment's contrast reads them)
+            L.check(lib.dg_head_post_fwd_sum(*hp_args, L.ptr(sums), sp), "dg_head_post_fwd_sum")
+            L.tag_sums(self.depth, sums)
+        else:
+            L.check(lib.dg_head_post_fwd(*hp_args, sp), "dg_head_post_fwd")
         out = OrderedDict()
         out["depth"] = self.depth
         if arch:
@@ -618,10 +623,18 @@ class DEngine:
         for i in (4, 3, 2):
             self._bwd_layer(st, i, slot, n, rowscale, want_dbias)
 
-    def backward_input(self, st, slot, n, dx):
-        """Continue a chain from e1 to the image: Down1 backward-data + BlurVH adjoint -> dx [n,1,H,W] fp32."""
+    def backward_input(self, st, slot, n, dx, r1=None):
+        """Continue a chain from e1 to the image: Down1 backward-data + BlurVH adjoint -> dx [n,1,H,W] fp32.
+        r1 = (oscale, ssq): the R1 form - dx = oscale * g and ssq[b] += |g_b|^2 in the same pass (ssq pre-zeroed); returns
+        False when the fused kernel does not take the shape (nothing written: call again without r1)."""
         c, o, lib = self.cfg, self.ops, L.lib()
         self._bwd_layer(st, 1, slot, n, None, False)
+        if r1 is not None:
+            rc = lib.dg_blur_bwd_r1(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), float(r1[0]), L.ptr(r1[1]),
+                                    n, c.H, c.W, int(c.ring), L.stream_ptr())
+            if rc != L.DG_EUNSUPPORTED:
+                L.check(rc, "dg_blur_bwd_r1")
+                return True
         L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")
 

@@ -165,6 +165,7 @@ class FlatAdam:
         # beta1 == 0 (the reference's solver): exp_avg == scaled gradient, so the kernel neither reads nor writes it
         m_ptr = None if self.betas[0] == 0.0 else L.ptr(st.m)
         lib = L.lib()
+        L.Counters.flush_if(self._step_dev)  # (a queued advance from an optimizer step that no step end has flushed)
         sdt = L.dtype_code(shadow_dtype)
         ses = 2 if shadow_dtype == torch.bfloat16 else 4
         ema_ptr = L.ptr(ema_store.flat) if ema_store is not None else None
@@ -189,7 +190,7 @@ class FlatAdam:
                                          sdt, st.n - off, gscale, self.lr, self.betas[0],
                                          self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
                 "dg_adam_ema_step_dev")
-        L.check(lib.dg_counter_add(L.ptr(self._step_dev), 1, L.stream_ptr()), "dg_counter_add")
+        L.Counters.add(self._step_dev, 1)  # (queued: one launch advances all of the step's counters)
         st.refresh_transposed()
         if ema_store is not None:
             ema_store._seen_version = -1  # its shadows are rebuilt lazily when G_ema is used
@@ -332,6 +333,13 @@ class Trainer:
         mask = raw_batch["mask"].to(self.device, non_blocking=True).float()
         return self.lidar.fetch_reals(pol, mask, float(self.cfg.model.gen.drop_const))
 
+    def _fetch_reals_in_step(self, raw_batch):
+        """fetch_reals as the first launch of a step: the step's accumulator arena is opened first, so the per-sample sums
+        the kernel produces beside x_real survive until DiffAugment reads them"""
+        L.AccArena.begin(self.device)
+        self._arena_ready = True
+        return self.fetch_reals(raw_batch)
+
     def _g_engines(self):
         """one generator workspace per micro-batch: the D phase's G activations are reused by the G phase (:196,256)"""
         if self._geng is None:
@@ -468,7 +476,9 @@ class Trainer:
         dev = self.device
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
         # every small accumulator of the step (these scalars, per-sample sums, logits) comes zeroed out of ONE arena
-        L.AccArena.begin(dev)
+        if not getattr(self, "_arena_ready", False):   # (the graph path opens it before its fetch_reals)
+            L.AccArena.begin(dev)
+        self._arena_ready = False
         scal = L.AccArena.take(16, dev)[:7]
         f32 = dict(dtype=torch.float32, device=dev)
         for j in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
@@ -504,17 +514,22 @@ class Trainer:
                     # rest of the R1 chain
                     deng.wgrad(Dst, 0, 0, 2 * B, rs)
                     deng.final_wgrad(Dst, 0, 2 * B, dy)
-                deng.backward_input(Dst, 0, B, g)
+                # R1 (:218-235): g = d sum(y_real) / dx_real, penalty = gp / 2 * mean_b |g_b|^2, and its double backward's
+                # tangent v = d penalty / dg = (gp / B) g, pushed forward through D below
+                vscale = gp / self.n_acc / B
                 ssq = L.AccArena.take(B, dev)
-                if ssq is not None:
-                    L.check(lib.dg_sample_sum_acc(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum_acc")
-                else:
-                    ssq = torch.empty(B, **f32)
-                    L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
-                L.check(lib.dg_mean_acc(L.ptr(ssq), B, L.ptr(scal) + 12, sp), "dg_mean_acc")  # :229
-                # R1 double backward: tangent v = d(gp/2 * mean_b |g_b|^2)/dg = (gp/B) g, pushed forward through D
                 vg = torch.empty_like(g)
-                L.check(lib.dg_scale(L.ptr(g), gp / self.n_acc / B, g.numel(), L.ptr(vg), sp), "dg_scale")
+                if ssq is None or not deng.backward_input(Dst, 0, B, vg, r1=(vscale, ssq)):
+                    # (shapes the fused adjoint does not take, or no arena: three passes.  The chain's last conv layer ran
+                    # in the refused call already when ssq is not None - backward_input repeats it, harmlessly)
+                    deng.backward_input(Dst, 0, B, g)
+                    if ssq is None:
+                        ssq = torch.empty(B, **f32)
+                        L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
+                    else:
+                        L.check(lib.dg_sample_sum_acc(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum_acc")
+                    L.check(lib.dg_scale(L.ptr(g), vscale, g.numel(), L.ptr(vg), sp), "dg_scale")
+                L.check(lib.dg_mean_acc(L.ptr(ssq), B, L.ptr(scal) + 12, sp), "dg_mean_acc")  # :229
                 deng.forward(Dst, vg, 2 * B, tangent_of=0)
                 if not bucketed:
                     deng.wgrad(Dst, 2 * B, 0, B, None)      # tangent (x) real chain
@@ -757,7 +772,8 @@ class Trainer:
         """the launch sequence of one iteration; returns the device tensor of (locally averaged) scalars"""
         self.optimize_D(reals, rands)
         scal = self.optimize_G()
-        scal = scal / self.n_acc
+        L.Counters.flush()  # Philox offsets and Adam step counts of this step: one launch
+        scal = scal / self.n_acc if self.n_acc > 1 else scal.clone()  # (a copy: `scal` lives in the step's arena)
         # (slices, not a Python index list: that would be a host-to-device copy, illegal during graph capture)
         end = 7 if "pl" in self.criterion else 5
         return scal[:end] if "gp" in self.criterion else torch.cat((scal[:3], scal[4:end]))
@@ -782,7 +798,9 @@ class Trainer:
         if self._graph is None:
             if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
                 self._eager_steps += 1
-                return self._step_eager(reals=[self.fetch_reals(batch)] if self.n_acc == 1 else None)
+                if self.n_acc != 1:
+                    return self._step_eager()
+                return self._step_eager(reals=[self._fetch_reals_in_step(batch)])
             self._g_pol = batch["depth"].to(self.device).clone()
             self._g_mask = batch["mask"].to(self.device).clone()
             torch.cuda.synchronize()
@@ -793,7 +811,7 @@ class Trainer:
             counts = (self.optim_D.step_count, self.optim_G.step_count)
             try:
                 self._cap_open()
-                self._g_out = self._step_eager(reals=[self.fetch_reals({"depth": self._g_pol, "mask": self._g_mask})])
+                self._g_out = self._step_eager(reals=[self._fetch_reals_in_step({"depth": self._g_pol, "mask": self._g_mask})])
                 self._cap_close()
             except BaseException:
                 if self._cap_cur is not None:
@@ -802,6 +820,7 @@ class Trainer:
                     except BaseException:
                         pass
                 self._cap, self._cap_cur = None, None
+                L.Counters.pending.clear()  # (advances queued by the aborted capture were never going to run)
                 if self.world == 1:
                     raise
                 # multi-rank: a runtime that refuses the capture must not take the job down - nothing was executed,
@@ -811,7 +830,7 @@ class Trainer:
                 self.optim_D.step_count, self.optim_G.step_count = counts
                 self.use_graph = False
                 self._mb = []
-                return self._step_eager(reals=[self.fetch_reals(batch)])
+                return self._step_eager(reals=[self._fetch_reals_in_step(batch)])
             self._graph, self._cap = self._cap, None
             # the capture did not execute anything, but the host mirrors of the Adam step counts advanced once
             self.optim_D.step_count -= 1
@@ -928,6 +947,7 @@ class Trainer:
 
         def mk(d):
             r = Philox(d["seed"], self.device, stream_id=d["stream_id"])
+            L.Counters.flush_if(r.ctr)
             r.ctr.fill_(int(d["offset"]))
             return r
         self.rng = mk(st["rng"])

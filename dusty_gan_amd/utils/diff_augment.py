@@ -51,6 +51,7 @@ class DiffAugment(nn.Module):
         r = self.rng(device)
         uf = torch.empty(3, n * B, dtype=torch.float32, device=device)
         qi = torch.empty(4, n * B, dtype=torch.int32, device=device)
+        r.sync()
         L.check(L.lib().dg_aug_draw_dev(r.seed, r.stream_id, L.ptr(r.ctr), n * B, H, W, L.ptr(uf), L.ptr(qi),
                                         L.stream_ptr()), "dg_aug_draw_dev")
         r.advance(2 * n * B)
@@ -94,6 +95,12 @@ class DiffAugment(nn.Module):
         x = x.contiguous()
         if out is None:
             out = torch.empty_like(x)
+        pre = L.tagged_sums(x)                # the producer of x already summed it per sample (fetch_reals / head kernels)
+        if pre is not None:
+            args, keep = self._args(rp, B, x.device)
+            L.check(L.lib().dg_diffaug_fwd_pre(L.ptr(x), *args, self.mask, B, H, W, L.ptr(pre), L.ptr(out), L.stream_ptr()),
+                    "dg_diffaug_fwd_pre")
+            return out
         ws = L.AccArena.take(B, x.device)     # per-sample sums: a pre-zeroed slice of the step's arena, if a step is running
         fn = L.lib().dg_diffaug_fwd_acc if ws is not None else L.lib().dg_diffaug_fwd
         if ws is None:

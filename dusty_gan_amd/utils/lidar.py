@@ -48,6 +48,12 @@ class LiDAR:
         pol = pol.contiguous().float()
         mask = mask.contiguous().float()
         out = torch.empty_like(pol)
+        B, HW = pol.shape[0], pol[0].numel()
+        sums = L.AccArena.take(B, pol.device) if HW % 256 == 0 else None
+        if sums is not None:  # per-sample sums of the result in the same pass (DiffAugment's contrast reads them)
+            L.check(L.lib().dg_fetch_reals_sum(L.ptr(pol), L.ptr(mask), self.min_depth, self.max_depth, float(drop_const),
+                                               B, HW, L.ptr(out), L.ptr(sums), L.stream_ptr()), "dg_fetch_reals_sum")
+            return L.tag_sums(out, sums), mask
         L.check(L.lib().dg_fetch_reals(L.ptr(pol), L.ptr(mask), self.min_depth, self.max_depth, float(drop_const),
                                        pol.numel(), L.ptr(out), L.stream_ptr()), "dg_fetch_reals")
         return out, mask

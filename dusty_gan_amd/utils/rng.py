@@ -18,13 +18,20 @@ class Philox:
 
     @property
     def offset(self):
+        L.Counters.flush_if(self.ctr)
         return int(self.ctr.item())
 
     def advance(self, n):
-        L.check(L.lib().dg_counter_add(L.ptr(self.ctr), int(n), L.stream_ptr()), "dg_counter_add")
+        """queued (L.Counters): applied with the step's other counters, or before this counter is read again"""
+        L.Counters.add(self.ctr, n)
+
+    def sync(self):
+        """the device counter is current (call before a kernel reads it)"""
+        L.Counters.flush_if(self.ctr)
 
     def _fill(self, kind, n, lo=0.0, hi=1.0, ilo=0, ihi=1):
         out = torch.empty(n, dtype=torch.int32 if kind == 3 else torch.float32, device=self.device)
+        self.sync()
         L.check(L.lib().dg_philox_fill_dev(self.seed, self.stream_id, L.ptr(self.ctr), kind, lo, hi, ilo, ihi, n,
                                            L.ptr(out), L.stream_ptr()), "dg_philox_fill_dev")
         self.advance((n + 3) // 4)

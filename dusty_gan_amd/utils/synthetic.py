@@ -21,7 +21,8 @@ class SyntheticLiDAR:
             mask = rng.uniform(n) < 0.85
             pol = (depth_m - min_depth) / (max_depth - min_depth)
             pol = torch.where(mask, pol, torch.zeros_like(pol))
-            self.batches.append({"depth": pol.view(batch, 1, H, W), "mask": mask.view(batch, 1, H, W)})
+            # (mask kept as float: fetch_reals' `.float()` is then a no-op instead of a conversion kernel per step)
+            self.batches.append({"depth": pol.view(batch, 1, H, W), "mask": mask.view(batch, 1, H, W).float()})
 
     def __iter__(self):
         return iter(self.batches)

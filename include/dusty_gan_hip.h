@@ -120,6 +120,10 @@ int dg_wgrad_kernel_variant(const DgWgrad* p, int force);
 /* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* stream);
 int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ring, void* stream);
+/* the same adjoint at the end of the R1 chain (trainers/dcgan_amp.py:218-235): dx = oscale * g and ssq[b] += sum of g_b^2
+ * (ssq zeroed by the caller) in one pass instead of dg_blur_bwd + dg_sample_sum + dg_scale; DG_EUNSUPPORTED unless W % 4 == 0
+ * and H W % 1024 == 0 */
+int dg_blur_bwd_r1(const void* d, int dtype, float* dx, float oscale, float* ssq, int B, int H, int W, int ring, void* stream);
 
 /* ---- final EqualLR(Conv2d(C,1,(h0,w0)))  models/gans/dcgan_eqlr.py:95 ------------------------------------ */
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
@@ -139,6 +143,10 @@ int dg_batch_wsum(const void* src, int dtype, const float* coef, float scale, in
 /* gout [B,1+k,H,W] planar fp32 (ch0 raw depth -> tanh in place, ch1.. logits); arch 0 none, 1 dusty1, 2 dusty2 */
 int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
                      float tau, float drop_const, int B, long HW, float* mask, float* depth, void* stream);
+/* + dsum[b] += sum of depth[b] (dsum zeroed by the caller; HW % 256 == 0 or DG_EUNSUPPORTED): the per-sample sums DiffAugment's
+ * contrast needs of its input, produced where the image is produced (dg_diffaug_fwd_pre then skips its own pass) */
+int dg_head_post_fwd_sum(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
+                         float tau, float drop_const, int B, long HW, float* mask, float* depth, float* dsum, void* stream);
 /* draw[n] = s_n * d(loss)/d(head output n) (s_depth for ch0, s_conf for the logits: the EqualLR scale of each head,
  * pre-multiplied so the head's backward-data / weight-gradient passes run with scale 1); dbias[n] += unscaled sums */
 int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
@@ -154,6 +162,9 @@ int dg_diffaug_fwd(const float* x, const float* u_b, const float* u_c, const int
                    const int* o_y, int policy, int B, int H, int W, float* xsum_ws, float* y, void* stream);
 int dg_diffaug_fwd_acc(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
                    const int* o_y, int policy, int B, int H, int W, float* xsum_ws, float* y, void* stream);
+/* xsum already holds the per-sample sums of x */
+int dg_diffaug_fwd_pre(const float* x, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                       const int* o_y, int policy, int B, int H, int W, const float* xsum, float* y, void* stream);
 int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
                    const int* o_y, int policy, int B, int H, int W, float* gsum_ws, float* gx, void* stream);
 int dg_diffaug_bwd_acc(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
@@ -201,6 +212,8 @@ int dg_head_post_bwd2(const float* gout, const float* noise_pixel, const float* 
 /* ---- Trainer.fetch_reals  trainers/dcgan_amp.py:154-160 (utils/lidar.py:31-36, utils/__init__.py:70-73) -- */
 int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,
                    float* out, void* stream);
+int dg_fetch_reals_sum(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, int B,
+                       long HW, float* out, float* xsum, void* stream); /* + xsum[b] += sum of out[b] (as dg_head_post_fwd_sum) */
 
 /* ---- data formats either side of the step ---------------------------------------------
  * dg_scan_to_polar: KITTIOdometry.preprocess + .transform  datasets/kitti.py:54-77, optionally fused with
@@ -293,6 +306,8 @@ int dg_aug_draw(uint64_t seed, uint64_t stream_id, uint64_t offset, int B, int H
 /* ---- device-resident counters (hipGraph-friendly variants): Philox offset / Adam step count read from device memory;
  *      dg_counter_add advances a counter after its consumers.  A step captured once replays with fresh draws. */
 int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* stream);
+/* k <= 8 distinct counters advanced by one launch (DG_EINVAL on duplicates) */
+int dg_counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, void* stream);
 int dg_philox_fill_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int kind, float lo,
                        float hi, int ilo, int ihi, long n, void* out, void* stream);
 int dg_aug_draw_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int B, int H, int W,

@@ -190,15 +190,16 @@ def test_two_ranks_fused_proj_optimizer_matches_unfused(pl):
     assert all(o["used"] for o in res[True]) and not any(o["used"] for o in res[False])
     for r in range(2):
         a, b = res[True][r], res[False][r]
-        # not bit-equal: the split-K atomics of the other weight gradients reorder fp32 sums from run to run, and a
-        # last-bit difference can flip a bf16 rounding of the next step's shadows or one pixel of the hard Gumbel
-        # threshold (runs cluster at ~1e-8 and ~1.4e-4, scripts/resume_noise.py); a wrong kernel would be O(1) off
-        assert rel_l2(a["G"], b["G"]) < 5e-4, rel_l2(a["G"], b["G"])
-        assert rel_l2(a["E"], b["E"]) < 5e-4, rel_l2(a["E"], b["E"])
-        assert rel_l2(a["V"], b["V"]) < 5e-3, rel_l2(a["V"], b["V"])
+        # not bit-equal: atomics reorder fp32 sums from run to run, and a last-bit difference can flip a bf16 rounding of the
+        # next step's shadows or one pixel of the hard Gumbel threshold.  Measured over repeated runs of this test: no
+        # flip -> G / E ~1e-5, V ~1e-3; one flipped pixel -> G / E 5.8e-4 (the same value every time), V 0.6-1.9e-2.  A
+        # wrong kernel would be O(1) off on Proj.weight, which is 96 % of these vectors.
+        assert rel_l2(a["G"], b["G"]) < 2e-3, rel_l2(a["G"], b["G"])
+        assert rel_l2(a["E"], b["E"]) < 2e-3, rel_l2(a["E"], b["E"])
+        assert rel_l2(a["V"], b["V"]) < 5e-2, rel_l2(a["V"], b["V"])
         for x, y in zip(a["scal"], b["scal"]):
             for k in x:
-                assert abs(x[k] - y[k]) < 5e-3 * max(1.0, abs(y[k])), (k, x[k], y[k])
+                assert abs(x[k] - y[k]) < 2e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
     assert torch.equal(res[True][0]["G"], res[True][1]["G"])
 
 
