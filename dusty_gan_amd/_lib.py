@@ -207,10 +207,16 @@ class AccArena:
     SIZE = 8192
     buf, pos, epoch = None, 0, 0               # epoch: counts begin() calls (a slice is only meaningful within its epoch)
 
+    @staticmethod
+    def _same(dev, want):
+        import torch
+        want = torch.device(want)
+        return dev.type == want.type and (want.index is None or dev.index == want.index)
+
     @classmethod
     def begin(cls, device):
         import torch
-        if cls.buf is None or cls.buf.device != torch.device(device):
+        if cls.buf is None or not cls._same(cls.buf.device, device):
             cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
         zero_(cls.buf)
         cls.pos = 0
@@ -219,7 +225,7 @@ class AccArena:
     @classmethod
     def take(cls, n, device=None):
         import torch
-        if cls.buf is None or (device is not None and cls.buf.device != torch.device(device)):
+        if cls.buf is None or (device is not None and not cls._same(cls.buf.device, device)):
             return None
         a = (cls.pos + 15) // 16 * 16          # 64-byte slices
         if a + n > cls.SIZE:

@@ -1,0 +1,211 @@
+"""GPU parity of the round-2 forms of the small kernels (through the C ABI): each fused / pre-zeroed / vector form against
+the plain entry point it replaces in the training step, and the scalar fall-backs of the 16-byte kernels against the
+oracle.  Reference call sites: trainers/dcgan_amp.py:154-160 (fetch_reals), :218-235 (R1), utils/diff_augment.py:29-33
+(contrast mean), models/ops/common.py:74-88 (BlurVH), models/gans/dcgan_eqlr.py:95 (final conv)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dusty_oracle as O
+from tests.golden_util import rel_l2
+from tests.test_gpu_ops import from_nhwc, nhwc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dusty_gan_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.mark.parametrize("H,W", [(32, 64), (64, 1024), (8, 48)])   # 8 x 48: H W % 1024 != 0 -> refused
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_blur_adjoint_r1_form(L, H, W, dtype):
+    """dg_blur_bwd_r1 == dg_blur_bwd, then |g_b|^2 per sample and the scaled copy (the three launches it replaces)"""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(H + W)
+    B = 5
+    d = torch.randn(B, H, W, 2, generator=g).to(DEV, dtype)
+    ref = torch.empty(B, 1, H, W, device=DEV)
+    L.check(lib.dg_blur_bwd(d.data_ptr(), L.dtype_code(dtype), ref.data_ptr(), B, H, W, 1, None))
+    out = torch.full((B, 1, H, W), 7.0, device=DEV)
+    ssq = torch.zeros(B, device=DEV)
+    rc = lib.dg_blur_bwd_r1(d.data_ptr(), L.dtype_code(dtype), out.data_ptr(), 0.375, ssq.data_ptr(), B, H, W, 1, None)
+    torch.cuda.synchronize()
+    if (H * W) % 1024 != 0:
+        assert rc == L.DG_EUNSUPPORTED and float(out.min()) == 7.0   # refused before anything was written
+        return
+    L.check(rc)
+    assert torch.equal(out, 0.375 * ref)
+    assert rel_l2(ssq.cpu(), ref.pow(2).sum(dim=[1, 2, 3]).cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("H,W", [(8, 32), (64, 1024), (5, 7)])   # 5 x 7: H W % 256 != 0 -> refused
+def test_fetch_reals_and_head_emit_per_sample_sums(L, H, W):
+    lib = L.lib()
+    g = torch.Generator().manual_seed(7 * H + W)
+    B, HW = 3, H * W
+    pol = torch.rand(B, 1, H, W, generator=g).to(DEV)
+    m = (torch.rand(B, 1, H, W, generator=g) < 0.8).float().to(DEV)
+    ref = torch.empty_like(pol)
+    L.check(lib.dg_fetch_reals(pol.data_ptr(), m.data_ptr(), 0.9, 120.0, -1.0, pol.numel(), ref.data_ptr(), None))
+    out, sums = torch.empty_like(pol), torch.zeros(B, device=DEV)
+    rc = lib.dg_fetch_reals_sum(pol.data_ptr(), m.data_ptr(), 0.9, 120.0, -1.0, B, HW, out.data_ptr(), sums.data_ptr(), None)
+    if HW % 256 != 0:
+        assert rc == L.DG_EUNSUPPORTED
+    else:
+        L.check(rc)
+        assert torch.equal(out, ref)
+        assert rel_l2(sums.cpu(), ref.sum(dim=[1, 2, 3]).cpu()) < 1e-6
+    for k in (0, 1, 2):  # none / dusty1 / dusty2 heads
+        raw = torch.randn(B, 1 + k, H, W, generator=g).to(DEV)
+        npx = torch.randn(B, H, W, generator=g).to(DEV)
+        nim = torch.randn(B, generator=g).to(DEV)
+        g1, g2 = raw.clone(), raw.clone()
+        m1, m2 = torch.zeros(B, max(k, 1), H, W, device=DEV), torch.zeros(B, max(k, 1), H, W, device=DEV)
+        d1, d2 = torch.empty(B, 1, H, W, device=DEV), torch.empty(B, 1, H, W, device=DEV)
+        L.check(lib.dg_head_post_fwd(g1.data_ptr(), npx.data_ptr(), nim.data_ptr(), k, 1, 1.0, -1.0, B, HW, m1.data_ptr(),
+                                     d1.data_ptr(), None))
+        ds = torch.zeros(B, device=DEV)
+        rc = lib.dg_head_post_fwd_sum(g2.data_ptr(), npx.data_ptr(), nim.data_ptr(), k, 1, 1.0, -1.0, B, HW, m2.data_ptr(),
+                                      d2.data_ptr(), ds.data_ptr(), None)
+        if HW % 256 != 0:
+            assert rc == L.DG_EUNSUPPORTED
+            continue
+        L.check(rc)
+        assert torch.equal(d1, d2) and torch.equal(g1, g2) and torch.equal(m1, m2)
+        assert rel_l2(ds.cpu(), d1.sum(dim=[1, 2, 3]).cpu()) < 1e-6
+
+
+def test_diffaug_takes_the_producers_sums_and_the_arena(L):
+    """DiffAugment.apply with (a) its own pass, (b) a pre-zeroed arena slice (dg_diffaug_fwd_acc), (c) the sums its input's
+    producer tagged on the tensor (dg_diffaug_fwd_pre): the same image; a stale tag (older arena epoch) is ignored"""
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    torch.manual_seed(5)
+    B, H, W = 4, 32, 64
+    A = DiffAugment(["brightness", "saturation", "contrast", "translation", "cutout"])
+    x = torch.rand(B, 1, H, W, device=DEV) * 2 - 1
+    rp = A.draw(B, H, W, DEV)
+    L.AccArena.buf = None                                   # (a) no arena
+    ya = A.apply(x, rp)
+    L.AccArena.begin(DEV)                                   # (b) arena slice
+    pos = L.AccArena.pos
+    yb = A.apply(x, rp)
+    assert L.AccArena.pos > pos and torch.equal(ya, yb)
+    sums = L.AccArena.take(B, DEV)                          # (c) tagged sums
+    sums.copy_(x.sum(dim=[1, 2, 3]))
+    L.tag_sums(x, sums)
+    pos = L.AccArena.pos
+    yc = A.apply(x, rp)
+    assert L.AccArena.pos == pos                            # no slice of its own
+    assert rel_l2(yc.cpu(), ya.cpu()) < 1e-6
+    sums.fill_(1e6)                                         # a wrong tag would show
+    L.AccArena.begin(DEV)                                   # new epoch: the tag is stale
+    assert L.tagged_sums(x) is None
+    assert torch.equal(A.apply(x, rp), ya)
+    x2 = x.clone()
+    L.tag_sums(x2, L.AccArena.take(B, DEV))
+    x2.add_(1.0)                                            # rewritten by a torch op: tag void
+    assert L.tagged_sums(x2) is None
+
+
+def test_arena_slices_are_zero_once_and_exhaustion_falls_back(L):
+    L.AccArena.begin(DEV)
+    a = L.AccArena.take(40, DEV)
+    b = L.AccArena.take(40, DEV)
+    assert a.data_ptr() % 64 == 0 and b.data_ptr() - a.data_ptr() == 48 * 4       # 64-byte slices, handed out once
+    assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+    a.fill_(3.0)
+    L.AccArena.begin(DEV)
+    assert float(L.AccArena.take(40, DEV).abs().max()) == 0.0                       # re-zeroed by the next step
+    assert L.AccArena.take(L.AccArena.SIZE, DEV) is None                            # exhausted -> caller's own buffer
+    # the self-zeroing and the _acc forms agree
+    lib = L.lib()
+    x = torch.randn(6, 4096, device=DEV)
+    o1, o2 = torch.full((6,), 9.0, device=DEV), torch.zeros(6, device=DEV)
+    L.check(lib.dg_sample_sum(x.data_ptr(), 6, 4096, 1, o1.data_ptr(), None))
+    L.check(lib.dg_sample_sum_acc(x.data_ptr(), 6, 4096, 1, o2.data_ptr(), None))
+    assert rel_l2(o1.cpu(), o2.cpu()) < 1e-6 and rel_l2(o1.cpu(), x.pow(2).sum(1).cpu()) < 1e-6
+
+
+def test_counters_queue_and_multi_add(L):
+    from dusty_gan_amd.utils.rng import Philox
+    lib = L.lib()
+    c = [torch.full((1,), 10 * i, dtype=torch.int64, device=DEV) for i in range(3)]
+    ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in c])
+    L.check(lib.dg_counter_add_multi(ptrs, (C.c_uint64 * 3)(1, 2, 3), 3, None))
+    torch.cuda.synchronize()
+    assert [int(t) for t in c] == [1, 12, 23]
+    dup = (C.c_void_p * 2)(c[0].data_ptr(), c[0].data_ptr())
+    assert lib.dg_counter_add_multi(dup, (C.c_uint64 * 2)(1, 1), 2, None) == L.DG_EINVAL
+    assert lib.dg_counter_add_multi(ptrs, (C.c_uint64 * 3)(1, 2, 3), 9, None) == L.DG_EINVAL
+    # queued advances: two draws from one generator see consecutive offsets, .offset is current, numbers == one long draw
+    L.Counters.flush()
+    r1, r2 = Philox(77, DEV, stream_id=3), Philox(77, DEV, stream_id=3)
+    a = r1.normal(1000)
+    assert r1.ctr.data_ptr() in L.Counters.pending           # the advance is waiting for a flush
+    b = r1.normal(1000)                                      # ... which the second draw triggers
+    assert r1.offset == 500 and not L.Counters.pending
+    ab = r2.normal(2000)
+    assert torch.equal(torch.cat([a, b]), ab)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_final_conv_kernels_scalar_fallbacks(L, dtype):
+    """n = 3 * 5 * 7 (not a multiple of the 16-byte vector) and C = 7: the scalar kernels behind dg_final_fwd /
+    dg_final_bwd_data / dg_batch_wsum, against the oracle ops (the vector forms: tests/test_gpu_ops.py)"""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    B, C3, h0, w0 = 5, 7, 3, 5
+    n = h0 * w0 * C3
+    d4 = torch.randn(B, C3, h0, w0, generator=g)
+    if dtype == torch.bfloat16:
+        d4 = d4.bfloat16().float()
+    d4r = d4.clone().requires_grad_()
+    wf = torch.randn(1, C3, h0, w0, generator=g).requires_grad_()
+    bf = torch.randn(1, generator=g)
+    yf = F.conv2d(d4r * O.equal_lr_scale(wf), wf, bf).view(B)
+    d4d = nhwc(d4).to(DEV, dtype)
+    wfd = wf.detach().permute(0, 2, 3, 1).contiguous().view(-1).to(DEV)
+    yd, bfd = torch.empty(B, device=DEV), bf.to(DEV)
+    L.check(lib.dg_final_fwd(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), bfd.data_ptr(), 1.0 / math.sqrt(n), B, n,
+                             yd.data_ptr(), None))
+    assert rel_l2(yd.cpu(), yf) < 1e-5
+    up = torch.randn(B, generator=g)
+    upd = up.to(DEV)
+    gd4, gwf = torch.autograd.grad(yf, [d4r, wf], up)
+    ref = gd4 * torch.where(d4 > 0, 1.0, 0.2) * math.sqrt(2.0)
+    dd4, db = torch.empty_like(d4d), torch.zeros(C3, device=DEV)
+    L.check(lib.dg_final_bwd_data(d4d.data_ptr(), L.dtype_code(dtype), wfd.data_ptr(), upd.data_ptr(), None,
+                                  1.0 / math.sqrt(n), B, n, C3, dd4.data_ptr(), db.data_ptr(), None))
+    assert rel_l2(from_nhwc(dd4.float().cpu(), B, C3, h0, w0), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < (1e-5 if dtype == torch.float32 else 2e-2)
+    dwf = torch.zeros(n, device=DEV)
+    L.check(lib.dg_batch_wsum(d4d.data_ptr(), L.dtype_code(dtype), upd.data_ptr(), 1.0 / math.sqrt(n), B, n,
+                              dwf.data_ptr(), None))
+    assert rel_l2(dwf.cpu().view(h0, w0, C3).permute(2, 0, 1), gwf[0]) < 1e-5
+
+
+@pytest.mark.parametrize("ring", [True, False])
+def test_blur_scalar_fallback_width_not_a_multiple_of_four(L, ring):
+    lib = L.lib()
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 2, 6, 10
+    x = torch.randn(B, 1, H, W, generator=g).requires_grad_()
+    y = O.blur_vh(x, ring)
+    out = torch.empty(B * H * W * 2, device=DEV)
+    xd = x.detach().to(DEV)
+    L.check(lib.dg_blur_fwd(xd.data_ptr(), out.data_ptr(), L.DG_F32, B, H, W, int(ring), None))
+    assert rel_l2(from_nhwc(out.cpu(), B, 2, H, W), y) < 1e-6
+    gy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    dx = torch.empty(B, 1, H, W, device=DEV)
+    gyd = nhwc(gy).to(DEV)
+    L.check(lib.dg_blur_bwd(gyd.data_ptr(), L.DG_F32, dx.data_ptr(), B, H, W, int(ring), None))
+    assert rel_l2(dx.cpu(), gx) < 1e-6
