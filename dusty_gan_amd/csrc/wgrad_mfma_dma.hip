@@ -38,9 +38,18 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 }
 
 #define DG_WAITV(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#ifdef DG_WG_DIAG
+#define TR16(dst, addr, imm) do { if (!(DG_WG_DIAG & 16)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory"); else asm volatile("" : "=v"(dst)); } while (0)
+#else
 #define TR16(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#endif
 
 // NT = W taps per workgroup: 1, or 2 = the pair (kx, kx + 2) on one G tile and one A image of 64 + 1 pixels
+#ifdef DG_WG_DIAG
+constexpr int wg_dbg = DG_WG_DIAG;   // ablation builds (make wgdiag WGDIAG=bits): 1 no DMA, 2 no MFMA, 4 no epilogue, 16 no LDS reads
+#else
+constexpr int wg_dbg = 0;
+#endif
 template <int WMODE, int BM, int BN, int NT>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n, int accumulate) {
   constexpr int RA = BM * 2, RG = BN * 2;                 // LDS row bytes (one pixel)
@@ -109,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   const int dg = WMODE == 1 ? (NT == 2 ? 1 - kxp : ((kxp == 0 || kxp == 2) ? 1 : 0)) : 0;   // column parity on the G grid
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   auto dma_s = [&](unsigned voff, const char* sbase, unsigned ldsaddr) __attribute__((always_inline)) {
+    if (wg_dbg & 1) return;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
   };
   const int nchunks = (int)nchunks64;
@@ -229,8 +239,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const i32x4 fa = {alo[set][t][i][0], alo[set][t][i][1], ahi[set][t][i][0], ahi[set][t][i][1]};
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                                   __builtin_bit_cast(bf16x8, fg), acc[t][i][j], 0, 0, 0);
+            if (!(wg_dbg & 2))
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
+                                                                     __builtin_bit_cast(bf16x8, fg), acc[t][i][j], 0, 0, 0);
+            else asm volatile("" ::"v"(fa), "v"(fg));
           }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
           const int co = co0 + wn * (BN / 2) + j * 32 + lr;
           const float v = acc[t][i][j][e] * (p.scale * cur_rs);
           float* dst = dw + (long)ci * p.Co + co;
+          if (wg_dbg & 4) { asm volatile("" ::"v"(v)); continue; }
           if (accumulate) atomicAdd(dst, v);
           else *dst = v;
         }
