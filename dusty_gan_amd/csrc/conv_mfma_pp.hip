@@ -12,17 +12,22 @@
 //     wave group A (waves 0-3):  LOAD(t) | MFMA(t) | LOAD(t+1) | MFMA(t+1) | ...
 //     wave group B (waves 4-7):          | LOAD(t) | MFMA(t)   | LOAD(t+1) | ...        ( | = workgroup barrier )
 //
-//   LOAD(t): all 16 fragment reads of K step t (ds_read_b128, 64 VGPRs) ; this wave's 6 LDS-DMA pieces of K step t+2 ;
-//            s_waitcnt {own pieces of t+1 landed, fragments in} ; (epilogue of the finished tile, if any)
+//   LOAD(t): all 16 fragment reads of K step t (ds_read_b128, 64 VGPRs) alternated with the step's LDS-DMA pieces ;
+//            s_waitcnt {everything but this half's pieces landed, fragments in} ; (epilogue of the finished tile, if any)
 //   MFMA(t): 32 x v_mfma_f32_16x16x32_bf16 straight from registers - no LDS, no waits.
-// Both groups run the same program; group B starts one barrier late.  Ring of 3 stages x 48 KB: stage t is read by A in
-// its LOAD(t) and by B one interval later; K step t+2 goes into the stage K step t-1 used, whose last reads retired (each
-// LOAD ends with lgkmcnt(0)) before the barrier in front of the interval that refills it.
+// Both groups run the same program; group B starts one barrier late.
+//
+// Ring stages hold a PAIR of K steps: the two W taps (kx, kx + 2) of a pair read the same input pixels one column apart,
+// so a stage is one pixel image of SW + 1 columns per sample segment (33 pieces of 8 rows) plus the two taps' weight
+// tiles (2 x 65 KB for the 128-channel N tile); tap t reads image rows r + t.  The compute side runs one pair behind the
+// issue side; a stage is refilled one pair after its last read (each LOAD half ends with lgkmcnt(0) in front of a
+// barrier).  Details at the issue side and at `pair_iter` below.
 //
 // Accumulators are TRANSPOSED (weights as the A operand, pixels as B): a lane then holds 4 consecutive channels of one
 // pixel per 16 x 16 block, and with the weight rows of block j permuted (row 16g+4j+r feeds lane group g, register r)
-// 16 CONSECUTIVE channels of its pixel - the epilogue stores 16-byte pieces of the NHWC rows straight from registers:
-// no LDS transpose, no barrier, and it runs while the other group's MFMAs keep the matrix pipe busy.
+// 16 CONSECUTIVE channels of its pixel: the epilogue's arithmetic and its mask source need no cross-lane movement.  The
+// output leaves through a wave-private 2 KB LDS strip per 16-pixel block row (128-channel N tile: whole 128-byte runs per
+// store instruction) or straight from registers (64-channel N tile: the four lanes of a pixel already cover its 64 bytes).
 #include "conv_mfma_persist_impl.h"
 
 #include <type_traits>
