@@ -592,6 +592,10 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
   if (p->mode != MODE_S2 && p->mode != MODE_UP) return DG_EUNSUPPORTED;
   if (p->in_dtype != DG_BF16 || p->out_dtype != DG_BF16 || p->w_dtype != DG_BF16) return DG_EUNSUPPORTED;
   if (p->K % 64 != 0 || !p->ring || p->nscale) return DG_EUNSUPPORTED;
+  // a tile must span at least two pair iterations (the compute side finishes the previous tile during the first one and
+  // its epilogue runs at the start of the second): the adjoint MODE_UP pass with K == 64 could have one (a single H tap at
+  // a border row x one channel chunk x one pair; the forward flavour reflects and always has two H taps)
+  if (p->mode == MODE_UP && p->adj && p->K < 128) return DG_EUNSUPPORTED;
   if (p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1) return DG_EUNSUPPORTED;
   if (p->out_sp % 8 != 0 || p->in_sp % 8 != 0 || p->w_sn % 8 != 0) return DG_EUNSUPPORTED;   // 16-byte pieces
   if (p->N > 512 || (p->bias && p->bias_mod < p->N && p->N % p->bias_mod != 0)) return DG_EUNSUPPORTED;
