@@ -268,14 +268,21 @@ def main():
     if world > 1:
         out["distributed"] = {"backend": backend, "world_size": dist.get_world_size(),
                               "devices_visible": torch.cuda.device_count()}
-        comm = tr.comm_profile(steps=3)
-        if comm:
-            out["distributed"]["exposed_ms_per_step"] = comm
+        try:  # (instrumentation after the timed region: never at the price of the line itself)
+            comm = tr.comm_profile(steps=3)
+            if comm:
+                out["distributed"]["exposed_ms_per_step"] = comm
+        except Exception as e:  # noqa: BLE001
+            out["distributed"]["exposed_ms_per_step"] = f"not measured ({type(e).__name__}: {e})"
     fl, f_g, f_d = flops_per_sample(args.shape, arch, args.gp)
     out["step_flops_fraction_of_mfma_peak"] = round(fl * args.batch * steps_s / 1e12 / PEAK_TFLOPS[args.precision], 4)
 
     if not args.no_roofline:
-        fam = roofline_pass(tr)
+        try:
+            fam = roofline_pass(tr)
+        except Exception as e:  # noqa: BLE001
+            fam = None
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0 and fam:
             name = max(fam, key=lambda k: fam[k]["ms"])
             f = fam[name]
