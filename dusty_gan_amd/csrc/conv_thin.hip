@@ -981,7 +981,8 @@ int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
   const int tiles_x = p->Wc / 32;
   const long ntiles = (long)p->B * p->Hc * tiles_x;
   long blocks = (ntiles + 3) / 4;
-  const long cap = 512;  // 2 blocks per CU: the per-wave weight preload amortises over more tiles
+  const long cap = 768;  // 3 blocks per CU = what 164 VGPRs allow resident (measured: 256 -> 50 us, 512 -> 34 us, 768 -> 31 us,
+                         // 1024 -> 38 us for Down1 forward at batch 32; the per-wave weight preload amortises over the tiles)
   if (blocks > cap) blocks = cap;
   if (p->in_sp == 2) thin_s2_mfma_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
   else thin_s2_mfma_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
