@@ -77,13 +77,15 @@ def test_two_ranks_on_one_gpu_match_single_process():
     with tempfile.TemporaryDirectory() as td:
         mp.spawn(worker, args=(2, os.path.join(td, "init"), td, sdG, sdD), nprocs=2, join=True)
         outs = [torch.load(os.path.join(td, f"r{r}.pt")) for r in range(2)]
+    # (measured ~1e-8; 5e-4 leaves room for one flipped pixel of the hard Gumbel threshold - the 1.4e-4 cluster of
+    #  scripts/resume_noise.py - where a wrong exchange is O(1e-2))
     for o in outs:
-        assert rel_l2(o["D"], ref.D.store.flat.cpu()) < 1e-4
-        assert rel_l2(o["G"], ref.G.store.flat.cpu()) < 1e-4
-        assert rel_l2(o["E"], ref.G_ema.store.flat.cpu()) < 1e-4
+        assert rel_l2(o["D"], ref.D.store.flat.cpu()) < 5e-4
+        assert rel_l2(o["G"], ref.G.store.flat.cpu()) < 5e-4
+        assert rel_l2(o["E"], ref.G_ema.store.flat.cpu()) < 5e-4
         for s_got, s_ref in zip(o["scal"], scal_ref):
             for k, v in s_ref.items():
-                assert abs(s_got[k] - v) < 1e-4 * max(1.0, abs(v)), k
+                assert abs(s_got[k] - v) < 1e-3 * max(1.0, abs(v)), k
     assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
 
 
