@@ -93,13 +93,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int dbg = 0;
 #endif
 
-  // ---- this workgroup's chunk of the tile order (XCD-aware, as the lock-step kernel: conv_mfma_persist_impl.h)
+  // ---- this workgroup's tiles.  XCD x (blocks x, x + 8, ...) owns a CONTIGUOUS range of the tile order (the split of
+  // the lock-step kernel, conv_mfma_persist_impl.h) and its workgroups walk that range ROUND-ROBIN: at any moment the
+  // XCD works on ~32 consecutive tiles - the N tiles, the two column parities and the neighbouring rows of the same
+  // input window - so one L2 fill serves them all (a contiguous chunk per workgroup kept those re-uses a whole chunk
+  // apart in time, by when the 4 MB L2 had been streamed through several times).
   const int G = gridDim.x;
   const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7;
-  const int gi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int gi0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int nwx = q8 + (xcd < r8 ? 1 : 0);     // workgroups on this XCD
   const int tq = g.ntiles / G, tr = g.ntiles % G;
-  const int t0 = gi * tq + (gi < tr ? gi : tr);
-  const int tcount = tq + (gi < tr ? 1 : 0);
+  const int xs = gi0 * tq + (gi0 < tr ? gi0 : tr);
+  const int xe = (gi0 + nwx) * tq + (gi0 + nwx < tr ? gi0 + nwx : tr);
+  const int t0 = xs + (int)(blockIdx.x >> 3);
+  const int tcount = t0 < xe ? (xe - t0 + nwx - 1) / nwx : 0;
   if (tcount == 0) return;
 
   const int tid = threadIdx.x;
@@ -109,18 +116,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const int rows = MODE == MODE_S2 ? p.Hc : 2 * p.Hc;
   const int tiles_n = g.tiles_n, tiles_x = g.tiles_x;
 
-  Tile first;
-  {
-    int mt = t0 / tiles_n;
-    first.nt = t0 % tiles_n;
-    first.px = 0;
-    first.xt = mt % tiles_x; mt /= tiles_x;
-    if (MODE == MODE_UP) { first.px = mt & 1; mt >>= 1; }
-    first.Y = mt % rows; first.bt = mt / rows;
-    first.nt = __builtin_amdgcn_readfirstlane(first.nt); first.xt = __builtin_amdgcn_readfirstlane(first.xt);
-    first.px = __builtin_amdgcn_readfirstlane(first.px); first.Y = __builtin_amdgcn_readfirstlane(first.Y);
-    first.bt = __builtin_amdgcn_readfirstlane(first.bt);
-  }
+  auto tile_at = [&](int t) {                  // tile order: N tile fastest, then column tile, parity, row, sample group
+    Tile r;
+    int mt = t / tiles_n;
+    r.nt = t % tiles_n;
+    r.px = 0;
+    r.xt = mt % tiles_x; mt /= tiles_x;
+    if (MODE == MODE_UP) { r.px = mt & 1; mt >>= 1; }
+    r.Y = mt % rows; r.bt = mt / rows;
+    r.nt = __builtin_amdgcn_readfirstlane(r.nt); r.xt = __builtin_amdgcn_readfirstlane(r.xt);
+    r.px = __builtin_amdgcn_readfirstlane(r.px); r.Y = __builtin_amdgcn_readfirstlane(r.Y);
+    r.bt = __builtin_amdgcn_readfirstlane(r.bt);
+    return r;
+  };
+  const Tile first = tile_at(t0);
 
   const bf16* in = (const bf16*)p.in;
   const bf16* w = (const bf16*)p.w;
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       }
     }
     tprev = ti;
-    persist::next_tile<MODE>(ti, tiles_n, tiles_x, rows);
+    ti = tile_at(t0 + (c + 1) * nwx);
   }
   pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr);
   if (pending && !(dbg & 4)) {
