@@ -211,6 +211,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1" and os.environ.get("DUSTY_BENCH_BACKEND") == "nccl":
+        # one rank, the multi-rank schedule, every exchange through RCCL (identity collectives): what the call pattern
+        # itself costs on one GPU, with no wire time (utils/dist.py through_backend)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     tr, arch = make_trainer(args, rank, local_rank, world)
@@ -265,8 +275,8 @@ def main():
                               "max": round(per[-1], 4), "note": "HIP events between consecutive steps, rank 0"},
            "launch_mode": tr.launch_mode(),
            "scalars_last_step": {k: round(v, 5) for k, v in scal.items()}}
-    if world > 1:
-        out["distributed"] = {"backend": backend, "world_size": dist.get_world_size(),
+    if dist.is_initialized():
+        out["distributed"] = {"backend": backend or dist.get_backend(), "world_size": dist.get_world_size(),
                               "devices_visible": torch.cuda.device_count()}
         try:  # (instrumentation after the timed region: never at the price of the line itself)
             comm = tr.comm_profile(steps=3)
@@ -303,7 +313,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, arch)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

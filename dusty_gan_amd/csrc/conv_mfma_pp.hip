@@ -1,7 +1,8 @@
 // "Ping-pong" persistent implicit-GEMM conv on the matrix cores (gfx950, bf16): the kernel behind the fat layers of the
 // benchmark step.  Same passes as conv_mfma_persist_impl.h (Down forward / R1 tangent, Up forward, both backward-data
 // passes; reference: models/gans/dcgan_eqlr.py:19-26,75-82 with Pad / EqualLR / FusedLeakyReLU of models/ops/common.py
-// fused), same tile order, same LDS-DMA issue side - a different compute side.
+// fused), same tile order (walked round-robin by the workgroups of an XCD, see the kernel), same LDS-DMA issue side - a
+// different compute side.
 //
 // Why: ablation builds of the previous kernel (scripts/bench_conv.py, DG_CONV_DBG) showed its time to be the SUM of its
 // parts - skeleton (LDS fragment reads + barriers) 41 %, MFMA 22 %, DMA issue 19 %, epilogue 18 % - i.e. nothing

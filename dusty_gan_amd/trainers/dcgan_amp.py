@@ -315,6 +315,7 @@ class Trainer:
         self._graph, self._eager_steps = None, 0
         self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
         self._force_seg = os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"  # one process runs the multi-rank schedule
+        self._multi = D_.through_backend()  # exchanges go through torch.distributed (utils/dist.py)
         self._works, self._comm_events = {}, None
         self._fuse_proj_ok = os.environ.get("DUSTY_GAN_FUSE_PROJ", "1") != "0"
 
@@ -420,7 +421,7 @@ class Trainer:
         import os
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while this thread captures
-        ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self.world > 1 else "global")
+        ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self._multi else "global")
         ctx.__enter__()
         self._cap_cur = (g, ctx)
 
@@ -441,7 +442,7 @@ class Trainer:
 
     def _allreduce(self, store):
         """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
-        if self.world > 1:
+        if self._multi:
             self._coll(lambda: D_.allreduce_grads(store.grad), name="all-reduce grads")
         elif self._force_seg:
             self._coll(lambda: None)
@@ -449,7 +450,7 @@ class Trainer:
 
     def _allreduce_async(self, key, buf):
         """issue half of a bucketed gradient exchange (`_comm_wait(key)` completes it)"""
-        if self.world > 1:
+        if self._multi:
             self._comm_issue(key, lambda: D_.allreduce_grads(buf, async_op=True)[0])
         elif self._force_seg:
             self._coll(lambda: None)

@@ -8,6 +8,8 @@ SUM.  With num_accumulation > 1 the exchange happens once, after the last micro-
 DDP.no_sync() schedule, utils/context_manager.py:21-35).  The path shards by sample only: there is no other
 collective on the data path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,6 +20,16 @@ def world_size():
 
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def through_backend():
+    """True when the step's exchanges go through torch.distributed: several ranks - or ONE rank with an initialised
+    process group and DUSTY_GAN_FORCE_SEG=1, which runs the multi-rank call pattern (async bucketed all-reduces, operand
+    all-gathers, work handles waited between hipGraph segments) through RCCL on a single-GPU box
+    (tests/test_gpu_ddp.py::test_single_rank_rccl_runs_the_multi_rank_schedule)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"
 
 
 def local_batch(global_batch, ngpus, num_accumulation):
@@ -39,7 +51,7 @@ def allreduce_grads(flat_grad, async_op=False):
     """SUM all-reduce of one network's flat gradient buffer; returns (work handle or None, gscale) where gscale is the
     factor the optimizer applies to turn the sum into DDP's average."""
     w = world_size()
-    if w == 1:
+    if not through_backend():
         return None, 1.0
     work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
     return (work if async_op else None), 1.0 / w
@@ -77,7 +89,7 @@ def all_gather_into(out, t, async_op=False):
     raw = t.contiguous().view(torch.uint8)
     dst = out.view(torch.uint8)
     work = None
-    if w == 1:
+    if not through_backend():
         dst.copy_(raw)
     elif dist.get_backend() == "nccl":
         work = dist.all_gather_into_tensor(dst, raw, async_op=async_op)

@@ -162,6 +162,55 @@ def test_forced_segments_single_process_match_one_graph(monkeypatch):
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
+def rccl_worker(rank, world, init_file, out_dir):
+    from tests.test_gpu_step import make_trainer
+    os.environ["DUSTY_GAN_FORCE_SEG"] = "1"
+    dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    from dusty_gan_amd.utils import dist as DD
+    assert DD.through_backend()
+    torch.manual_seed(77)
+    tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
+    assert tr._multi
+    sc = []
+    for i in range(5):
+        sc.append(dict(tr.step(i).items()))
+        if i % 2 == 1:
+            torch.cuda.synchronize()  # host-side synchronisation between replays (bench.py's sync / barrier pattern)
+            dist.barrier()
+    segs = sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
+    res = {"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": sc, "segs": segs}
+    res["prof"] = tr.comm_profile(2)
+    torch.save(res, os.path.join(out_dir, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_runs_the_multi_rank_schedule(monkeypatch):
+    """The one thing the gloo tests above cannot show on a one-GPU box: the multi-rank schedule on the "nccl" backend
+    (RCCL).  A process group of ONE rank with DUSTY_GAN_FORCE_SEG=1 sends every exchange of the step through RCCL -
+    asynchronous bucketed all-reduces on RCCL's stream, the Proj operand all-gathers (`all_gather_into_tensor` on byte
+    views), work handles waited between hipGraph segments, thread-local capture beside the RCCL watchdog - at the
+    benchmark's size (bf16, B = 32).  With one rank every collective is an identity, so the run must train like the
+    single-graph replay."""
+    from tests.test_gpu_step import make_trainer
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(rccl_worker, args=(1, os.path.join(td, "init"), td), nprocs=1, join=True)
+        a = torch.load(os.path.join(td, "rccl.pt"))
+    monkeypatch.setenv("DUSTY_GAN_FORCE_SEG", "0")
+    torch.manual_seed(77)
+    b = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
+    sb = [dict(b.step(i).items()) for i in range(5)]
+    assert a["segs"] >= 4
+    assert any("wait" in k for k in a["prof"]), a["prof"]
+    for x, y in zip(a["scal"], sb):
+        for k in x:
+            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+    for net, key in (("G", "G"), ("D", "D"), ("G_ema", "E")):
+        fb = getattr(b, net).store.flat.cpu()
+        assert rel_l2(a[key], fb) < 2e-3, (net, rel_l2(a[key], fb))
+
+
 def fused_worker(rank, world, init_file, out_dir, fuse, pl=0.0):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH"] = "0"
