@@ -581,57 +581,104 @@ __global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
 }
 
 #define TU_PX 64
-__global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p) {
+#define TU_RS 8
+typedef __attribute__((ext_vector_type(4))) unsigned tw_u32x4;
+// One block = (sample, segment of TU_RS image rows, 64-pixel column tile) and walks DOWN its rows with a ring of four
+// staged input rows in LDS: output row m reads rows m-1, m, m+1 from the ring while row m+2 is in flight in registers
+// (3 sixteen-byte pieces per thread) and is written into the slot nobody reads - ONE barrier per row, every input row
+// fetched once per segment (10 rows for 8) instead of three times, and everything the epilogue needs from global memory
+// (scale, bias) fetched once in front of the loop.  The first version - one block per image row, all three rows staged
+// per tile - made one round trip to memory PER PIECE (a loop the compiler did not unroll: load, s_waitcnt vmcnt(0),
+// ds_write) plus two per epilogue, ~5 us per tile; pipelining that design took it from 40 to 30 us, and it stayed bound
+// by the 3x re-read.
+__global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x, int nseg) {
   constexpr int RB = 144;                                            // LDS pixel stride: 128 B of channels + 16 B
-  __shared__ __attribute__((aligned(16))) unsigned char s_in[3 * (TU_PX + 2) * RB];
+  constexpr int RPX = TU_PX + 2, ROWB = RPX * RB;                    // a staged row: the tile's pixels + halo
+  constexpr int NLD = (RPX * 8 + 255) / 256;                         // 16-byte pieces per thread and row (the last partial)
+  __shared__ __attribute__((aligned(16))) unsigned char s_in[4 * ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, Wc = p.Wc, Hc = p.Hc;
-  // XCD-aware, bijective block remap (blocks id and id+8 share an XCD): consecutive image rows - which re-read each
-  // other's input rows - land on ONE XCD's L2 instead of being fetched from the fabric by three of them
+  // XCD-aware, bijective block remap (blocks id and id+8 share an XCD): the column tiles and row segments of one sample
+  // - which share halo columns / rows - land on ONE XCD's L2
   const int nwg = gridDim.x, id = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-  const int b = logical / Hc, m = logical % Hc;
-  const int cls = m == 0 ? 1 : (m == Hc - 1 ? 2 : 0);
-  const bf16* in = (const bf16*)p.in + (long)b * p.in_sb;
+  const int xt = logical % tiles_x, sg = (logical / tiles_x) % nseg, b = logical / (tiles_x * nseg);
+  const int m0 = sg * TU_RS, m1 = m0 + TU_RS < Hc ? m0 + TU_RS : Hc;
+  const char* in = (const char*)((const bf16*)p.in + (long)b * p.in_sb);
   const int col = lane & 15, kg = lane >> 4;
-  tw_bf16x8 fa[18];
+  const unsigned spb = (unsigned)p.in_sp * 2u;                       // bytes per pixel
+  unsigned goff[NLD], loff[NLD];                                     // piece u of a row: pixel (tid >> 3) + 32 u, channel piece tid & 7
 #pragma unroll
-  for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(g_up_frag + ((cls * 18 + f) * 64 + lane) * 16);
-  for (int n0 = 0; n0 < Wc; n0 += TU_PX) {
-    __syncthreads();
-    for (int i = tid; i < 3 * (TU_PX + 2) * 8; i += 256) {
-      const int ch = i & 7, c = (i >> 3) % (TU_PX + 2), rr = (i >> 3) / (TU_PX + 2);
-      int r = m - 1 + rr;
-      r = r < 0 ? 0 : (r >= Hc ? Hc - 1 : r);                        // rows outside the grid carry zero weights
-      int cc = n0 - 1 + c;
-      if (cc < 0) cc += Wc; else if (cc >= Wc) cc -= Wc;
-      *(uint4*)(s_in + (rr * (TU_PX + 2) + c) * RB + ch * 16) = *(const uint4*)(in + ((long)r * Wc + cc) * p.in_sp + ch * 8);
+  for (int u = 0; u < NLD; ++u) {
+    const int px = (tid >> 3) + 32 * u;
+    int cc = xt * TU_PX - 1 + px;
+    if (cc < 0) cc += Wc; else if (cc >= Wc) cc -= Wc;
+    goff[u] = (unsigned)cc * spb + (tid & 7) * 16;
+    loff[u] = px * RB + (tid & 7) * 16;
+  }
+  const bool last_ok = (tid >> 3) + 32 * (NLD - 1) < RPX;
+  auto fetch_row = [&](int r, tw_u32x4 (&st)[NLD]) __attribute__((always_inline)) {
+    r = r < 0 ? 0 : (r >= Hc ? Hc - 1 : r);                          // rows outside the grid carry zero weights
+    const char* row = in + (unsigned)(r * Wc) * spb;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      if (u < NLD - 1 || last_ok) st[u] = *(const tw_u32x4*)(row + goff[u]);
+  };
+  auto put_row = [&](int r, const tw_u32x4 (&st)[NLD]) __attribute__((always_inline)) {   // row r lives in slot (r + 1) & 3
+    unsigned char* dst = s_in + ((r + 1) & 3) * ROWB;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      if (u < NLD - 1 || last_ok) *(tw_u32x4*)(dst + loff[u]) = st[u];
+  };
+  tw_u32x4 st[NLD];
+  {
+    tw_u32x4 sa[NLD], sb[NLD];
+    fetch_row(m0 - 1, sa); fetch_row(m0, sb); fetch_row(m0 + 1, st);   // first: the block's longest round trip
+    put_row(m0 - 1, sa); put_row(m0, sb); put_row(m0 + 1, st);
+  }
+  // epilogue constants of this lane's two output rows q = 2 kg + h  (q = py * N + n)
+  float e_sc[2], e_bias[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int q = 2 * kg + h, n = q < 2 * N ? q % N : 0;
+    e_sc[h] = p.nscale ? p.scale * p.nscale[n] : p.scale;
+    e_bias[h] = p.bias ? p.bias[n % p.bias_mod] : 0.f;
+  }
+  int cls = -1;
+  tw_bf16x8 fa[18];
+  __syncthreads();
+  const int xl = wave * 16 + col;                                    // this lane's pixel inside the tile
+  const int x = xt * TU_PX + xl;
+  for (int m = m0; m < m1; ++m) {
+    const bool more = m + 1 < m1;
+    if (more) fetch_row(m + 2, st);                                  // in flight during the MFMAs and stores below
+    const int mcls = m == 0 ? 1 : (m == Hc - 1 ? 2 : 0);             // boundary class of the row: its weight fragments
+    if (mcls != cls) {                                               // (block-uniform; at most twice per block)
+      cls = mcls;
+#pragma unroll
+      for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(g_up_frag + ((cls * 18 + f) * 64 + lane) * 16);
     }
-    __syncthreads();
-    const int xl = wave * 16 + col;                                  // this lane's pixel inside the tile
     tw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
+    for (int rr = 0; rr < 3; ++rr) {
+      const unsigned char* rowp = s_in + ((m + rr) & 3) * ROWB + xl * RB + kg * 16;   // row m - 1 + rr
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        const unsigned char* px_ = s_in + (rr * (TU_PX + 2) + xl + d) * RB + kg * 16;
-        const tw_bf16x8 b0 = *(const tw_bf16x8*)(px_);
-        const tw_bf16x8 b1 = *(const tw_bf16x8*)(px_ + 64);
+        const tw_bf16x8 b0 = *(const tw_bf16x8*)(rowp + d * RB);
+        const tw_bf16x8 b1 = *(const tw_bf16x8*)(rowp + d * RB + 64);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 0], b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 1], b1, acc, 0, 0, 0);
       }
+    }
     // D: column = pixel (lane & 15), rows 4 kg + j  ->  m' = 4 kg + j = (py * N + n) * 2 + px
-    const int x = n0 + xl;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int q = 2 * kg + h;
       if (q >= 2 * N) continue;
       const int py = q / N, n = q % N;
-      const float sc = p.nscale ? p.scale * p.nscale[n] : p.scale;
-      const float bias = p.bias ? p.bias[n % p.bias_mod] : 0.f;
-      const float v0 = acc[2 * h] * sc + bias, v1 = acc[2 * h + 1] * sc + bias;
+      const float v0 = acc[2 * h] * e_sc[h] + e_bias[h], v1 = acc[2 * h + 1] * e_sc[h] + e_bias[h];
       const long o = (long)b * p.out_sb + ((long)(2 * m + py) * (2 * Wc) + 2 * x) * p.out_sp + (long)n * p.out_sn;
       if (p.out_dtype == DG_F32 && p.out_sp == 1) {
         *(float2*)((float*)p.out + o) = make_float2(v0, v1);
@@ -640,6 +687,8 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p) {
         dg_st(p.out, o + p.out_sp, p.out_dtype, v1);
       }
     }
+    if (more) put_row(m + 2, st);                                    // slot (m + 3) & 3 = the slot of row m - 2: not read this step
+    __syncthreads();                                                 // row m + 2 visible; row m - 1's slot free for row m + 3
   }
 }
 
@@ -657,7 +706,10 @@ int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
   thin_up_prep_kernel<<<dim3(36, 3), 256, 0, s>>>(*p);
   // (a column-walker variant with an LDS-DMA row ring that fetched every input row once instead of three times measured
   //  within noise of this kernel on the step - 0.277 vs 0.282 ms for the family - and was removed in round 2)
-  thin_up_mfma_kernel<<<(unsigned)((long)p->B * p->Hc), 256, 0, s>>>(*p);
+  const int tiles_x = p->Wc / TU_PX, nseg = (p->Hc + TU_RS - 1) / TU_RS;
+  const long blocks = (long)p->B * nseg * tiles_x;
+  if (blocks >= (1L << 31)) return DG_EUNSUPPORTED;
+  thin_up_mfma_kernel<<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, nseg);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
