@@ -336,18 +336,27 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_kernel(WgradP p, int ci_bas
 typedef __attribute__((ext_vector_type(8))) __bf16 tw_bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 tw_bf16x4;
 typedef __attribute__((ext_vector_type(16))) float tw_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned tw_u32x4;
 #define WG_ROWS_PB 2
+#define WG_GS 4                                  // K steps (16 pixels each) whose gradient tiles a wave fetches at once
 
-__global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
+// Memory schedule (round 2; the first version made one global round trip per staged dword batch and per K step - loops
+// hipcc does not unroll: load, s_waitcnt vmcnt(0), ds_write): the four input rows of a coarse row are fetched as NPT
+// sixteen-byte pieces per thread, the NEXT row's pieces in flight while the current row is computed; a wave requests the
+// gradient tiles of WG_GS K steps (2 x 16 B per lane each) in one batch before the row's barrier, so a row costs about one
+// exposed round trip instead of ~24.  LDS row layout: pixel c at dword c + 4 (16-byte aligned pieces), the circular halo
+// pixels -1 / Wf at dwords 3 / Wf + 4.  The cross-wave reduction buffer aliases the staging area (32 KB per block).
+template <int NPT>
+__global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p, int rows_pb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int Wf = 2 * p.Wc, ncol = Wf + 2;
+  const int Wf = 2 * p.Wc, ncol = Wf + 8;
   unsigned* s_a = (unsigned*)smem;                                   // [4 ky][ncol] dwords = (ci0, ci1)
   unsigned char* s_g = smem + (size_t)4 * ncol * 4;                  // [4 waves][16 px][144 B]
-  float* s_red = (float*)(s_g + 4 * 16 * 144);                       // [4 waves][32][64] fp32
+  float* s_red = (float*)smem;                                       // [4 waves][32][64] fp32 - after the row loop
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long units = (long)p.B * p.Hc;
-  const long u0 = (long)blockIdx.x * WG_ROWS_PB;
+  const long u0 = (long)blockIdx.x * rows_pb;
   const bf16* A = (const bf16*)p.a;
   const bf16* G = (const bf16*)p.g;
   // lane roles
@@ -362,32 +371,78 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   const int seg = p.Wc / 4;                                          // pixels per wave per row
-  for (long u = u0; u < u0 + WG_ROWS_PB && u < units; ++u) {
+  const int npc = Wf / 4;                                            // 16-byte pieces per staged row (4 rows: Wf pieces)
+  tw_u32x4 sa[NPT];
+  unsigned sh = 0;
+  auto fetch_a = [&](long u) __attribute__((always_inline)) {
     const int b = (int)(u / p.Hc), Y = (int)(u % p.Hc);
-    __syncthreads();
-    for (int i = tid; i < 4 * ncol; i += 256) {
-      const int col = i % ncol, kk = i / ncol;
-      int ra, rg;
-      dg_wgrad1d(0, 0, Y, p.Hc, kk, ra, rg);
-      int cc = col - 1;
-      if (cc < 0) cc += Wf; else if (cc >= Wf) cc -= Wf;
-      s_a[i] = *(const unsigned*)(A + (long)b * p.a_sb + ((long)ra * Wf + cc) * p.a_sp);
+    const bf16* img = A + (long)b * p.a_sb;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < Wf) {
+        const int kk = i / npc, pc = i % npc;
+        int ra, rg;
+        dg_wgrad1d(0, 0, Y, p.Hc, kk, ra, rg);
+        sa[k] = *(const tw_u32x4*)(img + ((long)ra * Wf + 4 * pc) * 2);
+      }
     }
-    __syncthreads();
-    const bf16* s_a16 = (const bf16*)s_a;
-    const bf16* grow = G + (long)b * p.g_sb + (long)Y * p.Wc * p.g_sp;
-    for (int xb = wave * seg; xb < (wave + 1) * seg; xb += 16) {
-      // stage G[xb .. xb+15][0..63] (128 B per pixel) into this wave's tile: 2 x (64 lanes x 16 B)
+    if (tid < 8) {                                                   // halo: pixel Wf - 1 in front, pixel 0 behind
+      int ra, rg;
+      dg_wgrad1d(0, 0, Y, p.Hc, tid >> 1, ra, rg);
+      sh = *(const unsigned*)(img + ((long)ra * Wf + ((tid & 1) ? 0 : Wf - 1)) * 2);
+    }
+  };
+  auto put_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < Wf) *(tw_u32x4*)(s_a + (i / npc) * ncol + 4 + 4 * (i % npc)) = sa[k];
+    }
+    if (tid < 8) s_a[(tid >> 1) * ncol + ((tid & 1) ? Wf + 4 : 3)] = sh;
+  };
+  const long uend = u0 + rows_pb < units ? u0 + rows_pb : units;
+  // the K steps of the block's rows in groups of WG_GS: group gq = (row u0 + gq / gpr, steps (gq % gpr) * WG_GS ...)
+  const int spr = seg / 16, gpr = (spr + WG_GS - 1) / WG_GS, ngr = (int)(uend - u0) * gpr;
+  auto load_group = [&](int gq, tw_u32x4 (&gt)[WG_GS][2]) __attribute__((always_inline)) {
+    const long u = u0 + gq / gpr;
+    const int s0 = (gq % gpr) * WG_GS;
+    const int b = (int)(u / p.Hc), Y = (int)(u % p.Hc);
+    const bf16* grow = G + (long)b * p.g_sb + ((long)Y * p.Wc + wave * seg + 16 * s0) * p.g_sp;
+    // the gradient tiles of the group's K steps: G[xb .. xb+15][0..63] (128 B per pixel) = 2 x (64 lanes x 16 B) each
+#pragma unroll
+    for (int st = 0; st < WG_GS; ++st)
+      if (s0 + st < spr) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int c = lane + 64 * v, row = c >> 3, part = c & 7;
+          gt[st][v] = *(const tw_u32x4*)(grow + (long)(16 * st + row) * p.g_sp + part * 8);
+        }
+      }
+  };
+  const bf16* s_a16 = (const bf16*)s_a;
+  auto run_group = [&](int gq, const tw_u32x4 (&gt)[WG_GS][2]) __attribute__((always_inline)) {
+    if (gq % gpr == 0) {                                             // first group of a row: its staged input rows
+      __syncthreads();                                               // (the previous row's gathers are done)
+      put_a();
+      __syncthreads();
+      if (u0 + gq / gpr + 1 < uend) fetch_a(u0 + gq / gpr + 1);      // in flight during this row's K steps
+    }
+    const int s0 = (gq % gpr) * WG_GS;
+#pragma unroll
+    for (int st = 0; st < WG_GS; ++st) {
+      if (s0 + st >= spr) break;
+      const int xb = wave * seg + 16 * (s0 + st);
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int c = lane + 64 * v, row = c >> 3, part = c & 7;
-        *(uint4*)(my_g + row * 144 + part * 16) = *(const uint4*)(grow + (long)(xb + row) * p.g_sp + part * 8);
+        *(tw_u32x4*)(my_g + row * 144 + part * 16) = gt[st][v];
       }
-      // A fragment: pixels xb + 8 lh + j, j = 0..7, of this lane's (ky,kx,ci)
+      // A fragment: pixels xb + 8 lh + j, j = 0..7, of this lane's (ky,kx,ci): fine column 2 x + kx - 1 -> dword + 4
       tw_bf16x8 fa;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        fa[j] = s_a16[((long)m_ky * ncol + 2 * (xb + 8 * lh + j) + m_kx) * 2 + m_ci];
+        fa[j] = s_a16[((long)m_ky * ncol + 2 * (xb + 8 * lh + j) + m_kx + 3) * 2 + m_ci];
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         const unsigned char* ptr = my_g + (8 * kh + q) * 144 + (jt * 32 + 16 * cb + 4 * pp) * 2;
@@ -397,6 +452,16 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p) {
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fg, acc[jt], 0, 0, 0);
       }
     }
+  };
+  // two register sets of gradient tiles: the next group's loads are in flight while the current group computes
+  tw_u32x4 gta[WG_GS][2], gtb[WG_GS][2];
+  fetch_a(u0);
+  load_group(0, gta);
+  for (int gq = 0; gq < ngr; gq += 2) {
+    if (gq + 1 < ngr) load_group(gq + 1, gtb);
+    run_group(gq, gta);
+    if (gq + 2 < ngr) load_group(gq + 2, gta);
+    if (gq + 1 < ngr) run_group(gq + 1, gtb);
   }
   // reduce the 4 waves, then one atomic per element.  D layout: col = lane & 31 (co), row = (e&3)+8(e>>2)+4 lh (m)
   const int b0 = (int)(u0 / p.Hc);
@@ -582,7 +647,6 @@ __global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
 
 #define TU_PX 64
 #define TU_RS 8
-typedef __attribute__((ext_vector_type(4))) unsigned tw_u32x4;
 // One block = (sample, segment of TU_RS image rows, 64-pixel column tile) and walks DOWN its rows with a ring of four
 // staged input rows in LDS: output row m reads rows m-1, m, m+1 from the ring while row m+2 is in flight in registers
 // (3 sixteen-byte pieces per thread) and is written into the slot nobody reads - ONE barrier per row, every input row
@@ -775,12 +839,21 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   unsigned grid = units < 1024 ? (unsigned)units : 1024u;
   if (p->wmode == 0 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 2 && p->Co == 64 && p->a_sc == 1 &&
       p->g_sc == 1 && p->a_sp == 2 && p->g_sp == 64 && p->Wc % 64 == 0 && p->Hc % WG_ROWS_PB == 0) {
-    const size_t lds = (size_t)4 * (2 * p->Wc + 2) * 4 + 4 * 16 * 144 + 4 * 32 * 64 * 4;
-    if (lds <= 160 * 1024) {
-      if (lds > 64 * 1024)  // 2048-wide images: opt in to more than the default 64 KiB of dynamic LDS
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_wgrad_down_mfma_kernel,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      thin_wgrad_down_mfma_kernel<<<(unsigned)(units / WG_ROWS_PB), 256, lds, s>>>(*p);
+    size_t lds = (size_t)4 * (2 * p->Wc + 8) * 4 + 4 * 16 * 144;      // staged rows + gradient tiles ...
+    if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;  // ... aliased by the cross-wave reduction
+    const int Wf = 2 * p->Wc;
+    if (lds <= 160 * 1024 && Wf <= 4096 && p->a_sb % 8 == 0 && ((size_t)p->a & 15) == 0 && p->g_sb % 8 == 0 &&
+        ((size_t)p->g & 15) == 0) {
+      const void* fn = Wf <= 256 ? (const void*)thin_wgrad_down_mfma_kernel<1>
+                                 : (Wf <= 1024 ? (const void*)thin_wgrad_down_mfma_kernel<4> : (const void*)thin_wgrad_down_mfma_kernel<16>);
+      if (lds > 64 * 1024)  // opt in to more than the default 64 KiB of dynamic LDS
+        HIP_CHECK_RET(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      // rows per block: every block ends in 2048 fp32 atomics on the same 8 KB; 4 rows once 2 rows give >= 1024 blocks
+      const int rows_pb = (units >= 2048 && p->Hc % 4 == 0) ? 4 : WG_ROWS_PB;
+      const unsigned nb = (unsigned)(units / rows_pb);
+      if (Wf <= 256) thin_wgrad_down_mfma_kernel<1><<<nb, 256, lds, s>>>(*p, rows_pb);
+      else if (Wf <= 1024) thin_wgrad_down_mfma_kernel<4><<<nb, 256, lds, s>>>(*p, rows_pb);
+      else thin_wgrad_down_mfma_kernel<16><<<nb, 256, lds, s>>>(*p, rows_pb);
       HIP_CHECK_RET(hipGetLastError());
       return DG_OK;
     }
