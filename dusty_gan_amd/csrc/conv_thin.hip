@@ -493,7 +493,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p, int
 // ds_read_b128, the `a` fragment from a wave-private [16][64] tile through the transposing read.  Waves are reduced
 // through LDS, then one fp32 atomic per element per block.
 #define WGU_ROWS_PB 2
+#define WGU_GS 4                                 // K steps (16 pixels each) whose `a` tiles a wave fetches at once
+#define WGU_TB 4                                 // im2col tasks per thread whose gradient dwords are fetched at once
 
+// Memory schedule: the `a` tiles come in groups of WGU_GS K steps, the next group's loads in flight while the current
+// one is computed, and the gradient dwords of WGU_TB im2col tasks per thread are requested in one batch (the first
+// version made one global round trip per K step and per task: load, s_waitcnt vmcnt(0), ds_write).
 __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int gpair) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Wc = p.Wc, Wf = 2 * p.Wc;
@@ -518,53 +523,113 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   const int nchunk = Wc / 8;
   const int b = (int)(u0 / p.Hc);
-  for (long u = u0; u < u0 + WGU_ROWS_PB; ++u) {
-    const int r = (int)(u % p.Hc);
-    __syncthreads();
-    // ---- im2col rows of input row r: task = (tap, chunk of 8 input pixels), both co at once
-    for (int t = tid; t < 16 * nchunk; t += 256) {
-      const int tap = t / nchunk, xi0 = (t % nchunk) * 8;
-      const int ky = tap >> 2, kx = tap & 3;
-      const int dky = ky == 0 ? 1 : (ky == 3 ? -1 : 0), pky = (ky == 0 || ky == 2) ? 1 : 0;
-      const int dkx = kx == 0 ? 1 : (kx == 3 ? -1 : 0), pkx = (kx == 0 || kx == 2) ? 1 : 0;
-      const int m = r - dky;
-      int fr0 = (m >= 0 && m < p.Hc) ? 2 * m + pky : -1;             // fine row of the regular term
-      int fr1 = -1;                                                  // mirror term of the reflected rows
-      if (ky == 3 && r == 1) fr1 = 0;
-      if (ky == 0 && r == p.Hc - 2) fr1 = 2 * p.Hc - 1;
-      if (fr0 < 0) { fr0 = fr1; fr1 = -1; }
-      unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};           // co0 / co1, 8 bf16 each
-      if (fr0 >= 0) {
-        const unsigned* g0 = G + (long)b * (p.g_sb / 2) + (long)fr0 * Wf * gsd;
-        const unsigned* g1 = fr1 >= 0 ? G + (long)b * (p.g_sb / 2) + (long)fr1 * Wf * gsd : nullptr;
+  // the K steps of the block's rows in groups of WGU_GS: a wave's step k of a row is the 16 pixels at wave * 16 + 64 k
+  const int spr = Wc / 64, gpr = (spr + WGU_GS - 1) / WGU_GS, ngr = WGU_ROWS_PB * gpr;
+  tw_u32x4 nxt[WGU_GS][2];
+  auto load_group = [&](int gq) __attribute__((always_inline)) {
+    const int r = (int)((u0 + gq / gpr) % p.Hc), s0 = (gq % gpr) * WGU_GS;
+    const bf16* arow = A + (long)b * p.a_sb + (long)r * Wc * p.a_sp;
+    // a[xb .. xb+15][0..63] (128 B per pixel) = 2 x (64 lanes x 16 B) per step
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          int x = xi0 + j - dkx;
-          if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
-          unsigned v = g0[(2 * x + pkx) * gsd];
-          if (g1) {                                                  // sum of two gradient rows, rounded once to bf16
-            const unsigned w2 = g1[(2 * x + pkx) * gsd];
-            const float s0 = __builtin_bit_cast(float, v << 16) + __builtin_bit_cast(float, w2 << 16);
-            const float s1 = __builtin_bit_cast(float, v & 0xffff0000u) + __builtin_bit_cast(float, w2 & 0xffff0000u);
-            const bf16 h0 = (bf16)s0, h1 = (bf16)s1;
-            v = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-          }
-          const unsigned c0 = v & 0xffffu, c1 = v >> 16;
-          if (j & 1) { lo[j >> 1] |= c0 << 16; hi[j >> 1] |= c1 << 16; }
-          else { lo[j >> 1] = c0; hi[j >> 1] = c1; }
+    for (int st = 0; st < WGU_GS; ++st)
+      if (s0 + st < spr) {
+        const int xb = wave * 16 + 64 * (s0 + st);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int c = lane + 64 * v, row = c >> 3, part = c & 7;
+          nxt[st][v] = *(const tw_u32x4*)(arow + (long)(xb + row) * p.a_sp + part * 8);
         }
       }
-      *(uint4*)(s_b + (size_t)(tap * 2 + 0) * RSB + xi0 * 2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-      *(uint4*)(s_b + (size_t)(tap * 2 + 1) * RSB + xi0 * 2) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  };
+  load_group(0);
+  for (int gq = 0; gq < ngr; ++gq) {
+    const int r = (int)((u0 + gq / gpr) % p.Hc), s0 = (gq % gpr) * WGU_GS;
+    if (gq % gpr == 0) {
+      __syncthreads();
+      // ---- im2col rows of input row r: task = (tap, chunk of 8 input pixels), both co at once; WGU_TB tasks per thread
+      //      and batch: all their gradient dwords are requested before the first is packed
+      const unsigned* Gb = G + (long)b * (p.g_sb / 2);
+      for (int tb = tid; tb < 16 * nchunk; tb += 256 * WGU_TB) {
+        unsigned gv[WGU_TB][8];
+#pragma unroll
+        for (int k = 0; k < WGU_TB; ++k) {
+          const int t = tb + 256 * k;
+          if (t < 16 * nchunk) {
+            const int tap = t / nchunk, xi0 = (t % nchunk) * 8;
+            const int ky = tap >> 2, kx = tap & 3;
+            const int dky = ky == 0 ? 1 : (ky == 3 ? -1 : 0), pky = (ky == 0 || ky == 2) ? 1 : 0;
+            const int dkx = kx == 0 ? 1 : (kx == 3 ? -1 : 0), pkx = (kx == 0 || kx == 2) ? 1 : 0;
+            const int m = r - dky;
+            int fr0 = (m >= 0 && m < p.Hc) ? 2 * m + pky : -1;           // fine row of the regular term
+            if (fr0 < 0) {                                               // only the mirror term of a reflected row is left
+              if (ky == 3 && r == 1) fr0 = 0;
+              if (ky == 0 && r == p.Hc - 2) fr0 = 2 * p.Hc - 1;
+            }
+            const unsigned* g0 = Gb + (long)(fr0 < 0 ? 0 : fr0) * Wf * gsd;   // (fr0 < 0: loaded, not used)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              int x = xi0 + j - dkx;
+              if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
+              gv[k][j] = g0[(2 * x + pkx) * gsd];
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < WGU_TB; ++k) {
+          const int t = tb + 256 * k;
+          if (t < 16 * nchunk) {
+            const int tap = t / nchunk, xi0 = (t % nchunk) * 8;
+            const int ky = tap >> 2, kx = tap & 3;
+            const int dky = ky == 0 ? 1 : (ky == 3 ? -1 : 0);
+            const int dkx = kx == 0 ? 1 : (kx == 3 ? -1 : 0), pkx = (kx == 0 || kx == 2) ? 1 : 0;
+            const int m = r - dky;
+            const bool reg_ok = m >= 0 && m < p.Hc;
+            int fr1 = -1;                                                // mirror term of the reflected rows
+            if (ky == 3 && r == 1) fr1 = 0;
+            if (ky == 0 && r == p.Hc - 2) fr1 = 2 * p.Hc - 1;
+            const bool any = reg_ok || fr1 >= 0;
+            if (!reg_ok) fr1 = -1;                                       // (the mirror row then IS gv)
+            unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};         // co0 / co1, 8 bf16 each
+            if (any) {
+              const unsigned* g1 = fr1 >= 0 ? Gb + (long)fr1 * Wf * gsd : nullptr;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                unsigned v = gv[k][j];
+                if (g1) {                                                // sum of two gradient rows, rounded once to bf16
+                  int x = xi0 + j - dkx;
+                  if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
+                  const unsigned w2 = g1[(2 * x + pkx) * gsd];
+                  const float s0f = __builtin_bit_cast(float, v << 16) + __builtin_bit_cast(float, w2 << 16);
+                  const float s1f = __builtin_bit_cast(float, v & 0xffff0000u) + __builtin_bit_cast(float, w2 & 0xffff0000u);
+                  const bf16 h0 = (bf16)s0f, h1 = (bf16)s1f;
+                  v = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                }
+                const unsigned c0 = v & 0xffffu, c1 = v >> 16;
+                if (j & 1) { lo[j >> 1] |= c0 << 16; hi[j >> 1] |= c1 << 16; }
+                else { lo[j >> 1] = c0; hi[j >> 1] = c1; }
+              }
+            }
+            *(uint4*)(s_b + (size_t)(tap * 2 + 0) * RSB + xi0 * 2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            *(uint4*)(s_b + (size_t)(tap * 2 + 1) * RSB + xi0 * 2) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    const bf16* arow = A + (long)b * p.a_sb + (long)r * Wc * p.a_sp;
-    for (int xb = wave * 16; xb < Wc; xb += 64) {
-      // stage a[xb .. xb+15][0..63] (128 B per pixel) into this wave's tile: 2 x (64 lanes x 16 B)
+    tw_u32x4 cur[WGU_GS][2];
+#pragma unroll
+    for (int st = 0; st < WGU_GS; ++st)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) cur[st][v] = nxt[st][v];
+    if (gq + 1 < ngr) load_group(gq + 1);                            // in flight during this group's K steps
+#pragma unroll
+    for (int st = 0; st < WGU_GS; ++st) {
+      if (s0 + st >= spr) break;
+      const int xb = wave * 16 + 64 * (s0 + st);
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int c = lane + 64 * v, row = c >> 3, part = c & 7;
-        *(uint4*)(my_t + row * 144 + part * 16) = *(const uint4*)(arow + (long)(xb + row) * p.a_sp + part * 8);
+        *(tw_u32x4*)(my_t + row * 144 + part * 16) = cur[st][v];
       }
       const tw_bf16x8 fa = *(const tw_bf16x8*)(s_b + (size_t)lr * RSB + (xb + 8 * lh) * 2);
 #pragma unroll
@@ -860,7 +925,8 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   }
   if (p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->a_sc == 1 &&
       p->a_sp == 64 && p->g_sc == 1 && (p->g_sp == 2 || p->g_sp == 4) && p->Co <= p->g_sp && p->g_sb % 2 == 0 &&
-      p->Wc % 64 == 0 && p->Hc >= 2 && p->Hc % WGU_ROWS_PB == 0) {
+      p->Wc % 64 == 0 && p->Hc >= 2 && p->Hc % WGU_ROWS_PB == 0 && p->a_sb % 8 == 0 &&
+      ((size_t)p->a & 15) == 0) {
     size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
     if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
     if (lds <= 160 * 1024) {
