@@ -1046,15 +1046,20 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt) bias2[jt] = p.bias ? p.bias[(jt * 32 + lr) % p.bias_mod] : 0.f;
   uint4 a_next[NS];
-  if (tcnt > 0) load_frags(xt, Y, b, a_next);
+  // per-sample weight of the bias-gradient sums: fetched with the tile's fragments (inside the store loop it cost a
+  // load + s_waitcnt vmcnt(0) per 16-byte store, draining the prefetched fragments four times per tile)
+  const bool want_rs = p.dbias && p.rowscale;
+  float rs_next = 1.f;
+  if (tcnt > 0) { load_frags(xt, Y, b, a_next); if (want_rs) rs_next = p.rowscale[b]; }
   for (int ti = 0; ti < tcnt; ++ti) {
     // the fragments of the NEXT tile are requested before this tile's MFMAs and epilogue
     uint4 a_cur[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) a_cur[s] = a_next[s];
+    const float rs = rs_next;
     int nxt = xt + 1, nY = Y, nb = b;
     if (nxt == tiles_x) { nxt = 0; if (++nY == p.Hc) { nY = 0; ++nb; } }
-    if (ti + 1 < tcnt) load_frags(nxt, nY, nb, a_next);
+    if (ti + 1 < tcnt) { load_frags(nxt, nY, nb, a_next); if (want_rs) rs_next = p.rowscale[nb]; }
     const int X = xt * 32 + lr;                  // this lane's output pixel (as A-fragment row)
     auto window = [&](int r, int c0) -> uint4 { return window_of(b, r, c0); };
     tw_f32x16 acc[2];
@@ -1137,7 +1142,6 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
         for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2));
       }
       if (p.dbias) {
-        const float rs = p.rowscale ? p.rowscale[b] : 1.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += rs * (float)v[e];
       }
