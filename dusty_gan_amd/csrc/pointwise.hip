@@ -331,12 +331,12 @@ __global__ void batch_wsum_scalar_kernel(const T* __restrict__ src, const float*
 // dsum != nullptr: dsum[b] += sum of depth[b] - the per-sample sum DiffAugment's contrast needs of its input, produced where
 // the image is produced.  A block then owns `chunk` consecutive pixels of ONE sample (HW % chunk == 0) and issues one atomic:
 // with one block per 256 pixels the 8192 atomics on 32 addresses cost 80 us (round 1 met the same in head_post_bwd).
+template <int arch>
 __device__ __forceinline__ float head_post_px(float* __restrict__ gout, const float* __restrict__ noise_pixel,
-                                              const float* __restrict__ noise_image, int arch, int training,
+                                              const float* __restrict__ noise_image, int training,
                                               float inv_tau, float drop_const, long HW, float* __restrict__ mask,
-                                              long idx) {
-  const int b = (int)(idx / HW);
-  const long p = idx - (long)b * HW;
+                                              int b, long p) {
+  const long idx = (long)b * HW + p;
   const int nch = 1 + (arch == 0 ? 0 : arch);
   float* g = gout + (long)b * nch * HW + p;
   const float t = tanhf(g[0]);
@@ -361,43 +361,56 @@ __device__ __forceinline__ float head_post_px(float* __restrict__ gout, const fl
   }
   return m * t + (1.f - m) * drop_const;
 }
+template <int arch>   // compile-time: the pixel function is then straight-line code and the unrolled trips batch their loads
 __global__ __launch_bounds__(256) void head_post_fwd_kernel(float* __restrict__ gout, const float* __restrict__ noise_pixel,
-                                     const float* __restrict__ noise_image, int arch, int training, float inv_tau,
+                                     const float* __restrict__ noise_image, int training, float inv_tau,
                                      float drop_const, int B, long HW, float* __restrict__ mask,
                                      float* __restrict__ depth, float* __restrict__ dsum, int chunk) {
   __shared__ float red[16];
   if (!dsum) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)B * HW)
-      depth[idx] = head_post_px(gout, noise_pixel, noise_image, arch, training, inv_tau, drop_const, HW, mask, idx);
+    if (idx < (long)B * HW) {
+      const int b = (int)(idx / HW);
+      depth[idx] = head_post_px<arch>(gout, noise_pixel, noise_image, training, inv_tau, drop_const, HW, mask, b, idx - (long)b * HW);
+    }
     return;
   }
+  // the block's pixels belong to ONE sample (HW % chunk == 0): the sample index is block-uniform, and the four pixels a
+  // thread handles per trip are independent - unrolled so that their loads are in flight together (a 64-bit division per
+  // pixel and one round trip per pixel made this 15 us for 25 MB)
   const long i0 = (long)blockIdx.x * chunk;
+  const int b = (int)(i0 / HW);
+  const long p0 = i0 - (long)b * HW;
   float acc = 0.f;
-  for (long idx = i0 + threadIdx.x; idx < i0 + chunk; idx += blockDim.x) {
-    const float dv = head_post_px(gout, noise_pixel, noise_image, arch, training, inv_tau, drop_const, HW, mask, idx);
-    depth[idx] = dv;
+#pragma unroll 4
+  for (int k = threadIdx.x; k < chunk; k += 256) {
+    const float dv = head_post_px<arch>(gout, noise_pixel, noise_image, training, inv_tau, drop_const, HW, mask, b, p0 + k);
+    depth[i0 + k] = dv;
     acc += dv;
   }
   const float sblk = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&dsum[i0 / HW], sblk);
+  if (threadIdx.x == 0) atomicAdd(&dsum[b], sblk);
 }
 
 // Backward of the above: ddepth [B,H,W] -> draw [B,1+k,H,W] planar (gradient w.r.t. the head conv outputs).
-__global__ void head_post_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ noise_pixel,
+template <int arch, int CP>   // CP: 0 no pixel-major copy, 2 / 4 that padded channel count, 1 any other (`cp`)
+__global__ __launch_bounds__(256) void head_post_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ noise_pixel,
                                      const float* __restrict__ noise_image, const float* __restrict__ mask,
-                                     const float* __restrict__ ddepth, int arch, float inv_tau, float drop_const,
+                                     const float* __restrict__ ddepth, float inv_tau, float drop_const,
                                      int B, long HW, float s_depth, float s_conf, float* __restrict__ draw,
                                      float* __restrict__ dbias, bf16* __restrict__ draw_pm, int cp) {
   __shared__ float red[16];
   // grid-stride: a block covers many pixels so that the bias-gradient sums cost one atomic per block per head (one
   // pixel per thread meant 8192 atomics on the same address: 100 us of the 108 us this kernel took at B = 32)
+  // blockIdx.y = sample (no 64-bit division per pixel); straight-line body (arch and the copy's layout are compile-time),
+  // four independent pixels per trip in flight together
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)B * HW; idx += (long)gridDim.x * blockDim.x) {
+  const int b = blockIdx.y;
+#pragma unroll 4
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+  const long idx = (long)b * HW + p;
   float d0 = 0.f, d1 = 0.f, d2 = 0.f;  // unscaled gradients w.r.t. the head outputs (= the head bias gradients)
   {
-  const int b = (int)(idx / HW);
-  const long p = idx - (long)b * HW;
   const int nch = 1 + (arch == 0 ? 0 : arch);
   const float* g = gout + (long)b * nch * HW + p;
   float* d = draw + (long)b * nch * HW + p;
@@ -424,13 +437,22 @@ __global__ void head_post_bwd_kernel(const float* __restrict__ gout, const float
     d[HW] = d1 * s_conf;
   }
   d[0] = d0 * s_depth;
-  if (draw_pm) {  // second copy, pixel-major / channel-minor bf16 [B,H,W,cp], channels zero-padded: the operand layout
-                  // of the MFMA backward-data kernel (thin_s2_mfma)
-    bf16* q = draw_pm + idx * cp;
-    q[0] = (bf16)(d0 * s_depth);
-    if (cp > 1) q[1] = (bf16)(arch >= 1 ? d1 * s_conf : 0.f);
-    if (cp > 2) q[2] = (bf16)(arch >= 2 ? d2 * s_conf : 0.f);
-    if (cp > 3) q[3] = (bf16)0.f;
+  if (CP != 0) {  // second copy, pixel-major / channel-minor bf16 [B,H,W,cp], channels zero-padded: the operand layout
+                  // of the MFMA backward-data kernel (thin_s2_mfma); one store per pixel for cp = 2 / 4
+    const unsigned short h0 = __builtin_bit_cast(unsigned short, (bf16)(d0 * s_depth));
+    const unsigned short h1 = __builtin_bit_cast(unsigned short, (bf16)(arch >= 1 ? d1 * s_conf : 0.f));
+    const unsigned short h2 = __builtin_bit_cast(unsigned short, (bf16)(arch >= 2 ? d2 * s_conf : 0.f));
+    if (CP == 2) {
+      *(unsigned*)(draw_pm + idx * 2) = (unsigned)h0 | ((unsigned)h1 << 16);
+    } else if (CP == 4) {
+      *(uint2*)(draw_pm + idx * 4) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2);
+    } else {      // any other padded channel count
+      bf16* q = draw_pm + idx * cp;
+      q[0] = __builtin_bit_cast(bf16, h0);
+      if (cp > 1) q[1] = __builtin_bit_cast(bf16, h1);
+      if (cp > 2) q[2] = __builtin_bit_cast(bf16, h2);
+      for (int c = 3; c < cp; ++c) q[c] = (bf16)0.f;
+    }
   }
   }
   a0 += d0; a1 += d1; a2 += d2;
@@ -595,79 +617,111 @@ __device__ __forceinline__ bool aug_cut(const AugP& a, int b, int y, int x) {
   return y >= r0 && y < r0 + a.cut_h && x >= c0 && x < c0 + a.cut_w;
 }
 
-__global__ void diffaug_fwd_kernel(AugP a, const float* __restrict__ x, const float* __restrict__ xsum,
-                                   float* __restrict__ y) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long HW = (long)a.H * a.W;
-  if (idx >= (long)a.B * HW) return;
-  const int b = (int)(idx / HW);
-  const int yy = (int)((idx - (long)b * HW) / a.W), xx = (int)(idx % a.W);
-  if (aug_cut(a, b, yy, xx)) { y[idx] = 0.f; return; }
-  int sy = yy, sx = xx;
+// One block per image row (blockIdx.x = row, blockIdx.y = sample): everything that depends on the sample or the row is
+// block-uniform, the per-pixel work is 32-bit (the first version decoded a flat 64-bit index per pixel: three 64-bit
+// divisions cost more than the pixel's memory traffic - 12.9 us for 16.8 MB).
+__global__ __launch_bounds__(256) void diffaug_fwd_kernel(AugP a, const float* __restrict__ x, const float* __restrict__ xsum,
+                                                          float* __restrict__ y) {
+  const int yy = blockIdx.x, b = blockIdx.y, W = a.W, Wm1 = a.W - 1;
+  const long HW = (long)a.H * W;
+  float* yrow = y + (long)b * HW + (long)yy * W;
+  int sy = yy, tw = 0;
+  bool row_ok = true;
   if (a.policy & 8) {
     sy = yy + a.t_h[b];
-    sx = (xx + a.t_w[b]) % (a.W - 1);
-    if (sx < 0) sx += a.W - 1;
-    if (sy < 0 || sy >= a.H) { y[idx] = 0.f; return; }
+    row_ok = sy >= 0 && sy < a.H;
+    tw = a.t_w[b] % Wm1;
+    if (tw < 0) tw += Wm1;                                           // (xx + t_w) mod (W - 1) = xx + tw, minus W - 1 once at most
   }
-  float v = x[(long)b * HW + (long)sy * a.W + sx];
-  float br = 0.f;
-  if (a.policy & 1) { const float u = a.u_b[b]; br = 0.5f * u * u; v += br; }
+  int c0 = 0, c1 = 0;                                                // cut-out columns [c0, c1) of this row
+  if (a.policy & 16) {
+    const int r0 = a.o_x[b] - a.cut_h / 2;
+    if (yy >= r0 && yy < r0 + a.cut_h) { c0 = a.o_y[b] - a.cut_w / 2; c1 = c0 + a.cut_w; }
+  }
+  float br = 0.f, cc = 1.f, mean = 0.f;
+  if (a.policy & 1) { const float u = a.u_b[b]; br = 0.5f * u * u; }
   if (a.policy & 4) {
     const float u = a.u_c[b];
-    const float c = 1.f + 0.5f * u * u;
-    const float mean = xsum[b] / (float)HW + br;
-    v = mean + c * (v - mean);
+    cc = 1.f + 0.5f * u * u;
+    mean = xsum[b] / (float)HW + br;
   }
-  y[idx] = v;
+  const float* xrow = x + (long)b * HW + (long)(row_ok ? sy : 0) * W;
+#pragma unroll 4
+  for (int xx = threadIdx.x; xx < W; xx += 256) {
+    int sx = xx;
+    if (a.policy & 8) { sx = xx + tw; if (sx >= Wm1) sx -= Wm1; }
+    float v = xrow[sx];                                              // always a valid address: loads of the unrolled trips batch
+    if (a.policy & 1) v += br;
+    if (a.policy & 4) v = mean + cc * (v - mean);
+    yrow[xx] = (row_ok && !(xx >= c0 && xx < c1)) ? v : 0.f;
+  }
 }
 
 // Backward pass 1: gsum[b] = sum over the augmented image of the gradient that reaches x2 (pre-translation
-// image): every (y,x) not cut out and with a valid source row contributes once.
+// image): every (y,x) not cut out and with a valid source row contributes once.  blockIdx.x strides the rows.
 __global__ __launch_bounds__(256) void diffaug_bwd_sum_kernel(AugP a, const float* __restrict__ gy,
                                                               float* __restrict__ gsum) {
   __shared__ float red[16];
-  const int b = blockIdx.y;
-  const long HW = (long)a.H * a.W;
+  const int b = blockIdx.y, W = a.W;
+  const long HW = (long)a.H * W;
+  const int th = (a.policy & 8) ? a.t_h[b] : 0;
+  const int r0 = (a.policy & 16) ? a.o_x[b] - a.cut_h / 2 : 0, cl = (a.policy & 16) ? a.o_y[b] - a.cut_w / 2 : 0;
   float acc = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
-    const int yy = (int)(i / a.W), xx = (int)(i % a.W);
-    if (aug_cut(a, b, yy, xx)) continue;
-    if (a.policy & 8) { const int sy = yy + a.t_h[b]; if (sy < 0 || sy >= a.H) continue; }
-    acc += gy[(long)b * HW + i];
+  for (int yy = blockIdx.x; yy < a.H; yy += gridDim.x) {
+    if (yy + th < 0 || yy + th >= a.H) continue;
+    int c0 = 0, c1 = 0;
+    if ((a.policy & 16) && yy >= r0 && yy < r0 + a.cut_h) { c0 = cl; c1 = cl + a.cut_w; }
+    const float* row = gy + (long)b * HW + (long)yy * W;
+    for (int xx = threadIdx.x; xx < W; xx += 256)
+      if (!(xx >= c0 && xx < c1)) acc += row[xx];
   }
   const float s = dg_block_sum(acc, red);
   if (threadIdx.x == 0) atomicAdd(&gsum[b], s);
 }
 
-// Backward pass 2 (gather form of the scatter): gx[b,r,c] from gy.
-__global__ void diffaug_bwd_kernel(AugP a, const float* __restrict__ gy, const float* __restrict__ gsum,
-                                   float* __restrict__ gx) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long HW = (long)a.H * a.W;
-  if (idx >= (long)a.B * HW) return;
-  const int b = (int)(idx / HW);
-  const int r = (int)((idx - (long)b * HW) / a.W), c = (int)(idx % a.W);
-  float g2 = 0.f;  // gradient w.r.t. the pre-translation image at (r,c)
+// Backward pass 2 (gather form of the scatter): gx[b,r,c] from gy.  One block per image row, as the forward kernel.
+__global__ __launch_bounds__(256) void diffaug_bwd_kernel(AugP a, const float* __restrict__ gy, const float* __restrict__ gsum,
+                                                          float* __restrict__ gx) {
+  const int r = blockIdx.x, b = blockIdx.y, W = a.W, Wm1 = a.W - 1;
+  const long HW = (long)a.H * W;
+  float* out = gx + (long)b * HW + (long)r * W;
+  int yy = r, tw = 0;
   if (a.policy & 8) {
-    const int yy = r - a.t_h[b];
-    if (yy >= 0 && yy < a.H && c <= a.W - 2) {
-      int w1 = (c - a.t_w[b]) % (a.W - 1);
-      if (w1 < 0) w1 += a.W - 1;
-      if (!aug_cut(a, b, yy, w1)) g2 += gy[(long)b * HW + (long)yy * a.W + w1];
-      // columns 0 and W-1 of the output both read source column (t_w mod (W-1))
-      if (w1 == 0 && !aug_cut(a, b, yy, a.W - 1)) g2 += gy[(long)b * HW + (long)yy * a.W + a.W - 1];
-    }
-  } else {
-    if (!aug_cut(a, b, r, c)) g2 = gy[idx];
+    yy = r - a.t_h[b];
+    tw = a.t_w[b] % Wm1;
+    if (tw < 0) tw += Wm1;
   }
-  float g = g2;
+  const bool row_ok = yy >= 0 && yy < a.H;
+  int c0 = 0, c1 = 0;                                                // cut-out columns [c0, c1) of row yy of the augmented image
+  if ((a.policy & 16) && row_ok) {
+    const int r0 = a.o_x[b] - a.cut_h / 2;
+    if (yy >= r0 && yy < r0 + a.cut_h) { c0 = a.o_y[b] - a.cut_w / 2; c1 = c0 + a.cut_w; }
+  }
+  float cc = 1.f, gm = 0.f;
   if (a.policy & 4) {
     const float u = a.u_c[b];
-    const float cc = 1.f + 0.5f * u * u;
-    g = cc * g2 + (1.f - cc) * gsum[b] / (float)HW;
+    cc = 1.f + 0.5f * u * u;
+    gm = (1.f - cc) * gsum[b] / (float)HW;
   }
-  gx[idx] = g;
+  const float* grow = gy + (long)b * HW + (long)(row_ok ? yy : 0) * W;
+#pragma unroll 4
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float g2 = 0.f;  // gradient w.r.t. the pre-translation image at (r,c)
+    if (a.policy & 8) {
+      int w1 = c - tw;                                               // (c - t_w) mod (W - 1)
+      if (w1 < 0) w1 += Wm1;
+      const float ga = grow[w1], gb = grow[W - 1];                   // (valid addresses whatever the predicates say)
+      if (row_ok && c <= W - 2) {
+        if (!(w1 >= c0 && w1 < c1)) g2 += ga;
+        // columns 0 and W-1 of the output both read source column (t_w mod (W-1))
+        if (w1 == 0 && !(W - 1 >= c0 && W - 1 < c1)) g2 += gb;
+      }
+    } else {
+      const float ga = grow[c];
+      if (!(c >= c0 && c < c1)) g2 = ga;
+    }
+    out[c] = (a.policy & 4) ? cc * g2 + gm : g2;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -897,7 +951,9 @@ __global__ __launch_bounds__(256) void fetch_reals_kernel(const float* __restric
   }
   const long i0 = (long)blockIdx.x * chunk;
   float acc = 0.f;
-  for (long i = i0 + threadIdx.x; i < i0 + chunk; i += blockDim.x) {
+#pragma unroll 4
+  for (int k = threadIdx.x; k < chunk; k += 256) {               // (independent pixels: their loads in flight together)
+    const long i = i0 + k;
     const float v = fetch_real_px(pol[i], mask[i], min_d, max_d, drop_const);
     out[i] = v;
     acc += v;
@@ -1062,8 +1118,13 @@ static int head_post_fwd_impl(float* gout, const float* noise_pixel, const float
   if (arch < 0 || arch > 2) return DG_EINVAL;
   if (dsum && HW % 256 != 0) return DG_EUNSUPPORTED;
   const int chunk = dsum ? sum_chunk(HW) : 256;
-  head_post_fwd_kernel<<<nblk((long)B * HW, chunk), 256, 0, s>>>(gout, noise_pixel, noise_image, arch, training, 1.f / tau,
-                                                                  drop_const, B, HW, mask, depth, dsum, chunk);
+  const unsigned nb = nblk((long)B * HW, chunk);
+  if (arch == 0)
+    head_post_fwd_kernel<0><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
+  else if (arch == 1)
+    head_post_fwd_kernel<1><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
+  else
+    head_post_fwd_kernel<2><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1085,10 +1146,21 @@ int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* n
                      void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (arch < 0 || arch > 2) return DG_EINVAL;
-  unsigned hb = nblk((long)B * HW);
-  if (hb > 1024) hb = 1024;
-  head_post_bwd_kernel<<<hb, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, arch,
-                                                           1.f / tau, drop_const, B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, cp);
+  unsigned hb = nblk(HW);                        // blocks per sample: ~1024 blocks in all, each one atomic per head
+  const unsigned per = B >= 1024 ? 1u : (unsigned)(1024 / B);
+  if (hb > per) hb = per;
+  const dim3 grid(hb, B);
+  const int cpk = !draw_pm ? 0 : (cp == 2 ? 2 : (cp == 4 ? 4 : 1));
+#define DG_HPB(A, C)                                                                                                   \
+  head_post_bwd_kernel<A, C><<<grid, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, 1.f / tau, drop_const, \
+                                                  B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, cp)
+#define DG_HPB_A(A)                                                                                  \
+  do {                                                                                               \
+    if (cpk == 0) DG_HPB(A, 0); else if (cpk == 2) DG_HPB(A, 2); else if (cpk == 4) DG_HPB(A, 4); else DG_HPB(A, 1); \
+  } while (0)
+  if (arch == 0) DG_HPB_A(0); else if (arch == 1) DG_HPB_A(1); else DG_HPB_A(2);
+#undef DG_HPB_A
+#undef DG_HPB
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1131,7 +1203,7 @@ static int diffaug_fwd_impl(const float* x, const float* u_b, const float* u_c, 
     const int rc = sample_sum_impl(x, B, (long)H * W, 0, xsum, zero, s);
     if (rc) return rc;
   }
-  diffaug_fwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, x, xsum, y);
+  diffaug_fwd_kernel<<<dim3(H, B), 256, 0, s>>>(a, x, xsum, y);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1153,7 +1225,7 @@ int dg_diffaug_fwd_pre(const float* x, const float* u_b, const float* u_c, const
                        void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
-  diffaug_fwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, x, xsum, y);
+  diffaug_fwd_kernel<<<dim3(H, B), 256, 0, s>>>(a, x, xsum, y);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1165,11 +1237,11 @@ static int diffaug_bwd_impl(const float* gy, const float* u_b, const float* u_c,
   const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
   if (policy & 4) {
     if (zero) { const int zrc = dg_zero_f32(gsum, B, s); if (zrc) return zrc; }
-    unsigned gxn = nblk((long)H * W, 256 * 8);
+    unsigned gxn = (unsigned)((H + 3) / 4);                            // a block sums ~4 rows: one atomic per block
     if (gxn > 64) gxn = 64;
     diffaug_bwd_sum_kernel<<<dim3(gxn, B), 256, 0, s>>>(a, gy, gsum);
   }
-  diffaug_bwd_kernel<<<nblk((long)B * H * W), 256, 0, s>>>(a, gy, gsum, gx);
+  diffaug_bwd_kernel<<<dim3(H, B), 256, 0, s>>>(a, gy, gsum, gx);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
