@@ -240,6 +240,11 @@ def main():
     # per-step device times: one HIP event after every step on the launch stream (the replayed graph / the eager
     # launches of a step run on torch's current stream, so consecutive events bracket exactly one step)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # no Python garbage-collection pass inside the timed region (one run of this script showed a single 12.6 ms step
+    # among 2.9 ms ones: a host-side stall, not device time)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     prev = None
@@ -252,6 +257,7 @@ def main():
     scal = dict(prev.items())
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
