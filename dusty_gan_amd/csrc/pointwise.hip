@@ -83,76 +83,84 @@ __global__ void blur_bwd_kernel(const T* __restrict__ d, float* __restrict__ dx,
 
 // Four pixels per thread (W % 4 == 0): 16-byte loads of the three rows, one 16-byte (bf16) / two (fp32) stores; the same
 // expressions as the scalar kernels above, which remain for other widths.
+// Grid = (row, sample): the row's neighbours and boundary cases are block-uniform and the per-quad work is 32-bit (the
+// first version decoded a flat 64-bit quad index per thread and, in the adjoint, loaded each neighbour row under its own
+// condition - one global round trip after the other).
 template <typename T>
 __global__ __launch_bounds__(256) void blur_fwd4_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H,
                                                         int W, int ring) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // quad index
-  const int W4 = W >> 2;
-  if (q >= (long)B * H * W4) return;
-  const int x0 = (int)(q % W4) * 4, y = (int)((q / W4) % H);
-  const long base = (q / W4 - y) * W;                            // b*H*W
+  const int y = blockIdx.x, W4 = W >> 2;
+  const long base = (long)blockIdx.y * H * W;                    // b*H*W
   const int yu = y == 0 ? 1 : y - 1, yd = y == H - 1 ? H - 2 : y + 1;
   const float* rc = x + base + (long)y * W;
-  const float4 c4 = *(const float4*)(rc + x0);
-  const float4 u4 = *(const float4*)(x + base + (long)yu * W + x0);
-  const float4 d4 = *(const float4*)(x + base + (long)yd * W + x0);
-  int xl = x0 - 1, xr = x0 + 4;
-  if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
-  else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
-  const float c[6] = {rc[xl], c4.x, c4.y, c4.z, c4.w, rc[xr]};
-  const float u[4] = {u4.x, u4.y, u4.z, u4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
-  float o[8];
+  const float* ru = x + base + (long)yu * W;
+  const float* rd = x + base + (long)yd * W;
+  for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+    const int x0 = q4 * 4;
+    const float4 c4 = *(const float4*)(rc + x0);
+    const float4 u4 = *(const float4*)(ru + x0);
+    const float4 d4 = *(const float4*)(rd + x0);
+    int xl = x0 - 1, xr = x0 + 4;
+    if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
+    else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
+    const float c[6] = {rc[xl], c4.x, c4.y, c4.z, c4.w, rc[xr]};
+    const float u[4] = {u4.x, u4.y, u4.z, u4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+    float o[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    o[2 * k] = 0.25f * u[k] + 0.5f * c[k + 1] + 0.25f * d[k];
-    o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
-  }
-  T* op = out + (base + (long)y * W + x0) * 2;
-  if constexpr (sizeof(T) == 2) {
-    Vec16<bf16>::store((bf16*)op, o);
-  } else {
-    *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
-    *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    for (int k = 0; k < 4; ++k) {
+      o[2 * k] = 0.25f * u[k] + 0.5f * c[k + 1] + 0.25f * d[k];
+      o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
+    }
+    T* op = out + (base + (long)y * W + x0) * 2;
+    if constexpr (sizeof(T) == 2) {
+      Vec16<bf16>::store((bf16*)op, o);
+    } else {
+      *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
   }
 }
 
 // ssq != nullptr (R1): dx = oscale * g and ssq[b] += sum of g^2 over the sample, g = the adjoint's result - the R1
-// penalty's per-sample |g|^2 and its tangent v = (gp / B) g in the pass that makes g (H W a multiple of 1024: a block
-// lies inside one sample).
+// penalty's per-sample |g|^2 and its tangent v = (gp / B) g in the pass that makes g.  A block owns `rows_pb` consecutive
+// rows of one sample (one atomic per block).
 template <typename T>
 __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d, float* __restrict__ dx, int B, int H,
-                                                        int W, int ring, float oscale, float* __restrict__ ssq, int qchunk) {
+                                                        int W, int ring, float oscale, float* __restrict__ ssq, int rows_pb) {
   __shared__ float red[16];
-  const int W4 = W >> 2;
+  const int W4 = W >> 2, b = blockIdx.y;
+  const long base = (long)b * H * W;
   float ssacc = 0.f;
-  // ssq: a block walks `qchunk` consecutive quads of one sample (one atomic per block); else one quad per thread
-  const long qbase = ssq ? (long)blockIdx.x * qchunk : (long)blockIdx.x * blockDim.x;
-  const long qend = ssq ? qbase + qchunk : qbase + blockDim.x;
-  for (long q = qbase + threadIdx.x; q < qend; q += blockDim.x) {
-  if (q >= (long)B * H * W4) break;             // (never taken when ssq is set: the grid is exact)
-  const int x0 = (int)(q % W4) * 4, y = (int)((q / W4) % H);
-  const long base = (q / W4 - y) * W;
+  const int y0 = blockIdx.x * rows_pb, y1 = y0 + rows_pb < H ? y0 + rows_pb : H;
+  for (int y = y0; y < y1; ++y)
+  for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+  const int x0 = q4 * 4;
   auto row8 = [&](int yy, float (&v)[8]) {                      // (ch0, ch1) of pixels x0 .. x0+3 of row yy
     const T* p = d + (base + (long)yy * W + x0) * 2;
     if constexpr (sizeof(T) == 2) {
       Vec16<bf16>::load((const bf16*)p, v);
     } else {
-      const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      const float4 a = *(const float4*)p, b2 = *(const float4*)(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b2.x; v[5] = b2.y; v[6] = b2.z; v[7] = b2.w;
     }
   };
   auto D1 = [&](int yy, int xq) { return (float)d[(base + (long)yy * W + xq) * 2 + 1]; };
-  float m[8];
+  // the row and its two vertical neighbours: three unconditional loads (clamped rows are loaded and not used)
+  float m[8], tu[8], td[8];
   row8(y, m);
+  row8(y > 0 ? y - 1 : y, tu);
+  row8(y < H - 1 ? y + 1 : y, td);
+  float el = 0.f, er = 0.f;                                      // ring: the horizontal neighbours outside the quad
+  if (ring) { el = D1(y, x0 == 0 ? W - 1 : x0 - 1); er = D1(y, x0 + 3 == W - 1 ? 0 : x0 + 4); }
   float v[4], h[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = 0.5f * m[2 * k];
-  if (y > 0) { float t[8]; row8(y - 1, t);
+  if (y > 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
-  if (y < H - 1) { float t[8]; row8(y + 1, t);
+    for (int k = 0; k < 4; ++k) v[k] += 0.25f * tu[2 * k]; }
+  if (y < H - 1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+    for (int k = 0; k < 4; ++k) v[k] += 0.25f * td[2 * k]; }
   if (y == 1) { float t[8]; row8(0, t);          // row 0 read x[1] as its reflected upper neighbour
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
@@ -165,8 +173,7 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
     h[k] = 0.5f * m[2 * k + 1];
     const bool hasl = k > 0, hasr = k < 3;       // neighbours inside the quad come from registers
     if (ring) {
-      h[k] += 0.25f * (hasl ? m[2 * k - 1] : D1(y, xx == 0 ? W - 1 : xx - 1)) +
-              0.25f * (hasr ? m[2 * k + 3] : D1(y, xx == W - 1 ? 0 : xx + 1));
+      h[k] += 0.25f * (hasl ? m[2 * k - 1] : el) + 0.25f * (hasr ? m[2 * k + 3] : er);
     } else {
       if (xx > 0) h[k] += 0.25f * (hasl ? m[2 * k - 1] : D1(y, xx - 1));
       if (xx < W - 1) h[k] += 0.25f * (hasr ? m[2 * k + 3] : D1(y, xx + 1));
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
   }
   if (ssq) {
     const float sblk = dg_block_sum(ssacc, red);
-    if (threadIdx.x == 0) atomicAdd(&ssq[qbase / ((long)H * W4)], sblk);
+    if (threadIdx.x == 0) atomicAdd(&ssq[b], sblk);
   }
 }
 
@@ -237,17 +244,27 @@ __global__ __launch_bounds__(256) void final_bwd_data_kernel(const T* __restrict
                                                              float* __restrict__ dbias) {
   constexpr int V = Vec16<T>::V;
   __shared__ float part[4][64 * V];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ float s_u[256], s_r[256];          // per-sample factors (B <= 256, checked by the launcher): LDS reads inside
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // the loop keep its global loads free of other waits
+  for (int b = threadIdx.x; b < B; b += 256) { s_u[b] = up ? up[b] : 1.f; s_r[b] = rowscale ? rowscale[b] : 1.f; }
   const long i = ((long)blockIdx.x * 64 + lane) * V;
   float w[V], db[V];
 #pragma unroll
-  for (int k = 0; k < V; ++k) { w[k] = i < n ? wf[i + k] * scale : 0.f; db[k] = 0.f; }
+  for (int k = 0; k < V; ++k) { w[k] = 0.f; db[k] = 0.f; }
+  if (i < n) {                                  // (n % V == 0: a thread's V elements are all inside)
+#pragma unroll
+    for (int k4 = 0; k4 < V; k4 += 4) {         // (wf 16-byte aligned: checked by the launcher)
+      const float4 r = *(const float4*)(wf + i + k4);
+      w[k4] = r.x * scale; w[k4 + 1] = r.y * scale; w[k4 + 2] = r.z * scale; w[k4 + 3] = r.w * scale;
+    }
+  }
+  __syncthreads();
   if (i < n) {
 #pragma unroll 4
     for (int b = wave; b < B; b += 4) {
       float a[V], g[V];
       Vec16<T>::load(d4 + (long)b * n + i, a);
-      const float u = up ? up[b] : 1.f, rs = rowscale ? rowscale[b] : 1.f;
+      const float u = s_u[b], rs = s_r[b];
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         g[k] = u * w[k] * (a[k] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
@@ -1005,8 +1022,8 @@ int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int r
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
   if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)x & 15) == 0 && ((size_t)out & 15) == 0) {
-    if (dtype == DG_BF16) blur_fwd4_kernel<bf16><<<nblk(n / 4), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
-    else blur_fwd4_kernel<float><<<nblk(n / 4), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
+    if (dtype == DG_BF16) blur_fwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
+    else blur_fwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
   } else if (dtype == DG_BF16) blur_fwd_kernel<bf16><<<nblk(n), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
   else blur_fwd_kernel<float><<<nblk(n), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
   HIP_CHECK_RET(hipGetLastError());
@@ -1017,8 +1034,8 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
   if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)d & 15) == 0 && ((size_t)dx & 15) == 0) {
-    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<nblk(n / 4), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, 1.f, nullptr, 256);
-    else blur_bwd4_kernel<float><<<nblk(n / 4), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, 1.f, nullptr, 256);
+    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, 1.f, nullptr, 1);
+    else blur_bwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, 1.f, nullptr, 1);
   } else if (dtype == DG_BF16) blur_bwd_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
   else blur_bwd_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
   HIP_CHECK_RET(hipGetLastError());
@@ -1055,12 +1072,12 @@ static int final_fwd_impl(const void* d4, int dtype, const float* wf, const floa
 int dg_blur_bwd_r1(const void* d, int dtype, float* dx, float oscale, float* ssq, int B, int H, int W, int ring, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (!ssq) return DG_EINVAL;
-  const long n = (long)B * H * W;
   if (W % 4 != 0 || W < 8 || H < 2 || ((long)H * W) % 1024 != 0 || ((size_t)d & 15) != 0 || ((size_t)dx & 15) != 0)
     return DG_EUNSUPPORTED;
-  const int qchunk = sum_chunk((long)H * W / 4) > 1024 ? 1024 : sum_chunk((long)H * W / 4);   // quads per block
-  if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<nblk(n / 4, qchunk), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, oscale, ssq, qchunk);
-  else blur_bwd4_kernel<float><<<nblk(n / 4, qchunk), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, oscale, ssq, qchunk);
+  const int rows_pb = H % 4 == 0 ? 4 : (H % 2 == 0 ? 2 : 1);    // rows per block = per atomic on ssq[b]
+  const dim3 grid((H + rows_pb - 1) / rows_pb, B);
+  if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, oscale, ssq, rows_pb);
+  else blur_bwd4_kernel<float><<<grid, 256, 0, s>>>((const float*)d, dx, B, H, W, ring, oscale, ssq, rows_pb);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1080,7 +1097,7 @@ int dg_final_bwd_data(const void* d4, int dtype, const float* wf, const float* u
                       int B, long n, int C, void* dd4, float* dbias, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const int V = dtype == DG_BF16 ? 8 : 4;
-  if (vec_ok(d4, n, dtype) && vec_ok(dd4, n, dtype) && C % V == 0) {
+  if (vec_ok(d4, n, dtype) && vec_ok(dd4, n, dtype) && C % V == 0 && B <= 256 && ((size_t)wf & 15) == 0) {
     const unsigned grid = nblk(n / V, 64);
     if (dtype == DG_BF16)
       final_bwd_data_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)d4, wf, up, rowscale, scale, B, n, C, (bf16*)dd4, dbias);
