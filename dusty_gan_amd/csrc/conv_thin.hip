@@ -1,13 +1,20 @@
-// Bandwidth-bound "thin" conv passes, VALU + LDS (nothing here is worth an MFMA: one side has <= 4 channels).
+// Bandwidth-bound "thin" conv passes of the two layers with <= 4 channels on one side (Down1, Head).
 //
+//   VALU + LDS fall-backs (fp32 mode, shapes the MFMA kernels refuse):
 //   thin_smallk : MODE_S2, K <= 4 input channels -> N = 64*j output channels
 //                 Down1 forward / R1 tangent (K = 2, models/gans/dcgan_eqlr.py:90) and Head backward-data (K = 1..3)
 //   thin_smalln : MODE_UP, K = 64*j input channels -> N <= 4 output channels
 //                 Head forward (dcgan_eqlr.py:29-46) and Down1 backward-data (N = 2)
-//   thin_wgrad  : weight gradients of the same two layers
+//   thin_wgrad_down / thin_wgrad_up : weight gradients of the same two layers
 //
-// Every kernel stages the input rows it needs in LDS once (coalesced), keeps the workgroup inside ONE output row so
-// the reflect / reflect-adjoint tap list is uniform, and writes whole 128-B channel rows per pixel.
+//   bf16 on the matrix cores (what the benchmark step runs; each has its own header comment further down):
+//   thin_s2_mfma, thin_up_mfma (+ thin_up_prep), thin_wgrad_down_mfma, thin_wgrad_up_mfma
+//
+// The fall-backs stage the input rows they need in LDS once (coalesced), keep the workgroup inside ONE output row so the
+// reflect / reflect-adjoint tap list is uniform, and write whole 128-B channel rows per pixel.  The MFMA kernels'
+// memory schedules are written out by hand (fixed-count unrolled load batches, the next row / group in flight in
+// registers, nothing but the prefetch outstanding when a wait comes): hipcc does not unroll a staging loop with a
+// run-time trip count, and a load inside an epilogue brings its own s_waitcnt vmcnt(0).
 #include "common.h"
 #include "mfma_common.h"
 
