@@ -198,6 +198,10 @@ def main():
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node: the ranks find each other on the loopback interface (a hostname that resolves to an unreachable
+        # address otherwise stalls the bootstrap of gloo / RCCL until their timeouts); the data path is xGMI, not sockets
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         # one rank per GPU over RCCL ("nccl" on ROCm).  DUSTY_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on
         # a single-GPU box (ranks share the device, buffers travel through the host) - a functional check, not a number.
         backend = os.environ.get("DUSTY_BENCH_BACKEND", "nccl")

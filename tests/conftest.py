@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # (pytest-timeout's marker, registered here too so that the suite also collects cleanly without the plugin)
+    config.addinivalue_line("markers", "timeout(seconds): fail the test after this many seconds (pytest-timeout)")
 
 
 def pytest_collection_modifyitems(config, items):

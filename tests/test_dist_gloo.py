@@ -3,6 +3,7 @@ as the trainer does (parameter broadcast, ONE SUM all-reduce per network on the 
 into Adam, one packed scalar reduce) must reproduce the single-process full-batch step -- the reference's DDP
 semantics (trainers/dcgan_amp.py:68-69, 235, 309, 319-323).  The per-rank compute is the CPU oracle (the HIP kernels
 need a GPU; their single-rank parity is the -m gpu suite)."""
+import datetime
 import os
 import tempfile
 
@@ -10,6 +11,10 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+# ranks of one node meet on the loopback interface (see tests/test_gpu_ddp.py); a bounded timeout instead of gloo's 30 min
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+PG_TIMEOUT = datetime.timedelta(seconds=240)
 
 from oracle import dusty_oracle as O
 from tests.golden_util import rel_l2
@@ -67,7 +72,7 @@ def grads_of(G, D, x, rand, cfg):
 
 def worker(rank, world, init_file, out_dir):
     from dusty_gan_amd.utils import dist as DD
-    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     torch.set_num_threads(2)
     G, D, x, rand = make_inputs()
     netG, netD = FlatNet(G), FlatNet(D)

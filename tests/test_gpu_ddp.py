@@ -2,6 +2,7 @@
 CUDA buffers through the host, RCCL refuses two ranks on one device) and must reproduce the single-process
 full-batch step: identical parameter broadcast, gradient averaging (one all-reduce per network), packed scalar
 reduce.  The 8-GPU RCCL run uses exactly this code with backend "nccl"."""
+import datetime
 import os
 import tempfile
 
@@ -13,7 +14,14 @@ import torch.multiprocessing as mp
 from oracle import dusty_oracle as O
 from tests.golden_util import rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+# Ranks of one node meet on the loopback interface: without this gloo binds to whatever the box's hostname resolves to,
+# and on a box where that address is not reachable the ranks wait for each other until the process-group timeout (one
+# MI355X box of the pool hung this file for 18 minutes, twice).  A bounded timeout turns any such wait into a failure.
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+PG_TIMEOUT = datetime.timedelta(seconds=240)
 
 ARCH, SHAPE, NZ, CB, CM, B = "dusty2", (32, 64), 8, 4, 16, 4
 
@@ -45,7 +53,7 @@ def run_steps(tr, x, rand, steps=2):
 
 def worker(rank, world, init_file, out_dir, sdG, sdD):
     from tests.test_gpu_step import make_trainer
-    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     torch.manual_seed(100 + rank)  # ranks build DIFFERENT nets; the constructor's broadcast must fix that
     tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
     if rank == 0:
@@ -92,7 +100,7 @@ def test_two_ranks_on_one_gpu_match_single_process():
 def graph_worker(rank, world, init_file, out_dir, use_graph, full=False):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH"] = "1" if use_graph else "0"
-    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     torch.manual_seed(300)  # same seed on both ranks: same initial nets, same device RNG streams
     if full:  # the benchmark's nets and image size, bf16, 8 images per rank
         tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8, amp=True)
@@ -166,7 +174,7 @@ def rccl_worker(rank, world, init_file, out_dir):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_FORCE_SEG"] = "1"
     dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", 0))
+                            device_id=torch.device("cuda", 0), timeout=PG_TIMEOUT)
     from dusty_gan_amd.utils import dist as DD
     assert DD.through_backend()
     torch.manual_seed(77)
@@ -215,7 +223,7 @@ def fused_worker(rank, world, init_file, out_dir, fuse, pl=0.0):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH"] = "0"
     os.environ["DUSTY_GAN_FUSE_PROJ"] = "1" if fuse else "0"
-    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     torch.manual_seed(400)
     # nz = 128 and Np = 2 * 4 * 16 = 128: the smallest Proj the MFMA epilogue takes; global batch 2 x 40 = 80 > 64
     tr = make_trainer("dusty1", True, (32, 64), 128, 4, 16, 40, amp=True, pl=pl)
