@@ -53,12 +53,21 @@ class DgWgrad(C.Structure):
         ("g", C.c_void_p), ("g_sb", C.c_long), ("g_sp", C.c_long), ("g_sc", C.c_long),
         ("dw", C.c_void_p), ("scale", C.c_float), ("rowscale", C.c_void_p),
         ("a_dtype", C.c_int), ("g_dtype", C.c_int),
+        ("ws", C.c_void_p), ("g_mod", C.c_int),
     ]
+
+
+class DgWgradPlan(C.Structure):
+    _fields_ = [("variant", C.c_int), ("splits", C.c_int), ("ws_floats", C.c_long), ("tap_pairs", C.c_int)]
+
+
+class DgWgradReduce(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("numel", C.c_long), ("splits", C.c_int), ("accumulate", C.c_int)]
 
 
 class DgConvPlan(C.Structure):
     _fields_ = [("family", C.c_int), ("bm", C.c_int), ("bn", C.c_int), ("tiles", C.c_int), ("workgroups", C.c_int),
-                ("tiles_per_wg", C.c_int)]
+                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int)]
 
 
 _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64
@@ -71,6 +80,8 @@ PROTOTYPES = {
     "dg_conv_mfma_supported": [C.POINTER(DgConv)],
     "dg_conv_kernel_choice": [C.POINTER(DgConv)],
     "dg_wgrad": [C.POINTER(DgWgrad), _I, _I, _P],
+    "dg_wgrad_plan": [C.POINTER(DgWgrad), _I, _I, C.POINTER(DgWgradPlan)],
+    "dg_wgrad_reduce": [C.POINTER(DgWgradReduce), _I, _P],
     "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_choice": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_variant": [C.POINTER(DgWgrad), _I],

@@ -6,9 +6,11 @@ int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
-int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, hipStream_t stream);
+int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_supported(const ConvP* p);
+int dg_conv_thin_mfma_variant(const ConvP* p);
+int dg_wgrad_thin_mfma_variant(const WgradP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream);
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
@@ -30,13 +32,13 @@ static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, 
   if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
-  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; }
+  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; }
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 4 || force == 5) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {
-    if (plan) { plan->family = 3; return DG_OK; }
+    if (plan) { plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); return DG_OK; }
     return dg_conv_thin_launch(p, s);
   }
   if (plan) { plan->family = 1; return DG_OK; }
@@ -60,15 +62,20 @@ int dg_conv_kernel_choice(const DgConv* p) {  // 2 = MFMA, 3 = thin, 1 = direct 
   return 1;
 }
 
-int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
+// force: 0 auto, 1 direct, 2 MFMA (the LDS-DMA kernel where the shape allows), 3 thin, 6 the register-staged MFMA kernel,
+//        7 / 8 the LDS-DMA kernel with / without W-tap pairs
+static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force, hipStream_t s, DgWgradPlan* plan) {
   if (!p || !p->a || !p->g || !p->dw) return DG_EINVAL;
   if (p->B <= 0 || p->Ci <= 0 || p->Co <= 0 || p->Hc <= 0 || p->Wc <= 0) return DG_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
   const bool thin_ok = dg_wgrad_thin_supported(p);
+  if (plan) { plan->variant = dg_wgrad_kernel_variant(p, force); plan->splits = 1; plan->ws_floats = 0; plan->tap_pairs = 0; }
   // bf16 Down / Up layers: LDS-DMA ring version (wgrad_mfma_dma.hip); force == 6 asks for the register-staged kernel
-  if ((force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
-    return dg_wgrad_mfma_dma_launch(p, accumulate, s);
+  if ((force == 0 || force == 2 || force == 7 || force == 8) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
+    return dg_wgrad_mfma_dma_launch(p, accumulate, force == 7 ? 1 : (force == 8 ? 2 : 0), s, plan);
+  if (force == 7 || force == 8) return DG_EUNSUPPORTED;
+  if (plan) return plan->variant ? DG_OK : DG_EUNSUPPORTED;
+  if (p->ws || p->g_mod) return DG_EUNSUPPORTED;   // only the LDS-DMA kernel has the workspace / index-map forms
   if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
   if (!accumulate) {
@@ -80,15 +87,26 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   return dg_wgrad_direct_launch(p, s);
 }
 
-// 5 = MFMA on the LDS-DMA ring (wgrad_mfma_dma.hip), 2 = register-staged MFMA, 3 = thin, 1 = direct: what `force` launches
+int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
+  return wgrad_dispatch(p, accumulate, force, (hipStream_t)stream, nullptr);
+}
+
+int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan) {
+  if (!plan) return DG_EINVAL;
+  return wgrad_dispatch(p, accumulate, force, nullptr, plan);
+}
+
+// 5 = MFMA on the LDS-DMA ring (wgrad_mfma_dma.hip), 2 = register-staged MFMA, 7 = thin on the matrix cores, 3 = thin
+// (VALU), 1 = direct: what `force` launches
 int dg_wgrad_kernel_variant(const DgWgrad* p, int force) {
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
-  if ((force == 0 || force == 2) && mfma_ok && dg_wgrad_mfma_dma_supported(p)) return 5;
-  if (force == 2) return mfma_ok ? 2 : 0;
+  if ((force == 0 || force == 2 || force == 7 || force == 8) && mfma_ok && dg_wgrad_mfma_dma_supported(p)) return 5;
+  if (force == 7 || force == 8) return 0;
+  if (force == 2 || force == 6) return mfma_ok ? 2 : 0;  // (6: the register-staged kernel, as dg_wgrad dispatches it)
   if (force == 0 && mfma_ok) return 2;
   const bool thin_ok = dg_wgrad_thin_supported(p);
-  if (force == 3) return thin_ok ? 3 : 0;
-  if (force == 0 && thin_ok) return 3;
+  if ((force == 3 || force == 0) && thin_ok) return dg_wgrad_thin_mfma_variant(p) ? 7 : 3;
+  if (force == 3) return 0;
   return 1;
 }
 

@@ -866,6 +866,12 @@ int dg_conv_thin_supported(const ConvP* p) {
   return 1;
 }
 
+// 1 = thin_s2_mfma, 2 = thin_up_mfma (matrix cores), 0 = the VALU kernels (or unsupported)
+int dg_conv_thin_mfma_variant(const ConvP* p) {
+  if (!dg_conv_thin_supported(p)) return 0;
+  return dg_conv_s2_mfma_supported(p) ? 1 : (dg_conv_up_mfma_supported(p) ? 2 : 0);
+}
+
 int dg_conv_thin_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_thin_supported(p)) return DG_EUNSUPPORTED;
   if (dg_conv_s2_mfma_supported(p)) return dg_conv_s2_mfma_launch(p, s);
@@ -905,17 +911,46 @@ int dg_wgrad_thin_supported(const WgradP* p) {
   return 0;
 }
 
+// shapes the two matrix-core weight-gradient kernels take (Down1: 2 -> 64 channels; Head: 64 -> <= 4 channels, pixel-major
+// gradient padded to 2 or 4 channels)
+static size_t wgrad_down_mfma_lds(const WgradP* p) {
+  size_t lds = (size_t)4 * (2 * p->Wc + 8) * 4 + 4 * 16 * 144;      // staged rows + gradient tiles ...
+  if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;  // ... aliased by the cross-wave reduction
+  return lds;
+}
+static bool wgrad_down_mfma_ok(const WgradP* p) {
+  if (!(p->wmode == 0 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 2 && p->Co == 64 && p->a_sc == 1 &&
+        p->g_sc == 1 && p->a_sp == 2 && p->g_sp == 64 && p->Wc % 64 == 0 && p->Hc % WG_ROWS_PB == 0))
+    return false;
+  return wgrad_down_mfma_lds(p) <= 160 * 1024 && 2 * p->Wc <= 4096 && p->a_sb % 8 == 0 && ((size_t)p->a & 15) == 0 &&
+         p->g_sb % 8 == 0 && ((size_t)p->g & 15) == 0;
+}
+static size_t wgrad_up_mfma_lds(const WgradP* p) {
+  size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
+  if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
+  return lds;
+}
+static bool wgrad_up_mfma_ok(const WgradP* p) {
+  if (!(p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->a_sc == 1 &&
+        p->a_sp == 64 && p->g_sc == 1 && (p->g_sp == 2 || p->g_sp == 4) && p->Co <= p->g_sp && p->g_sb % 2 == 0 &&
+        p->Wc % 64 == 0 && p->Hc >= 2 && p->Hc % WGU_ROWS_PB == 0 && p->a_sb % 8 == 0 && ((size_t)p->a & 15) == 0))
+    return false;
+  return wgrad_up_mfma_lds(p) <= 160 * 1024;
+}
+// 1 = thin_wgrad_down_mfma, 2 = thin_wgrad_up_mfma (matrix cores), 0 = the VALU kernels (or unsupported)
+int dg_wgrad_thin_mfma_variant(const WgradP* p) {
+  if (!dg_wgrad_thin_supported(p)) return 0;
+  return wgrad_down_mfma_ok(p) ? 1 : (wgrad_up_mfma_ok(p) ? 2 : 0);
+}
+
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (!dg_wgrad_thin_supported(p)) return DG_EUNSUPPORTED;
   const long units = (long)p->B * p->Hc;
   unsigned grid = units < 1024 ? (unsigned)units : 1024u;
-  if (p->wmode == 0 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 2 && p->Co == 64 && p->a_sc == 1 &&
-      p->g_sc == 1 && p->a_sp == 2 && p->g_sp == 64 && p->Wc % 64 == 0 && p->Hc % WG_ROWS_PB == 0) {
-    size_t lds = (size_t)4 * (2 * p->Wc + 8) * 4 + 4 * 16 * 144;      // staged rows + gradient tiles ...
-    if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;  // ... aliased by the cross-wave reduction
+  if (wgrad_down_mfma_ok(p)) {
+    const size_t lds = wgrad_down_mfma_lds(p);
     const int Wf = 2 * p->Wc;
-    if (lds <= 160 * 1024 && Wf <= 4096 && p->a_sb % 8 == 0 && ((size_t)p->a & 15) == 0 && p->g_sb % 8 == 0 &&
-        ((size_t)p->g & 15) == 0) {
+    {
       const void* fn = Wf <= 256 ? (const void*)thin_wgrad_down_mfma_kernel<1>
                                  : (Wf <= 1024 ? (const void*)thin_wgrad_down_mfma_kernel<4> : (const void*)thin_wgrad_down_mfma_kernel<16>);
       if (lds > 64 * 1024)  // opt in to more than the default 64 KiB of dynamic LDS
@@ -930,13 +965,9 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
       return DG_OK;
     }
   }
-  if (p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->a_sc == 1 &&
-      p->a_sp == 64 && p->g_sc == 1 && (p->g_sp == 2 || p->g_sp == 4) && p->Co <= p->g_sp && p->g_sb % 2 == 0 &&
-      p->Wc % 64 == 0 && p->Hc >= 2 && p->Hc % WGU_ROWS_PB == 0 && p->a_sb % 8 == 0 &&
-      ((size_t)p->a & 15) == 0) {
-    size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
-    if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
-    if (lds <= 160 * 1024) {
+  if (wgrad_up_mfma_ok(p)) {
+    const size_t lds = wgrad_up_mfma_lds(p);
+    {
       if (lds > 64 * 1024)
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_wgrad_up_mfma_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

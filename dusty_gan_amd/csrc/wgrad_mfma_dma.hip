@@ -28,9 +28,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) int i32x2;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int BKP = 64;  // coarse pixels per ring stage
 constexpr int NS = 2;    // ring stages
+constexpr int PAIR_MIN_WS = 24;  // tap pairs with a split-K workspace: chunks a workgroup must still walk
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -134,8 +136,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
       return (const char*)(((unsigned long long)hi << 32) | lo);
     };
+    const int bg = p.g_mod > 0 ? b % p.g_mod : b;          // (one launch over real | fake | tangent input samples)
     abase = uni(A + (long)b * p.a_sb + (long)rowa * Wa * asp + ci0);
-    gbase = uni(G + (long)b * p.g_sb + (long)rowg * Wg * gsp + co0);
+    gbase = uni(G + (long)bg * p.g_sb + (long)rowg * Wg * gsp + co0);
   };
   set_unit(ib, im);
   auto issue = [&](unsigned st_off) __attribute__((always_inline)) {
@@ -285,9 +288,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   }
 
   // D layout: col = lane & 31 (co), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (ci)
+  // split-K partial tiles: plain stores into the caller's workspace (summed by dg_wgrad_reduce), or fp32 atomics onto dw
+  float* const obase = p.ws ? p.ws + (long)bz * 16 * p.Ci * p.Co : p.dw;
+  const bool plain = p.ws || !accumulate;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    float* dw = p.dw + (long)(ky * 4 + (t == 0 ? kx_s0 : kx_s1)) * p.Ci * p.Co;
+    float* dw = obase + (long)(ky * 4 + (t == 0 ? kx_s0 : kx_s1)) * p.Ci * p.Co;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -299,19 +305,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
           const float v = acc[t][i][j][e] * (p.scale * cur_rs);
           float* dst = dw + (long)ci * p.Co + co;
           if (wg_dbg & 4) { asm volatile("" ::"v"(v)); continue; }
-          if (accumulate) atomicAdd(dst, v);
-          else *dst = v;
+          if (plain) *dst = v;
+          else atomicAdd(dst, v);
         }
   }
 }
 
+// pairs: 0 = by the K range per workgroup, 1 = always, 2 = never.  plan != NULL: describe the launch, launch nothing.
 template <int WMODE, int BM, int BN>
-int launch_dma(const WgradP* p, int accumulate, hipStream_t stream) {
+int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan) {
   const int tiles_m = p->Ci / BM, tiles_n = p->Co / BN;
   const long units = (long)p->B * p->Hc;
+  const bool ws = plan ? true : p->ws != nullptr;          // (a plan describes the launch WITH a workspace)
+  const bool can_split = accumulate || ws;
   auto split_for = [&](long tiles) {
     long split = 1;
-    if (accumulate) {
+    if (can_split) {
       split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
       if (split > units) split = units;
       if (split < 1) split = 1;
@@ -319,19 +328,56 @@ int launch_dma(const WgradP* p, int accumulate, hipStream_t stream) {
     return split;
   };
   // Tap pairs halve the DMA bytes and the (tile, tap) workgroups, so the same workgroup count needs twice the K split -
-  // twice the partial tiles to add atomically - and each workgroup's pixel range halves.  Measured (scripts/bench_conv.py):
-  // Down2 at batch 64 +16 % (64 chunks per workgroup), Up3 equal, the layers left with <= 32 chunks per workgroup
-  // 5-25 % slower.  So: pairs where a workgroup still walks >= 48 chunks.
+  // twice the partial tiles - and each workgroup's pixel range halves.  With atomics (no workspace) measured
+  // (scripts/bench_conv.py): Down2 at batch 64 +16 % (64 chunks per workgroup), Up3 equal, the layers left with <= 32
+  // chunks per workgroup 5-25 % slower: pairs where a workgroup still walks >= 48 chunks.  With the workspace the partial
+  // tiles are plain stores and the threshold is lower (PAIR_MIN_WS).
   const long split2 = split_for((long)tiles_m * tiles_n * 8);
-  if (accumulate && units / split2 * (p->Wc / BKP) >= 48) {
-    dim3 grid((unsigned)(tiles_m * tiles_n), 8u, (unsigned)split2);
+  const long chunks2 = units / split2 * (p->Wc / BKP);
+  const bool use_pairs = pairs == 1 ? can_split : (pairs == 2 ? false : (can_split && chunks2 >= (ws ? PAIR_MIN_WS : 48)));
+  const long split = use_pairs ? split2 : split_for((long)tiles_m * tiles_n * 16);
+  if (plan) {
+    plan->splits = (int)split;
+    plan->ws_floats = split * 16L * p->Ci * p->Co;
+    plan->tap_pairs = use_pairs ? 1 : 0;
+    return DG_OK;
+  }
+  if (use_pairs) {
+    dim3 grid((unsigned)(tiles_m * tiles_n), 8u, (unsigned)split);
     wgrad_dma_kernel<WMODE, BM, BN, 2><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   } else {
-    dim3 grid((unsigned)(tiles_m * tiles_n), 16u, (unsigned)split_for((long)tiles_m * tiles_n * 16));
+    dim3 grid((unsigned)(tiles_m * tiles_n), 16u, (unsigned)split);
     wgrad_dma_kernel<WMODE, BM, BN, 1><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+
+// dw[i] (+)= sum_s ws[s * numel + i]: one thread per 16 bytes of each layer, the splits' loads in flight eight at a time
+struct ReduceItems { DgWgradReduce it[8]; int first_block[9]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceItems r) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < r.n && (int)blockIdx.x >= r.first_block[i]) k = i;
+  const DgWgradReduce it = r.it[k];
+  const long i4 = (long)(blockIdx.x - r.first_block[k]) * 256 + threadIdx.x;
+  if (4 * i4 >= it.numel) return;
+  const f32x4* src = (const f32x4*)it.ws + i4;
+  const long stride = it.numel / 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= it.splits; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + (long)(s + j) * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; s < it.splits; ++s) acc += __builtin_nontemporal_load(src + (long)s * stride);
+  f32x4* dst = (f32x4*)it.dw + i4;
+  if (it.accumulate) acc += *dst;
+  *dst = acc;
 }
 
 }  // namespace
@@ -348,17 +394,37 @@ int dg_wgrad_mfma_dma_supported(const WgradP* p) {
   return 1;
 }
 
-int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, hipStream_t stream) {
+int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan) {
   if (!dg_wgrad_mfma_dma_supported(p)) return DG_EUNSUPPORTED;
+  if (p->g_mod < 0 || (p->ws && ((size_t)p->ws & 15) != 0)) return DG_EINVAL;
   const bool m128 = p->Ci % 128 == 0, n128 = p->Co % 128 == 0;
   if (p->wmode == 0) {
-    if (m128 && n128) return launch_dma<0, 128, 128>(p, accumulate, stream);
-    if (m128) return launch_dma<0, 128, 64>(p, accumulate, stream);
-    if (n128) return launch_dma<0, 64, 128>(p, accumulate, stream);
-    return launch_dma<0, 64, 64>(p, accumulate, stream);
+    if (m128 && n128) return launch_dma<0, 128, 128>(p, accumulate, pairs, stream, plan);
+    if (m128) return launch_dma<0, 128, 64>(p, accumulate, pairs, stream, plan);
+    if (n128) return launch_dma<0, 64, 128>(p, accumulate, pairs, stream, plan);
+    return launch_dma<0, 64, 64>(p, accumulate, pairs, stream, plan);
   }
-  if (m128 && n128) return launch_dma<1, 128, 128>(p, accumulate, stream);
-  if (m128) return launch_dma<1, 128, 64>(p, accumulate, stream);
-  if (n128) return launch_dma<1, 64, 128>(p, accumulate, stream);
-  return launch_dma<1, 64, 64>(p, accumulate, stream);
+  if (m128 && n128) return launch_dma<1, 128, 128>(p, accumulate, pairs, stream, plan);
+  if (m128) return launch_dma<1, 128, 64>(p, accumulate, pairs, stream, plan);
+  if (n128) return launch_dma<1, 64, 128>(p, accumulate, pairs, stream, plan);
+  return launch_dma<1, 64, 64>(p, accumulate, pairs, stream, plan);
+}
+
+extern "C" int dg_wgrad_reduce(const DgWgradReduce* items, int n, void* stream) {
+  if (!items || n < 1 || n > 8) return DG_EINVAL;
+  ReduceItems r{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const DgWgradReduce& it = items[i];
+    if (!it.ws || !it.dw || it.numel <= 0 || it.numel % 4 != 0 || it.splits < 1) return DG_EINVAL;
+    if (((size_t)it.ws & 15) != 0 || ((size_t)it.dw & 15) != 0) return DG_EINVAL;
+    r.it[i] = it;
+    r.first_block[i] = blocks;
+    blocks += (int)((it.numel / 4 + 255) / 256);
+  }
+  r.first_block[n] = blocks;
+  r.n = n;
+  wgrad_reduce_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(r);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
 }

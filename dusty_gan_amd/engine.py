@@ -164,6 +164,84 @@ class NetCfg:
             raise NotImplementedError("discriminator in_ch != 1 (the range-image path is single channel)")
 
 
+def conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, reads_aux):
+    """(FLOPs, bytes) one conv-like launch needs at minimum: 2 MAC per tap, every operand moved once.
+    MODE_S2: output on the coarse grid (Hc x Wc, N channels), input on the fine grid (2Hc x 2Wc, K channels), 16 taps per
+    output pixel; MODE_UP: output on the fine grid, input on the coarse grid, 4 taps per output pixel (16 weight taps over
+    the four sub-pixel parities); MODE_GEMM: B rows.  `reads_aux`: EPI_MASK also reads the saved activation at every
+    output element."""
+    if mode == L.MODE_GEMM:
+        pin, pout, taps_px, wtaps = B, B, 1, 1
+    elif mode == L.MODE_S2:
+        pin, pout, taps_px, wtaps = B * 4 * Hc * Wc, B * Hc * Wc, 16, 16
+    else:
+        pin, pout, taps_px, wtaps = B * Hc * Wc, B * 4 * Hc * Wc, 4, 16
+    flops = 2.0 * pout * N * K * taps_px
+    nbytes = pin * K * ies + pout * N * oes * (2 if reads_aux else 1) + wtaps * N * K * wes
+    return flops, nbytes
+
+
+def wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, aes, ges):
+    """(FLOPs, bytes) of one weight-gradient launch.  wmode 0 (Down): the layer input `a` lives on the fine grid, the
+    gradient `g` on the coarse grid; wmode 1 (Up): `a` coarse, `g` fine; wmode 2: a plain [rows, Ci]^T [rows, Co] GEMM.
+    16 taps per coarse pixel either way; dW (fp32) written once."""
+    rows = B * Hc * Wc
+    if wmode == 2:
+        return 2.0 * rows * Ci * Co, rows * (Ci * aes + Co * ges) + Ci * Co * 4
+    fa, fg = (4, 1) if wmode == 0 else (1, 4)
+    return 2.0 * rows * Ci * Co * 16, rows * (fa * Ci * aes + fg * Co * ges) + 16 * Ci * Co * 4
+
+
+class WgradWorkspace:
+    """Split-K partial tiles of the step's weight-gradient launches (DgWgrad.ws): the MFMA LDS-DMA kernel stores every
+    split's [16][Ci][Co] partial here with plain stores, and `flush` sums them into the gradients with ONE
+    dg_wgrad_reduce launch per <= 8 layers - instead of fp32 atomics onto dW, which the memory side executes at ~1.3 TB/s
+    (8x dW's bytes per launch: VERDICT r02).  A bump allocator over one caller-owned buffer; the reduce is deferred to
+    the point where the gradient is first needed (before an exchange / the optimizer), so one launch serves a whole
+    network.  Fixed summation order: the gradients are bit-reproducible."""
+    FLOATS = 96 << 20   # 384 MB: D's three fat layers at 3B rows + G's three (80 MB each) with room for the path-length terms
+
+    def __init__(self):
+        self.buf, self.pos, self.items = None, 0, []
+
+    def take(self, nfloats, device):
+        if self.buf is None or self.buf.device != device:
+            self.flush()
+            self.buf = torch.empty(self.FLOATS, dtype=torch.float32, device=device)
+            self.pos = 0
+        if nfloats > self.FLOATS:
+            return None
+        if self.pos + nfloats > self.FLOATS:
+            self.flush()        # (stream order: the reduce has read the partials before the next launch overwrites them)
+        off = self.pos
+        self.pos = (off + nfloats + 63) // 64 * 64
+        return L.ptr(self.buf) + 4 * off
+
+    def add(self, ws_ptr, dw_ptr, numel, splits, accumulate):
+        self.items.append((ws_ptr, dw_ptr, numel, splits, accumulate))
+
+    def flush(self):
+        """sum every pending layer's partials into its gradient (stream order after the launches that wrote them)"""
+        items, self.items, self.pos = self.items, [], 0
+        for i in range(0, len(items), 8):
+            chunk = items[i:i + 8]
+            arr = (L.DgWgradReduce * len(chunk))()
+            for a, (ws, dw, numel, splits, acc) in zip(arr, chunk):
+                a.ws, a.dw, a.numel, a.splits, a.accumulate = ws, dw, numel, splits, acc
+            if PROFILE is None:
+                L.check(L.lib().dg_wgrad_reduce(arr, len(chunk), L.stream_ptr()), "dg_wgrad_reduce")
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(L.lib().dg_wgrad_reduce(arr, len(chunk), L.stream_ptr()), "dg_wgrad_reduce")
+            e1.record()
+            nbytes = sum(4 * numel * (splits + 1 + acc) for _, _, numel, splits, acc in chunk)
+            PROFILE.append(("wgrad_reduce_kernel", 0.0, nbytes, e0, e1, f"{len(chunk)} layers"))
+
+
+WGRAD_WS = WgradWorkspace()
+
+
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
     default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
@@ -176,6 +254,7 @@ class Ops:
         # dg_conv / dg_wgrad `force` (0 auto; the parity tests set 1 direct, 2 MFMA, 3 thin, 4 / 5 persistent kernels)
         self.force = 0
         self.wg_cap = Ops.default_wg_cap  # dg_conv_ex: cap on the persistent conv's workgroup count (0 = one residency wave)
+        self.use_ws = True  # split-K partials through WGRAD_WS + dg_wgrad_reduce (False: fp32 atomics onto dW)
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
@@ -206,16 +285,14 @@ class Ops:
             pl = L.DgConvPlan()
             L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
             TRACE.append(("conv", pl.family, pl.bm, pl.bn, pl.tiles, pl.workgroups, pl.tiles_per_wg,
-                          f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
+                          f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}", pl.thin_mfma))
         if PROFILE is None:
             L.check(self.lib.dg_conv_ex(C.byref(p), self.force, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
-        taps = 1 if mode == L.MODE_GEMM else (16 if mode == L.MODE_S2 else 4)
-        npix = B if mode == L.MODE_GEMM else (B * Hc * Wc if mode == L.MODE_S2 else B * 4 * Hc * Wc)
-        flops = 2.0 * npix * N * K * taps
-        nbytes = npix * (N * oes + K * ies * (1 if mode != L.MODE_S2 else 4)) + taps * N * K * self.es
+        wes = 2 if p.w_dtype == L.DG_BF16 else 4
+        flops, nbytes = conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, epi == L.EPI_MASK)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
@@ -223,8 +300,50 @@ class Ops:
         PROFILE.append(({2: "conv_mfma_kernel", 3: "conv_thin_kernel"}.get(choice, "conv_direct_kernel"), flops, nbytes, e0, e1,
                         f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
 
+    def wgrad_plan(self, p, accumulate=1):
+        pl = L.DgWgradPlan()
+        L.check(self.lib.dg_wgrad_plan(C.byref(p), accumulate, self.force, C.byref(pl)), "dg_wgrad_plan")
+        return pl
+
     def wgrad(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale=None,
-              accumulate=1, a_dt=None, g_dt=None, a_off=0, g_off=0):
+              accumulate=1, a_dt=None, g_dt=None, a_off=0, g_off=0, g_mod=0, defer=False):
+        """dW (+)= scale * sum_b rowscale[b] a_b (x) g_(b % g_mod).  Kernels with a split-K workspace form (the MFMA LDS-DMA
+        kernel) write their partial tiles to WGRAD_WS; `defer=True` leaves the sum to the caller's WGRAD_WS.flush() (one
+        launch for a whole network), otherwise it follows at once.  g_mod > 0 needs that kernel: check `wgrad_takes_map`."""
+        p = self._wgrad_params(wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale, a_dt,
+                               g_dt, a_off, g_off, g_mod)
+        pl = self.wgrad_plan(p, accumulate) if self.use_ws else None
+        if pl is not None and pl.ws_floats > 0:
+            p.ws = WGRAD_WS.take(pl.ws_floats, a.device)
+        if TRACE is not None:
+            TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self.force),
+                          f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}", 0 if pl is None else pl.splits,
+                          0 if pl is None else pl.tap_pairs, bool(p.ws), g_mod))
+        if PROFILE is None:
+            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
+        else:
+            choice = self.lib.dg_wgrad_kernel_choice(C.byref(p)) if self.force in (0, 7, 8) else self.force
+            flops, nbytes = wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4,
+                                              2 if p.g_dtype == L.DG_BF16 else 4)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
+            e1.record()
+            PROFILE.append(({2: "wgrad_mfma_kernel", 3: "wgrad_thin_kernel"}.get(choice, "wgrad_direct_kernel"), flops, nbytes,
+                            e0, e1, f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
+        if p.ws:
+            WGRAD_WS.add(p.ws, dw_ptr, (1 if wmode == 2 else 16) * Ci * Co, pl.splits, int(accumulate))
+            if not defer:
+                WGRAD_WS.flush()
+
+    def wgrad_takes_map(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr):
+        """whether the kernel that would run this launch has the g-sample index map (DgWgrad.g_mod): the LDS-DMA kernel"""
+        p = self._wgrad_params(wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, 1.0, None, None, None,
+                               0, 0, 0)
+        return self.lib.dg_wgrad_kernel_variant(C.byref(p), self.force) == 5
+
+    def _wgrad_params(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale, a_dt, g_dt,
+                      a_off, g_off, g_mod):
         p = L.DgWgrad()
         p.wmode, p.ring = wmode, int(ring)
         p.B, p.Hc, p.Wc, p.Ci, p.Co = B, Hc, Wc, Ci, Co
@@ -236,22 +355,8 @@ class Ops:
         p.g_sb, p.g_sp, p.g_sc = g_strides
         p.dw, p.scale, p.rowscale = dw_ptr, scale, L.ptr(rowscale)
         p.a_dtype, p.g_dtype = a_dt, g_dt
-        if TRACE is not None:
-            TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self.force),
-                          f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
-        if PROFILE is None:
-            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
-            return
-        choice = self.lib.dg_wgrad_kernel_choice(C.byref(p)) if self.force == 0 else self.force
-        taps = 1 if wmode == 2 else 16
-        flops = 2.0 * B * Hc * Wc * Ci * Co * taps
-        nbytes = B * Hc * Wc * (Ci + Co) * self.es * (1 if wmode == 2 else 4) + taps * Ci * Co * 4
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
-        e1.record()
-        PROFILE.append(({2: "wgrad_mfma_kernel", 3: "wgrad_thin_kernel"}.get(choice, "wgrad_direct_kernel"), flops, nbytes, e0, e1,
-                        f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
+        p.ws, p.g_mod = None, int(g_mod)
+        return p
 
 
 class GEngine:
@@ -397,7 +502,7 @@ class GEngine:
             hc, wc = self.grid[i - 1]
             ci, co = chs[i - 1], chs[i]
             o.wgrad(1, c.ring, B, hc, wc, ci, co, self.a[i - 1], (hc * wc * ci, ci, 1), self.dp[i],
-                    (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), 1.0 / math.sqrt(co * 16))
+                    (4 * hc * wc * co, co, 1), st.fptr(f"up{i}_w", st.grad), 1.0 / math.sqrt(co * 16), defer=True)
 
         def up_bwd_data(i):
             hc, wc = self.grid[i - 1]
@@ -477,7 +582,7 @@ class GEngine:
             if full:
                 for a_src, g_src in ((self.a[i - 1], dp[i]), (acts[i - 1], chain[2][i])):
                     o.wgrad(1, c.ring, B, hc, wc, ci, co, a_src, (hc * wc * ci, ci, 1), g_src, (4 * hc * wc * co, co, 1),
-                            st.fptr(f"up{i}_w", g), s)
+                            st.fptr(f"up{i}_w", g), s, defer=True)
             prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, dp[i], (4 * hc * wc * co, co, 1), dp[i - 1],
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
@@ -623,30 +728,56 @@ class DEngine:
         for i in (4, 3, 2):
             self._bwd_layer(st, i, slot, n, rowscale, want_dbias)
 
+    def r1_fused_ok(self):
+        """whether dg_blur_bwd_r1 (BlurVH adjoint + R1 tangent + |g|^2 in one pass) takes this image shape
+        (pointwise.hip: four pixels per thread, 1024-pixel blocks)"""
+        c = self.cfg
+        return c.W % 4 == 0 and (c.H * c.W) % 1024 == 0
+
     def backward_input(self, st, slot, n, dx, r1=None):
         """Continue a chain from e1 to the image: Down1 backward-data + BlurVH adjoint -> dx [n,1,H,W] fp32.
-        r1 = (oscale, ssq): the R1 form - dx = oscale * g and ssq[b] += |g_b|^2 in the same pass (ssq pre-zeroed); returns
-        False when the fused kernel does not take the shape (nothing written: call again without r1)."""
+        r1 = (oscale, ssq): the R1 form - dx = oscale * g and ssq[b] += |g_b|^2 in the same pass (ssq pre-zeroed).
+        Returns True when dx was written; False - with NOTHING launched - when r1 was asked for a shape the fused
+        adjoint does not take (the caller then runs the plain form and its own sum / scale passes)."""
         c, o, lib = self.cfg, self.ops, L.lib()
+        if r1 is not None and not self.r1_fused_ok():
+            return False
         self._bwd_layer(st, 1, slot, n, None, False)
         if r1 is not None:
-            rc = lib.dg_blur_bwd_r1(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), float(r1[0]), L.ptr(r1[1]),
-                                    n, c.H, c.W, int(c.ring), L.stream_ptr())
-            if rc != L.DG_EUNSUPPORTED:
-                L.check(rc, "dg_blur_bwd_r1")
-                return True
+            L.check(lib.dg_blur_bwd_r1(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), float(r1[0]),
+                                       L.ptr(r1[1]), n, c.H, c.W, int(c.ring), L.stream_ptr()), "dg_blur_bwd_r1")
+            return True
         L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")
+        return True
 
-    def wgrad(self, st, a_slot, g_slot, n, rowscale, layers=(1, 2, 3, 4)):
-        """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot+b]) for the Down layers in `layers`."""
+    def wgrad(self, st, a_slot, g_slot, n, rowscale, layers=(1, 2, 3, 4), g_mod=0):
+        """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot + b % g_mod]) for the Down layers in `layers`.
+        The split-K partials of the fat layers wait in engine.WGRAD_WS: the caller flushes before the gradient is read."""
         c, o = self.cfg, self.ops
         for i in layers:
             hc, wc = self.grid[i]
             ci, co = self.chs[i - 1], self.chs[i]
             o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
                     (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
-                    a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i])
+                    a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i], g_mod=g_mod, defer=True)
+
+    def wgrad_r1(self, st, B, rs3, layers=(1, 2, 3, 4)):
+        """The D phase's weight gradients with R1 on (trainers/dcgan_amp.py:235 through :218-232): per layer
+        wgrad(h[real | fake], e[real | fake], rs) + wgrad(t, e[real]) - the ordinary term over 2B samples and the R1 term
+        (tangent activations t in slots [2B, 3B) against the real batch's chain).  Both sums have the same output, so on the
+        kernel that has the gradient-sample index map they are ONE launch over the 3B input slots with g sample = b % 2B
+        and per-sample weights rs3 = [dLoss/dy_real | 1 | 1]: half the launches and half the split-K partial tiles."""
+        c, o = self.cfg, self.ops
+        for i in layers:
+            hc, wc = self.grid[i]
+            ci, co = self.chs[i - 1], self.chs[i]
+            if o.wgrad_takes_map(0, c.ring, 3 * B, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
+                                 (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad)):
+                self.wgrad(st, 0, 0, 3 * B, rs3, layers=(i,), g_mod=2 * B)
+            else:
+                self.wgrad(st, 0, 0, 2 * B, rs3, layers=(i,))
+                self.wgrad(st, 2 * B, 0, B, None, layers=(i,))
 
     def final_wgrad(self, st, slot, n, coef):
         """dwf += s_f * sum_b coef[b] * h4[slot+b]"""

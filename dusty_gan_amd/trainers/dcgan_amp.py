@@ -160,6 +160,7 @@ class FlatAdam:
         its gradient is NOT in st.grad - the kernel forms wscale * dp0^T zT itself (dg_adam_proj_fused).  Returns
         False (and does nothing) if that kernel refuses the shape, so the caller can fall back."""
         st = self.store
+        E.WGRAD_WS.flush()  # (split-K partials still waiting to be summed into st.grad)
         if self._step_dev is None or self._step_dev.device != st.flat.device:
             self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=st.flat.device)
         # beta1 == 0 (the reference's solver): exp_avg == scaled gradient, so the kernel neither reads nor writes it
@@ -225,7 +226,13 @@ class Trainer:
         self.G_ema = define_G(self.cfg)
         self.G_ema.eval()
         self.dtype = _backbone(self.G).compute_dtype
-        self.A = DiffAugment(policy=list(self.cfg.solver.augment) if self.cfg.solver.augment is not None else None)
+        # one job-level seed (rank 0's torch seed) from which every rank derives its Philox streams: rank r's position
+        # in a run is then a function of rank 0's, which is what the checkpoint - written by rank 0 alone, like the
+        # reference's (train.py:159-166) - records
+        self.world = _world()
+        self._job_seed = D_.broadcast_int(torch.initial_seed() & (2**62 - 1), self.device, src=0)
+        self.A = DiffAugment(policy=list(self.cfg.solver.augment) if self.cfg.solver.augment is not None else None,
+                             seed=None if self.world == 1 else self._job_seed + 101 + 7919 * _rank())
         H, W = self.cfg.dataset.shape
         self.H, self.W = int(H), int(W)
         self.lidar = LiDAR(num_ring=H, num_points=W, min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth,
@@ -241,7 +248,6 @@ class Trainer:
             net.store.ensure_train_state()
 
         # DDP construction broadcasts rank 0's parameters (reference :68-69)
-        self.world = _world()
         if self.world > 1:
             D_.broadcast_params([self.G.store.flat, self.D.store.flat], src=0)
             self.G.store._seen_version = -1
@@ -290,7 +296,7 @@ class Trainer:
         self.batches_drawn = 0
         resume_extra = None
         if self.cfg.resume is not None:
-            sd = torch.load(self.cfg.resume, map_location="cpu", weights_only=False)
+            sd = torch.load(self.cfg.resume, map_location="cpu", weights_only=True)  # tensors, ints, strs only
             resume_extra = sd.get("resume_state")
             self.start_iteration = sd["step"] // self.cfg.solver.batch_size
             self.G.load_state_dict(sd["G"])
@@ -302,7 +308,7 @@ class Trainer:
                 self.pl_ema.copy_(torch.as_tensor(sd["pl_ema"]).reshape(1))
 
         self.n_acc = int(self.cfg.solver.num_accumulation)
-        self.rng = Philox(torch.initial_seed() + 7919 * _rank(), self.device, stream_id=1)
+        self.rng = Philox(self._job_seed + 7919 * _rank(), self.device, stream_id=1)
         self.fixed_noise = self.sample_latents(self.local_batch)
         if resume_extra is not None:
             self._restore_position(resume_extra)
@@ -438,10 +444,19 @@ class Trainer:
 
     def _bucketed(self):
         """multi-rank schedule (also with DUSTY_GAN_FORCE_SEG=1 in one process): bucketed, overlapped exchanges"""
-        return (self.world > 1 or self._force_seg) and self.n_acc == 1
+        on = (self.world > 1 or self._force_seg) and self.n_acc == 1
+        if on and not getattr(self, "_buckets_checked", False):
+            # the buckets are cut by OFFSET in the flat gradient buffers and travel while later kernels still write other
+            # offsets: that is only sound for this segment order (engine.g_segments / d_segments)
+            dn, gn = list(self.D.store.seg), list(_backbone(self.G).store.seg)
+            assert dn[dn.index("d4_w"):] == ["d4_w", "d4_b", "final_w", "final_b"], dn
+            assert gn == ["proj_w", "proj_b", "up1_w", "up1_b", "up2_w", "up2_b", "up3_w", "up3_b", "head_w", "head_b"], gn
+            self._buckets_checked = True
+        return on
 
     def _allreduce(self, store):
         """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
+        E.WGRAD_WS.flush()  # the split-K partials of the weight gradients become the gradient here
         if self._multi:
             self._coll(lambda: D_.allreduce_grads(store.grad), name="all-reduce grads")
         elif self._force_seg:
@@ -450,6 +465,7 @@ class Trainer:
 
     def _allreduce_async(self, key, buf):
         """issue half of a bucketed gradient exchange (`_comm_wait(key)` completes it)"""
+        E.WGRAD_WS.flush()
         if self._multi:
             self._comm_issue(key, lambda: D_.allreduce_grads(buf, async_op=True)[0])
         elif self._force_seg:
@@ -498,7 +514,13 @@ class Trainer:
             # `rs`: the real half's ordinary backward is the same chain weighted per sample by dLoss/dy_real
             dy = torch.empty(2 * B, **f32)
             up = torch.empty(2 * B, **f32) if gp > 0 else None
-            rs = torch.empty(2 * B, **f32) if gp > 0 else None
+            rs = None
+            if gp > 0:
+                # per-sample weights of the weight-gradient sums over the 3B input slots real | fake | tangent: the kernel
+                # below writes [dLoss/dy_real | 1]; the tangent rows' 1s are written once, here
+                if getattr(self, "_rs3", None) is None or self._rs3.numel() != 3 * B or self._rs3.device != self.device:
+                    self._rs3 = torch.ones(3 * B, **f32)
+                rs = self._rs3
             L.check(lib.dg_gan_d_step(self.gan_code, float(self.criterion["gan"].smoothing), L.ptr(y),
                                       L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs), L.ptr(scal),
                                       Dst.fptr("final_b", Dst.grad), sp), "dg_gan_d_step")
@@ -510,19 +532,14 @@ class Trainer:
             if gp > 0:
                 deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
                 g = torch.empty(B, 1, self.H, self.W, **f32)
-                if not bucketed:
-                    # (side stream) weight gradients of the real (weighted by dLoss/dy_real) + fake halves, beside the
-                    # rest of the R1 chain
-                    deng.wgrad(Dst, 0, 0, 2 * B, rs)
-                    deng.final_wgrad(Dst, 0, 2 * B, dy)
                 # R1 (:218-235): g = d sum(y_real) / dx_real, penalty = gp / 2 * mean_b |g_b|^2, and its double backward's
                 # tangent v = d penalty / dg = (gp / B) g, pushed forward through D below
                 vscale = gp / self.n_acc / B
                 ssq = L.AccArena.take(B, dev)
                 vg = torch.empty_like(g)
                 if ssq is None or not deng.backward_input(Dst, 0, B, vg, r1=(vscale, ssq)):
-                    # (shapes the fused adjoint does not take, or no arena: three passes.  The chain's last conv layer ran
-                    # in the refused call already when ssq is not None - backward_input repeats it, harmlessly)
+                    # (shapes the fused adjoint does not take - refused before anything is launched - or no arena:
+                    # three passes)
                     deng.backward_input(Dst, 0, B, g)
                     if ssq is None:
                         ssq = torch.empty(B, **f32)
@@ -532,16 +549,14 @@ class Trainer:
                     L.check(lib.dg_scale(L.ptr(g), vscale, g.numel(), L.ptr(vg), sp), "dg_scale")
                 L.check(lib.dg_mean_acc(L.ptr(ssq), B, L.ptr(scal) + 12, sp), "dg_mean_acc")  # :229
                 deng.forward(Dst, vg, 2 * B, tangent_of=0)
-                if not bucketed:
-                    deng.wgrad(Dst, 2 * B, 0, B, None)      # tangent (x) real chain
-                    deng.final_wgrad(Dst, 2 * B, B, None)
-                else:
-                    for layers in ((4,), (3, 2, 1)):
-                        deng.wgrad(Dst, 0, 0, 2 * B, rs, layers=layers)
-                        deng.wgrad(Dst, 2 * B, 0, B, None, layers=layers)
-                        if layers == (4,):
-                            deng.final_wgrad(Dst, 0, 2 * B, dy)
-                            deng.final_wgrad(Dst, 2 * B, B, None)
+                # weight gradients: real (weighted by dLoss/dy_real) + fake halves and tangent (x) real chain, one launch
+                # per fat layer (engine.DEngine.wgrad_r1)
+                for layers in (((4,), (3, 2, 1)) if bucketed else ((4, 3, 2, 1),)):
+                    deng.wgrad_r1(Dst, B, rs, layers=layers)
+                    if 4 in layers:
+                        deng.final_wgrad(Dst, 0, 2 * B, dy)
+                        deng.final_wgrad(Dst, 2 * B, B, None)
+                        if bucketed:
                             self._allreduce_async("D.hi", Dst.grad[cut:])
             else:
                 deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
@@ -655,6 +670,7 @@ class Trainer:
                 self._comm_wait("G.hi", "G.lo")
             else:
                 tail = Gst.grad[Gst.seg["proj_b"].off:]
+                E.WGRAD_WS.flush()
                 self._coll(lambda: D_.allreduce_grads(tail), name="all-reduce G tail")
             gscale = 1.0 / self.world
         else:
@@ -795,6 +811,11 @@ class Trainer:
         step cost ~5 ms of Python/ctypes time when issued one by one, more than the kernels themselves; captured once
         they replay from one host call.  Everything that changes between steps lives in device memory (Philox
         counters, Adam step counts, the input batch in a static buffer), so replays draw fresh randomness."""
+        # an eager draw between two steps (validation() / generate() call sample_latents on the trainer's generator)
+        # leaves its counter advance queued: apply it now, outside the graph - a replay reads the device counters as
+        # they are, and an advance still pending when the capture starts would be baked into the graph and re-added
+        # on every replay
+        L.Counters.flush()
         batch = self._next_batch()
         if self._graph is None:
             if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
@@ -822,6 +843,7 @@ class Trainer:
                         pass
                 self._cap, self._cap_cur = None, None
                 L.Counters.pending.clear()  # (advances queued by the aborted capture were never going to run)
+                E.WGRAD_WS.items, E.WGRAD_WS.pos = [], 0
                 if self.world == 1:
                     raise
                 # multi-rank: a runtime that refuses the capture must not take the job down - nothing was executed,
@@ -940,21 +962,30 @@ class Trainer:
                 "fixed_noise": self.fixed_noise.detach().cpu(), "batches_drawn": self.batches_drawn}
 
     def _restore_position(self, st):
+        """Continue from a checkpoint's position record.  The record is the WRITING rank's (rank 0 saves, as in the
+        reference); every rank's streams are `job seed + 7919 rank` and every rank makes the same number of draws per
+        step, so rank r's position is the writer's with its own seed: same counter offsets, same loader position, and
+        its fixed evaluation latents are the first draw of its own stream (what __init__ just made)."""
         from ..utils.rng import Philox
-        if int(st.get("world", 1)) != self.world or int(st.get("rank", 0)) != _rank():
+        if int(st.get("world", 1)) != self.world:
             import warnings
-            warnings.warn("checkpoint position belongs to another rank layout; random streams restart")
+            warnings.warn("checkpoint position belongs to another world size; random streams and the loader restart")
             return
+        shift = 7919 * (_rank() - int(st.get("rank", 0)))
 
         def mk(d):
-            r = Philox(d["seed"], self.device, stream_id=d["stream_id"])
+            r = Philox(int(d["seed"]) + shift, self.device, stream_id=d["stream_id"])
             L.Counters.flush_if(r.ctr)
             r.ctr.fill_(int(d["offset"]))
             return r
+        if shift == 0:
+            self.fixed_noise = st["fixed_noise"].to(self.device)
+        else:
+            self.fixed_noise = Philox(int(st["rng"]["seed"]) + shift, self.device,
+                                      stream_id=st["rng"]["stream_id"]).normal(self.fixed_noise.numel()).view_as(self.fixed_noise)
         self.rng = mk(st["rng"])
         if st.get("augment_rng") is not None:
             self.A._rng = mk(st["augment_rng"])
-        self.fixed_noise = st["fixed_noise"].to(self.device)
         # the loader: same epoch, same position inside it
         n = int(st["batches_drawn"])
         self.batches_drawn = n

@@ -47,6 +47,15 @@ def broadcast_params(flats, src=0):
             dist.broadcast(t, src=src)
 
 
+def broadcast_int(value, device, src=0):
+    """rank `src`'s integer on every rank (< 2^63); the value itself without a process group"""
+    if world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def allreduce_grads(flat_grad, async_op=False):
     """SUM all-reduce of one network's flat gradient buffer; returns (work handle or None, gscale) where gscale is the
     factor the optimizer applies to turn the sum into DDP's average."""

@@ -75,6 +75,14 @@ typedef struct DgWgrad {
   float scale;
   const float* rowscale;     /* optional [B] */
   int a_dtype, g_dtype;
+  /* Optional (zero = off).  ws: caller-owned workspace for the split-K partial tiles of the MFMA LDS-DMA kernel: split s
+   * stores its [16][Ci][Co] partial at ws + s * 16 Ci Co with plain stores and NOTHING is added to dw - the caller sums
+   * the partials with dg_wgrad_reduce (sizes from dg_wgrad_plan).  Without it the partial tiles meet in dw through fp32
+   * atomics, which the memory side executes at ~1.3 TB/s against ~6 TB/s for stores (8x the bytes of dw per launch).
+   * g_mod: the gradient's sample index is b % g_mod, so ONE launch over 3B input samples (real | fake | R1 tangent) can
+   * pair the tangent rows with the real batch's gradient chain again (trainers/dcgan_amp.py:229-235). */
+  float* ws;
+  int g_mod;
 } DgWgrad;
 
 /* ---- conv-like passes ------------------------------------------------------------------------------------
@@ -102,6 +110,7 @@ typedef struct DgConvPlan {
   int tiles;         /* tiles of the launch */
   int workgroups;    /* grid size */
   int tiles_per_wg;  /* most tiles any workgroup walks */
+  int thin_mfma;     /* family 3: 1 = thin_s2_mfma, 2 = thin_up_mfma (matrix cores), 0 = the VALU kernels */
 } DgConvPlan;
 int dg_conv_ex(const DgConv* p, int force, int wg_cap, void* stream);
 int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan);
@@ -111,10 +120,29 @@ int dg_conv_kernel_choice(const DgConv* p);   /* what force == 0 launches: 2 MFM
 /* dg_wgrad replaces the weight-gradient half of the same autograd calls.  accumulate: 1 = atomically add onto dw
  * (dw zeroed by the caller at step start: optim.zero_grad, trainers/dcgan_amp.py:177,246), 0 = overwrite. */
 int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream);
+/* What dg_wgrad launches for these arguments, and the split-K workspace it can use: `splits` partial tiles of
+ * 16 Ci Co floats (ws_floats = splits * 16 Ci Co; 0 when the kernel that runs has no workspace form).  force 7 / 8:
+ * the LDS-DMA kernel with / without W-tap pairs (A/B measurements; 0 / 2 choose by the K range per workgroup). */
+typedef struct DgWgradPlan {
+  int variant;      /* as dg_wgrad_kernel_variant */
+  int splits;
+  long ws_floats;
+  int tap_pairs;    /* 1: one workgroup computes the W taps (kx, kx + 2) from one staged image */
+} DgWgradPlan;
+int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan);
+/* dw[i] (+)= sum_s ws[s * numel + i] for up to 8 layers in one launch (fixed summation order: deterministic gradients) */
+typedef struct DgWgradReduce {
+  const float* ws;
+  float* dw;
+  long numel;       /* 16 Ci Co, a multiple of 4 */
+  int splits;
+  int accumulate;   /* 1: add onto dw, 0: overwrite */
+} DgWgradReduce;
+int dg_wgrad_reduce(const DgWgradReduce* items, int n, void* stream);
 int dg_wgrad_mfma_supported(const DgWgrad* p);
 int dg_wgrad_kernel_choice(const DgWgrad* p);
 /* which kernel `force` launches: 5 MFMA on the LDS-DMA ring (bf16 Down/Up layers), 2 register-staged MFMA (also
- * force == 6), 3 thin, 1 direct, 0 unsupported */
+ * force == 6), 7 thin on the matrix cores (bf16 Down1 / Head), 3 thin (VALU), 1 direct, 0 unsupported */
 int dg_wgrad_kernel_variant(const DgWgrad* p, int force);
 
 /* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */

@@ -32,6 +32,68 @@ LRELU_GAIN = math.sqrt(2.0)
 
 
 # --------------------------------------------------------------------------
+# bf16 emulation (checker for the engine's `enable_amp` mode; off = the fp32 restatement pinned by tests/golden)
+# --------------------------------------------------------------------------
+class _Emu:
+    """With `bf16` on, the restatement rounds to bfloat16 exactly where the HIP engine STORES bfloat16:
+    weight shadows, the latent, every feature map after its activation, BlurVH's output, and every gradient with
+    respect to a pre-activation (the backward-data chains, which are also the weight-gradient operands); all
+    arithmetic, bias gradients, head outputs, images, losses and the optimizer stay fp32, as in the engine.  The
+    reference's own autocast path (trainers/dcgan_amp.py:194,219,226) is fp16 and rounds at ATen's op boundaries
+    instead; this mode exists so that the timed bf16 path can be held to a tight gradient bound against a checker
+    that makes the same leaky-relu slope decisions, not as a model of autocast."""
+    bf16 = False
+
+
+EMU = _Emu()
+
+
+class _Round(torch.autograd.Function):
+    """x -> bf16(x); its derivative is taken to be the same rounding, so the function is closed under differentiation
+    (R1's double backward rounds the tangent where the first backward rounded the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Round.apply(g)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """stored-as-bf16 value: rounded forward, straight-through backward"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """stored-as-bf16 gradient: identity forward, the gradient passing back through this point is rounded"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Round.apply(g)
+
+
+def _rf(x):
+    return _RoundFwd.apply(x) if EMU.bf16 else x
+
+
+def _rg(x):
+    return _RoundGrad.apply(x) if EMU.bf16 else x
+
+
+# --------------------------------------------------------------------------
 # models/ops/common.py
 # --------------------------------------------------------------------------
 def pad_ring(h, ring=True):
@@ -68,7 +130,7 @@ def blur_vh(x, ring=True):
     # blur_h: padding=(1,1,0,0) -> only horizontal pad
     hh = F.pad(x, (1, 1, 0, 0), mode="circular" if ring else "reflect")
     hh = F.conv2d(hh, kh, groups=C)
-    return torch.cat([hv, hh], dim=1)
+    return _rf(_rg(torch.cat([hv, hh], dim=1)))
 
 
 # --------------------------------------------------------------------------
@@ -80,23 +142,26 @@ def _g_prefix(params):
 
 def proj(z, weight, bias):
     """Proj.forward dcgan_eqlr.py:6-16 (EqualLR(ConvTranspose2d(k=shape_in,s=1,p=0)) + FusedLeakyReLU)."""
-    h = z[..., None, None]
-    h = F.conv_transpose2d(h * equal_lr_scale(weight), weight, None, 1, 0)
-    return fused_leaky_relu(h, bias)
+    h = _rf(z)[..., None, None]
+    h = _rg(F.conv_transpose2d(h * equal_lr_scale(weight), _rf(weight), None, 1, 0))
+    return _rf(fused_leaky_relu(h, bias))
 
 
 def up(x, weight, bias, ring=True):
     """Up dcgan_eqlr.py:19-26: Pad(1) -> EqualLR(ConvTranspose2d(4,2,padding=3,bias=False)) -> FusedLeakyReLU."""
     h = pad_ring(x, ring)
-    h = F.conv_transpose2d(h * equal_lr_scale(weight), weight, None, 2, 3)
-    return fused_leaky_relu(h, bias)
+    h = _rg(F.conv_transpose2d(h * equal_lr_scale(weight), _rf(weight), None, 2, 3))
+    return _rf(fused_leaky_relu(h, bias))
 
 
 def head(x, weight, bias, ring=True):
     """One Head branch dcgan_eqlr.py:36-40: Pad(1) -> EqualLR(ConvTranspose2d(4,2,3,bias=True)).
     The bias is added after the (input-)scaled conv, i.e. it is NOT scaled."""
     h = pad_ring(x, ring)
-    return F.conv_transpose2d(h * equal_lr_scale(weight), weight, bias, 2, 3)
+    if not EMU.bf16:
+        return F.conv_transpose2d(h * equal_lr_scale(weight), weight, bias, 2, 3)
+    # (the engine's head output is fp32; the gradient it sends back into the backbone / the weight gradient is bf16)
+    return _rg(F.conv_transpose2d(h * equal_lr_scale(weight), _rf(weight), None, 2, 3)) + bias.view(1, -1, 1, 1)
 
 
 def generator_backbone(params, z, ring=True):
@@ -117,8 +182,8 @@ def generator_backbone(params, z, ring=True):
 def down(x, weight, bias, ring=True):
     """Down dcgan_eqlr.py:75-82: Pad(1) -> EqualLR(Conv2d(4,2,0,bias=False)) -> FusedLeakyReLU."""
     h = pad_ring(x, ring)
-    h = F.conv2d(h * equal_lr_scale(weight), weight, None, 2, 0)
-    return fused_leaky_relu(h, bias)
+    h = _rg(F.conv2d(h * equal_lr_scale(weight), _rf(weight), None, 2, 0))
+    return _rf(fused_leaky_relu(h, bias))
 
 
 def discriminator(params, x, ring=True):
@@ -362,7 +427,8 @@ class StepConfig:
 
     def __init__(self, arch="none", ring=True, tau=1.0, gan_mode="nsgan", w_gan=1.0, w_gp=1.0, w_pl=0.0,
                  lr_g=0.002, lr_d=0.002, beta1=0.0, beta2=0.99, ema_decay=0.998,
-                 policy=("brightness", "saturation", "contrast", "translation", "cutout")):
+                 policy=("brightness", "saturation", "contrast", "translation", "cutout"), emulate_bf16=False):
+        self.emulate_bf16 = bool(emulate_bf16)  # round where the engine's bf16 mode stores bf16 (see _Emu)
         self.arch, self.ring, self.tau = arch, ring, tau
         self.gan_mode, self.w_gan, self.w_gp, self.w_pl = gan_mode, w_gan, w_gp, w_pl
         self.lr_g, self.lr_d, self.beta1, self.beta2 = lr_g, lr_d, beta1, beta2
@@ -376,6 +442,15 @@ def new_optim_state(params):
 
 
 def train_step(G, D, G_ema, opt_G, opt_D, step_no, cfg, x_real, rand, return_grads=False):
+    """`_train_step` under the configuration's precision model (fp32, or the bf16 storage emulation of `_Emu`)."""
+    prev, EMU.bf16 = EMU.bf16, bool(getattr(cfg, "emulate_bf16", False))
+    try:
+        return _train_step(G, D, G_ema, opt_G, opt_D, step_no, cfg, x_real, rand, return_grads)
+    finally:
+        EMU.bf16 = prev
+
+
+def _train_step(G, D, G_ema, opt_G, opt_D, step_no, cfg, x_real, rand, return_grads=False):
     """One `Trainer.step` trainers/dcgan_amp.py:162-325 (num_accumulation=1, world size 1, no AMP scaling,
     path-length regulariser off), restated with stock torch CPU ops + autograd.
 

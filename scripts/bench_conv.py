@@ -81,25 +81,46 @@ if CONV:
 
 if len(sys.argv) > 3 and sys.argv[3] == "convonly":
     sys.exit(0)
-o.force = 2
-tot_ms, tot_fl = 0.0, 0.0
+# weight gradients: the step's launches (D layers: ONE launch over 3B input samples real | fake | tangent against the 2B
+# gradient chain; G layers: B samples) in four forms - fp32 atomics onto dW, split-K workspace + reduce with the launcher's
+# tap-pair choice, with pairs forced, with single taps forced
+from dusty_gan_amd import engine as E
+FORMS = [("atomics", 2, False), ("ws auto", 2, True), ("ws pairs", 7, True), ("ws single", 8, True)]
+tot = {f[0]: 0.0 for f in FORMS}
+tot_fl = 0.0
 for name, wmode, Hc, Wc, Ci, Co, bm in WGRAD:
-    n = B * bm
+    merged = bm == 2          # a D layer: 3B input samples, gradient sample b % 2B
+    n = 3 * B if merged else B
+    ng = 2 * B if merged else B
     wa = 2 * Wc if wmode == 0 else Wc
     ha = 2 * Hc if wmode == 0 else Hc
     wg = 2 * Wc if wmode == 1 else Wc
     hg = 2 * Hc if wmode == 1 else Hc
     a = torch.randn(n * ha * wa * Ci, device=dev).to(dtype)
-    g = torch.randn(n * hg * wg * Co, device=dev).to(dtype)
+    g = torch.randn(ng * hg * wg * Co, device=dev).to(dtype)
     dw = torch.zeros(16 * Ci * Co, device=dev)
     rs = torch.rand(n, device=dev)
-
-    def run():
-        o.wgrad(wmode, True, n, Hc, Wc, Ci, Co, a, (ha * wa * Ci, Ci, 1), g, (hg * wg * Co, Co, 1), dw.data_ptr(), 0.01,
-                rowscale=rs)
-    ms = timeit(run)
     fl = 2.0 * n * Hc * Wc * Ci * Co * 16
-    tot_ms += ms
     tot_fl += fl
-    print(f"{name:10s} B{n:3d} {Hc:2d}x{Wc:3d} Ci{Ci:3d} Co{Co:3d}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TFLOP/s")
-print(f"wgrad total {tot_ms * 1e3:.1f} us  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+    line = f"{name:10s} B{n:3d} {Hc:2d}x{Wc:3d} Ci{Ci:3d} Co{Co:3d}:"
+    for form, force, ws in FORMS:
+        o.force, o.use_ws = force, ws
+        E.TRACE = []
+
+        def run():
+            if merged and not ws:   # the atomics form is what round 2 ran: two launches per D layer
+                o.wgrad(wmode, True, ng, Hc, Wc, Ci, Co, a, (ha * wa * Ci, Ci, 1), g, (hg * wg * Co, Co, 1), dw.data_ptr(),
+                        0.01, rowscale=rs)
+                o.wgrad(wmode, True, B, Hc, Wc, Ci, Co, a, (ha * wa * Ci, Ci, 1), g, (hg * wg * Co, Co, 1), dw.data_ptr(),
+                        0.01, a_off=ng * ha * wa * Ci)
+            else:
+                o.wgrad(wmode, True, n, Hc, Wc, Ci, Co, a, (ha * wa * Ci, Ci, 1), g, (hg * wg * Co, Co, 1), dw.data_ptr(),
+                        0.01, rowscale=rs, g_mod=ng if merged else 0)
+        ms = timeit(run)
+        tr = [t for t in E.TRACE if t[0] == "wgrad"][-1]
+        E.TRACE = None
+        tot[form] += ms
+        line += f"  {form} {ms * 1e3:6.1f} us {fl / ms / 1e9:6.1f} TF (split {tr[3]}{' pairs' if tr[4] else ''})"
+    print(line)
+for form, _, _ in FORMS:
+    print(f"wgrad total [{form:9s}] {tot[form] * 1e3:.1f} us  {tot_fl / tot[form] / 1e9:.1f} TFLOP/s (reduce launches included)")

@@ -1,6 +1,6 @@
 """profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes of the eager training step (one with --pmc FETCH_SIZE, one
 with --pmc WRITE_SIZE; TCC has too few slots for both).  usage:
-    python scripts/pmc_traffic.py out.json <fetch counter_collection.csv> <write counter_collection.csv>
+    python scripts/pmc_traffic.py out.json <fetch counter_collection.csv> <write counter_collection.csv> [bench.py options of the passes]
 Units: KB; FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md "HBM"); Infinity
 Cache hits are included.  The file records the hash of the kernel sources it was collected on (bench.py refuses a
 number from other sources) and the kernel symbols behind each family."""
@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import kernel_source_sha  # noqa: E402
+from bench import bench_config_key, kernel_source_sha, parse  # noqa: E402
 
 FAMILIES = {  # bench.py family name -> substrings of the kernel symbols it covers
     "conv_mfma_kernel": ("conv_pp_kernel", "persist11conv_kernel", "conv_mfma_kernel"),
@@ -38,6 +38,7 @@ def load(path, counter):
 
 def main():
     out, fetch_csv, write_csv = sys.argv[1:4]
+    bench_args = parse(sys.argv[4:])  # the bench.py options the two PMC passes were run with (none = the default workload)
     fk, fn, names = load(fetch_csv, "FETCH_SIZE")
     wk, wn, _ = load(write_csv, "WRITE_SIZE")
     try:
@@ -45,7 +46,8 @@ def main():
     except OSError:
         sha = ""
     res = {"_note": __doc__.strip().split("usage")[0].strip() + " bytes_per_launch = (2*FETCH_KB + WRITE_KB)*1024 / launches.",
-           "kernel_source_sha": kernel_source_sha(), "git_sha": sha or "(collected on the GPU box: no .git there)", "kernels": {}}
+           "kernel_source_sha": kernel_source_sha(), "config": bench_config_key(bench_args, bench_args.arch or "none"),
+           "git_sha": sha or "(collected on the GPU box: no .git there)", "kernels": {}}
     for fam in FAMILIES:
         if fn[fam] == 0:
             continue

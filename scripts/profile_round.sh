@@ -2,16 +2,16 @@
 # The profiles a round commits (run on the GPU box from the repo root): kernel-trace stats of bench.py, HBM-side traffic
 # (two PMC passes on the eager step), SQ counters of the eager step, and the bench lines of the other configurations.
 #   usage: scripts/profile_round.sh <tag, e.g. r02a> [outdir]
-tag=${1:-r02}
+tag=${1:-r03}
 out=${2:-gpurun_out/prof_$tag}
 root=$(pwd)
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/kt -- python3 $root/bench.py --no-cpu-baseline > $root/$out/bench_under_profiler.json 2> $root/$out/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/kt -- python3 $root/bench.py --no-other-configs --no-cpu-baseline > $root/$out/bench_under_profiler.json 2> $root/$out/kt.log
 export DUSTY_GAN_GRAPH=0
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/$out/fetch -- python3 $root/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /dev/null 2> $root/$out/fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/$out/write -- python3 $root/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /dev/null 2> $root/$out/write.log
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VALU --output-format csv -d $root/$out/sq -- python3 $root/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /dev/null 2> $root/$out/sq.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/$out/fetch -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /dev/null 2> $root/$out/fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/$out/write -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /dev/null 2> $root/$out/write.log
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VALU --output-format csv -d $root/$out/sq -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 4 --warmup 2 > /dev/null 2> $root/$out/sq.log
 unset DUSTY_GAN_GRAPH
 cd $root
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_bench_bf16_b32.csv

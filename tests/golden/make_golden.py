@@ -13,6 +13,8 @@ usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz
         python tests/golden/make_golden.py pl         (only the three step_*_pl.npz files)
         python tests/golden/make_golden.py lidar      (only lidar.npz)
         python tests/golden/make_golden.py metrics    (only metrics.npz)
+        python tests/golden/make_golden.py full       (only full_dusty2.npz: the 64x1024 / 512-channel pin, digests)
+        python tests/golden/make_golden.py covmmd     (only covmmd.npz: COV / MMD / 1-NNA from the reference's functions)
 """
 import importlib.util
 import math
@@ -436,6 +438,177 @@ def make_metrics_golden():
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_covmmd_golden():
+    """utils/metrics/cov_mmd_1nna.py (plain torch) loaded by path.  Its `from .distance import chamfer_distance,
+    earth_mover_distance` pulls in two CUDA extensions that are JIT-built at import (not buildable
+    here), so the package slot `.distance` gets a placeholder whose `chamfer_distance` is the reference's OWN CPU search
+    - `nnsearch` of utils/metrics/distance/cd/chamfer_distance.cpp:39-66, compiled from its source by oracle/Makefile.ref
+    into oracle/_ref/libref_cd.so, the code path its extension takes for CPU tensors (chamfer_distance.py:33-36) - and
+    whose `earth_mover_distance` is absent (CUDA only).  Stored: `_compute_cov_mmd` / `_compute_nna` on crafted matrices
+    (ties, k = 1 and 3, sqrt on / off) and `compute_cov_mmd_1nna(..., ("cd",))` end to end on seeded clouds, with the
+    three pairwise matrices."""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libref_cd.so")
+    lib = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+
+    def chamfer_distance(x1, x2):  # (b,n,3), (b,m,3) -> dist1 (b,n), dist2 (b,m): ChamferDistanceFunction.forward, CPU branch
+        a, b = np.ascontiguousarray(x1.numpy(), np.float32), np.ascontiguousarray(x2.numpy(), np.float32)
+        bs, n, m = a.shape[0], a.shape[1], b.shape[1]
+        d1, i1 = np.zeros((bs, n), np.float32), np.zeros((bs, n), np.int32)
+        d2, i2 = np.zeros((bs, m), np.float32), np.zeros((bs, m), np.int32)
+        lib.ref_cd_nnsearch(bs, n, m, a.ctypes.data_as(vp), b.ctypes.data_as(vp), d1.ctypes.data_as(vp), i1.ctypes.data_as(vp))
+        lib.ref_cd_nnsearch(bs, m, n, b.ctypes.data_as(vp), a.ctypes.data_as(vp), d2.ctypes.data_as(vp), i2.ctypes.data_as(vp))
+        return torch.from_numpy(d1), torch.from_numpy(d2)
+
+    pkg = types.ModuleType("ref_metrics")
+    pkg.__path__ = [os.path.join(REF, "utils", "metrics")]
+    sys.modules["ref_metrics"] = pkg
+    dist = types.ModuleType("ref_metrics.distance")
+    dist.chamfer_distance, dist.earth_mover_distance = chamfer_distance, None
+    sys.modules["ref_metrics.distance"] = dist
+    spec = importlib.util.spec_from_file_location("ref_metrics.cov_mmd_1nna",
+                                                  os.path.join(REF, "utils", "metrics", "cov_mmd_1nna.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_metrics.cov_mmd_1nna"] = mod
+    spec.loader.exec_module(mod)
+
+    torch.manual_seed(51)
+    d = {"meta/torch": np.array(torch.__version__)}
+    # crafted matrices: random, then quantised so that minima tie
+    for tag, (nr, ng, quant) in {"rand": (9, 7, None), "ties": (8, 8, 0.25), "wide": (5, 12, 0.5)}.items():
+        def sym(n):
+            M = torch.rand(n, n)
+            M = (M + M.t()) / 2
+            M.fill_diagonal_(0.0)
+            return M
+        M_rr, M_gg, M_rg = sym(nr), sym(ng), torch.rand(nr, ng)
+        if quant:
+            M_rr, M_gg, M_rg = [(M / quant).round() * quant for M in (M_rr, M_gg, M_rg)]
+        d[f"mat/{tag}/M_rr"], d[f"mat/{tag}/M_rg"], d[f"mat/{tag}/M_gg"] = M_rr.numpy(), M_rg.numpy(), M_gg.numpy()
+        for k, v in mod._compute_cov_mmd(M_rg).items():
+            d[f"mat/{tag}/covmmd/{k}"] = np.array(v, np.float64)
+        for kk, sq in ((1, False), (3, False), (1, True)):
+            for k, v in mod._compute_nna(M_rr, M_rg, M_gg, k=kk, sqrt=sq).items():
+                d[f"mat/{tag}/nna_k{kk}_sqrt{int(sq)}/{k}"] = np.array(v, np.float64)
+    # end to end on clouds (two populations of different spread, a few duplicates across the sets)
+    pcs_ref = torch.randn(12, 96, 3) * 0.30
+    pcs_gen = torch.randn(10, 96, 3) * 0.22 + 0.05
+    pcs_gen[0] = pcs_ref[3]
+    d["pcs_ref"], d["pcs_gen"] = pcs_ref.numpy(), pcs_gen.numpy()
+    res = mod.compute_cov_mmd_1nna(pcs_gen, pcs_ref, 5, ("cd",), verbose=False)  # (batch 5: a ragged last batch)
+    for k, v in res.items():
+        d[f"e2e/{k}"] = np.array(v, np.float64)
+    for tag, (a, b) in {"M_rr": (pcs_ref, pcs_ref), "M_rg": (pcs_ref, pcs_gen), "M_gg": (pcs_gen, pcs_gen)}.items():
+        d[f"e2e_mat/{tag}"] = mod._pairwise_distance(a, b, 5, ("cd",), verbose=False)["cd"].numpy()
+    path = os.path.join(HERE, "covmmd.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB", {k: round(v, 4) for k, v in res.items()})
+
+
+def make_full_golden(name="full_dusty2", arch="dusty2", seed=20261, B=2, shape=(64, 1024), in_ch=512, ch_base=64,
+                     ch_max=512):
+    """One step of the REFERENCE's modules at the benchmark's full width (BASELINE configs 2-4: 64x1024, 512 latent,
+    channels 64..512; dusty2 = the superset of the three archs), B = 2.  Parameters and inputs come from torch's CPU
+    generator (tests/golden_util.full_inputs - regenerated identically on the checking side) and are LOADED into the
+    reference's modules; the Gumbel noise is injected through the reference's own `GumbelSigmoid.fixed_noise` attribute;
+    DiffAugment's draws are captured by replay as in make_step_golden.  Stored:
+    digests (golden_util.digest) of every output, logit, augmented image, R1 gradient, parameter gradient and updated
+    parameter, plus the scalars."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.golden_util import digest, full_inputs
+    H, W = shape
+    Gp, Dp, pol, mask_b, z, u = full_inputs(arch, in_ch, ch_base, ch_max, shape, B, seed)
+    cfg = make_cfg(arch, in_ch, ch_base, ch_max, list(shape), True)
+    torch.manual_seed(seed)
+    G, D, G_ema = models.define_G(cfg), models.define_D(cfg), models.define_G(cfg)
+    G.load_state_dict(Gp)
+    sdD = D.state_dict()
+    sdD.update(Dp)
+    D.load_state_dict(sdD)
+    G_ema.eval()
+    ema_inplace(G_ema, G, 0.0)
+    A = diff_augment.DiffAugment(policy=None)
+    crit = GANLoss("nsgan")
+    lr, b1, b2 = 0.002, 0.0, 0.99
+    optG = torch.optim.Adam(G.parameters(), lr=lr, betas=(b1, b2))
+    optD = torch.optim.Adam(D.parameters(), lr=lr, betas=(b1, b2))
+    decay = 0.5 ** (B / (10 * 1000))
+    lidar = _load_lidar()
+    data = {"meta/arch": np.array(arch), "meta/shape": np.array(shape), "meta/in_ch": np.array(in_ch),
+            "meta/ch_base": np.array(ch_base), "meta/ch_max": np.array(ch_max), "meta/B": np.array(B),
+            "meta/seed": np.array(seed), "meta/lr": np.array(lr), "meta/ema_decay": np.array(decay),
+            "meta/torch": np.array(torch.__version__)}
+
+    def put(key, t):
+        data[f"{key}/stats"], data[f"{key}/sample"] = digest(t)
+
+    inv = lidar.Coordinate.invert_depth(Cfg(min_depth=0.9, max_depth=120.0,
+                                            denormalize_minmax=lidar.Coordinate.denormalize_minmax,
+                                            normalize_minmax=lidar.Coordinate.normalize_minmax), pol)
+    m = mask_b.float()
+    x_real = m * (inv * 2.0 - 1.0) + (1 - m) * (-1.0)
+    put("x_real", x_real)
+
+    # Gumbel noise through the reference's own injection point: GumbelSigmoid.forward adds `fixed_noise` instead of drawing
+    # when the attribute is set (models/dusty.py:45-50, the hook utils/__init__.py:141-149 uses for evaluation); the noise
+    # is the module's own formula (:33-36) applied to the regenerable uniforms
+    eps = 1e-10
+    ln = lambda u1, u2: -torch.log(torch.log(u1 + eps) / torch.log(u2 + eps) + eps)
+    G.gumbel_pixel.fixed_noise = ln(u[0], u[1])
+    G.gumbel_image.fixed_noise = ln(u[2], u[3])
+    G.train()
+    synth = G(latent=z)
+    for k, v in synth.items():
+        put(f"synth/{k}", v)
+    x_real_aug, rp0 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
+    x_real_aug = x_real_aug.detach().requires_grad_()
+    x_fake_aug, rp1 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
+    x_fake_aug = x_fake_aug.detach()
+    put("x_real_aug", x_real_aug)
+    put("x_fake_aug", x_fake_aug)
+    y_real, y_fake = D(x_real_aug), D(x_fake_aug)
+    data["y_real"], data["y_fake"] = y_real.detach().numpy().copy(), y_fake.detach().numpy().copy()
+    sc = {"loss/D/output/real": y_real.mean().item(), "loss/D/output/fake": y_fake.mean().item()}
+    loss_gan = crit(y_real, y_fake, "D")
+    sc["loss/D/adversarial"] = loss_gan.item()
+    (grads,) = torch.autograd.grad(outputs=y_real.sum(), inputs=[x_real_aug], create_graph=True, only_inputs=True)
+    r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
+    sc["loss/D/gradient_penalty"] = r1.item()
+    loss_D = loss_gan + 0.5 * r1 + 0.0 * y_real.squeeze()[0]
+    put("r1_grads", grads)
+    optD.zero_grad(set_to_none=True)
+    loss_D.backward()
+    for k, p in D.named_parameters():
+        put(f"grad_D/{k}", p.grad)
+    optD.step()
+    for p in D.parameters():
+        p.requires_grad = False
+    optG.zero_grad(set_to_none=True)
+    _, rp2 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
+    x_fake_aug2, rp3 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
+    y_fake2 = D(x_fake_aug2)
+    data["y_fake2"] = y_fake2.detach().numpy().copy()
+    loss_gan_g = crit(None, y_fake2, "G")
+    sc["loss/G/adversarial"] = loss_gan_g.item()
+    loss_gan_g.backward()
+    for k, p in G.named_parameters():
+        put(f"grad_G/{k}", p.grad)
+    optG.step()
+    ema_inplace(G_ema, G, decay)
+    for tag, mod in (("G", G), ("D", D), ("G_ema", G_ema)):
+        for k, v in mod.state_dict().items():
+            put(f"after/{tag}/{k}", v)
+    for j, rp in enumerate((rp0, rp1, rp2, rp3)):
+        for k, v in rp.items():
+            data[f"aug{j}/{k}"] = v.numpy()
+    for k, v in sc.items():
+        data[f"scalar/{k}"] = np.array(v, dtype=np.float64)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **data)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB", sc)
+
+
 def make_pl_goldens():
     """path-length regularisation on (solver.loss.pl = 2, the value commented in configs/solver/nsgan_eqlr.yaml:21), two
     steps so the running baseline pl_ema is exercised; B = 4 -> B_pl = 2"""
@@ -463,6 +636,13 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["metrics"]:
         make_metrics_golden()
         sys.exit(0)
+    if sys.argv[1:] == ["covmmd"]:
+        make_covmmd_golden()
+        sys.exit(0)
+    if sys.argv[1:] == ["full"]:
+        torch.set_num_threads(8)
+        make_full_golden()
+        sys.exit(0)
     if sys.argv[1:] == ["lidar"]:
         make_lidar_golden()
         sys.exit(0)
@@ -482,3 +662,5 @@ if __name__ == "__main__":
     make_pl_goldens()
     make_lidar_golden()
     make_metrics_golden()
+    make_covmmd_golden()
+    make_full_golden()

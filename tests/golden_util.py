@@ -50,3 +50,59 @@ def step_rand(npz, it):
 
 def meta_pl(npz):
     return float(npz["meta/pl"]) if "meta/pl" in npz.files else 0.0
+
+
+# ---------------------------------------------------------------- full-width pin (tests/golden/full_dusty2.npz)
+# At 64x1024 / 512 channels the parameters alone are 280 MB, so the fixture holds DIGESTS of what the reference computed
+# (three float64 statistics + a strided sample of <= 2048 elements per tensor) and the seeds from which both sides
+# regenerate bit-identical parameters and inputs with torch's CPU generator (torch version recorded in the file).
+FULL_SAMPLE = 2048
+
+
+def digest(t):
+    """(stats [sum, sum |x|, l2 norm] float64, strided sample float32) of a tensor"""
+    f = torch.as_tensor(t).detach().flatten()
+    d = f.to(torch.float64)
+    stride = max(1, f.numel() // FULL_SAMPLE)
+    return (np.array([float(d.sum()), float(d.abs().sum()), float(d.norm())], dtype=np.float64),
+            f[::stride][:FULL_SAMPLE].to(torch.float32).numpy().copy())
+
+
+def full_inputs(arch, in_ch, ch_base, ch_max, shape, B, seed):
+    """parameters (the reference's state_dict layout, N(0,1) / zero bias = EqualLR's init, models/ops/common.py:128-130),
+    one batch, the latent and the Gumbel noise of the full-width case, from torch's CPU generator seeded `seed`"""
+    from oracle import dusty_oracle as O
+    gen = torch.Generator().manual_seed(int(seed))
+    H, W = shape
+    G = O.init_G(f"{arch}/dcgan_eqlr", in_ch, ch_base, ch_max, shape, gen)
+    D = O.init_D(1, ch_base, ch_max, shape, gen)
+    pol = torch.rand(B, 1, H, W, generator=gen)
+    mask = torch.rand(B, 1, H, W, generator=gen) > 0.15
+    pol = pol * mask
+    z = torch.randn(B, in_ch, generator=gen)
+    u = [torch.rand(B, 1, H, W, generator=gen) for _ in range(2)] + [torch.rand(B, 1, 1, 1, generator=gen) for _ in range(2)]
+    return G, D, pol, mask, z, u
+
+
+def check_digest(npz, key, t, tol, what=""):
+    """hold tensor `t` to the digest stored under `key`: l2 norm and sum |x| within `tol` relative, the sum within `tol` of
+    sum |x|, the strided sample within `tol` relative L2"""
+    stats, sample = digest(t)
+    ref_stats, ref_sample = npz[f"{key}/stats"], npz[f"{key}/sample"]
+    scale = max(float(ref_stats[1]), 1e-30)
+    assert abs(stats[0] - ref_stats[0]) <= tol * scale, (what, key, "sum", stats[0], ref_stats[0])
+    assert abs(stats[1] - ref_stats[1]) <= tol * scale, (what, key, "abs sum", stats[1], ref_stats[1])
+    assert abs(stats[2] - ref_stats[2]) <= tol * max(float(ref_stats[2]), 1e-30), (what, key, "norm", stats[2], ref_stats[2])
+    err = rel_l2(sample, ref_sample)
+    assert err <= tol, (what, key, "sample", err)
+
+
+def full_case(npz):
+    """regenerated inputs of the full-width fixture: (G, D, x-side tensors, rand bundle)"""
+    from oracle import dusty_oracle as O
+    arch, shape = str(npz["meta/arch"]), tuple(int(v) for v in npz["meta/shape"])
+    G, D, pol, mask, z, u = full_inputs(arch, int(npz["meta/in_ch"]), int(npz["meta/ch_base"]), int(npz["meta/ch_max"]),
+                                        shape, int(npz["meta/B"]), int(npz["meta/seed"]))
+    rand = {"z": z, "noise": {"pixel": O.logistic_noise(u[0], u[1]), "image": O.logistic_noise(u[2], u[3])},
+            "aug": [sub(npz, f"aug{j}") for j in range(4)]}
+    return G, D, pol, mask, rand

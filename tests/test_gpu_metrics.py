@@ -87,6 +87,32 @@ def test_cov_mmd_1nna_matches_oracle():
         compute_cov_mmd_1nna(torch.from_numpy(gen).to(DEV), torch.from_numpy(ref).to(DEV), 512, ("swd",))
 
 
+def test_cov_mmd_1nna_matches_the_reference_functions():
+    """`utils.metrics.compute_cov_mmd_1nna`, `_compute_cov_mmd`, `_compute_nna` (device tensors, the all-pairs Chamfer
+    kernel) against tests/golden/covmmd.npz: the outputs of the reference's own functions (cov_mmd_1nna.py:55-148) with its
+    own CPU Chamfer search underneath.  Parity-unpinned and staying so: furthest point sampling and the EMD, which the
+    reference holds only as CUDA sources (their tests compare against restatements of those sources)."""
+    from tests.golden_util import load, sub
+    from dusty_gan_amd.utils.metrics import compute_cov_mmd_1nna
+    from dusty_gan_amd.utils.metrics.cov_mmd_1nna import _compute_cov_mmd, _compute_nna
+    from dusty_gan_amd.utils.metrics.distance import chamfer_distance_matrix
+    g = load("covmmd")
+    for tag in ("rand", "ties", "wide"):
+        M_rr, M_rg, M_gg = (torch.from_numpy(g[f"mat/{tag}/{k}"]).to(DEV) for k in ("M_rr", "M_rg", "M_gg"))
+        for k, v in _compute_cov_mmd(M_rg).items():
+            assert abs(v - float(g[f"mat/{tag}/covmmd/{k}"])) <= 1e-6, (tag, k)
+        for kk, sq in ((1, False), (3, False), (1, True)):
+            for k, v in _compute_nna(M_rr, M_rg, M_gg, k=kk, sqrt=sq).items():
+                assert abs(v - float(g[f"mat/{tag}/nna_k{kk}_sqrt{int(sq)}/{k}"])) <= 1e-6, (tag, kk, sq, k)
+    ref, gen = torch.from_numpy(g["pcs_ref"]).to(DEV), torch.from_numpy(g["pcs_gen"]).to(DEV)
+    assert rel_l2(chamfer_distance_matrix(ref, gen).cpu(), g["e2e_mat/M_rg"]) < 1e-5
+    got = compute_cov_mmd_1nna(gen, ref, 5, ("cd",), verbose=False)
+    want = sub(g, "e2e", as_torch=False)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert abs(got[k] - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (k, got[k], float(v))
+
+
 @pytest.mark.parametrize("n,m", [(64, 64), (200, 200), (96, 32), (50, 150)])
 def test_emd_matches_oracle(n, m):
     """approxmatch + matchcost (earth_mover_distance.cu) fused: paired costs and the all-pairs matrix against the numpy

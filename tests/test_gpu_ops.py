@@ -188,6 +188,74 @@ def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     assert rel_l2(dw.cpu().view(4, 4, Ci, Co).permute(2, 3, 0, 1), gw) < tol
 
 
+@pytest.mark.parametrize("force", [2, 7, 8], ids=["auto", "tap-pairs", "single-taps"])
+@pytest.mark.parametrize("wmode,Ci,Co,H,W", [(0, 128, 128, 4, 128), (1, 128, 64, 4, 64), (0, 64, 128, 8, 64)])
+def test_wgrad_workspace_and_sample_map(L, wmode, Ci, Co, H, W, force):
+    """The LDS-DMA weight-gradient kernel's split-K workspace form (DgWgrad.ws + dg_wgrad_reduce) and its gradient-sample
+    index map (DgWgrad.g_mod) against the register-staged kernel with atomics (force 6, itself held to autograd above):
+      (a) workspace partials, reduce adding onto a pre-filled dW == atomics onto the same dW;
+      (b) deferred: two layers' partials summed by ONE reduce launch;
+      (c) one launch over 3n input samples with g sample = b % 2n and per-sample weights == the two launches it replaces
+          (the D phase's ordinary + R1 weight gradients, trainers/dcgan_amp.py:229-235).
+    W-tap pairs forced / forbidden / chosen (force 7 / 8 / 2)."""
+    from dusty_gan_amd import engine as E
+    g = torch.Generator().manual_seed(wmode * 7 + Ci + W)
+    n = 2
+    fa, fg = (4, 1) if wmode == 0 else (1, 4)
+    a = torch.randn(3 * n * fa * H * W * Ci, generator=g).to(DEV, torch.bfloat16)
+    e = torch.randn(2 * n * fg * H * W * Co, generator=g).to(DEV, torch.bfloat16)
+    rs = (torch.rand(3 * n, generator=g) + 0.5).to(DEV)
+    rs[2 * n:] = 1.0
+    sa, sg = (fa * H * W * Ci, Ci, 1), (fg * H * W * Co, Co, 1)
+    base = torch.randn(16, Ci, Co, generator=g).to(DEV)
+    ref_o, o = E.Ops(torch.bfloat16), E.Ops(torch.bfloat16)
+    ref_o.force, ref_o.use_ws, o.force = 6, False, force
+
+    def ref(B, a_off, rowscale):
+        dw = base.clone()
+        ref_o.wgrad(wmode, True, B, H, W, Ci, Co, a, sa, e, sg, dw.data_ptr(), 0.05, rowscale=rowscale, a_off=a_off)
+        return dw
+    want2 = ref(2 * n, 0, rs[:2 * n].contiguous())
+    # (a) immediate reduce, accumulate onto a pre-filled dW
+    E.TRACE = []
+    try:
+        dw = base.clone()
+        o.wgrad(wmode, True, 2 * n, H, W, Ci, Co, a, sa, e, sg, dw.data_ptr(), 0.05, rowscale=rs[:2 * n].contiguous())
+        tr = [t for t in E.TRACE if t[0] == "wgrad"][0]
+    finally:
+        E.TRACE = None
+    assert tr[1] == 5 and tr[5] and tr[3] >= 1, tr                     # LDS-DMA kernel, workspace in use
+    assert (tr[4] == 1) == (force == 7) or force == 2, tr               # tap pairs as forced
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu() - base.cpu(), want2.cpu() - base.cpu()) < 1e-5
+    # the same launch through atomics (no workspace) still works
+    o_at = E.Ops(torch.bfloat16)
+    o_at.force, o_at.use_ws = force, False
+    dwa = base.clone()
+    o_at.wgrad(wmode, True, 2 * n, H, W, Ci, Co, a, sa, e, sg, dwa.data_ptr(), 0.05, rowscale=rs[:2 * n].contiguous())
+    torch.cuda.synchronize()
+    assert rel_l2(dwa.cpu() - base.cpu(), want2.cpu() - base.cpu()) < 1e-5
+    # (b) deferred: two launches into different gradients, one reduce
+    d1, d2 = base.clone(), torch.zeros_like(base)
+    o.wgrad(wmode, True, 2 * n, H, W, Ci, Co, a, sa, e, sg, d1.data_ptr(), 0.05, rowscale=rs[:2 * n].contiguous(), defer=True)
+    o.wgrad(wmode, True, n, H, W, Ci, Co, a, sa, e, sg, d2.data_ptr(), 0.05, a_off=2 * n * sa[0], defer=True)
+    assert len(E.WGRAD_WS.items) == 2
+    E.WGRAD_WS.flush()
+    torch.cuda.synchronize()
+    want_t = ref(n, 2 * n * sa[0], None) - base
+    assert rel_l2(d1.cpu() - base.cpu(), want2.cpu() - base.cpu()) < 1e-5
+    assert rel_l2(d2.cpu(), want_t.cpu()) < 1e-5
+    # (c) the merged launch: 3n input samples, gradient sample b % 2n
+    assert o.wgrad_takes_map(wmode, True, 3 * n, H, W, Ci, Co, a, sa, e, sg, base.data_ptr())
+    dm = torch.zeros_like(base)
+    o.wgrad(wmode, True, 3 * n, H, W, Ci, Co, a, sa, e, sg, dm.data_ptr(), 0.05, rowscale=rs, g_mod=2 * n)
+    torch.cuda.synchronize()
+    assert rel_l2(dm.cpu(), (want2 - base + want_t).cpu()) < 1e-5
+    # kernels without the map refuse it instead of ignoring it
+    with pytest.raises(L.DgError):
+        ref_o.wgrad(wmode, True, 3 * n, H, W, Ci, Co, a, sa, e, sg, dm.data_ptr(), 0.05, g_mod=2 * n)
+
+
 @pytest.mark.parametrize("dtype,force,B,nz,C3", [(torch.float32, 1, 3, 5, 6), (torch.float32, 2, 5, 64, 64),
                                                  (torch.bfloat16, 2, 32, 128, 64)])
 def test_proj_gemm_and_wgrad(L, dtype, force, B, nz, C3):

@@ -117,13 +117,25 @@ def oracle_state(tr):
     return G, D
 
 
-def run_both(arch, shape, in_ch, ch_base, ch_max, B, amp, steps=1, seed=0, pl=0.0):
+def sync_D(tr, D):
+    """give the engine the oracle's discriminator (parameters only; the BlurVH kernels are buffers of the module)"""
+    sd = tr.D.state_dict()
+    sd.update({k: v.detach().clone() for k, v in D.items()})
+    tr.D.load_state_dict(sd)
+
+
+def run_both(arch, shape, in_ch, ch_base, ch_max, B, amp, steps=1, seed=0, pl=0.0, emulate=False, sync=False):
+    """One trainer and the oracle on the same parameters, batches and randomness.
+    emulate: the oracle rounds to bf16 where the engine's bf16 mode stores bf16 (oracle `_Emu`).
+    sync:    between the two phases the engine takes over the ORACLE's updated discriminator, so that both G phases
+             differentiate the same D (the first Adam step at beta1 = 0 is lr * sign(g): D weights whose gradient is
+             rounding noise otherwise land 2 lr apart in the two implementations and the G gradients inherit it)."""
     torch.manual_seed(4321 + seed)  # the nets draw their N(0,1) init from torch's global generator
     tr = make_trainer(arch, True, shape, in_ch, ch_base, ch_max, B, amp=amp, pl=pl)
     G, D = oracle_state(tr)
     G_ema = {k: v.clone() for k, v in G.items()}
     oG, oD = O.new_optim_state(G), O.new_optim_state(D)
-    cfg = O.StepConfig(arch=arch, ema_decay=tr.ema_decay, w_pl=pl)
+    cfg = O.StepConfig(arch=arch, ema_decay=tr.ema_decay, w_pl=pl, emulate_bf16=emulate)
     pl_ema = torch.tensor(0.0)
     gen = torch.Generator().manual_seed(seed)
     H, W = shape
@@ -150,6 +162,9 @@ def run_both(arch, shape, in_ch, ch_base, ch_max, B, amp, steps=1, seed=0, pl=0.
         tr.optimize_D(reals=[(x_real, m_real)], rands=[rand])
         synth = {k: v.detach().cpu().clone() for k, v in tr._mb[0]["synth"].items()}
         gD = grads_by_name(tr.optim_D)
+        if sync:
+            ex["D_engine_after"] = {k: v.detach().cpu().clone() for k, v in tr.D.state_dict().items()}
+            sync_D(tr, D)
         scal = tr.optimize_G().cpu().tolist()
         gG = grads_by_name(tr.optim_G)
         res.append((sc_ref, ex, synth, gD, gG, scal))
@@ -355,6 +370,35 @@ def test_graph_replay_matches_eager_launches(monkeypatch, gan_mode):
     for x, y in zip(sa, sb):
         for k in x:
             assert abs(x[k] - y[k]) < 1e-4 * max(1.0, abs(y[k])), k
+
+
+def test_eager_draw_between_graph_replays(monkeypatch):
+    """An eager draw from the trainer's generator between two steps (validation() / generate() call sample_latents)
+    queues its counter advance on the host; the replayed graph reads the DEVICE counter.  The advance must be applied
+    before the capture and before every replay: otherwise the step re-draws the evaluation latents (stale counter) and,
+    when the advance is pending at capture time, bakes it into the graph.  Same seeds, same interleaving -> the graph run
+    draws exactly what the eager run draws."""
+    def run(graph):
+        monkeypatch.setenv("DUSTY_GAN_GRAPH", "1" if graph else "0")
+        torch.manual_seed(77)
+        tr = make_trainer("none", True, (32, 64), 8, 4, 16, 4)
+        zs, evs = [], []
+        for i in range(7):
+            if i >= 2:  # i == 2: pending at capture time; i >= 3: pending before a replay
+                evs.append(tr.sample_latents(4).clone())
+            tr.step(i)
+            zs.append(tr._g_engines()[0].zT.float().view(4, -1).clone())
+            if i >= 2:
+                assert not torch.equal(zs[-1], evs[-1]), i  # the step did not re-draw the evaluation latents
+        assert (tr._graph is not None) == graph
+        return tr, zs, evs
+    a, za, ea = run(True)
+    b, zb, eb = run(False)
+    for i, (x, y) in enumerate(zip(za, zb)):
+        assert torch.equal(x, y), i
+    for x, y in zip(ea, eb):
+        assert torch.equal(x, y)
+    assert a.rng.offset == b.rng.offset and a.A._rng.offset == b.A._rng.offset
 
 
 def test_graph_replay_survives_host_sync():

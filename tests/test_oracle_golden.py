@@ -350,3 +350,72 @@ def test_chamfer_oracle_pinned_by_the_reference_nnsearch():
                 dl, _ = ref_nnsearch(A[i][None], B[i][None])
                 dr, _ = ref_nnsearch(B[i][None], A[i][None])
                 assert abs(M[i, i] - (dl.mean() + dr.mean())) <= 1e-6 * max(1.0, abs(M[i, i]))
+
+
+def test_oracle_matches_reference_at_full_width():
+    """The benchmark's width - 64x1024, 512 latent, channels 64..512 (BASELINE configs 2-4), dusty2, B = 2, one step -
+    as the REFERENCE's modules computed it (tests/golden/make_golden.py full): parameters and inputs are regenerated
+    from the fixture's seed (280 MB of weights do not fit a fixture), the expectations are digests - three float64
+    statistics and a strided 2048-element sample per tensor - of every output, logit, R1 gradient, parameter gradient
+    and updated parameter.  Pins oracle == reference beyond the toy nets of the step_* fixtures."""
+    from tests.golden_util import check_digest, full_case
+    g = load("full_dusty2")
+    if str(g["meta/torch"]) != torch.__version__:
+        pytest.skip(f"fixture made with torch {g['meta/torch']}: the regenerated inputs need the same CPU generator")
+    G, D, pol, mask, rand = full_case(g)
+    G_ema = {k: v.clone() for k, v in G.items()}
+    x_real, _ = O.fetch_reals(pol, mask)
+    check_digest(g, "x_real", x_real, 1e-6)
+    cfg = O.StepConfig(arch=str(g["meta/arch"]), ema_decay=float(g["meta/ema_decay"]))
+    sc, ex = O.train_step(G, D, G_ema, O.new_optim_state(G), O.new_optim_state(D), 1, cfg, x_real, rand,
+                          return_grads=True)
+    for k, v in sub(g, "scalar").items():
+        assert abs(sc[k] - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (k, sc[k], float(v))
+    tol = 1e-4
+    for k, v in ex["synth"].items():
+        if k == "mask":
+            from tests.golden_util import digest
+            stats, sample = digest(v)
+            assert abs(stats[0] - g["synth/mask/stats"][0]) <= 2, "hard masks differ in more than two pixels"
+            assert (sample != g["synth/mask/sample"]).mean() <= 1e-3
+        else:
+            check_digest(g, f"synth/{k}", v, tol)
+    for key in ("x_real_aug", "x_fake_aug"):
+        check_digest(g, key, ex[key], tol)
+    check_digest(g, "r1_grads", ex["r1_grads"], tol)
+    for key in ("y_real", "y_fake", "y_fake2"):
+        assert rel_l2(ex[key], g[key]) <= tol, key
+    for k, v in ex["grad_D"].items():
+        check_digest(g, f"grad_D/{k}", v, tol, "grad_D")
+    for k, v in ex["grad_G"].items():
+        check_digest(g, f"grad_G/{k}", v, tol, "grad_G")
+    for tag, net in (("G", G), ("D", D), ("G_ema", G_ema)):
+        for k, v in net.items():
+            check_digest(g, f"after/{tag}/{k}", v, tol, tag)
+
+
+def test_cov_mmd_1nna_oracle_pinned_by_the_reference_functions():
+    """oracle/metrics_oracle.py `cov_mmd`, `nna` and `compute_cov_mmd_1nna` against what the reference's own
+    `_compute_cov_mmd` / `_compute_nna` / `compute_cov_mmd_1nna` (utils/metrics/cov_mmd_1nna.py:55-148, loaded by path, its
+    Chamfer distance = its own CPU `nnsearch`) returned: tests/golden/covmmd.npz, made by make_golden.py covmmd.  Crafted
+    matrices with ties, k = 1 and 3, sqrt on and off; then clouds end to end incl. the three pairwise matrices.
+    (FPS and EMD exist in the reference only as CUDA sources - furthest_point_sampling.cu, earth_mover_distance.cu - and
+    stay parity-unpinned: their oracles are restatements of those sources with no reference-made vector.)"""
+    from oracle import metrics_oracle as MO
+    g = load("covmmd")
+    for tag in ("rand", "ties", "wide"):
+        M_rr, M_rg, M_gg = (torch.from_numpy(g[f"mat/{tag}/{k}"]) for k in ("M_rr", "M_rg", "M_gg"))
+        for k, v in MO.cov_mmd(M_rg).items():
+            assert abs(v - float(g[f"mat/{tag}/covmmd/{k}"])) <= 1e-6, (tag, k)
+        for kk, sq in ((1, False), (3, False), (1, True)):
+            for k, v in MO.nna(M_rr, M_rg, M_gg, k=kk, sqrt=sq).items():
+                assert abs(v - float(g[f"mat/{tag}/nna_k{kk}_sqrt{int(sq)}/{k}"])) <= 1e-6, (tag, kk, sq, k)
+    ref, gen = g["pcs_ref"], g["pcs_gen"]
+    assert rel_l2(MO.pairwise_cd(ref, gen), g["e2e_mat/M_rg"]) < 1e-6
+    assert rel_l2(MO.pairwise_cd(ref, ref), g["e2e_mat/M_rr"]) < 1e-6
+    assert rel_l2(MO.pairwise_cd(gen, gen), g["e2e_mat/M_gg"]) < 1e-6
+    got = MO.compute_cov_mmd_1nna(gen, ref)
+    want = sub(g, "e2e", as_torch=False)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert abs(got[k] - float(v)) <= 1e-6 * max(1.0, abs(float(v))), (k, got[k], float(v))
