@@ -57,6 +57,11 @@ class DgWgrad(C.Structure):
     ]
 
 
+class DgAugSet(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("xsum", C.c_void_p), ("u_b", C.c_void_p), ("u_c", C.c_void_p), ("t_h", C.c_void_p),
+                ("t_w", C.c_void_p), ("o_x", C.c_void_p), ("o_y", C.c_void_p)]
+
+
 class DgWgradPlan(C.Structure):
     _fields_ = [("variant", C.c_int), ("splits", C.c_int), ("ws_floats", C.c_long), ("tap_pairs", C.c_int)]
 
@@ -101,6 +106,10 @@ PROTOTYPES = {
     "dg_diffaug_fwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_fwd_pre": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_diffaug_blur_fwd": [C.POINTER(DgAugSet), _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "dg_blur_bwd_augsum": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "dg_diffaug_bwd_pre": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_fetch_reals_pool_sum": [_P, _P, _P, _I, _F, _F, _F, _I, _L, _P, _P, _P],
     "dg_nsgan_d": [_P, _P, _I, _F, _P, _P, _P, _P],
     "dg_nsgan_g": [_P, _I, _F, _P, _P, _P],
     "dg_nsgan_d_step": [_P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
@@ -128,6 +137,7 @@ PROTOTYPES = {
     "dg_sample_sum_acc": [_P, _I, _L, _I, _P, _P],
     "dg_scale": [_P, _F, _L, _P, _P],
     "dg_zero": [_P, _L, _P],
+    "dg_zero_multi": [_P, _P, _I, _P],
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dg_cast": [_P, _P, _I, _L, _P],
     "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
@@ -210,6 +220,19 @@ def zero_(t):
     return t
 
 
+def zero_multi(tensors):
+    """zero-fill up to 4 contiguous fp32 tensors (numel % 4 == 0) in one launch"""
+    import ctypes as C
+    import torch
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    for i in range(0, len(ts), 4):
+        chunk = ts[i:i + 4]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0 for t in chunk)
+        ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+        cnts = (C.c_long * len(chunk))(*[t.numel() for t in chunk])
+        check(lib().dg_zero_multi(ptrs, cnts, len(chunk), stream_ptr()), "dg_zero_multi")
+
+
 class AccArena:
     """Small fp32 accumulators that must start at zero (per-sample sums, logits, the logged scalars), carved from ONE
     buffer that one kernel zero-fills at the start of a training step - instead of one ~5 us zero-fill node per
@@ -225,11 +248,13 @@ class AccArena:
         return dev.type == want.type and (want.index is None or dev.index == want.index)
 
     @classmethod
-    def begin(cls, device):
+    def begin(cls, device, also=()):
+        """open a new epoch: the arena - and the fp32 buffers in `also` (the step's gradient buffers) - zero-filled by
+        one launch"""
         import torch
         if cls.buf is None or not cls._same(cls.buf.device, device):
             cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
-        zero_(cls.buf)
+        zero_multi([cls.buf] + list(also))
         cls.pos = 0
         cls.epoch += 1
 

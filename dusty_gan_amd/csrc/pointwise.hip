@@ -124,14 +124,27 @@ __global__ __launch_bounds__(256) void blur_fwd4_kernel(const float* __restrict_
 // ssq != nullptr (R1): dx = oscale * g and ssq[b] += sum of g^2 over the sample, g = the adjoint's result - the R1
 // penalty's per-sample |g|^2 and its tangent v = (gp / B) g in the pass that makes g.  A block owns `rows_pb` consecutive
 // rows of one sample (one atomic per block).
+// The rows / columns of sample b's augmented image whose gradient reaches the source image (DiffAugment's adjoint sums
+// exactly these: diffaug_bwd_sum_kernel): rows y with 0 <= y + t_h < H, minus the cut-out box.
+struct AugWin { const int *t_h, *o_x, *o_y; int policy, cut_h, cut_w; };
+
+// ssq != nullptr && !win: R1 form (below).  win != nullptr: ssq[b] += sum of g over the sample's window `win` instead
+// (the contrast term of DiffAugment's adjoint) - the pass that makes g also makes the sum its adjoint needs.
 template <typename T>
 __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d, float* __restrict__ dx, int B, int H,
-                                                        int W, int ring, float oscale, float* __restrict__ ssq, int rows_pb) {
+                                                        int W, int ring, float oscale, float* __restrict__ ssq, int rows_pb,
+                                                        AugWin win, int use_win) {
   __shared__ float red[16];
   const int W4 = W >> 2, b = blockIdx.y;
   const long base = (long)b * H * W;
   float ssacc = 0.f;
   const int y0 = blockIdx.x * rows_pb, y1 = y0 + rows_pb < H ? y0 + rows_pb : H;
+  int w_th = 0, w_r0 = 0, w_c0 = 0;
+  if (use_win) {
+    w_th = (win.policy & 8) ? win.t_h[b] : 0;
+    w_r0 = (win.policy & 16) ? win.o_x[b] - win.cut_h / 2 : 0;
+    w_c0 = (win.policy & 16) ? win.o_y[b] - win.cut_w / 2 : 0;
+  }
   for (int y = y0; y < y1; ++y)
   for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
   const int x0 = q4 * 4;
@@ -183,7 +196,15 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
   }
   const float g0 = v[0] + h[0], g1 = v[1] + h[1], g2 = v[2] + h[2], g3 = v[3] + h[3];
   *(float4*)(dx + base + (long)y * W + x0) = make_float4(oscale * g0, oscale * g1, oscale * g2, oscale * g3);
-  ssacc += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
+  if (!use_win) {
+    ssacc += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
+  } else if (y + w_th >= 0 && y + w_th < H) {
+    const bool cutrow = (win.policy & 16) && y >= w_r0 && y < w_r0 + win.cut_h;
+    const float gq[4] = {g0, g1, g2, g3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (!(cutrow && x0 + k >= w_c0 && x0 + k < w_c0 + win.cut_w)) ssacc += gq[k];
+  }
   }
   if (ssq) {
     const float sblk = dg_block_sum(ssacc, red);
@@ -674,6 +695,83 @@ __global__ __launch_bounds__(256) void diffaug_fwd_kernel(AugP a, const float* _
   }
 }
 
+// DiffAugment + BlurVH in one pass (utils/diff_augment.py:114-132 -> models/ops/common.py:74-88): the augmented image is
+// only ever the discriminator's input, so it is never written - every output pixel evaluates the augmentation at its five
+// blur taps straight from the source image.  Up to two source sets in one launch (the D phase's real | fake halves,
+// trainers/dcgan_amp.py:199-204): sample b < a[0].B reads set 0, the rest set 1.  Grid (row, sample), 4 pixels per thread.
+struct AugSrc { AugP a; const float* x; const float* xsum; };
+// The three source rows of an output row go through LDS with 16-byte loads (the translation wraps columns modulo W - 1,
+// so the augmented row is a rotated copy: unaligned - read from LDS, not from global memory, where a first version with
+// 14 scalar gathers per 4 pixels ran no faster than the two kernels it replaced).
+template <typename T>
+__global__ __launch_bounds__(256) void diffaug_blur_fwd_kernel(AugSrc s0, AugSrc s1, T* __restrict__ out, int ring) {
+  extern __shared__ float s_rows[];               // [3][W] source rows (row k of the three: up, centre, down)
+  const int set = (int)blockIdx.y >= s0.a.B;
+  const AugP& a = set ? s1.a : s0.a;
+  const float* x = set ? s1.x : s0.x;
+  const float* xsum = set ? s1.xsum : s0.xsum;
+  const int b = (int)blockIdx.y - (set ? s0.a.B : 0);
+  const int y = blockIdx.x, H = a.H, W = a.W, Wm1 = a.W - 1, W4 = a.W >> 2;
+  const long HW = (long)H * W;
+  int th = 0, tw = 0;
+  if (a.policy & 8) {
+    th = a.t_h[b];
+    tw = a.t_w[b] % Wm1;
+    if (tw < 0) tw += Wm1;
+  }
+  const int r0 = (a.policy & 16) ? a.o_x[b] - a.cut_h / 2 : 0, cl = (a.policy & 16) ? a.o_y[b] - a.cut_w / 2 : 0;
+  float br = 0.f, cc = 1.f, mean = 0.f;
+  if (a.policy & 1) { const float u = a.u_b[b]; br = 0.5f * u * u; }
+  if (a.policy & 4) {
+    const float u = a.u_c[b];
+    cc = 1.f + 0.5f * u * u;
+    mean = xsum[b] / (float)HW + br;
+  }
+  // the three augmented rows of this output row (reflected at the border): source row, validity, cut-out columns
+  const int yr[3] = {y == 0 ? 1 : y - 1, y, y == H - 1 ? H - 2 : y + 1};
+  bool ok[3];
+  int c0[3], c1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int sy = yr[k] + th;
+    ok[k] = sy >= 0 && sy < H;
+    const float* src = x + (long)b * HW + (long)(ok[k] ? sy : 0) * W;
+    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) *(float4*)(s_rows + k * W + q4 * 4) = *(const float4*)(src + q4 * 4);
+    const bool cutrow = (a.policy & 16) && yr[k] >= r0 && yr[k] < r0 + a.cut_h;
+    c0[k] = cutrow ? cl : 0;
+    c1[k] = cutrow ? cl + a.cut_w : 0;
+  }
+  __syncthreads();
+  auto aug = [&](int k, int xx) {                 // augmented image at (row k of the three, column xx)
+    int sx = xx + tw;
+    if (sx >= Wm1) sx -= Wm1;
+    float v = s_rows[k * W + sx] + br;
+    v = mean + cc * (v - mean);
+    return (ok[k] && !(xx >= c0[k] && xx < c1[k])) ? v : 0.f;
+  };
+  T* orow = out + ((long)blockIdx.y * HW + (long)y * W) * 2;
+  for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+    const int x0 = q4 * 4;
+    int xl = x0 - 1, xr = x0 + 4;
+    if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
+    else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
+    const float c[6] = {aug(1, xl), aug(1, x0), aug(1, x0 + 1), aug(1, x0 + 2), aug(1, x0 + 3), aug(1, xr)};
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[2 * k] = 0.25f * aug(0, x0 + k) + 0.5f * c[k + 1] + 0.25f * aug(2, x0 + k);
+      o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
+    }
+    T* op = orow + x0 * 2;
+    if constexpr (sizeof(T) == 2) {
+      Vec16<bf16>::store((bf16*)op, o);
+    } else {
+      *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
 // Backward pass 1: gsum[b] = sum over the augmented image of the gradient that reaches x2 (pre-translation
 // image): every (y,x) not cut out and with a valid source row contributes once.  blockIdx.x strides the rows.
 __global__ __launch_bounds__(256) void diffaug_bwd_sum_kernel(AugP a, const float* __restrict__ gy,
@@ -956,11 +1054,19 @@ __device__ __forceinline__ float fetch_real_px(float pol, float m, float min_d, 
   return m * inv + (1.f - m) * drop_const;
 }
 // xsum != nullptr: per-sample sums of the result, one atomic per block of `chunk` pixels (see head_post_fwd_kernel)
+// pool_ctr != nullptr: `pol` / `mask` are pools of `npool` batches of n pixels and the batch is *pool_ctr % npool (a
+// device-resident loader position: a captured training step replays on the next pooled batch without a copy)
 __global__ __launch_bounds__(256) void fetch_reals_kernel(const float* __restrict__ pol, const float* __restrict__ mask,
                                                           float min_d, float max_d, float drop_const, long n,
                                                           float* __restrict__ out, float* __restrict__ xsum, long HW,
-                                                          int chunk) {
+                                                          int chunk, const unsigned long long* __restrict__ pool_ctr,
+                                                          int npool) {
   __shared__ float red[16];
+  if (pool_ctr) {
+    const long off = (long)(*pool_ctr % (unsigned long long)npool) * n;
+    pol += off;
+    mask += off;
+  }
   if (!xsum) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fetch_real_px(pol[i], mask[i], min_d, max_d, drop_const);
@@ -1007,6 +1113,21 @@ __global__ void dg_zero_kernel(float* __restrict__ p, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
 }
 
+// several buffers in one launch (a step's accumulator arena and gradient buffers: one graph node instead of three)
+struct ZeroItems { float* p[4]; long n[4]; long first[5]; int k; };
+__global__ void dg_zero_multi_kernel(ZeroItems z) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long total = z.first[z.k];
+  for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; 4 * i4 < total; i4 += stride) {
+    const long i = 4 * i4;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (q < z.k && i >= z.first[q]) j = q;
+    *(float4*)(z.p[j] + (i - z.first[j])) = make_float4(0.f, 0.f, 0.f, 0.f);   // (counts are multiples of 4: the launcher pads down)
+  }
+}
+
 int dg_zero_f32(float* p, long n, hipStream_t s) {
   if (n <= 0) return DG_OK;
   unsigned g = nblk(n);
@@ -1017,6 +1138,26 @@ int dg_zero_f32(float* p, long n, hipStream_t s) {
 }
 
 extern "C" {
+
+// k <= 4 fp32 buffers (16-byte aligned, counts multiples of 4) zero-filled by one launch
+int dg_zero_multi(float* const* ptrs, const long* counts, int k, void* s_) {
+  if (!ptrs || !counts || k < 1 || k > 4) return DG_EINVAL;
+  ZeroItems z{};
+  long tot = 0;
+  for (int i = 0; i < k; ++i) {
+    if (!ptrs[i] || counts[i] < 0 || counts[i] % 4 != 0 || ((size_t)ptrs[i] & 15) != 0) return DG_EINVAL;
+    z.p[i] = ptrs[i]; z.n[i] = counts[i]; z.first[i] = tot;
+    tot += counts[i];
+  }
+  z.first[k] = tot;
+  z.k = k;
+  if (tot == 0) return DG_OK;
+  unsigned g = nblk(tot / 4);
+  if (g > 2048) g = 2048;
+  dg_zero_multi_kernel<<<g, 256, 0, (hipStream_t)s_>>>(z);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
 
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* s_) {
   hipStream_t s = (hipStream_t)s_;
@@ -1034,8 +1175,8 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
   if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)d & 15) == 0 && ((size_t)dx & 15) == 0) {
-    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, 1.f, nullptr, 1);
-    else blur_bwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, 1.f, nullptr, 1);
+    if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, 1.f, nullptr, 1, AugWin{}, 0);
+    else blur_bwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>((const float*)d, dx, B, H, W, ring, 1.f, nullptr, 1, AugWin{}, 0);
   } else if (dtype == DG_BF16) blur_bwd_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring);
   else blur_bwd_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)d, dx, B, H, W, ring);
   HIP_CHECK_RET(hipGetLastError());
@@ -1076,8 +1217,8 @@ int dg_blur_bwd_r1(const void* d, int dtype, float* dx, float oscale, float* ssq
     return DG_EUNSUPPORTED;
   const int rows_pb = H % 4 == 0 ? 4 : (H % 2 == 0 ? 2 : 1);    // rows per block = per atomic on ssq[b]
   const dim3 grid((H + rows_pb - 1) / rows_pb, B);
-  if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, oscale, ssq, rows_pb);
-  else blur_bwd4_kernel<float><<<grid, 256, 0, s>>>((const float*)d, dx, B, H, W, ring, oscale, ssq, rows_pb);
+  if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, oscale, ssq, rows_pb, AugWin{}, 0);
+  else blur_bwd4_kernel<float><<<grid, 256, 0, s>>>((const float*)d, dx, B, H, W, ring, oscale, ssq, rows_pb, AugWin{}, 0);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1247,6 +1388,61 @@ int dg_diffaug_fwd_pre(const float* x, const float* u_b, const float* u_c, const
   return DG_OK;
 }
 
+// DiffAugment + BlurVH forward for one or two source sets (set k fills samples [k B, (k + 1) B) of `out`); xsum_k = the
+// per-sample sums of x_k (dg_fetch_reals_sum / dg_head_post_fwd_sum).  DG_EUNSUPPORTED unless W % 4 == 0.
+int dg_diffaug_blur_fwd(const DgAugSet* sets, int nsets, int policy, int B, int H, int W, int ring, void* out, int dtype,
+                        void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!sets || nsets < 1 || nsets > 2 || !out || B <= 0) return DG_EINVAL;
+  if (W % 4 != 0 || W < 8 || H < 2 || ((size_t)out & 15) != 0) return DG_EUNSUPPORTED;
+  for (int k = 0; k < nsets; ++k)
+    if (((size_t)sets[k].x & 15) != 0) return DG_EUNSUPPORTED;       // 16-byte row loads
+  AugSrc src[2];
+  for (int k = 0; k < 2; ++k) {
+    const DgAugSet& q = sets[k < nsets ? k : 0];
+    if (!q.x || ((policy & 4) && !q.xsum)) return DG_EINVAL;
+    src[k].a = make_aug(q.u_b, q.u_c, q.t_h, q.t_w, q.o_x, q.o_y, policy, B, H, W);
+    src[k].x = q.x;
+    src[k].xsum = q.xsum;
+  }
+  const dim3 grid(H, nsets * B);
+  const size_t lds = (size_t)3 * W * sizeof(float);
+  if (lds > 64 * 1024) return DG_EUNSUPPORTED;
+  if (dtype == DG_BF16) diffaug_blur_fwd_kernel<bf16><<<grid, 256, lds, s>>>(src[0], src[1], (bf16*)out, ring);
+  else diffaug_blur_fwd_kernel<float><<<grid, 256, lds, s>>>(src[0], src[1], (float*)out, ring);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// BlurVH adjoint that also accumulates what DiffAugment's adjoint needs from its input: gsum[b] += sum of dx[b] over the
+// rows / columns whose gradient reaches the source image (gsum zeroed by the caller); then dg_diffaug_bwd_pre.
+int dg_blur_bwd_augsum(const void* d, int dtype, float* dx, const int* t_h, const int* o_x, const int* o_y, int policy,
+                       float* gsum, int B, int H, int W, int ring, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!gsum) return DG_EINVAL;
+  if (W % 4 != 0 || W < 8 || H < 2 || ((size_t)d & 15) != 0 || ((size_t)dx & 15) != 0) return DG_EUNSUPPORTED;
+  AugWin w;
+  w.t_h = t_h; w.o_x = o_x; w.o_y = o_y; w.policy = policy;
+  w.cut_h = (int)(H * 0.5 + 0.5); w.cut_w = (int)(W * 0.5 + 0.5);
+  const int rows_pb = H % 4 == 0 ? 4 : (H % 2 == 0 ? 2 : 1);
+  const dim3 grid((H + rows_pb - 1) / rows_pb, B);
+  if (dtype == DG_BF16) blur_bwd4_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)d, dx, B, H, W, ring, 1.f, gsum, rows_pb, w, 1);
+  else blur_bwd4_kernel<float><<<grid, 256, 0, s>>>((const float*)d, dx, B, H, W, ring, 1.f, gsum, rows_pb, w, 1);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// DiffAugment's adjoint with gsum already made (dg_blur_bwd_augsum): the gather pass only
+int dg_diffaug_bwd_pre(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                       const int* o_x, const int* o_y, int policy, int B, int H, int W, const float* gsum, float* gx,
+                       void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  const AugP a = make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W);
+  diffaug_bwd_kernel<<<dim3(H, B), 256, 0, s>>>(a, gy, gsum, gx);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 static int diffaug_bwd_impl(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
                             const int* o_x, const int* o_y, int policy, int B, int H, int W, float* gsum, float* gx,
                             bool zero, void* s_) {
@@ -1291,7 +1487,7 @@ int dg_nsgan_g(const float* y_fake, int B, float w_gan, float* dy, float* scal, 
 int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, long n,
                    float* out, void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  fetch_reals_kernel<<<nblk(n), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, n, out, nullptr, 1, 256);
+  fetch_reals_kernel<<<nblk(n), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, n, out, nullptr, 1, 256, nullptr, 1);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -1303,7 +1499,20 @@ int dg_fetch_reals_sum(const float* pol, const float* mask, float min_depth, flo
   if (HW % 256 != 0) return DG_EUNSUPPORTED;
   const int chunk = sum_chunk(HW);
   fetch_reals_kernel<<<nblk((long)B * HW, chunk), 256, 0, s>>>(pol, mask, min_depth, max_depth, drop_const, (long)B * HW, out,
-                                                                xsum, HW, chunk);
+                                                                xsum, HW, chunk, nullptr, 1);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+// ... from a device-resident pool of `npool` batches: batch index = *pool_ctr % npool, read on the device
+int dg_fetch_reals_pool_sum(const float* pol_pool, const float* mask_pool, const unsigned long long* pool_ctr, int npool,
+                            float min_depth, float max_depth, float drop_const, int B, long HW, float* out, float* xsum,
+                            void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!xsum || !pool_ctr || npool < 1) return DG_EINVAL;
+  if (HW % 256 != 0) return DG_EUNSUPPORTED;
+  const int chunk = sum_chunk(HW);
+  fetch_reals_kernel<<<nblk((long)B * HW, chunk), 256, 0, s>>>(pol_pool, mask_pool, min_depth, max_depth, drop_const,
+                                                                (long)B * HW, out, xsum, HW, chunk, pool_ctr, npool);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

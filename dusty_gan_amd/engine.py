@@ -675,11 +675,37 @@ class DEngine:
         lrelu masks gate the R1 tangent pass (then no bias, no activation: the Jacobian-vector product)."""
         c, o, lib = self.cfg, self.ops, L.lib()
         n = x.shape[0]
+        L.check(lib.dg_blur_fwd(L.ptr(x), L.ptr(self.h[0]) + o.es * slot * self.per[0], o.dt, n, c.H, c.W, int(c.ring),
+                                L.stream_ptr()), "dg_blur_fwd")
+        return self._layers(st, n, slot, tangent_of)
+
+    def forward_aug(self, st, A, sources, slot):
+        """D(A(x_0) | A(x_1)): `sources` = one or two (x [n,1,H,W] fp32, DiffAugment draws) pairs filling consecutive
+        slots (trainers/dcgan_amp.py:199-204: real | fake; :256-260: fake).  The augmented images are never needed again
+        (D is piecewise linear and BlurVH linear: the backward passes need the draws, not the pixels), so DiffAugment and
+        BlurVH run as ONE pass that writes h[0] directly (dg_diffaug_blur_fwd) when every source carries the per-sample
+        sums its producer made; otherwise DiffAugment, then BlurVH."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        n = sources[0][0].shape[0]
+        sets = [A.aug_set(x, rp) for x, rp in sources] if (c.W % 4 == 0 and len(sources) <= 2) else [None]
+        if all(q is not None for q in sets):
+            arr = (L.DgAugSet * len(sets))(*[q[0] for q in sets])
+            rc = lib.dg_diffaug_blur_fwd(arr, len(sets), A.mask, n, c.H, c.W, int(c.ring),
+                                         L.ptr(self.h[0]) + o.es * slot * self.per[0], o.dt, L.stream_ptr())
+            if rc != L.DG_EUNSUPPORTED:
+                L.check(rc, "dg_diffaug_blur_fwd")
+                return self._layers(st, n * len(sets), slot, None)
+        xcat = torch.empty(n * len(sources), 1, c.H, c.W, dtype=torch.float32, device=sources[0][0].device)
+        for k, (x, rp) in enumerate(sources):
+            A.apply(x, rp, out=xcat[k * n:(k + 1) * n])
+        return self.forward(st, xcat, slot)
+
+    def _layers(self, st, n, slot, tangent_of):
+        """Down x4 + the final conv on h[0][slot : slot + n]"""
+        c, o, lib = self.cfg, self.ops, L.lib()
         sp = L.stream_ptr()
         st.refresh_shadows(self.dtype)
         es = o.es
-        L.check(lib.dg_blur_fwd(L.ptr(x), L.ptr(self.h[0]) + es * slot * self.per[0], o.dt, n, c.H, c.W, int(c.ring),
-                                sp), "dg_blur_fwd")
         for i in range(1, 5):
             hc, wc = self.grid[i]
             ci, co = self.chs[i - 1], self.chs[i]
@@ -750,6 +776,25 @@ class DEngine:
         L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")
         return True
+
+    def backward_input_aug(self, st, slot, n, A, rp):
+        """d loss / d x for D(A(x)): Down1 backward-data, then BlurVH's adjoint and DiffAugment's adjoint - two launches:
+        the BlurVH adjoint also accumulates the masked per-sample sums DiffAugment's contrast term needs
+        (dg_blur_bwd_augsum + dg_diffaug_bwd_pre); three (adjoint, sum, gather) where that form does not apply."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        self._bwd_layer(st, 1, slot, n, None, False)
+        dx = torch.empty(n, 1, c.H, c.W, dtype=torch.float32, device=self.e[0].device)
+        gsum = L.AccArena.take(n, dx.device) if c.W % 4 == 0 else None
+        if gsum is not None:
+            args, keep = A._args(rp, n, dx.device)
+            rc = lib.dg_blur_bwd_augsum(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), args[2], args[4],
+                                        args[5], A.mask, L.ptr(gsum), n, c.H, c.W, int(c.ring), L.stream_ptr())
+            if rc != L.DG_EUNSUPPORTED:
+                L.check(rc, "dg_blur_bwd_augsum")
+                return A.backward_pre(dx, rp, gsum)
+        L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
+                                int(c.ring), L.stream_ptr()), "dg_blur_bwd")
+        return A.backward(dx, rp)
 
     def wgrad(self, st, a_slot, g_slot, n, rowscale, layers=(1, 2, 3, 4), g_mod=0):
         """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot + b % g_mod]) for the Down layers in `layers`.

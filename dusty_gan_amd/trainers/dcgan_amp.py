@@ -315,6 +315,7 @@ class Trainer:
         self._geng = None
         self._pending = None
         self._dev_scal = None
+        self._pool_ctr = None   # device-resident loader position of the synthetic pool (dg_fetch_reals_pool_sum)
         # hipGraph replay of the step (single GPU, synthetic device-resident data); DUSTY_GAN_GRAPH=0 disables it
         import os
         self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
@@ -340,11 +341,40 @@ class Trainer:
         mask = raw_batch["mask"].to(self.device, non_blocking=True).float()
         return self.lidar.fetch_reals(pol, mask, float(self.cfg.model.gen.drop_const))
 
-    def _fetch_reals_in_step(self, raw_batch):
-        """fetch_reals as the first launch of a step: the step's accumulator arena is opened first, so the per-sample sums
-        the kernel produces beside x_real survive until DiffAugment reads them"""
-        L.AccArena.begin(self.device)
+    def _begin_step(self):
+        """Open the step's accumulator arena and zero both networks' gradient buffers (optim.zero_grad, reference :177 and
+        :246) with ONE launch; `optimize_D` / `optimize_G` then skip their own fills (a single micro-batch overwrites
+        Proj.weight's 268 MB gradient, or never forms it, so that segment is not filled)."""
+        Gst, Dst = _backbone(self.G).store, self.D.store
+        g = Gst.grad
+        if self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w":
+            g = Gst.grad[Gst.seg["proj_b"].off:]
+        ok = g.numel() % 4 == 0 and Dst.grad.numel() % 4 == 0 and g.data_ptr() % 16 == 0
+        L.AccArena.begin(self.device, also=(Dst.grad, g) if ok else ())
         self._arena_ready = True
+        self._grads_zeroed = {"D", "G"} if ok else set()
+
+    def _pooled(self):
+        """the loader is the device-resident synthetic pool and its batches can be picked by a device-side index"""
+        ds = getattr(self, "dataset", None)
+        return (isinstance(ds, SyntheticLiDAR) and getattr(ds, "pool_depth", None) is not None
+                and (self.H * self.W) % 256 == 0 and self.n_acc == 1)
+
+    def _fetch_reals_in_step(self, raw_batch, pooled=False):
+        """fetch_reals as the first launch of a step: the step's accumulator arena is opened first, so the per-sample sums
+        the kernel produces beside x_real survive until DiffAugment reads them.  pooled: `raw_batch` is the batch the
+        synthetic loader just yielded (number batches_drawn - 1); the kernel picks that same batch ON THE DEVICE from the
+        pool by a counter the step advances (dg_fetch_reals_pool_sum), so a hipGraph replay needs no copy of it."""
+        self._begin_step()
+        if pooled:
+            ds = self.dataset
+            if self._pool_ctr is None:
+                self._pool_ctr = torch.full((1,), self.batches_drawn - 1, dtype=torch.int64, device=self.device)
+            L.Counters.flush_if(self._pool_ctr)
+            x = self.lidar.fetch_reals_pool(ds.pool_depth, ds.pool_mask, self._pool_ctr,
+                                            float(self.cfg.model.gen.drop_const))
+            L.Counters.add(self._pool_ctr, 1)   # (queued: applied with the step's other counters, inside the graph)
+            return x, raw_batch["mask"]
         return self.fetch_reals(raw_batch)
 
     def _g_engines(self):
@@ -480,7 +510,6 @@ class Trainer:
         B = self.local_batch
         Gb, D = _backbone(self.G), self.D
         self.G.train()
-        self.optim_D.zero_grad()
         gengs = self._g_engines()
         deng = D.engine()
         deng.alloc(3 * B, self.device)
@@ -494,8 +523,12 @@ class Trainer:
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
         # every small accumulator of the step (these scalars, per-sample sums, logits) comes zeroed out of ONE arena
         if not getattr(self, "_arena_ready", False):   # (the graph path opens it before its fetch_reals)
-            L.AccArena.begin(dev)
+            self._begin_step()
         self._arena_ready = False
+        if "D" in self._grads_zeroed:
+            self._grads_zeroed.discard("D")
+        else:
+            self.optim_D.zero_grad()
         scal = L.AccArena.take(16, dev)[:7]
         f32 = dict(dtype=torch.float32, device=dev)
         for j in gradient_accumulation(self.n_acc, True, (self.G, self.D)):
@@ -505,10 +538,8 @@ class Trainer:
                 x_real, m_real = self.fetch_reals(self._next_batch())
             rand = self._prep_rand(rands[j] if rands is not None else None, B)
             synth = gengs[j].forward(Gst, rand["z"], rand["noise"], training=True)  # :195 (graph kept = workspaces)
-            xcat = torch.empty(2 * B, 1, self.H, self.W, **f32)
-            self.A.apply(x_real, rand["aug"][0], out=xcat[:B])  # :199
-            self.A.apply(synth["depth"], rand["aug"][1], out=xcat[B:])  # :200
-            y = deng.forward(Dst, xcat, 0)  # :203-204, real | fake in one pass
+            # :199-204  A(real) | A(fake) -> D, one pass; DiffAugment fused into BlurVH's pass where the sums exist
+            y = deng.forward_aug(Dst, self.A, [(x_real, rand["aug"][0]), (synth["depth"], rand["aug"][1])], 0)
             # loss + dLoss/dy + the R1 schedule's per-sample vectors + scalar sums + final-bias gradient: one launch
             # chain upstream `up`: 1 for the real half (that IS d sum(y_real)/dx, :218-223), dLoss/dy for the fake half;
             # `rs`: the real half's ordinary backward is the same chain weighted per sample by dLoss/dy_real
@@ -586,7 +617,10 @@ class Trainer:
         Gb, D = _backbone(self.G), self.D
         Gst, Dst = Gb.store, D.store
         pl_on = "pl" in self.criterion
-        self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
+        if "G" in getattr(self, "_grads_zeroed", ()):
+            self._grads_zeroed.discard("G")     # (filled with the step's arena: _begin_step)
+        else:
+            self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
         gather_proj = (self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
         fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
                      and next(iter(Gst.seg)) == "proj_w" and Gst.seg["proj_w"].off == 0 and self._fuse_proj_ok
@@ -606,21 +640,16 @@ class Trainer:
             # loss_G never reads pred_real (loss.py:66-75), so that pass is not run for them
             dy = torch.empty(B, **f32)
             if self.criterion["gan"].relativistic:
-                xcat = torch.empty(2 * B, 1, self.H, self.W, **f32)  # fake first: its slots 0..B carry the backward
-                self.A.apply(mb["synth"]["depth"], rand["aug"][3], out=xcat[:B])  # :256
-                self.A.apply(mb["x_real"], rand["aug"][2], out=xcat[B:])  # :255
-                y = deng.forward(Dst, xcat, 0)  # :259-260, updated D
+                # fake first: its slots 0..B carry the backward (:256, :255, :259-260, updated D)
+                y = deng.forward_aug(Dst, self.A, [(mb["synth"]["depth"], rand["aug"][3]), (mb["x_real"], rand["aug"][2])], 0)
                 y_real = L.ptr(y) + 4 * B
             else:
-                x_aug = self.A.apply(mb["synth"]["depth"], rand["aug"][3])  # :256
-                y = deng.forward(Dst, x_aug, 0)  # :260, updated D
+                y = deng.forward_aug(Dst, self.A, [(mb["synth"]["depth"], rand["aug"][3])], 0)  # :256, :260, updated D
                 y_real = None
             L.check(lib.dg_gan_g_step(self.gan_code, y_real, L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp),
                     "dg_gan_g_step")
             deng.backward_data(Dst, 0, B, dy, None, want_dbias=False)
-            dx = torch.empty(B, 1, self.H, self.W, **f32)
-            deng.backward_input(Dst, 0, B, dx)
-            ddepth = self.A.backward(dx, rand["aug"][3])
+            ddepth = deng.backward_input_aug(Dst, 0, B, self.A, rand["aug"][3])
             overlap = gather_proj and not pl_on  # (the path-length block adds to every gradient after this pass)
             if overlap:
                 geng = mb["geng"]
@@ -790,7 +819,11 @@ class Trainer:
         self.optimize_D(reals, rands)
         scal = self.optimize_G()
         L.Counters.flush()  # Philox offsets and Adam step counts of this step: one launch
-        scal = scal / self.n_acc if self.n_acc > 1 else scal.clone()  # (a copy: `scal` lives in the step's arena)
+        if self.n_acc > 1:
+            scal = scal / self.n_acc
+        elif self._cap is None:
+            scal = scal.clone()  # (a copy: `scal` lives in the step's arena, re-zeroed when the next step begins)
+        # (while capturing: the replay loop copies the arena slice after every replay - no copy node inside the graph)
         # (slices, not a Python index list: that would be a host-to-device copy, illegal during graph capture)
         end = 7 if "pl" in self.criterion else 5
         return scal[:end] if "gp" in self.criterion else torch.cat((scal[:3], scal[4:end]))
@@ -817,14 +850,16 @@ class Trainer:
         # on every replay
         L.Counters.flush()
         batch = self._next_batch()
+        pooled = self._pooled()
         if self._graph is None:
             if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
                 self._eager_steps += 1
                 if self.n_acc != 1:
                     return self._step_eager()
-                return self._step_eager(reals=[self._fetch_reals_in_step(batch)])
-            self._g_pol = batch["depth"].to(self.device).clone()
-            self._g_mask = batch["mask"].to(self.device).clone()
+                return self._step_eager(reals=[self._fetch_reals_in_step(batch, pooled)])
+            if not pooled:  # any other fixed-shape device loader: the replay reads static copies of the batch
+                self._g_pol = batch["depth"].to(self.device).clone()
+                self._g_mask = batch["mask"].to(self.device).clone()
             torch.cuda.synchronize()
             # One hipGraph per stretch between collectives (world > 1: gradient all-reduce of D, operand gather and
             # tail all-reduce of G); a single graph when world == 1.  The segments share one memory pool, so a
@@ -833,7 +868,8 @@ class Trainer:
             counts = (self.optim_D.step_count, self.optim_G.step_count)
             try:
                 self._cap_open()
-                self._g_out = self._step_eager(reals=[self._fetch_reals_in_step({"depth": self._g_pol, "mask": self._g_mask})])
+                src = batch if pooled else {"depth": self._g_pol, "mask": self._g_mask}
+                self._g_out = self._step_eager(reals=[self._fetch_reals_in_step(src, pooled)])
                 self._cap_close()
             except BaseException:
                 if self._cap_cur is not None:
@@ -853,13 +889,14 @@ class Trainer:
                 self.optim_D.step_count, self.optim_G.step_count = counts
                 self.use_graph = False
                 self._mb = []
-                return self._step_eager(reals=[self._fetch_reals_in_step(batch)])
+                return self._step_eager(reals=[self._fetch_reals_in_step(batch, pooled)])
             self._graph, self._cap = self._cap, None
             # the capture did not execute anything, but the host mirrors of the Adam step counts advanced once
             self.optim_D.step_count -= 1
             self.optim_G.step_count -= 1
-        self._g_pol.copy_(batch["depth"], non_blocking=True)
-        self._g_mask.copy_(batch["mask"], non_blocking=True)
+        if not pooled:
+            self._g_pol.copy_(batch["depth"], non_blocking=True)
+            self._g_mask.copy_(batch["mask"], non_blocking=True)
         for item in self._graph:
             if isinstance(item, torch.cuda.CUDAGraph):
                 item.replay()

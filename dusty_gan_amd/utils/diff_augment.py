@@ -84,6 +84,18 @@ class DiffAugment(nn.Module):
         keep = (z_f, z_i)
         return (g("u_b", z_f), g("u_c", z_f), g("t_h", z_i), g("t_w", z_i), g("o_x", z_i), g("o_y", z_i)), keep
 
+    def aug_set(self, x, rp):
+        """(DgAugSet, keep-alive) for the fused DiffAugment + BlurVH pass of the discriminator's input, or None when the
+        per-sample sums of x were not made by its producer in this step (the caller then runs `apply` + BlurVH)"""
+        pre = L.tagged_sums(x)
+        if pre is None or not x.is_contiguous() or x.dtype != torch.float32 or x.shape[1] != 1:
+            return None
+        args, keep = self._args(rp, x.shape[0], x.device)
+        q = L.DgAugSet()
+        q.x, q.xsum = L.ptr(x), L.ptr(pre)
+        q.u_b, q.u_c, q.t_h, q.t_w, q.o_x, q.o_y = args
+        return q, (keep, pre, x)
+
     # ---- forward / backward
     def apply(self, x, rp, out=None):
         """y = A(x) with the given draws.  x [B,1,H,W] fp32 (cuda)."""
@@ -121,6 +133,17 @@ class DiffAugment(nn.Module):
             ws = torch.empty(B, dtype=torch.float32, device=gy.device)
         args, keep = self._args(rp, B, gy.device)
         L.check(fn(L.ptr(gy), *args, self.mask, B, H, W, L.ptr(ws), L.ptr(out), L.stream_ptr()), "dg_diffaug_bwd")
+        return out
+
+    def backward_pre(self, gy, rp, gsum, out=None):
+        """`backward` with gsum[b] = the sum of gy[b] over the window that reaches the source (made by the BlurVH
+        adjoint that produced gy: dg_blur_bwd_augsum)"""
+        B, _, H, W = gy.shape
+        if out is None:
+            out = torch.empty_like(gy)
+        args, keep = self._args(rp, B, gy.device)
+        L.check(L.lib().dg_diffaug_bwd_pre(L.ptr(gy), *args, self.mask, B, H, W, L.ptr(gsum), L.ptr(out), L.stream_ptr()),
+                "dg_diffaug_bwd_pre")
         return out
 
     def forward(self, x):

@@ -43,6 +43,21 @@ class LiDAR:
             self.angle = self.angle.to(device).contiguous()
         return self
 
+    def fetch_reals_pool(self, pool_pol, pool_mask, pool_ctr, drop_const):
+        """fetch_reals of batch (*pool_ctr % pool size) of a device-resident pool [P,B,1,H,W]: the index is read on the
+        device (a hipGraph replay then moves on to the next batch by itself).  None unless the step's accumulator arena
+        is open and H W % 256 == 0 (the per-sample sums are made in the same pass)."""
+        P, B = pool_pol.shape[0], pool_pol.shape[1]
+        HW = pool_pol[0, 0].numel()
+        sums = L.AccArena.take(B, pool_pol.device) if HW % 256 == 0 else None
+        if sums is None:
+            return None
+        out = torch.empty_like(pool_pol[0])
+        L.check(L.lib().dg_fetch_reals_pool_sum(L.ptr(pool_pol), L.ptr(pool_mask), L.ptr(pool_ctr), P, self.min_depth,
+                                                self.max_depth, float(drop_const), B, HW, L.ptr(out), L.ptr(sums),
+                                                L.stream_ptr()), "dg_fetch_reals_pool_sum")
+        return L.tag_sums(out, sums)
+
     def fetch_reals(self, pol, mask, drop_const):
         """pol [B,1,H,W] in [0,1], mask [B,1,H,W] {0,1} float -> inverse depth in [-1,1], dropped pixels = drop_const"""
         pol = pol.contiguous().float()

@@ -197,6 +197,27 @@ int dg_diffaug_bwd(const float* gy, const float* u_b, const float* u_c, const in
                    const int* o_y, int policy, int B, int H, int W, float* gsum_ws, float* gx, void* stream);
 int dg_diffaug_bwd_acc(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
                    const int* o_y, int policy, int B, int H, int W, float* gsum_ws, float* gx, void* stream);
+/* DiffAugment.forward + BlurVH.forward in one pass (utils/diff_augment.py:114-132 -> models/ops/common.py:74-88, the first
+ * two modules every D(A(x)) call runs, trainers/dcgan_amp.py:199-204,255-260): the augmented image is only ever D's input,
+ * so it is not written - out = BlurVH(A(x)) [nsets B, H, W, 2] in `dtype`.  One or two source sets per launch (the D
+ * phase's real | fake halves); xsum = the per-sample sums of x (dg_fetch_reals_sum / dg_head_post_fwd_sum), read by the
+ * contrast stage.  DG_EUNSUPPORTED unless W % 4 == 0. */
+typedef struct DgAugSet {
+  const float* x;            /* [B,1,H,W] fp32 */
+  const float* xsum;         /* [B] */
+  const float *u_b, *u_c;    /* [B] the uniform(-1,1) draws of brightness / contrast */
+  const int *t_h, *t_w, *o_x, *o_y;
+} DgAugSet;
+int dg_diffaug_blur_fwd(const DgAugSet* sets, int nsets, int policy, int B, int H, int W, int ring, void* out, int dtype,
+                        void* stream);
+/* The adjoint pair BlurVH^T -> DiffAugment^T of the G phase (loss_G.backward() through :256-260) in two launches instead
+ * of three: dg_blur_bwd_augsum is dg_blur_bwd that also accumulates gsum[b] += the sum of dx[b] over the rows / columns
+ * whose gradient reaches the source image (gsum zeroed by the caller; DG_EUNSUPPORTED unless W % 4 == 0), and
+ * dg_diffaug_bwd_pre is dg_diffaug_bwd with that sum given. */
+int dg_blur_bwd_augsum(const void* d, int dtype, float* dx, const int* t_h, const int* o_x, const int* o_y, int policy,
+                       float* gsum, int B, int H, int W, int ring, void* stream);
+int dg_diffaug_bwd_pre(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
+                       const int* o_y, int policy, int B, int H, int W, const float* gsum, float* gx, void* stream);
 
 /* ---- GANLoss(nsgan)  models/loss.py:39-41,68-69 + gradient w.r.t. the logits ----------------------------- */
 /* scal[0]=mean(y_real) scal[1]=mean(y_fake) scal[2]=loss_D */
@@ -242,6 +263,12 @@ int dg_fetch_reals(const float* pol, const float* mask, float min_depth, float m
                    float* out, void* stream);
 int dg_fetch_reals_sum(const float* pol, const float* mask, float min_depth, float max_depth, float drop_const, int B,
                        long HW, float* out, float* xsum, void* stream); /* + xsum[b] += sum of out[b] (as dg_head_post_fwd_sum) */
+/* the same from a device-resident pool of `npool` batches (the synthetic loader): the batch index is
+ * *pool_ctr % npool, read ON THE DEVICE, so a training step captured in a hipGraph replays on the next batch without a
+ * host-side copy into a static buffer (next(loader) at trainers/dcgan_amp.py:186) */
+int dg_fetch_reals_pool_sum(const float* pol_pool, const float* mask_pool, const unsigned long long* pool_ctr, int npool,
+                            float min_depth, float max_depth, float drop_const, int B, long HW, float* out, float* xsum,
+                            void* stream);
 
 /* ---- data formats either side of the step ---------------------------------------------
  * dg_scan_to_polar: KITTIOdometry.preprocess + .transform  datasets/kitti.py:54-77, optionally fused with
@@ -307,6 +334,9 @@ int dg_scale(const float* x, float a, long n, float* y, void* stream);
 /* p[0..n) = 0 as a kernel launch (optim.zero_grad, trainers/dcgan_amp.py:177,246, and the step's accumulators).  The
  * library never uses hipMemsetAsync: its small fills replayed wrong from a hipGraph after a host-side synchronize. */
 int dg_zero(float* p, long n, void* stream);
+/* k <= 4 fp32 buffers (16-byte aligned, counts multiples of 4) zero-filled by ONE launch: the step's accumulator arena and
+ * the two networks' gradient buffers (optim.zero_grad, trainers/dcgan_amp.py:177,246) as one graph node */
+int dg_zero_multi(float* const* ptrs, const long* counts, int k, void* stream);
 
 /* ---- optim.Adam.step + ema_inplace  trainers/dcgan_amp.py:116-125,238,312,316 and :30-35 ------------------ */
 int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema, void* shadow, int shadow_dtype,

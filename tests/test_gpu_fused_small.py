@@ -209,3 +209,100 @@ def test_blur_scalar_fallback_width_not_a_multiple_of_four(L, ring):
     gyd = nhwc(gy).to(DEV)
     L.check(lib.dg_blur_bwd(gyd.data_ptr(), L.DG_F32, dx.data_ptr(), B, H, W, int(ring), None))
     assert rel_l2(dx.cpu(), gx) < 1e-6
+
+
+def _aug_params(B, H, W, seed, extreme=False):
+    g = torch.Generator().manual_seed(seed)
+    rp = O.draw_augment_params(B, H, W, g)
+    if extreme:  # shifts / boxes at their limits: rows shifted out, wrap at W - 1, boxes clipped by the border
+        sh, sw = O.translation_shift(H, W)
+        rp["t_h"][0], rp["t_w"][0] = -sh, sw
+        rp["t_h"][1], rp["t_w"][1] = sh, -sw
+        rp["o_x"][0], rp["o_y"][0] = 0, 0
+        rp["o_x"][1], rp["o_y"][1] = H - 1, W - 1
+    return rp
+
+
+@pytest.mark.parametrize("H,W,ring", [(32, 64, 1), (64, 1024, 1), (16, 40, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nsets", [1, 2])
+def test_diffaug_blurvh_one_pass(L, H, W, ring, dtype, nsets):
+    """dg_diffaug_blur_fwd (DiffAugment + BlurVH, the augmented image never written; one or two source sets per launch)
+    == dg_diffaug_fwd_pre into a buffer, then dg_blur_fwd - the launches it replaces in D(A(x)); and the augmented
+    image itself against the oracle's DiffAugment (utils/diff_augment.py:114-132)"""
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    lib = L.lib()
+    B = 3
+    A = DiffAugment()
+    g = torch.Generator().manual_seed(H * 3 + W + nsets)
+    xs = [torch.randn(B, 1, H, W, generator=g) for _ in range(nsets)]
+    rps = [_aug_params(B, H, W, 11 + k, extreme=True) for k in range(nsets)]
+    ref = torch.empty(nsets * B, H, W, 2, device=DEV, dtype=dtype)
+    sets, keep = [], []
+    for k in range(nsets):
+        xd = xs[k].to(DEV)
+        rp = DiffAugment.params_to_device(rps[k], DEV)
+        sums = xd.sum(dim=[1, 2, 3]).contiguous()
+        args, kp = A._args(rp, B, xd.device)
+        aug = torch.empty_like(xd)
+        L.check(lib.dg_diffaug_fwd_pre(xd.data_ptr(), *args, A.mask, B, H, W, sums.data_ptr(), aug.data_ptr(), None))
+        assert rel_l2(aug.cpu(), O.diff_augment(xs[k], rps[k])) < 1e-6
+        L.check(lib.dg_blur_fwd(aug.data_ptr(), ref[k * B:].data_ptr(), L.dtype_code(dtype), B, H, W, ring, None))
+        q = L.DgAugSet()
+        q.x, q.xsum = xd.data_ptr(), sums.data_ptr()
+        q.u_b, q.u_c, q.t_h, q.t_w, q.o_x, q.o_y = args
+        sets.append(q)
+        keep += [xd, rp, sums, kp]
+    out = torch.empty_like(ref)
+    arr = (L.DgAugSet * nsets)(*sets)
+    L.check(lib.dg_diffaug_blur_fwd(arr, nsets, A.mask, B, H, W, ring, out.data_ptr(), L.dtype_code(dtype), None))
+    torch.cuda.synchronize()
+    # same expressions; the compiler may contract a multiply-add differently in the two kernels
+    assert float((out.float() - ref.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(out.float().cpu(), ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("H,W", [(32, 64), (64, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_blurvh_adjoint_with_augment_sum(L, H, W, dtype):
+    """dg_blur_bwd_augsum + dg_diffaug_bwd_pre == dg_blur_bwd + dg_diffaug_bwd (adjoint, masked sum, gather: the three
+    launches of the G phase's way back through BlurVH and DiffAugment)"""
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    lib = L.lib()
+    B = 4
+    A = DiffAugment()
+    g = torch.Generator().manual_seed(H + 5 * W)
+    d = torch.randn(B, H, W, 2, generator=g).to(DEV, dtype)
+    rp = DiffAugment.params_to_device(_aug_params(B, H, W, 23, extreme=True), DEV)
+    args, kp = A._args(rp, B, d.device)
+    dx = torch.empty(B, 1, H, W, device=DEV)
+    L.check(lib.dg_blur_bwd(d.data_ptr(), L.dtype_code(dtype), dx.data_ptr(), B, H, W, 1, None))
+    ws, ref = torch.empty(B, device=DEV), torch.empty_like(dx)
+    L.check(lib.dg_diffaug_bwd(dx.data_ptr(), *args, A.mask, B, H, W, ws.data_ptr(), ref.data_ptr(), None))
+    dx2, gsum, got = torch.empty_like(dx), torch.zeros(B, device=DEV), torch.empty_like(dx)
+    L.check(lib.dg_blur_bwd_augsum(d.data_ptr(), L.dtype_code(dtype), dx2.data_ptr(), args[2], args[4], args[5], A.mask,
+                                   gsum.data_ptr(), B, H, W, 1, None))
+    L.check(lib.dg_diffaug_bwd_pre(dx2.data_ptr(), *args, A.mask, B, H, W, gsum.data_ptr(), got.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    assert rel_l2(gsum.cpu(), ws.cpu()) < 1e-5
+    assert rel_l2(got.cpu(), ref.cpu()) < 1e-5
+
+
+def test_fetch_reals_from_the_device_resident_pool(L):
+    """dg_fetch_reals_pool_sum picks batch (*counter % pool) on the device: == dg_fetch_reals_sum of that batch"""
+    lib = L.lib()
+    P, B, H, W = 3, 2, 8, 32
+    g = torch.Generator().manual_seed(9)
+    pol = torch.rand(P, B, 1, H, W, generator=g).to(DEV)
+    m = (torch.rand(P, B, 1, H, W, generator=g) < 0.8).float().to(DEV)
+    for k in (0, 1, 2, 4, 8):
+        ctr = torch.full((1,), k, dtype=torch.int64, device=DEV)
+        ref, rs = torch.empty(B, 1, H, W, device=DEV), torch.zeros(B, device=DEV)
+        L.check(lib.dg_fetch_reals_sum(pol[k % P].data_ptr(), m[k % P].data_ptr(), 0.9, 120.0, -1.0, B, H * W, ref.data_ptr(),
+                                       rs.data_ptr(), None))
+        out, s = torch.empty_like(ref), torch.zeros(B, device=DEV)
+        L.check(lib.dg_fetch_reals_pool_sum(pol.data_ptr(), m.data_ptr(), ctr.data_ptr(), P, 0.9, 120.0, -1.0, B, H * W,
+                                            out.data_ptr(), s.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and rel_l2(s.cpu(), rs.cpu()) < 1e-6
