@@ -21,7 +21,8 @@ extern "C" {
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
 // force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
-//        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error.
+//        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error (9: without its
+//        both-parities tile for 64-channel MODE_UP layers).
 //        plan != NULL: describe the launch instead of making it.
 static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
@@ -34,7 +35,7 @@ static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, 
   const bool thin_ok = dg_conv_thin_supported(p);
   if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; }
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
-  if (force == 4 || force == 5) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (force == 4 || force == 5 || force == 9) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {

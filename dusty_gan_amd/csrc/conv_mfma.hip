@@ -362,7 +362,7 @@ extern "C" int dg_conv_mfma_supported(const ConvP* p) {
 int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream, int auto_rule, int wg_cap, DgConvPlan* plan);
 int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule, int wg_cap, DgConvPlan* plan);
 
-int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan);
+int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan, int dual);
 
 // plan != NULL: fill it with what would be launched and launch nothing.
 // Auto rule: bf16 layers with >= 256 tiles of 256 pixels -> ping-pong persistent kernel (conv_mfma_pp.hip, family 5);
@@ -371,7 +371,7 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
   if (p->in_dtype == DG_BF16) {
-    const int rc = dg_conv_mfma_pp_launch(p, stream, 256, wg_cap, plan);
+    const int rc = dg_conv_mfma_pp_launch(p, stream, 256, wg_cap, plan, 1);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
   {
@@ -397,7 +397,8 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
 // small problems): dg_conv force == 4 -> the lock-step kernel, force == 5 -> the ping-pong kernel
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  if (family == 5) return p->in_dtype == DG_BF16 ? dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (family == 5 || family == 9)   // 9: the ping-pong kernel without its both-parities tile (A/B, parity tests)
+    return p->in_dtype == DG_BF16 ? dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan, family == 5) : DG_EUNSUPPORTED;
   return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0, wg_cap, plan)
                                 : dg_conv_mfma_persist_launch_f32(p, stream, 0, wg_cap, plan);
 }

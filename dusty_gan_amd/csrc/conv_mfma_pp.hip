@@ -64,8 +64,15 @@ __device__ __forceinline__ float row_add(float v) {  // v + (v of the lane CTRL 
 // MASK: the backward / tangent flavour (EPI_MASK: multiply by the saved activation's slope, optional bias-gradient sums,
 // no bias); otherwise EPI_LRELU / EPI_LINEAR with bias.  Two instantiations keep either epilogue's registers out of the
 // other (both in one kernel spilled past 256 VGPRs, and a scratch reload next to LDS-DMA costs a vmcnt(0) drain).
-template <int BN, int MODE, bool MASK>
+// DUAL (MODE_UP, 64 output channels): the tile is 256 coarse columns x BOTH column parities x 64 channels - the "N"
+// dimension of the 128-row weight tile is (parity, channel): rows 0-63 hold parity 0's W tap, rows 64-127 parity 1's, and
+// wave column wn IS the parity (its pixel fragments sit one image row further).  One pixel image of SW + 2 columns then
+// feeds four W taps instead of two: the 64-channel MODE_UP layers (Down2 backward-data, Up3 forward) were bound by the
+// LDS-DMA issue of their LOAD halves - 6 pieces per wave and pair for 32 MFMAs against 8 for 64 in the 128-channel tile.
+template <int BN, int MODE, bool MASK, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
+  static_assert(!DUAL || (MODE == MODE_UP && BN == 128), "DUAL: both column parities of a 64-channel MODE_UP layer");
+  constexpr int NCH = DUAL ? BN / 2 : BN;      // real output channels per tile
   constexpr int BM = 256, NWV = 8, WN = 2;
   constexpr int SB = 128;                      // bytes of K per tile row and stage (64 bf16 channels)
   constexpr int WC = BN / WN;                  // channels per wave
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     r.nt = t % tiles_n;
     r.px = 0;
     r.xt = mt % tiles_x; mt /= tiles_x;
-    if (MODE == MODE_UP) { r.px = mt & 1; mt >>= 1; }
+    if (MODE == MODE_UP && !DUAL) { r.px = mt & 1; mt >>= 1; }
     r.Y = mt % rows; r.bt = mt / rows;
     r.nt = __builtin_amdgcn_readfirstlane(r.nt); r.xt = __builtin_amdgcn_readfirstlane(r.xt);
     r.px = __builtin_amdgcn_readfirstlane(r.px); r.Y = __builtin_amdgcn_readfirstlane(r.Y);
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   int colA[IA + 1];                            // (stride-scaled) image column inside its sample segment
   unsigned sampA[IA + 1];                      // byte offset of the row's sample inside the sample group + swizzled chunk
   {
-    const int pitch = g.SW + 1;
+    const int pitch = g.SW + (DUAL ? 2 : 1);
 #pragma unroll
     for (int u = 0; u <= IA; ++u) {
       const int m = (u < IA ? (wave + NWV * u) : 32) * 8 + lrow;
@@ -168,8 +175,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   }
 #pragma unroll
   for (int u = 0; u < IB; ++u) {
-    const int row = (wave + NWV * u) * 8 + lrow;
-    voffB[u] = (unsigned)(row * (int)p.w_sn * 2 + (pos ^ swzB(row)) * 16);
+    const int row = (wave + NWV * u) * 8 + lrow;   // (DUAL: LDS rows 64-127 are channels 0-63 of the other parity's tap)
+    voffB[u] = (unsigned)((DUAL ? row & 63 : row) * (int)p.w_sn * 2 + (pos ^ swzB(row)) * 16);
   }
   const unsigned dst_wave = (unsigned)wave * 1024u;
 
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // operand); k-step 1 = ^ 64.  The wave's 64 tile rows lie in one sample segment (SW >= 64).
   unsigned pbase[2];
   {
-    const int rowbase = ((wm * 64) >> g.lsw) * (g.SW + 1) + ((wm * 64) & (g.SW - 1));
+    const int rowbase = ((wm * 64) >> g.lsw) * (g.SW + (DUAL ? 2 : 1)) + ((wm * 64) & (g.SW - 1));
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int r = rowbase + a16 + t;
+      const int r = rowbase + a16 + t + (DUAL ? wn : 0);
       pbase[t] = (unsigned)(r * SB + ((g4 ^ swzA(r)) << 4));
     }
   }
@@ -216,13 +223,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 
   // ---- epilogue pieces
   bf16* out = (bf16*)p.out;
-  const unsigned lane_coff = (unsigned)((wn * WC + g4 * CPL) * 2);  // this lane's first channel inside the N tile, bytes
+  const unsigned lane_coff = (unsigned)(((DUAL ? 0 : wn * WC) + g4 * CPL) * 2);  // this lane's first channel inside the N tile, bytes
+  const unsigned par_off = DUAL ? (unsigned)(wn * (int)p.out_sp * 2) : 0u;          // DUAL: the wave's column parity, bytes
   const long px_b = (long)(MODE == MODE_S2 ? 1 : 2) * p.out_sp * 2;   // bytes between consecutive tile rows of a segment
   unsigned pix_off;                            // byte offset of this lane's pixel of block row 0 from the tile base
   {
     const int trow = wm * 64 + a16;
     const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
-    pix_off = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2) + lane_coff;
+    pix_off = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2) + lane_coff + par_off;
   }
   // Output stores go through a wave-private LDS strip, one 16-pixel block row at a time: a lane owns 16 B pieces of 16
   // DIFFERENT pixels' rows (stride out_sp), so a store straight from the accumulator layout touched 64 cache lines per
@@ -244,13 +252,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     scr_r = scr0 + (unsigned)(pr * (CH * 16) + ((c ^ swzS(pr)) << 4));                            // store h: + h * 1024
     const int trow = wm * 64 + pr;
     const int sb = trow >> g.lsw, x = trow & (g.SW - 1);
-    st_off = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2 + (wn * WC) * 2 + c * 16);
+    st_off = (unsigned)((sb * (int)p.out_sb + (MODE == MODE_S2 ? x : 2 * x) * (int)p.out_sp) * 2 + c * 16) +
+             (DUAL ? par_off : (unsigned)((wn * WC) * 2));
   }
   static_assert(NRD == 1 || RPB * CH * 16 == 1024, "strip read offset");
   auto tile_off = [&](const Tile& t) __attribute__((always_inline)) -> long {  // element offset of (sample group, row Y, first column, first channel)
     const int n0 = t.xt * BM;
     return (long)(t.bt * g.NSB) * p.out_sb + ((long)t.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + t.px)) * p.out_sp +
-           t.nt * BN;
+           t.nt * NCH;
   };
   // The leaky-relu mask source of a tile being finished (EPI_MASK) is fetched during the tile's last MFMA half into
   // registers of its own (one lane's 4 pixels x 16 TN bytes); the epilogue runs at the END of the next LOAD half, behind that
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0x128>(dbacc[c]);   // row_ror 8
     if (a16 == 0) {
-      const unsigned ad = sdb0 + (unsigned)(nt * BN * 4) + lane_coff * 2;
+      const unsigned ad = sdb0 + (unsigned)(nt * NCH * 4) + lane_coff * 2;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(ad), "v"(dbacc[c]), "n"(c * 4) : "memory");
     }
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       asm volatile("ds_read_b32 %0, %1" : "=v"(rs) : "v"(ra) : "memory");
     }
     if (!MASK) {
-      const unsigned ba = sbias0 + (unsigned)(t.nt * BN * 4) + lane_coff * 2;
+      const unsigned ba = sbias0 + (unsigned)(t.nt * NCH * 4) + lane_coff * 2;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[j]) : "v"(ba), "n"(j * 16) : "memory");
@@ -418,8 +427,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // interval to land before the stage is read and tile 1 one and a half.  A stage is refilled one pair after its last
   // read (each LOAD half ends with lgkmcnt(0) in front of a barrier).
   // first: the pair opens a tile (or is the drain pair after the last one): its compute steps close the previous tile.
-  auto pair_iter = [&](auto iss_tag, const bool first, const int pi, const char* sA, const char* sB0, const char* sB1)
-      __attribute__((always_inline)) {
+  // sB0 / sB1: weight tap of K step 0 / 1 of the pair; DUAL: sB0b / sB1b = the taps of parity 1 (rows 64-127 of the tile)
+  auto pair_iter = [&](auto iss_tag, const bool first, const int pi, const char* sA, const char* sB0, const char* sB1,
+                       const char* sB0b, const char* sB1b) __attribute__((always_inline)) {
     constexpr bool ISS = decltype(iss_tag)::value;
     const bool comp = !warm;
     auto step = [&](auto t_tag) __attribute__((always_inline)) {
@@ -437,8 +447,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           constexpr int q = decltype(q_tag)::value;
           if (!ISS || (dbg & 1)) return;
           if constexpr (t == 0 && q < IA) dma_s(voffA[pi][q], sA, dst, std::integral_constant<int, NWV * q * 1024>{});
-          else if constexpr (t == 0) dma_s(voffB[q - IA], sB0, dst, std::integral_constant<int, AIMG + NWV * (q - IA) * 1024>{});
-          else dma_s(voffB[q], sB1, dst, std::integral_constant<int, AIMG + BT + NWV * q * 1024>{});
+          else if constexpr (t == 0) dma_s(voffB[q - IA], (DUAL && q - IA == 1) ? sB0b : sB0, dst, std::integral_constant<int, AIMG + NWV * (q - IA) * 1024>{});
+          else dma_s(voffB[q], (DUAL && q == 1) ? sB1b : sB1, dst, std::integral_constant<int, AIMG + BT + NWV * q * 1024>{});
         };
         if (ISS && t == 0 && wave == 0 && !(dbg & 1))
           dma_s(voffA[pi][IA], sA, lds0 + so_i, std::integral_constant<int, 32 * 1024>{});
@@ -523,16 +533,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     unsigned long long hl;
     const int nh = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl);
     const char* in_t = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb);
-    const char* w_t = (const char*)(w + (long)(ti.nt * BN) * p.w_sn);
+    const char* w_t = (const char*)(w + (long)(ti.nt * NCH) * p.w_sn);
     const int x0 = cmul * ti.xt * BM;
 #pragma unroll
     for (int pi = 0; pi < NPAIR; ++pi) {
-      const int cb = MODE == MODE_S2 ? pi - 1 : (ti.px == 0 ? -1 : 0);
+      const int cb = MODE == MODE_S2 ? pi - 1 : ((DUAL || ti.px == 0) ? -1 : 0);
 #pragma unroll
       for (int u = 0; u <= IA; ++u)              // circular columns: Ws is a power of two (checked by the launcher)
         voffA[pi][u] = __umul24((unsigned)((x0 + colA[u] + cb) & (Ws - 1)), spb) + sampA[u];
     }
     // weight taps of the pair's two K steps (see the table at the issue side)
+    // (DUAL: ti.px == 0, i.e. kx 3, 1 for parity 0; parity 1 reads kx 2, 0 one image row further)
     const int kxa = MODE == MODE_S2 ? 0 : (ti.px == 0 ? 3 : 2), kxb = MODE == MODE_S2 ? 2 : (ti.px == 0 ? 1 : 0);
     bool firstg = true;
     for (int h = 0; h < nh; ++h) {
@@ -545,7 +556,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
         const char* sB_k = sB_row + kc * SB;
 #pragma unroll
         for (int pi = 0; pi < NPAIR; ++pi) {
-          pair_iter(std::true_type{}, firstg, pi, sA_k, sB_k + (long)(kxa + pi) * tap_b, sB_k + (long)(kxb + pi) * tap_b);
+          pair_iter(std::true_type{}, firstg, pi, sA_k, sB_k + (long)(kxa + pi) * tap_b, sB_k + (long)(kxb + pi) * tap_b,
+                    sB_k + 2 * tap_b, sB_k);
           if (firstg) { firstg = false; warm = false; }
         }
       }
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     tprev = ti;
     ti = tile_at(t0 + (c + 1) * nwx);
   }
-  pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr);
+  pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (pending && !(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epilogue(tprev);
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   }
 }
 
-template <int BN, int MODE, bool MASK>
+template <int BN, int MODE, bool MASK, bool DUAL = false>
 int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   Geo g = g0;
   static int resident = 0;
@@ -585,11 +597,11 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
   const int cap = (wg_cap > 0 && wg_cap < resident) ? wg_cap : resident;
   const int G = g.ntiles < cap ? g.ntiles : cap;
   if (plan) {
-    plan->family = 5; plan->bm = 256; plan->bn = BN; plan->tiles = g.ntiles; plan->workgroups = G;
+    plan->family = 5; plan->bm = DUAL ? 512 : 256; plan->bn = DUAL ? BN / 2 : BN; plan->tiles = g.ntiles; plan->workgroups = G;
     plan->tiles_per_wg = (g.ntiles + G - 1) / G;
     return DG_OK;
   }
-  conv_pp_kernel<BN, MODE, MASK><<<(unsigned)G, 512, 0, stream>>>(*p, g);
+  conv_pp_kernel<BN, MODE, MASK, DUAL><<<(unsigned)G, 512, 0, stream>>>(*p, g);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -598,7 +610,8 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
 
 // bf16 layers that tile into 256-pixel x 128- (or 64-) channel tiles; DG_EUNSUPPORTED otherwise (the caller falls back
 // to the lock-step kernels).  min_tiles: the auto rule wants every CU busy.
-int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan) {
+// dual: 1 = a 64-channel MODE_UP layer may take the both-parities tile (512 pixels x 64 channels), 0 = never (A/B, tests)
+int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan, int dual) {
   if (p->mode != MODE_S2 && p->mode != MODE_UP) return DG_EUNSUPPORTED;
   if (p->in_dtype != DG_BF16 || p->out_dtype != DG_BF16 || p->w_dtype != DG_BF16) return DG_EUNSUPPORTED;
   if (p->K % 64 != 0 || !p->ring || p->nscale) return DG_EUNSUPPORTED;
@@ -617,6 +630,12 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
   if (p->rowscale && p->B > 512) return DG_EUNSUPPORTED;
   persist::Geo g;
   int bn = 0;
+  if (dual && p->mode == MODE_UP && p->N % 128 != 0 && p->N % 64 == 0 && persist::make_geo<256, 64>(p, g) && g.SW >= 64 &&
+      g.NSB * (g.SW + 2) <= 264 && g.ntiles / 2 >= min_tiles) {
+    g.ntiles /= 2;                             // one tile = both column parities of 256 coarse columns
+    return mask ? pp::launch<128, MODE_UP, true, true>(p, g, stream, wg_cap, plan)
+                : pp::launch<128, MODE_UP, false, true>(p, g, stream, wg_cap, plan);
+  }
   if (p->N % 128 == 0 && persist::make_geo<256, 128>(p, g) && g.SW >= 64 && g.ntiles >= min_tiles) bn = 128;
   else if (p->N % 64 == 0 && persist::make_geo<256, 64>(p, g) && g.SW >= 64 && g.ntiles >= min_tiles) bn = 64;
   if (!bn) return DG_EUNSUPPORTED;

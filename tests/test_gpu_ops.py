@@ -92,7 +92,10 @@ CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct, 2 = MFMA,
     (256, 128, 4, 128, 2, True, torch.bfloat16, 5),
     (128, 128, 2, 512, 1, True, torch.bfloat16, 5),
     (128, 256, 4, 64, 8, True, torch.bfloat16, 5),
-    (64, 128, 2, 256, 1, True, torch.bfloat16, 5),   # backward-data: 256 x 64 tiles
+    (64, 128, 2, 256, 1, True, torch.bfloat16, 5),   # Down backward-data: 64 channels, both-parities tile (512 px x 64)
+    (64, 128, 4, 64, 8, True, torch.bfloat16, 5),    # ... 4 sample segments of 64 + 2 columns
+    (64, 128, 2, 512, 1, True, torch.bfloat16, 5),   # ... two column tiles per row
+    (64, 128, 2, 256, 1, True, torch.bfloat16, 9),   # force 9: the single-parity 256 x 64 tile those layers ran on before
 ]
 
 
@@ -132,7 +135,7 @@ def test_down_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     # weight gradient
     from dusty_gan_amd.engine import Ops
     o = Ops(dtype)
-    o.force = 2 if force in (4, 5) else force
+    o.force = 2 if force in (4, 5, 9) else force
     xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
     dw = torch.zeros(16, Ci, Co, device=DEV)
     o.wgrad(0, ring, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw.data_ptr(), s)
@@ -180,12 +183,37 @@ def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     assert rel_l2(db, ref_dx.sum(dim=[0, 2, 3])) < (tol if dtype == torch.float32 else 5e-2)
     from dusty_gan_amd.engine import Ops
     o = Ops(dtype)
-    o.force = 2 if force in (4, 5) else force
+    o.force = 2 if force in (4, 5, 9) else force
     xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
     dw = torch.zeros(16, Ci, Co, device=DEV)
     o.wgrad(1, ring, B, H, W, Ci, Co, xd, (H * W * Ci, Ci, 1), ed, (4 * H * W * Co, Co, 1), dw.data_ptr(), s)
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().view(4, 4, Ci, Co).permute(2, 3, 0, 1), gw) < tol
+
+
+@pytest.mark.parametrize("force", [5, 9], ids=["both-parities-tile", "single-parity-tile"])
+@pytest.mark.parametrize("Ci,H,W,B", [(128, 4, 128, 2), (64, 2, 256, 1), (128, 4, 64, 4), (128, 2, 512, 1)])
+def test_up_forward_64_channels_on_the_pingpong_kernel(L, Ci, H, W, B, force):
+    """Up forward with 64 output channels (Up3: dcgan_eqlr.py:19-26 at 128 -> 64): MODE_UP, bias + leaky-relu epilogue, on
+    the ping-pong kernel's both-parities tile (512 pixels x 64 channels, force 5) and on the single-parity 256 x 64 tile
+    it replaces (force 9); 1 / 2 / 4 sample segments per tile and two column tiles per row.  (The Down / Up case list above
+    cannot hold this shape: its backward-data pass has K = 64, which the adjoint MODE_UP flavour refuses.)"""
+    from dusty_gan_amd import engine as E
+    Co = 64
+    g = torch.Generator().manual_seed(Ci + H + W)
+    x = torch.randn(B, Ci, H, W, generator=g).bfloat16().float()
+    w = torch.randn(Ci, Co, 4, 4, generator=g).bfloat16().float()
+    b = torch.randn(Co, generator=g)
+    y = O.up(x, w, b, True)
+    fwd, _ = pack_up(w)
+    E.TRACE = []
+    try:
+        out = run_conv(L, L.MODE_UP, 0, True, x, fwd, Co, 1.0 / math.sqrt(Co * 16), L.EPI_LRELU, torch.bfloat16, force, bias=b)
+        tr = [t for t in E.TRACE if t[0] == "conv"][0]
+    finally:
+        E.TRACE = None
+    assert tr[1] == 5 and (tr[2], tr[3]) == ((512, 64) if force == 5 else (256, 64)), tr
+    assert rel_l2(out, y) < TOLBF
 
 
 @pytest.mark.parametrize("force", [2, 7, 8], ids=["auto", "tap-pairs", "single-taps"])
