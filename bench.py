@@ -366,6 +366,11 @@ def main():
     if dist.is_initialized():
         out["distributed"] = {"backend": backend or dist.get_backend(), "world_size": dist.get_world_size(),
                               "devices_visible": torch.cuda.device_count()}
+        out["distributed"]["exchanges_per_step"] = 4  # D.hi, D.lo, G.gather (one coalesced pair), G.tail (+ the async scalars)
+        try:
+            out["distributed"]["bytes_per_step"] = tr.comm_bytes()
+        except Exception as e:  # noqa: BLE001
+            out["distributed"]["bytes_per_step"] = f"not computed ({type(e).__name__}: {e})"
         try:  # (instrumentation after the timed region: never at the price of the line itself)
             comm = tr.comm_profile(steps=3)
             if comm:

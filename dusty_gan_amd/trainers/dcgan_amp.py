@@ -48,11 +48,14 @@ class LazyScalars(Mapping):
     (`[]`, get, items, keys, values, iteration, ==, dict(x)) resolves first; it is deliberately NOT a dict subclass:
     dict's C fast paths (json.dumps, dict.update, copy) would see an empty table before the read-back."""
 
-    def __init__(self, keys, dev_tensor):
-        self._keys, self._dev, self._vals = list(keys), dev_tensor, None
+    def __init__(self, keys, dev_tensor, finish=None):
+        self._keys, self._dev, self._vals, self._finish = list(keys), dev_tensor, None, finish
 
     def _resolve(self):
         if self._vals is None:
+            if self._finish is not None:    # the asynchronous rank average of a multi-GPU run completes here
+                self._dev = self._finish()
+                self._finish = None
             self._vals = dict(zip(self._keys, self._dev.tolist()))
             self._dev = None
         return self._vals
@@ -155,7 +158,7 @@ class FlatAdam:
         if pos < st.n:
             L.zero_(st.grad[pos:])
 
-    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None):
+    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None, between=None):
         """fused_proj = (dp0, zT, op_dtype, nb, Np, K, wscale): the first segment of the store is Proj.weight [Np][K] and
         its gradient is NOT in st.grad - the kernel forms wscale * dp0^T zT itself (dg_adam_proj_fused).  Returns
         False (and does nothing) if that kernel refuses the shape, so the caller can fall back."""
@@ -182,6 +185,8 @@ class FlatAdam:
                 return False
             L.check(rc, "dg_adam_proj_fused")
             off = Np * K
+            if between is not None:
+                between()   # (multi-GPU: the tail bucket's exchange has been travelling beside the kernel above)
         self.step_count += 1
         self._last_gscale = gscale
         # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
@@ -654,13 +659,14 @@ class Trainer:
             if overlap:
                 geng = mb["geng"]
                 zg, dg = self._gather_bufs(geng, B)
-                hi0, hi1 = Gst.seg["proj_b"].off, Gst.seg["up2_w"].off
+                # two exchanges: the operand gather starts behind the backward-data chain and travels beside every weight
+                # gradient; the tail bucket (all of G's gradient but Proj.weight, 11 MB) starts behind the last weight
+                # gradient and travels beside the fused Proj optimizer (0.3 ms), which only needs the gather - the rest of
+                # the optimizer waits for it (FlatAdam.step `between`)
                 geng.backward(
                     Gst, ddepth, skip_proj=True, chain_first=True,
-                    after_chain=lambda: self._comm_issue("G.gather", lambda: D_.Works(
-                        [D_.all_gather_into(zg, geng.zT, async_op=True), D_.all_gather_into(dg, geng.dp[0], async_op=True)])),
-                    after_up1=lambda: self._allreduce_async("G.hi", Gst.grad[hi0:hi1]))
-                self._allreduce_async("G.lo", Gst.grad[hi1:])
+                    after_chain=lambda: self._comm_issue("G.gather", lambda: D_.all_gather_pair((zg, dg), (geng.zT, geng.dp[0]))))
+                self._allreduce_async("G.tail", Gst.grad[Gst.seg["proj_b"].off:])
             else:
                 mb["geng"].backward(Gst, ddepth, accumulate_proj=(j > 0), skip_proj=gather_proj or fuse_proj)
             if pl_on:
@@ -696,7 +702,8 @@ class Trainer:
             else:
                 geng.proj_wgrad(Gst, dg, zg, nbg)
             if not pl_on:
-                self._comm_wait("G.hi", "G.lo")
+                if fused is None:
+                    self._comm_wait("G.tail")   # (no fused Proj optimizer to hide it behind)
             else:
                 tail = Gst.grad[Gst.seg["proj_b"].off:]
                 E.WGRAD_WS.flush()
@@ -712,9 +719,12 @@ class Trainer:
                 fused = (dp0, zT, L.dtype_code(self.dtype), nloc, Np, c.nz, 1.0 / math.sqrt(Np))
                 self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, dp0, zT, nloc, False)
         # Adam + EMA fused (:312, :316); single-GPU bf16 runs also fold Proj.weight's gradient GEMM into the kernel
+        tail_wait = (lambda: self._comm_wait("G.tail")) if (gather_proj and not pl_on and fused is not None) else None
         ok = self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
-                               shadow_dtype=self.dtype, fused_proj=fused)
+                               shadow_dtype=self.dtype, fused_proj=fused, between=tail_wait)
         if not ok:  # shape the fused kernel does not take: materialise the gradient and run the plain optimizer
+            if tail_wait is not None:
+                tail_wait()
             self.optim_G.regen_grad()
             self.optim_G.regen_grad = None
             self._fuse_proj_ok = False
@@ -736,6 +746,21 @@ class Trainer:
             return "eager launches"
         n = sum(isinstance(g, torch.cuda.CUDAGraph) for g in self._graph)
         return "one hipGraph per step" if n == 1 else f"{n} hipGraph segments per step, collectives between them"
+
+    def comm_bytes(self):
+        """bytes each rank contributes to the step's exchanges (the multi-rank schedule at one micro-batch): D's gradient
+        in two buckets, Proj's gradient operands (gathered instead of reducing the 268 MB gradient), the rest of G's
+        gradient in one bucket, the packed scalars"""
+        Gst, Dst = _backbone(self.G).store, self.D.store
+        geng = self._g_engines()[0]
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        cut = Dst.seg["d4_w"].off
+        out = {"all-reduce D.hi": 4 * (Dst.n - cut), "all-reduce D.lo": 4 * cut,
+               "all-gather G.gather (Proj operands, per rank)": es * (geng.zT.numel() + geng.dp[0].numel()) if geng.ws_B else 0,
+               "all-reduce G.tail": 4 * (Gst.n - Gst.seg["proj_b"].off), "all-reduce scalars": 4 * 7}
+        out["total"] = sum(out.values())
+        out["not exchanged: Proj.weight gradient"] = 4 * Gst.seg["proj_w"].numel
+        return out
 
     def comm_profile(self, steps=3):
         """Exposed communication time per step [ms] by collective: HIP events on the launch stream around every
@@ -915,8 +940,8 @@ class Trainer:
             out = self._step_graph()
         else:
             out = self._step_eager(reals, rands)
-        out = D_.mean_scalars(out)  # one packed collective instead of 5-7 (:319-323)
-        return LazyScalars(self._scalar_keys()[0], out)
+        out, finish = D_.mean_scalars(out)  # one packed, asynchronous collective instead of 5-7 blocking ones (:319-323)
+        return LazyScalars(self._scalar_keys()[0], out, finish)
 
     # ------------------------------------------------------------------ inference / checkpoints
     def postprocess(self, synth):

@@ -68,12 +68,37 @@ def allreduce_grads(flat_grad, async_op=False):
 
 def mean_scalars(t):
     """one packed collective for the logged scalars (the reference does one all_reduce + .item() per key,
-    trainers/dcgan_amp.py:319-323)"""
+    trainers/dcgan_amp.py:319-323), issued asynchronously: returns (tensor, finish) where `finish()` waits for the
+    exchange and returns the rank average - called when the values are first READ (the step that follows never waits for
+    it; the reference blocks on every key's .item())"""
     w = world_size()
-    if w > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        t = t / w
-    return t
+    if w == 1:
+        return t, None
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish():
+        work.wait()
+        return t / w
+    return t, finish
+
+
+def all_gather_pair(outs, ins):
+    """two all-gathers (Proj's gradient operands) as ONE asynchronous exchange: on the nccl backend both calls are
+    coalesced into one RCCL group (one enqueue on RCCL's stream, one event hand-off instead of two); elsewhere two async
+    calls.  Returns something with .wait()."""
+    if not through_backend():
+        for o, t in zip(outs, ins):
+            o.view(torch.uint8).copy_(t.contiguous().view(torch.uint8))
+        return Works([])
+    if dist.get_backend() == "nccl" and hasattr(dist, "_coalescing_manager"):
+        try:
+            with dist._coalescing_manager(device=ins[0].device, async_ops=True) as cm:
+                for o, t in zip(outs, ins):
+                    dist.all_gather_into_tensor(o.view(torch.uint8), t.contiguous().view(torch.uint8))
+            return cm
+        except (RuntimeError, TypeError, AttributeError):  # a torch without coalesced all-gathers: two exchanges
+            pass
+    return Works([all_gather_into(o, t, async_op=True) for o, t in zip(outs, ins)])
 
 
 def all_gather_cat(t):

@@ -89,7 +89,8 @@ def worker(rank, world, init_file, out_dir):
     netG.grad.copy_(torch.cat([gG[k].flatten() for k in netG.keys]))
     _, gsD = DD.allreduce_grads(netD.grad)
     _, gsG = DD.allreduce_grads(netG.grad)
-    scal = DD.mean_scalars(torch.tensor([sc[k] for k in sorted(sc)]))
+    scal, finish = DD.mean_scalars(torch.tensor([sc[k] for k in sorted(sc)]))   # (asynchronous: `finish` completes it)
+    scal = finish() if finish is not None else scal
     torch.save({"gD": netD.grad * gsD, "gG": netG.grad * gsG, "scal": scal, "G0": netG.flat, "keys": sorted(sc)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

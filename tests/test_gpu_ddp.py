@@ -45,17 +45,22 @@ def shard(x, rand, s):
 def run_steps(tr, x, rand, steps=2):
     out = []
     for i in range(steps):
-        xd = x.to("cuda")
+        xd = x.to(tr.device)
         s = tr.step(i, reals=[(xd, torch.ones_like(xd))], rands=[rand])
         out.append(dict(s.items()))
     return out
 
 
-def worker(rank, world, init_file, out_dir, sdG, sdD):
+def worker(rank, world, init_file, out_dir, sdG, sdD, backend="gloo"):
     from tests.test_gpu_step import make_trainer
-    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
+    if backend == "nccl":   # one device per rank (RCCL refuses two ranks on one device)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank), timeout=PG_TIMEOUT)
+    else:
+        dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     torch.manual_seed(100 + rank)  # ranks build DIFFERENT nets; the constructor's broadcast must fix that
-    tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world)
+    tr = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B // world, gpu=rank if backend == "nccl" else 0)
     if rank == 0:
         tr.G.load_state_dict(sdG)
         tr.D.load_state_dict(sdD)
@@ -118,6 +123,31 @@ def graph_worker(rank, world, init_file, out_dir, use_graph, full=False):
                 "segs": segs}, os.path.join(out_dir, f"g{int(use_graph)}_r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: this box has one GPU")
+def test_two_ranks_over_rccl_match_single_process():
+    """The same check as above on the backend the multi-GPU runs use: two ranks on two devices over RCCL ("nccl") must
+    reproduce the single-process full-batch steps.  Skipped on the one-GPU boxes of the builder's pool; it runs wherever
+    the test suite sees two or more devices (the driver's multi-GPU node)."""
+    from tests.test_gpu_step import make_trainer
+    torch.manual_seed(5)
+    ref = make_trainer(ARCH, True, SHAPE, NZ, CB, CM, B)
+    sdG = {k: v.detach().cpu().clone() for k, v in ref.G.state_dict().items()}
+    sdD = {k: v.detach().cpu().clone() for k, v in ref.D.state_dict().items()}
+    x, rand = make_rand()
+    scal_ref = run_steps(ref, x, rand)
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(worker, args=(2, os.path.join(td, "init"), td, sdG, sdD, "nccl"), nprocs=2, join=True)
+        outs = [torch.load(os.path.join(td, f"r{r}.pt")) for r in range(2)]
+    for o in outs:
+        assert rel_l2(o["D"], ref.D.store.flat.cpu()) < 5e-4
+        assert rel_l2(o["G"], ref.G.store.flat.cpu()) < 5e-4
+        assert rel_l2(o["E"], ref.G_ema.store.flat.cpu()) < 5e-4
+        for s_got, s_ref in zip(o["scal"], scal_ref):
+            for k, v in s_ref.items():
+                assert abs(s_got[k] - v) < 1e-3 * max(1.0, abs(v)), k
+    assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
 
 
 @pytest.mark.parametrize("full", [False, True], ids=["tiny-fp32", "64x1024-bf16-B8"])
@@ -281,5 +311,6 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
     assert out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
     assert "segments" in out["launch_mode"]
-    assert set(out["distributed"]["exposed_ms_per_step"]) >= {"wait D.hi+D.lo", "wait G.gather", "wait G.hi+G.lo"}
+    assert set(out["distributed"]["exposed_ms_per_step"]) >= {"wait D.hi+D.lo", "wait G.gather", "wait G.tail"}
+    assert out["distributed"]["exchanges_per_step"] == 4 and out["distributed"]["bytes_per_step"]["total"] > 0
     assert out["step_ms_device"]["p50"] > 0

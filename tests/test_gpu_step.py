@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False, n_acc=1, gan_mode="nsgan", pl=0.0):
+def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False, n_acc=1, gan_mode="nsgan", pl=0.0, gpu=0):
     from dusty_gan_amd.trainers.dcgan_amp import Trainer
     from dusty_gan_amd.utils.config import load_config
     model = {"none": "dcgan_eqlr", "dusty1": "dusty1_dcgan_eqlr", "dusty2": "dusty2_dcgan_eqlr"}[arch]
@@ -27,7 +27,7 @@ def make_trainer(arch, ring, shape, in_ch, ch_base, ch_max, B, gp=1.0, amp=False
                        f"solver.batch_size={B * n_acc}", f"solver.loss.gp={gp}", f"enable_amp={str(amp).lower()}",
                        f"solver.num_accumulation={n_acc}", "dataset.pool=1", f"solver.gan_mode={gan_mode}",
                        f"solver.loss.pl={pl}"])
-    return Trainer(cfg, {"gpu": 0, "ngpus": 1, "batch_size": B, "num_workers": 0})
+    return Trainer(cfg, {"gpu": gpu, "ngpus": 1, "batch_size": B, "num_workers": 0})
 
 
 def grads_by_name(optim):
