@@ -90,6 +90,7 @@ PROTOTYPES = {
     "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_choice": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_variant": [C.POINTER(DgWgrad), _I],
+    "dg_wgrad_has_sample_map": [C.POINTER(DgWgrad), _I],
     "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "dg_blur_bwd_r1": [_P, _I, _P, _F, _P, _I, _I, _I, _I, _P],

@@ -76,7 +76,10 @@ static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force, hipStream
     return dg_wgrad_mfma_dma_launch(p, accumulate, force == 7 ? 1 : (force == 8 ? 2 : 0), s, plan);
   if (force == 7 || force == 8) return DG_EUNSUPPORTED;
   if (plan) return plan->variant ? DG_OK : DG_EUNSUPPORTED;
-  if (p->ws || p->g_mod) return DG_EUNSUPPORTED;   // only the LDS-DMA kernel has the workspace / index-map forms
+  if (p->ws) return DG_EUNSUPPORTED;                // only the LDS-DMA kernel has the workspace form ...
+  // ... and the gradient-sample map exists there and in the thin matrix-core kernel of Down1 (checked by its launcher)
+  const bool thin_map = p->g_mod && thin_ok && !mfma_ok && (force == 0 || force == 3);
+  if (p->g_mod && !thin_map) return DG_EUNSUPPORTED;
   if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
   if (!accumulate) {
@@ -109,6 +112,13 @@ int dg_wgrad_kernel_variant(const DgWgrad* p, int force) {
   if ((force == 3 || force == 0) && thin_ok) return dg_wgrad_thin_mfma_variant(p) ? 7 : 3;
   if (force == 3) return 0;
   return 1;
+}
+
+// 1 when the kernel dg_wgrad(p, force) launches honours DgWgrad.g_mod (the LDS-DMA kernel, Down1's thin matrix-core kernel)
+int dg_wgrad_has_sample_map(const DgWgrad* p, int force) {
+  const int v = dg_wgrad_kernel_variant(p, force);
+  if (v == 5) return 1;
+  return v == 7 && p->wmode == 0 && dg_wgrad_thin_mfma_variant(p) == 1;
 }
 
 int dg_zero(float* p, long n, void* stream) { return p ? dg_zero_f32(p, n, (hipStream_t)stream) : DG_EINVAL; }

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p, int
     const long u = u0 + gq / gpr;
     const int s0 = (gq % gpr) * WG_GS;
     const int b = (int)(u / p.Hc), Y = (int)(u % p.Hc);
-    const bf16* grow = G + (long)b * p.g_sb + ((long)Y * p.Wc + wave * seg + 16 * s0) * p.g_sp;
+    const int bg = p.g_mod > 0 ? b % p.g_mod : b;                    // (one launch over real | fake | tangent input samples)
+    const bf16* grow = G + (long)bg * p.g_sb + ((long)Y * p.Wc + wave * seg + 16 * s0) * p.g_sp;
     // the gradient tiles of the group's K steps: G[xb .. xb+15][0..63] (128 B per pixel) = 2 x (64 lanes x 16 B) each
 #pragma unroll
     for (int st = 0; st < WG_GS; ++st)
@@ -945,6 +946,7 @@ int dg_wgrad_thin_mfma_variant(const WgradP* p) {
 
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (!dg_wgrad_thin_supported(p)) return DG_EUNSUPPORTED;
+  if (p->ws || (p->g_mod && !wgrad_down_mfma_ok(p))) return DG_EUNSUPPORTED;   // only thin_wgrad_down_mfma has the sample map
   const long units = (long)p->B * p->Hc;
   unsigned grid = units < 1024 ? (unsigned)units : 1024u;
   if (wgrad_down_mfma_ok(p)) {

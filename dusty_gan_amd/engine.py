@@ -337,10 +337,11 @@ class Ops:
                 WGRAD_WS.flush()
 
     def wgrad_takes_map(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr):
-        """whether the kernel that would run this launch has the g-sample index map (DgWgrad.g_mod): the LDS-DMA kernel"""
+        """whether the kernel that would run this launch has the g-sample index map (DgWgrad.g_mod): the LDS-DMA kernel
+        and Down1's thin matrix-core kernel"""
         p = self._wgrad_params(wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, 1.0, None, None, None,
                                0, 0, 0)
-        return self.lib.dg_wgrad_kernel_variant(C.byref(p), self.force) == 5
+        return self.lib.dg_wgrad_has_sample_map(C.byref(p), self.force) == 1
 
     def _wgrad_params(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale, a_dt, g_dt,
                       a_off, g_off, g_mod):

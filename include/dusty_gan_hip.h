@@ -144,6 +144,8 @@ int dg_wgrad_kernel_choice(const DgWgrad* p);
 /* which kernel `force` launches: 5 MFMA on the LDS-DMA ring (bf16 Down/Up layers), 2 register-staged MFMA (also
  * force == 6), 7 thin on the matrix cores (bf16 Down1 / Head), 3 thin (VALU), 1 direct, 0 unsupported */
 int dg_wgrad_kernel_variant(const DgWgrad* p, int force);
+/* 1 when the kernel `force` launches honours DgWgrad.g_mod (the LDS-DMA kernel; Down1's thin matrix-core kernel) */
+int dg_wgrad_has_sample_map(const DgWgrad* p, int force);
 
 /* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* stream);

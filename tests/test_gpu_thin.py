@@ -207,3 +207,34 @@ def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
     torch.cuda.synchronize()
     got = dw.cpu().view(4, 4, C0, nh).permute(2, 3, 0, 1)
     assert rel_l2(got, ref) < 1e-2
+
+
+def test_down1_wgrad_one_launch_over_real_fake_tangent(L):
+    """thin_wgrad_down_mfma with the gradient-sample map (DgWgrad.g_mod): one launch over 3n input samples real | fake |
+    tangent against the 2n-sample gradient chain (g sample = b % 2n, per-sample weights) == the two launches it replaces in
+    the D phase (ordinary + R1 weight gradient of Down1, trainers/dcgan_amp.py:229-235)"""
+    from dusty_gan_amd import engine as E
+    g = torch.Generator().manual_seed(3)
+    n, Hc, Wc, Ci, Co = 2, 8, 64, 2, 64
+    a = torch.randn(3 * n * 4 * Hc * Wc * Ci, generator=g).to(DEV, torch.bfloat16)
+    e = torch.randn(2 * n * Hc * Wc * Co, generator=g).to(DEV, torch.bfloat16)
+    rs = (torch.rand(3 * n, generator=g) + 0.5).to(DEV)
+    rs[2 * n:] = 1.0
+    sa, sg = (4 * Hc * Wc * Ci, Ci, 1), (Hc * Wc * Co, Co, 1)
+    o = E.Ops(torch.bfloat16)
+    E.TRACE = []
+    try:
+        two = torch.zeros(16, Ci, Co, device=DEV)
+        o.wgrad(0, True, 2 * n, Hc, Wc, Ci, Co, a, sa, e, sg, two.data_ptr(), 0.1, rowscale=rs[:2 * n].contiguous())
+        o.wgrad(0, True, n, Hc, Wc, Ci, Co, a, sa, e, sg, two.data_ptr(), 0.1, a_off=2 * n * sa[0])
+        assert o.wgrad_takes_map(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, two.data_ptr())
+        one = torch.zeros(16, Ci, Co, device=DEV)
+        o.wgrad(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, one.data_ptr(), 0.1, rowscale=rs, g_mod=2 * n)
+        assert all(t[1] == 7 for t in E.TRACE if t[0] == "wgrad"), E.TRACE     # the thin matrix-core kernel
+    finally:
+        E.TRACE = None
+    torch.cuda.synchronize()
+    assert rel_l2(one.cpu(), two.cpu()) < 1e-5
+    o.force = 1                                    # the direct kernel has no map: refused, not ignored
+    with pytest.raises(L.DgError):
+        o.wgrad(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, one.data_ptr(), 0.1, g_mod=2 * n)

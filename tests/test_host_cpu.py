@@ -202,3 +202,22 @@ def test_scan_dataset_file_lists_and_sampler(tmp_path):
     for n, world in ((10, 1), (10, 4), (3, 8)):
         for rank in range(world):
             assert sampler_indices(n, world, rank) == LO.sampler_indices(n, world, rank)
+
+
+def test_registry_is_a_table_and_refuses_unknown_archs():
+    """models.define_G / define_D (reference models/__init__.py:5-50): "<masker>/<backbone>" strings from tables, the
+    reference's NotImplementedError for anything that is not in them"""
+    from dusty_gan_amd import models
+    from dusty_gan_amd.utils.config import load_config
+    assert set(models.GENERATORS) == {"dcgan_eqlr"} == set(models.DISCRIMINATORS) and set(models.MASKERS) == {"none", "dusty1", "dusty2"}
+    cfg = load_config(["model=dusty1_dcgan_eqlr", "dataset=synthetic", "dataset.shape=[32,64]"])
+    cfg.model.gen.shape = cfg.model.dis.shape = cfg.dataset.shape
+    G, D = models.define_G(cfg), models.define_D(cfg)
+    assert type(G).__name__ == "DUSty1" and type(G.backbone).__name__ == "Generator" and type(D).__name__ == "Discriminator"
+    for bad in ("dusty3/dcgan_eqlr", "none/stylegan"):
+        cfg.model.gen.arch = bad
+        with pytest.raises(NotImplementedError):
+            models.define_G(cfg)
+    cfg.model.dis.arch = "patchgan"
+    with pytest.raises(NotImplementedError):
+        models.define_D(cfg)
