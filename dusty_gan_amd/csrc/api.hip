@@ -9,6 +9,8 @@ int dg_wgrad_mfma_dma_supported(const WgradP* p);
 int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_supported(const ConvP* p);
+int dg_proj_stream_supported(const ConvP* p);
+int dg_proj_stream_launch(const ConvP* p, hipStream_t stream, DgConvPlan* plan);
 int dg_conv_thin_mfma_variant(const ConvP* p);
 int dg_wgrad_thin_mfma_variant(const WgradP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
@@ -22,7 +24,7 @@ const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
 // force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
 //        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error (9: without its
-//        both-parities tile for 64-channel MODE_UP layers).
+//        both-parities tile for 64-channel MODE_UP layers), 10 the weight-streaming Proj forward or error.
 //        plan != NULL: describe the launch instead of making it.
 static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
@@ -34,6 +36,10 @@ static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, 
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
   if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; }
+  // Proj forward (bf16, K = 512, B <= 32): the weight-streaming kernel (proj_stream.hip); force 10 asks for it, 2 for the
+  // general MFMA kernel it replaces
+  if ((force == 0 || force == 10) && dg_proj_stream_supported(p)) return dg_proj_stream_launch(p, s, plan);
+  if (force == 10) return DG_EUNSUPPORTED;
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 4 || force == 5 || force == 9) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
@@ -58,6 +64,7 @@ int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan) {
 }
 
 int dg_conv_kernel_choice(const DgConv* p) {  // 2 = MFMA, 3 = thin, 1 = direct (what force == 0 would pick)
+  if (dg_proj_stream_supported(p)) return 2;
   if (!p->nscale && dg_conv_mfma_supported(p)) return 2;
   if (dg_conv_thin_supported(p)) return 3;
   return 1;

@@ -101,7 +101,8 @@ typedef struct DgWgrad {
 int dg_conv(const DgConv* p, int force, void* stream);
 /* What a dg_conv call launches (introspection for the parity tests and the benchmark: which kernel family / tile ran,
  * and how many tiles each persistent workgroup walks).  family: 1 direct, 2 one-tile-per-workgroup MFMA, 3 thin,
- * 4 persistent large-tile MFMA (lock step: fp32, small layers), 5 persistent ping-pong MFMA (bf16 fat layers).  dg_conv_ex = dg_conv with a cap on the persistent kernel's workgroup count
+ * 4 persistent large-tile MFMA (lock step: fp32, small layers), 5 persistent ping-pong MFMA (bf16 fat layers),
+ * 6 weight-streaming Proj forward (bf16 DG_MODE_GEMM with K = 512, B <= 32; dg_conv force 10 asks for it).  dg_conv_ex = dg_conv with a cap on the persistent kernel's workgroup count
  * (wg_cap <= 0: one residency wave of the device); dg_conv_plan fills `plan` for the same arguments and launches
  * nothing. */
 typedef struct DgConvPlan {

@@ -191,6 +191,41 @@ def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     assert rel_l2(dw.cpu().view(4, 4, Ci, Co).permute(2, 3, 0, 1), gw) < tol
 
 
+@pytest.mark.parametrize("B,N,epi", [(32, 4096, "lrelu"), (17, 2048, "lrelu"), (8, 1024, "linear"), (32, 131072, "lrelu")])
+def test_proj_forward_weight_streaming_kernel(L, B, N, epi):
+    """Proj forward (dcgan_eqlr.py:6-16) on the weight-streaming kernel (proj_stream.hip: dg_conv force 10 / what force 0
+    picks for bf16, K = 512, B <= 32) against the general MFMA kernel (force 2) and a float64 GEMM of the same bf16
+    operands; ragged batch (17 of 32 MFMA columns), both epilogues, the benchmark's 131072-row shape."""
+    from dusty_gan_amd import engine as E
+    K, C = 512, 64
+    g = torch.Generator().manual_seed(B + N)
+    z = torch.randn(B, K, generator=g).to(DEV, torch.bfloat16)
+    w = torch.randn(N, K, generator=g).to(DEV, torch.bfloat16)
+    bias = torch.randn(C, generator=g).to(DEV)
+    s = 1.0 / math.sqrt(N)
+    code = L.EPI_LRELU if epi == "lrelu" else L.EPI_LINEAR
+    outs = {}
+    for force in (10, 2, 0):
+        o = E.Ops(torch.bfloat16)
+        o.force = force
+        out = torch.full((B, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        E.TRACE = []
+        try:
+            o.conv(L.MODE_GEMM, 0, 1, B, 1, 1, K, N, z, (K, 0, 1), out, (N, 0, 1), w.data_ptr(), s, code,
+                   bias=bias.data_ptr(), bias_mod=C)
+            fam = [t for t in E.TRACE if t[0] == "conv"][0][1]
+        finally:
+            E.TRACE = None
+        torch.cuda.synchronize()
+        assert fam == (2 if force == 2 else 6), (force, fam)
+        outs[force] = out.float().cpu()
+    ref = (z.double().cpu() @ w.double().cpu().t()) * s + bias.double().cpu().repeat(N // C)[None, :]
+    if epi == "lrelu":
+        ref = torch.where(ref > 0, ref, 0.2 * ref) * math.sqrt(2.0)
+    assert rel_l2(outs[10], ref) < TOLBF and rel_l2(outs[2], ref) < TOLBF
+    assert rel_l2(outs[10], outs[2]) < 2e-3 and torch.equal(outs[0], outs[10])
+
+
 @pytest.mark.parametrize("force", [5, 9], ids=["both-parities-tile", "single-parity-tile"])
 @pytest.mark.parametrize("Ci,H,W,B", [(128, 4, 128, 2), (64, 2, 256, 1), (128, 4, 64, 4), (128, 2, 512, 1)])
 def test_up_forward_64_channels_on_the_pingpong_kernel(L, Ci, H, W, B, force):
