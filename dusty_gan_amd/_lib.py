@@ -150,6 +150,7 @@ PROTOTYPES = {
     "dg_counter_add_multi": [_P, _P, _I, _P],
     "dg_philox_fill_dev": [_U64, _U64, _P, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw_dev": [_U64, _U64, _P, _I, _I, _I, _P, _P, _P],
+    "dg_philox_logistic_dev": [_U64, _U64, _P, _F, _L, _P, _P],
     "dg_adam_ema_step_dev": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _P, _F, _P],
     "dg_adam_proj_fused": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _L, _I, _F, _F, _F, _F, _F, _P, _F, _P],
 }

@@ -324,6 +324,27 @@ __global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const uns
     }
   }
 }
+// GumbelSigmoid.logistic_noise (models/dusty.py:30-36) straight from the generator: element o of U1 is word o & 3 of Philox
+// counter offset + o / 4, U2 the same (n + 3) / 4 counters further - exactly what two uniform fills of n elements followed
+// by dg_logistic_noise produce, in one launch and without the two 4 n-byte round trips
+__global__ void philox_logistic_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
+                                           float eps, long n, float* __restrict__ out) {
+  const uint64_t offset = *offp;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * i >= n) return;
+  const uint64_t n4 = (uint64_t)((n + 3) / 4);
+  uint32_t r1[4], r2[4];
+  philox4x32_10(seed, offset + (uint64_t)i, stream, r1);
+  philox4x32_10(seed, offset + n4 + (uint64_t)i, stream, r2);
+  const float s24 = 1.f / 16777216.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long o = 4 * i + j;
+    if (o >= n) break;
+    const float u1 = (float)(r1[j] >> 8) * s24, u2 = (float)(r2[j] >> 8) * s24;
+    out[o] = -logf(logf(u1 + eps) / logf(u2 + eps) + eps);
+  }
+}
 __global__ void aug_draw_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp, int B,
                                     int sh, int sw, int nx, int ny, float* __restrict__ uf, int* __restrict__ qi) {
   const uint64_t offset = *offp;
@@ -437,6 +458,15 @@ int dg_philox_fill_dev(uint64_t seed, uint64_t stream, const unsigned long long*
   if (kind < 0 || kind > 3) return DG_EINVAL;
   if (kind == 3 && ihi <= ilo) return DG_EINVAL;
   philox_fill_dev_kernel<<<nblk((n + 3) / 4), 256, 0, s>>>(seed, stream, offset_dev, kind, lo, hi, ilo, ihi, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// logistic noise of n elements from the device-resident Philox offset; the caller advances the counter by 2 ((n + 3) / 4)
+int dg_philox_logistic_dev(uint64_t seed, uint64_t stream, const unsigned long long* offset_dev, float eps, long n,
+                           float* out, void* s_) {
+  if (!offset_dev || !out || n <= 0) return DG_EINVAL;
+  philox_logistic_dev_kernel<<<nblk((n + 3) / 4), 256, 0, (hipStream_t)s_>>>(seed, stream, offset_dev, eps, n, out);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -5,7 +5,7 @@
 // Here every WAVE is its own stream: it owns every (4 x gridDim)-th block of 16 weight rows, keeps the whole latent
 // operand in registers (the MFMA B fragments of all 16 K steps), and moves its row blocks global -> LDS by LDS-DMA into a
 // wave-private two-stage ring (16 KB per stage = 16 rows x 1 KB, one wave instruction per row, non-temporal: the shadow
-// is read once per step) - no workgroup barrier anywhere, 32 KB in flight per wave, 128 KB per CU.
+// is read once per step) - no workgroup barrier in the loop, 32 KB in flight per wave, 128 KB per CU.
 //   * MFMA: v_mfma_f32_16x16x32_bf16, A = 16 weight rows x 32 k, B = 32 k x 16 samples; D[row n'][sample b];
 //   * LDS rows are unpadded (a DMA piece is lane-linear); the 16-byte chunk c of row r lives at chunk c ^ r (r = 0..15),
 //     applied on the DMA source address and undone in the fragment read address: conflict-free for ds_read_b128's lane
@@ -19,6 +19,7 @@ constexpr int PS_K = 512;                        // latent width this kernel is 
 constexpr int PS_ROWS = 16;                      // weight rows per stage
 constexpr int PS_STAGE = PS_ROWS * PS_K * 2;     // 16 KB
 constexpr int PS_NS = 2, PS_WAVES = 4;
+constexpr int PS_MAXBIAS = 2048;
 
 __device__ __forceinline__ void ps_dma16_nt(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -30,6 +31,8 @@ __device__ __forceinline__ void ps_dma16_nt(const void* gsrc, void* lds_dst) {
 template <int NB>  // blocks of 16 samples: B <= 16 NB
 __global__ __launch_bounds__(256, 1) void proj_stream_kernel(ConvP p, int tiles) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[PS_WAVES * PS_NS * PS_STAGE];
+  __shared__ float s_bias[PS_MAXBIAS];           // (bias reads through LDS: a global load per tile would sit in vmcnt between
+                                                 //  the ring's pieces and force a full drain before its use)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kg = lane >> 4;
@@ -73,6 +76,9 @@ __global__ __launch_bounds__(256, 1) void proj_stream_kernel(ConvP p, int tiles)
   const float c_lin = p.epi == EPI_LRELU ? p.scale * SQRT2 : p.scale;
   const float slope = p.epi == EPI_LRELU ? LRELU_SLOPE : 1.f;
   const float bmul = p.epi == EPI_LRELU ? SQRT2 : 1.f;
+  const int bmod = p.bias ? p.bias_mod : 1;
+  for (int i = tid; i < bmod; i += 256) s_bias[i] = p.bias ? p.bias[i] * bmul : 0.f;
+  __syncthreads();                               // (the only workgroup barrier: before the streams start)
 
   int t = gw;
   if (t < tiles) issue(t, 0);
@@ -80,8 +86,9 @@ __global__ __launch_bounds__(256, 1) void proj_stream_kernel(ConvP p, int tiles)
   for (int i = 0; t < tiles; ++i, t += GW) {
     const int st = i & 1;
     const bool next = t + GW < tiles;           // the other stage holds a tile in flight
-    // loads retire in issue order: behind this tile sit at most the next tile's 16 pieces and the previous tile's stores
-    if (next) PS_WAITV(16 + NB); else PS_WAITV(0);
+    // loads retire in issue order: behind this tile's pieces sit at least the next tile's 16 pieces (first iteration:
+    // exactly those - a count of 16 + NB there let the tile's last row still be in flight: NaNs from one row in 8192)
+    if (next) PS_WAITV(16); else PS_WAITV(0);
     i32x4 af[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -102,11 +109,9 @@ __global__ __launch_bounds__(256, 1) void proj_stream_kernel(ConvP p, int tiles)
         acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[s]), zf[s][nb], acc[nb], 0, 0, 0);
     // D[row 4 kg + j][col r16]: four consecutive n' of sample 16 nb + r16
     const int n0 = t * PS_ROWS + 4 * kg;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    float bias[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bias[j] = p.bias[(n0 + j) % p.bias_mod] * bmul;
-    }
+    for (int j = 0; j < 4; ++j) bias[j] = s_bias[(n0 + j) % bmod];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int b = 16 * nb + r16;
@@ -134,7 +139,7 @@ int dg_proj_stream_supported(const ConvP* p) {
   if (p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1 || p->w_sn != PS_K) return 0;
   if (p->in_sb % 8 != 0 || p->out_sb % 4 != 0) return 0;
   if (((size_t)p->in & 15) != 0 || ((size_t)p->w & 15) != 0 || ((size_t)p->out & 7) != 0) return 0;
-  if (p->bias && p->bias_mod <= 0) return 0;
+  if (p->bias && (p->bias_mod <= 0 || p->bias_mod > PS_MAXBIAS)) return 0;
   if ((long)p->N / PS_ROWS > 0x7fffffffL) return 0;
   return 1;
 }

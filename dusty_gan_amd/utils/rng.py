@@ -48,12 +48,15 @@ class Philox:
         return self._fill(3, n, ilo=lo, ihi=hi)
 
     def logistic_noise(self, shape, eps=1e-10):
-        """GumbelSigmoid.logistic_noise (reference: models/dusty.py:30-36)"""
+        """GumbelSigmoid.logistic_noise (reference: models/dusty.py:30-36): U1 and U2 drawn and combined in ONE launch
+        (dg_philox_logistic_dev) - the same numbers, and the same counter advance, as two `uniform` fills followed by
+        dg_logistic_noise (tests/test_gpu_ops.py)"""
         n = 1
         for s in shape:
             n *= s
-        u1, u2 = self.uniform(n), self.uniform(n)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
-        L.check(L.lib().dg_logistic_noise(L.ptr(u1), L.ptr(u2), eps, n, L.ptr(out), L.stream_ptr()),
-                "dg_logistic_noise")
+        self.sync()
+        L.check(L.lib().dg_philox_logistic_dev(self.seed, self.stream_id, L.ptr(self.ctr), eps, n, L.ptr(out),
+                                               L.stream_ptr()), "dg_philox_logistic_dev")
+        self.advance(2 * ((n + 3) // 4))
         return out.view(*shape)

@@ -371,6 +371,10 @@ int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* 
 int dg_counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, void* stream);
 int dg_philox_fill_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int kind, float lo,
                        float hi, int ilo, int ihi, long n, void* out, void* stream);
+/* GumbelSigmoid.logistic_noise (models/dusty.py:30-36) in one launch: the same numbers as two dg_philox_fill_dev uniform
+ * fills of n elements (U1, then U2) followed by dg_logistic_noise; the caller advances the counter by 2 ((n + 3) / 4) */
+int dg_philox_logistic_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, float eps, long n,
+                           float* out, void* stream);
 int dg_aug_draw_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int B, int H, int W,
                     float* uf, int* qi, void* stream);
 /* Adam with the (0-based, already-completed) step count in device memory: this call is step *step_dev + 1 */

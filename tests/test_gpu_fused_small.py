@@ -306,3 +306,25 @@ def test_fetch_reals_from_the_device_resident_pool(L):
                                             out.data_ptr(), s.data_ptr(), None))
         torch.cuda.synchronize()
         assert torch.equal(out, ref) and rel_l2(s.cpu(), rs.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 8, 32), (2, 1, 1, 1), (5, 1, 7, 9)])
+def test_logistic_noise_in_one_launch(L, shape):
+    """Philox.logistic_noise (dg_philox_logistic_dev: U1, U2 drawn and combined in one launch) == two uniform fills of the
+    same stream followed by dg_logistic_noise (GumbelSigmoid.logistic_noise, models/dusty.py:30-36), and the same counter
+    position afterwards - also for element counts that are not multiples of 4"""
+    from dusty_gan_amd.utils.rng import Philox
+    n = 1
+    for s in shape:
+        n *= s
+    a, b = Philox(1234, torch.device(DEV), stream_id=3), Philox(1234, torch.device(DEV), stream_id=3)
+    a.uniform(5)
+    b.uniform(5)                                   # (a non-zero starting offset)
+    got = a.logistic_noise(shape)
+    u1, u2 = b.uniform(n), b.uniform(n)
+    want = torch.empty(n, device=DEV)
+    L.check(L.lib().dg_logistic_noise(u1.data_ptr(), u2.data_ptr(), 1e-10, n, want.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert got.shape == tuple(shape) and torch.equal(got.flatten(), want)
+    assert a.offset == b.offset
+    assert rel_l2(got.flatten().cpu(), O.logistic_noise(u1.cpu(), u2.cpu())) < 1e-5
