@@ -45,8 +45,8 @@ def parse(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short lines for BASELINE configs 3 / 4-share / 5-share appended after the timed region")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each appended configuration")
-    ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the bounded CPU-oracle sample")
-    ap.add_argument("--cpu-steps", type=int, default=16, help="timed oracle steps of the CPU sample (~10 s of CPU work)")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the bounded CPU-oracle sample (default: the workload's own)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps of the CPU sample (~13 s of CPU work at batch 32)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU-oracle sample")
     return ap.parse_args(argv)
 
@@ -134,7 +134,8 @@ def roofline_pass(tr, steps=2):
 
 def cpu_baseline(args, arch):
     """The CPU oracle (oracle/dusty_oracle.py: the reference's algorithm in stock torch CPU ops, validated against the
-    reference's modules) timed on this host: one warm-up + one timed step at a reduced batch (bounded sample)."""
+    reference's modules) timed on this host: one warm-up + `--cpu-steps` timed steps of the SAME workload (batch 32 at
+    64x1024: 6.6 s per step on 16 threads of the GPU box; the batch-4 sample of rounds 1-2 ran 1.3x more images/s)."""
     from oracle import dusty_oracle as O
     # torch's CPU conv kernels stop scaling (and then collapse) far below this host's thread count at batch 4:
     # measured on the GPU box (scripts/cpu_threads.py: 8/16/32/64/128 threads -> 0.85/0.73/0.86/1.27/2.83 s per
