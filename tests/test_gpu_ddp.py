@@ -314,3 +314,4 @@ def test_bench_launches_its_own_ranks():
     assert set(out["distributed"]["exposed_ms_per_step"]) >= {"wait D.hi+D.lo", "wait G.gather", "wait G.tail"}
     assert out["distributed"]["exchanges_per_step"] == 4 and out["distributed"]["bytes_per_step"]["total"] > 0
     assert out["step_ms_device"]["p50"] > 0
+    assert out["roofline"]["model_self_check"] == "ok" and 0 < out["roofline"]["step"]["frac"] < 1

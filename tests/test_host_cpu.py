@@ -221,3 +221,36 @@ def test_registry_is_a_table_and_refuses_unknown_archs():
     cfg.model.dis.arch = "patchgan"
     with pytest.raises(NotImplementedError):
         models.define_D(cfg)
+
+
+def test_algorithmic_work_model_matches_the_survey():
+    """engine.conv_algorithmic / wgrad_algorithmic (what bench.py's roofline divides by): FLOPs of SURVEY.md section 8a/8d per
+    sample at 64x1024 - 536 870 912 MAC for each fat layer pass - and byte counts from the operand shapes: MODE_S2 reads the
+    FINE grid and writes the coarse one, MODE_UP the reverse (round 2 counted MODE_UP's input at the fine pixel count and one
+    weight-gradient family ran "above" the HBM peak), EPI_MASK also reads the saved activation, 16 weight taps either way."""
+    from dusty_gan_amd import _lib as L
+    from dusty_gan_amd import engine as E
+    # Down2 forward: 64 -> 128 channels, coarse 16 x 256
+    fl, nb = E.conv_algorithmic(L.MODE_S2, 1, 16, 256, 64, 128, 2, 2, 2, False)
+    assert fl == 2 * 536870912 and nb == 4 * 4096 * 64 * 2 + 4096 * 128 * 2 + 16 * 128 * 64 * 2
+    # Up3 forward: 128 -> 64 channels, coarse 16 x 256 -> fine 32 x 512
+    fl, nb = E.conv_algorithmic(L.MODE_UP, 1, 16, 256, 128, 64, 2, 2, 2, False)
+    assert fl == 2 * 536870912 and nb == 4096 * 128 * 2 + 4 * 4096 * 64 * 2 + 16 * 64 * 128 * 2
+    # Down2 backward-data (MODE_UP, mask epilogue): the mask source doubles the output-side bytes
+    _, nb_m = E.conv_algorithmic(L.MODE_UP, 1, 16, 256, 128, 64, 2, 2, 2, True)
+    assert nb_m - nb == 4 * 4096 * 64 * 2
+    # Proj: B rows
+    fl, nb = E.conv_algorithmic(L.MODE_GEMM, 32, 1, 1, 512, 131072, 2, 2, 2, False)
+    assert fl == 2 * 32 * 67108864 and nb == 32 * 512 * 2 + 32 * 131072 * 2 + 131072 * 512 * 2
+    # weight gradients: Down (input fine, gradient coarse) and Up (input coarse, gradient fine), dW in fp32 once
+    fl, nb = E.wgrad_algorithmic(0, 1, 16, 256, 64, 128, 2, 2)
+    assert fl == 2 * 536870912 and nb == 4096 * (4 * 64 + 128) * 2 + 16 * 64 * 128 * 4
+    fl, nb = E.wgrad_algorithmic(1, 1, 16, 256, 128, 64, 2, 2)
+    assert fl == 2 * 536870912 and nb == 4096 * (128 + 4 * 64) * 2 + 16 * 128 * 64 * 4
+    # bench.py's whole-step model at config 2: executed FLOPs 3 F_G + 10 F_D per sample
+    import bench
+    sf, sb = bench.step_model([64, 1024], "none", 1.0, 32, 2, 69863424, 2886656)
+    f_g = 2 * (67108864 + 3 * 536870912 + 16777216)
+    f_d = 2 * (393216 + 33554432 + 3 * 536870912 + 131072)
+    assert sf == 32 * (3 * f_g + 10 * f_d) and 5.5e9 < sb < 6.2e9
+
