@@ -100,7 +100,7 @@ PROTOTYPES = {
     "dg_batch_wsum": [_P, _I, _P, _F, _I, _L, _P, _P],
     "dg_head_post_fwd": [_P, _P, _P, _I, _I, _F, _F, _I, _L, _P, _P, _P],
     "dg_head_post_fwd_sum": [_P, _P, _P, _I, _I, _F, _F, _I, _L, _P, _P, _P, _P],
-    "dg_head_post_bwd": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _L, _F, _F, _P, _P, _P, _I, _P],
+    "dg_head_post_bwd": [_P, _P, _P, _P, _P, _I, _F, _F, _I, _L, _F, _F, _P, _P, _P, _I, _P, _P],
     "dg_logistic_noise": [_P, _P, _F, _L, _P, _P],
     "dg_diffaug_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "dg_diffaug_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],

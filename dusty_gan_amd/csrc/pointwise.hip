@@ -399,6 +399,66 @@ __device__ __forceinline__ float head_post_px(float* __restrict__ gout, const fl
   }
   return m * t + (1.f - m) * drop_const;
 }
+// Four consecutive pixels per thread (HW % 1024 == 0, sums wanted): 16-byte loads / stores of every plane; same arithmetic
+// as head_post_px (which remains for other sizes).
+template <int arch>
+__global__ __launch_bounds__(256) void head_post_fwd4_kernel(float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                      const float* __restrict__ noise_image, int training, float inv_tau,
+                                      float drop_const, int B, long HW, float* __restrict__ mask,
+                                      float* __restrict__ depth, float* __restrict__ dsum, int chunk) {
+  __shared__ float red[16];
+  const long i0 = (long)blockIdx.x * chunk;
+  const int b = (int)(i0 / HW);
+  const long p0 = i0 - (long)b * HW;
+  constexpr int nch = 1 + (arch == 0 ? 0 : arch);
+  float* g = gout + (long)b * nch * HW + p0;
+  const float ni = (arch == 2 && training) ? noise_image[b] : 0.f;
+  float acc = 0.f;
+#pragma unroll 2
+  for (int k = threadIdx.x * 4; k < chunk; k += 1024) {
+    float4 g0 = *(const float4*)(g + k);
+    float t[4] = {tanhf(g0.x), tanhf(g0.y), tanhf(g0.z), tanhf(g0.w)};
+    *(float4*)(g + k) = make_float4(t[0], t[1], t[2], t[3]);
+    float dv[4] = {t[0], t[1], t[2], t[3]};
+    if (arch >= 1) {
+      const float4 g1 = *(const float4*)(g + HW + k), np = *(const float4*)(noise_pixel + (long)b * HW + p0 + k);
+      const float l1[4] = {g1.x + np.x, g1.y + np.y, g1.z + np.z, g1.w + np.w};
+      float mp[4], m[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float sp = 1.f / (1.f + __expf(-l1[q] * inv_tau));
+        mp[q] = sp > 0.5f ? 1.f : 0.f;
+        m[q] = mp[q];
+      }
+      if (arch == 1) {
+        *(float4*)(mask + (long)b * HW + p0 + k) = make_float4(mp[0], mp[1], mp[2], mp[3]);
+      } else {
+        const float4 g2 = *(const float4*)(g + 2 * HW + k);
+        const float l2[4] = {g2.x, g2.y, g2.z, g2.w};
+        float mi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (training) {
+            const float si = 1.f / (1.f + __expf(-(l2[q] + ni) * inv_tau));
+            mi[q] = si > 0.5f ? 1.f : 0.f;
+          } else {
+            mi[q] = l2[q] > 0.f ? 1.f : 0.f;
+          }
+          m[q] = mp[q] * mi[q];
+        }
+        *(float4*)(mask + (long)b * 2 * HW + p0 + k) = make_float4(mp[0], mp[1], mp[2], mp[3]);
+        *(float4*)(mask + (long)b * 2 * HW + HW + p0 + k) = make_float4(mi[0], mi[1], mi[2], mi[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dv[q] = m[q] * t[q] + (1.f - m[q]) * drop_const;
+    }
+    *(float4*)(depth + i0 + k) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    acc += (dv[0] + dv[1]) + (dv[2] + dv[3]);
+  }
+  const float sblk = dg_block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(&dsum[b], sblk);
+}
+
 template <int arch>   // compile-time: the pixel function is then straight-line code and the unrolled trips batch their loads
 __global__ __launch_bounds__(256) void head_post_fwd_kernel(float* __restrict__ gout, const float* __restrict__ noise_pixel,
                                      const float* __restrict__ noise_image, int training, float inv_tau,
@@ -500,6 +560,117 @@ __global__ __launch_bounds__(256) void head_post_bwd_kernel(const float* __restr
     if (threadIdx.x == 0) atomicAdd(&dbias[0], s0);
     if (arch >= 1) { const float s1 = dg_block_sum(a1, red); if (threadIdx.x == 0) atomicAdd(&dbias[1], s1); }
     if (arch >= 2) { const float s2 = dg_block_sum(a2, red); if (threadIdx.x == 0) atomicAdd(&dbias[2], s2); }
+  }
+}
+
+// Four consecutive pixels per thread (HW % 4 == 0): 16-byte loads of every plane, 16-byte stores; `draw` (the planar fp32
+// copy) may be null - the bf16 path consumes only the pixel-major copy, and three 8 MB planes were written for nobody.
+template <int arch, int CP>   // CP: 2 / 4 padded channel count of the pixel-major copy, 0 none
+__global__ __launch_bounds__(256) void head_post_bwd4_kernel(const float* __restrict__ gout, const float* __restrict__ noise_pixel,
+                                      const float* __restrict__ noise_image, const float* __restrict__ mask,
+                                      const float* __restrict__ ddepth, float inv_tau, float drop_const, int B, long HW,
+                                      float s_depth, float s_conf, float* __restrict__ draw, float* __restrict__ dbias,
+                                      bf16* __restrict__ draw_pm, float* __restrict__ bias_ws) {
+  __shared__ float red[16];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const int b = blockIdx.y;
+  constexpr int nch = 1 + (arch == 0 ? 0 : arch);
+  const float* g = gout + (long)b * nch * HW;
+  const float ni = arch == 2 ? noise_image[b] : 0.f;
+  auto ld = [](const float* q) { const float4 v = *(const float4*)q; return v; };
+  for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; p < HW; p += (long)gridDim.x * blockDim.x * 4) {
+    const long idx = (long)b * HW + p;
+    const float4 t4 = ld(g + p), go4 = ld(ddepth + idx);
+    const float t[4] = {t4.x, t4.y, t4.z, t4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+    float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (arch == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d0[q] = go[q] * (1.f - t[q] * t[q]);
+    } else {
+      const float4 g14 = ld(g + HW + p), np4 = ld(noise_pixel + idx);
+      const float l1[4] = {g14.x + np4.x, g14.y + np4.y, g14.z + np4.z, g14.w + np4.w};
+      float mp[4], mi[4] = {1.f, 1.f, 1.f, 1.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (arch == 1) {
+        const float4 m4 = ld(mask + idx);
+        mp[0] = m4.x; mp[1] = m4.y; mp[2] = m4.z; mp[3] = m4.w;
+      } else {
+        const float4 m4 = ld(mask + (long)b * 2 * HW + p), i4 = ld(mask + (long)b * 2 * HW + HW + p), g24 = ld(g + 2 * HW + p);
+        mp[0] = m4.x; mp[1] = m4.y; mp[2] = m4.z; mp[3] = m4.w;
+        mi[0] = i4.x; mi[1] = i4.y; mi[2] = i4.z; mi[3] = i4.w;
+        l2[0] = g24.x; l2[1] = g24.y; l2[2] = g24.z; l2[3] = g24.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float dt = 1.f - t[q] * t[q];
+        const float sp = 1.f / (1.f + __expf(-l1[q] * inv_tau));
+        const float dmask = go[q] * (t[q] - drop_const);
+        if (arch == 1) {
+          d0[q] = mp[q] * go[q] * dt;
+          d1[q] = dmask * sp * (1.f - sp) * inv_tau;
+        } else {
+          const float si = 1.f / (1.f + __expf(-(l2[q] + ni) * inv_tau));
+          d0[q] = mp[q] * mi[q] * go[q] * dt;
+          d1[q] = dmask * mi[q] * sp * (1.f - sp) * inv_tau;
+          d2[q] = dmask * mp[q] * si * (1.f - si) * inv_tau;
+        }
+      }
+    }
+    if (draw) {
+      float* d = draw + (long)b * nch * HW + p;
+      *(float4*)d = make_float4(d0[0] * s_depth, d0[1] * s_depth, d0[2] * s_depth, d0[3] * s_depth);
+      if (arch >= 1) *(float4*)(d + HW) = make_float4(d1[0] * s_conf, d1[1] * s_conf, d1[2] * s_conf, d1[3] * s_conf);
+      if (arch >= 2) *(float4*)(d + 2 * HW) = make_float4(d2[0] * s_conf, d2[1] * s_conf, d2[2] * s_conf, d2[3] * s_conf);
+    }
+    if (CP != 0) {
+      unsigned w01[4], w2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned short h0 = __builtin_bit_cast(unsigned short, (bf16)(d0[q] * s_depth));
+        const unsigned short h1 = __builtin_bit_cast(unsigned short, (bf16)(arch >= 1 ? d1[q] * s_conf : 0.f));
+        const unsigned short h2 = __builtin_bit_cast(unsigned short, (bf16)(arch >= 2 ? d2[q] * s_conf : 0.f));
+        w01[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+        w2[q] = (unsigned)h2;
+      }
+      if (CP == 2) {
+        *(uint4*)(draw_pm + idx * 2) = make_uint4(w01[0], w01[1], w01[2], w01[3]);
+      } else {
+        *(uint4*)(draw_pm + idx * 4) = make_uint4(w01[0], w2[0], w01[1], w2[1]);
+        *(uint4*)(draw_pm + idx * 4 + 8) = make_uint4(w01[2], w2[2], w01[3], w2[3]);
+      }
+    }
+    a0 += (d0[0] + d0[1]) + (d0[2] + d0[3]);
+    a1 += (d1[0] + d1[1]) + (d1[2] + d1[3]);
+    a2 += (d2[0] + d2[1]) + (d2[2] + d2[3]);
+  }
+  if (dbias) {
+    // Atomics on ONE address retire at ~10 ns each (they execute memory-side): a thousand blocks adding straight into
+    // dbias[n] cost 10 us per head - more than the pass over the data.  With `bias_ws` (4 KB per sample, zero on entry and
+    // left zero) the blocks of a sample add into that sample's slot - B independent addresses - and the last one to
+    // arrive (a ticket in the slot) folds the slot into dbias: gridDim.x adds per slot, B per dbias[n].
+    const float s0 = dg_block_sum(a0, red);
+    const float s1 = arch >= 1 ? dg_block_sum(a1, red) : 0.f;
+    const float s2 = arch >= 2 ? dg_block_sum(a2, red) : 0.f;
+    if (threadIdx.x == 0) {
+      if (bias_ws && gridDim.x > 1) {
+        float* w = bias_ws + (long)b * 1024;                // (4 KB apart: slots in one interleave unit serialise just the same)
+        atomicAdd(&w[0], s0);
+        if (arch >= 1) atomicAdd(&w[1], s1);
+        if (arch >= 2) atomicAdd(&w[2], s2);
+        // the adds above before the ticket: they are acknowledged from memory-side when vmcnt drains (a __threadfence()
+        // here is buffer_wbl2 - a write-back of the megabytes of gradient this kernel has just stored, per block)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd((unsigned*)&w[3], 1u) == gridDim.x - 1) {
+          atomicAdd(&dbias[0], atomicExch(&w[0], 0.f));
+          if (arch >= 1) atomicAdd(&dbias[1], atomicExch(&w[1], 0.f));
+          if (arch >= 2) atomicAdd(&dbias[2], atomicExch(&w[2], 0.f));
+          atomicExch((unsigned*)&w[3], 0u);
+        }
+      } else {
+        atomicAdd(&dbias[0], s0);
+        if (arch >= 1) atomicAdd(&dbias[1], s1);
+        if (arch >= 2) atomicAdd(&dbias[2], s2);
+      }
+    }
   }
 }
 
@@ -1277,6 +1448,17 @@ static int head_post_fwd_impl(float* gout, const float* noise_pixel, const float
   if (dsum && HW % 256 != 0) return DG_EUNSUPPORTED;
   const int chunk = dsum ? sum_chunk(HW) : 256;
   const unsigned nb = nblk((long)B * HW, chunk);
+  if (dsum && chunk % 1024 == 0 && ((size_t)gout & 15) == 0 && ((size_t)depth & 15) == 0 && ((size_t)mask & 15) == 0 &&
+      ((size_t)noise_pixel & 15) == 0) {
+    if (arch == 0)
+      head_post_fwd4_kernel<0><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
+    else if (arch == 1)
+      head_post_fwd4_kernel<1><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
+    else
+      head_post_fwd4_kernel<2><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
+    HIP_CHECK_RET(hipGetLastError());
+    return DG_OK;
+  }
   if (arch == 0)
     head_post_fwd_kernel<0><<<nb, 256, 0, s>>>(gout, noise_pixel, noise_image, training, 1.f / tau, drop_const, B, HW, mask, depth, dsum, chunk);
   else if (arch == 1)
@@ -1300,7 +1482,7 @@ int dg_head_post_fwd_sum(float* gout, const float* noise_pixel, const float* noi
 
 int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
                      const float* ddepth, int arch, float tau, float drop_const, int B, long HW, float s_depth,
-                     float s_conf, float* draw, float* dbias, void* draw_pm, int cp,
+                     float s_conf, float* draw, float* dbias, void* draw_pm, int cp, float* bias_ws,
                      void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (arch < 0 || arch > 2) return DG_EINVAL;
@@ -1309,6 +1491,23 @@ int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* n
   if (hb > per) hb = per;
   const dim3 grid(hb, B);
   const int cpk = !draw_pm ? 0 : (cp == 2 ? 2 : (cp == 4 ? 4 : 1));
+  if (!draw && !draw_pm) return DG_EINVAL;
+  auto al = [](const void* q) { return ((size_t)q & 15) == 0; };
+  if (HW % 4 == 0 && cpk != 1 && al(gout) && al(ddepth) && al(draw) && al(draw_pm) && al(noise_pixel) && al(mask)) {
+    unsigned hb4 = nblk(HW / 4);
+    if (hb4 > per) hb4 = per;
+    const dim3 grid4(hb4, B);
+#define DG_HPB4(A, C)                                                                                                    \
+    head_post_bwd4_kernel<A, C><<<grid4, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, 1.f / tau, drop_const, \
+                                                      B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, bias_ws)
+#define DG_HPB4_A(A) do { if (cpk == 0) DG_HPB4(A, 0); else if (cpk == 2) DG_HPB4(A, 2); else DG_HPB4(A, 4); } while (0)
+    if (arch == 0) DG_HPB4_A(0); else if (arch == 1) DG_HPB4_A(1); else DG_HPB4_A(2);
+#undef DG_HPB4_A
+#undef DG_HPB4
+    HIP_CHECK_RET(hipGetLastError());
+    return DG_OK;
+  }
+  if (!draw) return DG_EUNSUPPORTED;   // (the scalar kernel always writes the planar copy)
 #define DG_HPB(A, C)                                                                                                   \
   head_post_bwd_kernel<A, C><<<grid, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, 1.f / tau, drop_const, \
                                                   B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, cp)

@@ -384,6 +384,7 @@ class GEngine:
         self.cp = 2 if c.nheads <= 2 else 4  # channel padding of the pixel-major head gradient
         self.draw_pm = (torch.empty(B, c.H, c.W, self.cp, dtype=torch.bfloat16, device=device)
                         if (T == torch.bfloat16 and c.nheads <= 4 and c.ring) else None)
+        self.hp_ws = torch.zeros(B * 1024, dtype=torch.float32, device=device)  # dg_head_post_bwd's per-sample bias staging
         self.mask = torch.empty(B, max(c.nheads - 1, 1), c.H, c.W, dtype=torch.float32, device=device)
         self.depth = torch.empty(B, 1, c.H, c.W, dtype=torch.float32, device=device)
         self.zT = torch.empty(B * c.nz, dtype=T, device=device)
@@ -479,8 +480,8 @@ class GEngine:
         L.check(lib.dg_head_post_bwd(L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
                                      L.ptr(self.noise_image) if arch == 2 else None,
                                      L.ptr(self.mask) if arch else None, L.ptr(ddepth), arch, c.tau, c.drop_const, B,
-                                     self.HW, s_depth, s_conf, L.ptr(self.draw), st.fptr("head_b", st.grad),
-                                     L.ptr(self.draw_pm), self.cp, sp),
+                                     self.HW, s_depth, s_conf, None if self.draw_pm is not None else L.ptr(self.draw),
+                                     st.fptr("head_b", st.grad), L.ptr(self.draw_pm), self.cp, L.ptr(self.hp_ws), sp),
                 "dg_head_post_bwd")
         pl = (c.nheads * self.HW, 1, self.HW)
         pm = self.draw_pm is not None  # bf16: the pixel-major copy of the head gradient feeds the two thin MFMA kernels
@@ -558,8 +559,9 @@ class GEngine:
                                           L.ptr(draw), st.fptr("head_b", g), L.ptr(draw_pm), self.cp, sp),
                     "dg_head_post_bwd2")
         else:
-            L.check(lib.dg_head_post_bwd(*common, arch, c.tau, c.drop_const, B, self.HW, s_depth, s_conf, L.ptr(draw),
-                                         None, L.ptr(draw_pm), self.cp, sp), "dg_head_post_bwd")
+            L.check(lib.dg_head_post_bwd(*common, arch, c.tau, c.drop_const, B, self.HW, s_depth, s_conf,
+                                         None if draw_pm is not None else L.ptr(draw),   # (pixel-major copy only)
+                                         None, L.ptr(draw_pm), self.cp, None, sp), "dg_head_post_bwd")
         hc, wc = self.grid[3]
         pl = (c.nheads * self.HW, 1, self.HW)
         pm = draw_pm is not None

@@ -179,11 +179,15 @@ int dg_head_post_fwd(float* gout, const float* noise_pixel, const float* noise_i
 int dg_head_post_fwd_sum(float* gout, const float* noise_pixel, const float* noise_image, int arch, int training,
                          float tau, float drop_const, int B, long HW, float* mask, float* depth, float* dsum, void* stream);
 /* draw[n] = s_n * d(loss)/d(head output n) (s_depth for ch0, s_conf for the logits: the EqualLR scale of each head,
- * pre-multiplied so the head's backward-data / weight-gradient passes run with scale 1); dbias[n] += unscaled sums */
+ * pre-multiplied so the head's backward-data / weight-gradient passes run with scale 1); dbias[n] += unscaled sums.
+ * `draw` (planar fp32) may be NULL when the pixel-major bf16 copy is the only consumer (cp 2 / 4, HW % 4 == 0, 16-byte
+ * aligned planes; DG_EUNSUPPORTED otherwise, DG_EINVAL when both are NULL).  `bias_ws` (optional, 1024 floats per sample,
+ * zero on entry, left zero): per-sample staging of the bias sums - a thousand atomics on one address serialise at
+ * ~10 ns each, B slots take them in parallel and the last block of each sample folds its slot into dbias */
 int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
                      const float* ddepth, int arch, float tau, float drop_const, int B, long HW, float s_depth,
                      float s_conf, float* draw, float* dbias, void* draw_pm /* optional bf16 [B,H,W,cp] copy */, int cp,
-                     void* stream);
+                     float* bias_ws, void* stream);
 /* GumbelSigmoid.logistic_noise  models/dusty.py:30-36 */
 int dg_logistic_noise(const float* u1, const float* u2, float eps, long n, float* out, void* stream);
 

@@ -419,12 +419,15 @@ def test_blur_and_final(L, ring, dtype):
     assert rel_l2(dwf.cpu().view(h0, w0, C3).permute(2, 0, 1), gwf[0]) < 1e-5
 
 
+@pytest.mark.parametrize("H,W", [(8, 32), (3, 7), (64, 1024)])
 @pytest.mark.parametrize("arch", ["none", "dusty1", "dusty2"])
-def test_head_post_fwd_bwd(L, arch):
-    """tanh + GumbelSigmoid + maskout (dcgan_eqlr.py:71; dusty.py:45-59,77-91,107-127) forward and backward."""
+def test_head_post_fwd_bwd(L, arch, H, W):
+    """tanh + GumbelSigmoid + maskout (dcgan_eqlr.py:71; dusty.py:45-59,77-91,107-127) forward and backward: the scalar
+    kernels (3x7), the four-pixels-per-thread backward (HW % 4 == 0) and forward-with-sums (HW % 1024 == 0), every
+    pixel-major padding, and the bf16 mode's call without the planar copy."""
     lib = L.lib()
     g = torch.Generator().manual_seed(11)
-    B, H, W = 2, 8, 32
+    B = 2
     k = {"none": 0, "dusty1": 1, "dusty2": 2}[arch]
     raw = torch.randn(B, 1 + k, H, W, generator=g).requires_grad_()
     noise = {"pixel": O.logistic_noise(torch.rand(B, 1, H, W, generator=g), torch.rand(B, 1, H, W, generator=g)),
@@ -437,27 +440,54 @@ def test_head_post_fwd_bwd(L, arch):
     mask = torch.empty(B, max(k, 1), H, W, device=DEV)
     depth = torch.empty(B, 1, H, W, device=DEV)
     npx, nim = noise["pixel"].to(DEV).contiguous(), noise["image"].to(DEV).contiguous().view(B)
-    L.check(lib.dg_head_post_fwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), k, 1, 1.0, -1.0, B, H * W,
-                                 mask.data_ptr(), depth.data_ptr(), None))
+    if (H * W) % 256 == 0:
+        dsum = torch.zeros(B, device=DEV)
+        L.check(lib.dg_head_post_fwd_sum(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), k, 1, 1.0, -1.0, B, H * W,
+                                         mask.data_ptr(), depth.data_ptr(), dsum.data_ptr(), None))
+        assert rel_l2(dsum.cpu(), out["depth"].detach().sum(dim=[1, 2, 3])) < 1e-5
+    else:
+        L.check(lib.dg_head_post_fwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), k, 1, 1.0, -1.0, B, H * W,
+                                     mask.data_ptr(), depth.data_ptr(), None))
     assert rel_l2(depth.cpu(), out["depth"]) < 1e-5
     if k:
-        assert torch.equal(mask.cpu(), out["mask"].detach())
+        # (a logit within fp32 rounding of zero may take the other side of the straight-through threshold)
+        assert (mask.cpu() != out["mask"].detach()).float().mean() <= (0 if H * W < 1000 else 1e-5)
         assert rel_l2(gd[:, 0:1].cpu(), out["depth_orig"]) < 1e-6
     go = torch.randn(B, 1, H, W, generator=g)
     (graw,) = torch.autograd.grad(out["depth"], raw, go)
-    draw = torch.empty(B, 1 + k, H, W, device=DEV)
     god = go.to(DEV)
-    draw_pm = torch.empty(B, H, W, 4, device=DEV, dtype=torch.bfloat16)
-    dbias = torch.zeros(3, device=DEV)
     s_d, s_c = 0.25, 0.125
-    L.check(lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(),
-                                 god.data_ptr(), k, 1.0, -1.0, B, H * W, s_d, s_c, draw.data_ptr(),
-                                 dbias.data_ptr(), draw_pm.data_ptr(), 4, None))
     scale = torch.tensor([s_d] + [s_c] * k).view(1, -1, 1, 1)
-    assert rel_l2(draw.cpu(), graw * scale) < 1e-5
-    assert rel_l2(dbias.cpu()[:1 + k], graw.sum(dim=[0, 2, 3])) < 1e-4
-    pm = draw_pm.float().cpu().permute(0, 3, 1, 2)
-    assert rel_l2(pm[:, :1 + k], graw * scale) < 1e-2 and float(pm[:, 1 + k:].abs().max()) == 0.0
+    same_mask = torch.equal(mask.cpu(), out["mask"].detach()) if k else True
+    ws = torch.zeros(B * 1024, device=DEV)
+    for cp in ([4] if k == 2 else [2, 4]):
+        for planar in (True, False):
+            if not planar and (H * W) % 4:
+                draw_pm = torch.empty(B, H, W, cp, device=DEV, dtype=torch.bfloat16)
+                rc = lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(), god.data_ptr(),
+                                          k, 1.0, -1.0, B, H * W, s_d, s_c, None, None, draw_pm.data_ptr(), cp, None, None)
+                assert rc == L.DG_EUNSUPPORTED
+                continue
+            draw = torch.full((B, 1 + k, H, W), 7.0, device=DEV)
+            draw_pm = torch.full((B, H, W, cp), 7.0, device=DEV, dtype=torch.bfloat16)
+            dbias = torch.zeros(3, device=DEV)
+            L.check(lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(),
+                                         god.data_ptr(), k, 1.0, -1.0, B, H * W, s_d, s_c,
+                                         draw.data_ptr() if planar else None, dbias.data_ptr(), draw_pm.data_ptr(), cp,
+                                         None if planar else ws.data_ptr(), None))
+            assert float(ws.abs().max()) == 0.0          # (the staging slots are left zero: the next launch reuses them)
+            tol = 1e-5 if same_mask else 1e-2
+            if planar:
+                assert rel_l2(draw.cpu(), graw * scale) < tol
+            else:
+                assert float((draw - 7.0).abs().max()) == 0.0
+            assert rel_l2(dbias.cpu()[:1 + k], graw.sum(dim=[0, 2, 3])) < max(tol, 1e-4)
+            pm = draw_pm.float().cpu().permute(0, 3, 1, 2)
+            assert rel_l2(pm[:, :1 + k], graw * scale) < 1e-2
+            if 1 + k < cp:
+                assert float(pm[:, 1 + k:].abs().max()) == 0.0
+    assert lib.dg_head_post_bwd(gd.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(), god.data_ptr(),
+                                k, 1.0, -1.0, B, H * W, s_d, s_c, None, None, None, 0, None, None) == L.DG_EINVAL
 
 
 @pytest.mark.parametrize("H,W", [(16, 32), (64, 1024)])
