@@ -148,6 +148,7 @@ PROTOTYPES = {
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
     "dg_counter_add": [_P, _U64, _P],
     "dg_counter_add_multi": [_P, _P, _I, _P],
+    "dg_counter_add_multi_snap": [_P, _P, _I, _I, _P, _I, _P, _I, _P],
     "dg_philox_fill_dev": [_U64, _U64, _P, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw_dev": [_U64, _U64, _P, _I, _I, _I, _P, _P, _P],
     "dg_philox_logistic_dev": [_U64, _U64, _P, _F, _L, _P, _P],
@@ -277,6 +278,12 @@ class Counters:
     queued here and applied by ONE kernel at the end of the step (`flush`); anything that reads a counter with a queued
     advance - the next draw from the same generator, `Philox.offset`, the next optimizer step - flushes first."""
     pending = {}
+    snap = None   # (counter tensor, src pointer, n, ring pointer, ring slots): filed by the next flush (dg_counter_add_multi_snap)
+
+    @classmethod
+    def snapshot(cls, ctr, src_ptr, n, ring_ptr, ring):
+        """with the next flush - which must advance `ctr` - src[0..n) goes to slot (old ctr) % ring of the ring buffer"""
+        cls.snap = (ctr, int(src_ptr), int(n), int(ring_ptr), int(ring))
 
     @classmethod
     def add(cls, t, n):
@@ -293,11 +300,19 @@ class Counters:
         import ctypes as C
         items = list(cls.pending.values())
         cls.pending.clear()
+        snap, cls.snap = cls.snap, None
+        if snap is not None and snap[0].data_ptr() not in [t.data_ptr() for t, _ in items]:
+            raise RuntimeError("Counters.snapshot: the snapshot's counter has no queued advance")
         for i in range(0, len(items), 8):
             chunk = items[i:i + 8]
             ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t, _ in chunk])
             dels = (C.c_uint64 * len(chunk))(*[d for _, d in chunk])
-            check(lib().dg_counter_add_multi(ptrs, dels, len(chunk), stream_ptr()), "dg_counter_add_multi")
+            at = [j for j, (t, _) in enumerate(chunk) if snap is not None and t.data_ptr() == snap[0].data_ptr()]
+            if at:
+                check(lib().dg_counter_add_multi_snap(ptrs, dels, len(chunk), at[0], snap[1], snap[2], snap[3], snap[4],
+                                                      stream_ptr()), "dg_counter_add_multi_snap")
+            else:
+                check(lib().dg_counter_add_multi(ptrs, dels, len(chunk), stream_ptr()), "dg_counter_add_multi")
 
 
 def tag_sums(t, sums):

@@ -295,9 +295,19 @@ __global__ void aug_draw_kernel(uint64_t seed, uint64_t stream, uint64_t offset,
 __global__ void counter_add_kernel(unsigned long long* c, unsigned long long delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
 }
-struct CounterAdds { unsigned long long* c[8]; unsigned long long d[8]; int k; };
+struct CounterAdds {
+  unsigned long long* c[8]; unsigned long long d[8]; int k;
+  int snap_idx, snap_n, snap_ring; const float* snap_src; float* snap_dst;   // snap_idx < 0: no snapshot
+};
 __global__ void counter_add_multi_kernel(CounterAdds a) {
-  if (blockIdx.x == 0 && threadIdx.x < a.k) *a.c[threadIdx.x] += a.d[threadIdx.x];
+  if (blockIdx.x != 0 || (int)threadIdx.x >= a.k) return;
+  const unsigned long long v = *a.c[threadIdx.x];
+  *a.c[threadIdx.x] = v + a.d[threadIdx.x];
+  if ((int)threadIdx.x == a.snap_idx) {          // the thread that advances the counter also files the snapshot under its old value
+    float* dst = a.snap_dst + (long)(v % (unsigned long long)a.snap_ring) * a.snap_n;
+    for (int i = 0; i < a.snap_n; ++i) dst[i] = a.snap_src[i];
+    __threadfence_system();                      // (dst may be mapped host memory)
+  }
 }
 __global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
                                        int kind, float lo, float hi, int ilo, int ihi, long n, void* __restrict__ out) {
@@ -437,9 +447,12 @@ int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* 
 
 // k <= 8 DISTINCT counters advanced by one launch (a step's Philox offsets and Adam step counts, queued by the caller
 // behind their consumers: one graph node instead of one per counter)
-int dg_counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, void* s_) {
+static int counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, int snap_idx,
+                             const float* src, int n, float* dst_ring, int ring, void* s_) {
   if (k < 1 || k > 8 || !counters || !deltas) return DG_EINVAL;
+  if (snap_idx >= 0 && (snap_idx >= k || !src || !dst_ring || n < 1 || n > 64 || ring < 1)) return DG_EINVAL;
   CounterAdds a{};
+  a.snap_idx = snap_idx; a.snap_n = n; a.snap_ring = ring; a.snap_src = src; a.snap_dst = dst_ring;
   for (int i = 0; i < k; ++i) {
     if (!counters[i]) return DG_EINVAL;
     for (int j = 0; j < i; ++j)
@@ -450,6 +463,17 @@ int dg_counter_add_multi(unsigned long long* const* counters, const unsigned lon
   counter_add_multi_kernel<<<1, 64, 0, (hipStream_t)s_>>>(a);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+int dg_counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, void* s_) {
+  return counter_add_multi(counters, deltas, k, -1, nullptr, 0, nullptr, 1, s_);
+}
+// ... and slot (old value of counters[snap_idx]) % ring of `dst_ring` (n floats per slot; device memory or mapped pinned host
+// memory) receives src[0..n): the step's logged scalars leave the device from the step's last launch - no copy node behind
+// the graph, and the host reads slot i once an event recorded behind step i has completed, never blocking the launch stream
+int dg_counter_add_multi_snap(unsigned long long* const* counters, const unsigned long long* deltas, int k, int snap_idx,
+                              const float* src, int n, float* dst_ring, int ring, void* s_) {
+  if (snap_idx < 0) return DG_EINVAL;
+  return counter_add_multi(counters, deltas, k, snap_idx, src, n, dst_ring, ring, s_);
 }
 
 int dg_philox_fill_dev(uint64_t seed, uint64_t stream, const unsigned long long* offset_dev, int kind, float lo,

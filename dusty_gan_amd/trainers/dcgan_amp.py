@@ -56,7 +56,10 @@ class LazyScalars(Mapping):
             if self._finish is not None:    # the asynchronous rank average of a multi-GPU run completes here
                 self._dev = self._finish()
                 self._finish = None
-            self._vals = dict(zip(self._keys, self._dev.tolist()))
+            if isinstance(self._dev, RingSlot):
+                self._vals = dict(zip(self._keys, self._dev.read()))
+            else:
+                self._vals = dict(zip(self._keys, self._dev.tolist()))
             self._dev = None
         return self._vals
 
@@ -79,6 +82,24 @@ class LazyScalars(Mapping):
 
     def __repr__(self):
         return repr(self._resolve())
+
+
+class RingSlot:
+    """One step's logged scalars in the trainer's ring of mapped pinned host memory: the step's last launch
+    (dg_counter_add_multi_snap) stored them there, `event` was recorded behind it.  `read()` waits for that event - not
+    for the launch stream, on which later steps may already be queued - and copies the slot out; the ring has
+    Trainer.SCALAR_RING slots, so a slot is valid until that many later steps have run."""
+
+    def __init__(self, ring, slot, event, idx, serial, trainer):
+        self.ring, self.slot, self.event, self.idx, self.serial, self.trainer = ring, slot, event, idx, serial, trainer
+
+    def read(self):
+        self.event.synchronize()
+        if self.trainer._snap_pos - self.serial > self.ring.shape[0]:
+            raise RuntimeError(f"the scalars of step serial {self.serial} were overwritten: read a step's values within "
+                               f"{self.ring.shape[0]} steps")
+        row = self.ring[self.slot].tolist()
+        return [row[i] for i in self.idx]
 
 
 class FlatAdam:
@@ -321,6 +342,9 @@ class Trainer:
         self._pending = None
         self._dev_scal = None
         self._pool_ctr = None   # device-resident loader position of the synthetic pool (dg_fetch_reals_pool_sum)
+        # the logged scalars leave the device with the step's last launch, into a ring of mapped pinned host memory
+        # (RingSlot); DUSTY_GAN_SCALAR_RING=0: a device copy + a blocking read-back per step instead
+        self._snap_ring, self._snap_ctr, self._snap_pos = None, None, 0
         # hipGraph replay of the step (single GPU, synthetic device-resident data); DUSTY_GAN_GRAPH=0 disables it
         import os
         self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
@@ -839,10 +863,33 @@ class Trainer:
             idx += [5, 6]
         return keys, idx
 
+    SCALAR_RING = 64
+
+    def _use_ring(self):
+        import os
+        return self.world == 1 and self.n_acc == 1 and os.environ.get("DUSTY_GAN_SCALAR_RING", "1") != "0"
+
+    def _ring_slot(self):
+        """the slot the step that has just been launched files its scalars in (host mirror of the device-side serial)"""
+        ev = torch.cuda.Event()
+        ev.record()
+        slot = RingSlot(self._snap_ring, self._snap_pos % self.SCALAR_RING, ev, self._scalar_keys()[1], self._snap_pos, self)
+        self._snap_pos += 1
+        return slot
+
     def _step_eager(self, reals=None, rands=None):
-        """the launch sequence of one iteration; returns the device tensor of (locally averaged) scalars"""
+        """the launch sequence of one iteration; returns the (locally averaged) scalars: a device tensor, or - single
+        process, one micro-batch - the RingSlot they are filed in by the step's last launch (None while capturing)"""
         self.optimize_D(reals, rands)
         scal = self.optimize_G()
+        if self._use_ring():
+            if self._snap_ring is None:
+                self._snap_ring = torch.zeros(self.SCALAR_RING, 8, dtype=torch.float32).pin_memory()
+                self._snap_ctr = torch.full((1,), self._snap_pos, dtype=torch.int64, device=self.device)
+            L.Counters.add(self._snap_ctr, 1)
+            L.Counters.snapshot(self._snap_ctr, scal.data_ptr(), 8, self._snap_ring.data_ptr(), self.SCALAR_RING)
+            L.Counters.flush()  # Philox offsets, Adam step counts, the scalar snapshot: one launch
+            return None if self._cap is not None else self._ring_slot()
         L.Counters.flush()  # Philox offsets and Adam step counts of this step: one launch
         if self.n_acc > 1:
             scal = scal / self.n_acc
@@ -932,7 +979,7 @@ class Trainer:
         # the replayed Adam+EMA kernel rewrote G_ema's master through raw pointers: its low-precision / transposed
         # shadows (built lazily, only when G_ema is evaluated) are stale now
         _backbone(self.G_ema).store._seen_version = -1
-        return self._g_out.clone()
+        return self._ring_slot() if self._g_out is None else self._g_out.clone()
 
     def step(self, i=0, reals=None, rands=None):
         """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""
@@ -940,6 +987,8 @@ class Trainer:
             out = self._step_graph()
         else:
             out = self._step_eager(reals, rands)
+        if isinstance(out, RingSlot):
+            return LazyScalars(self._scalar_keys()[0], out)
         out, finish = D_.mean_scalars(out)  # one packed, asynchronous collective instead of 5-7 blocking ones (:319-323)
         return LazyScalars(self._scalar_keys()[0], out, finish)
 

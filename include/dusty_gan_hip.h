@@ -373,6 +373,12 @@ int dg_aug_draw(uint64_t seed, uint64_t stream_id, uint64_t offset, int B, int H
 int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* stream);
 /* k <= 8 distinct counters advanced by one launch (DG_EINVAL on duplicates) */
 int dg_counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, void* stream);
+/* the same, and src[0..n) (n <= 64) is filed in slot (OLD value of counters[snap_idx]) % ring of dst_ring (n floats per slot;
+ * device memory or mapped pinned host memory): the logged scalars of Trainer.step (trainers/dcgan_amp.py:319-323, five
+ * blocking all_reduce + .item() there) leave the device with the step's last launch and are read by the host behind an
+ * event, without a copy node or a blocking read on the launch stream */
+int dg_counter_add_multi_snap(unsigned long long* const* counters, const unsigned long long* deltas, int k, int snap_idx,
+                              const float* src, int n, float* dst_ring, int ring, void* stream);
 int dg_philox_fill_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int kind, float lo,
                        float hi, int ilo, int ihi, long n, void* out, void* stream);
 /* GumbelSigmoid.logistic_noise (models/dusty.py:30-36) in one launch: the same numbers as two dg_philox_fill_dev uniform

@@ -134,6 +134,37 @@ def test_arena_slices_are_zero_once_and_exhaustion_falls_back(L):
     assert rel_l2(o1.cpu(), o2.cpu()) < 1e-6 and rel_l2(o1.cpu(), x.pow(2).sum(1).cpu()) < 1e-6
 
 
+def test_counter_add_multi_snap_into_pinned_host_ring(L):
+    """dg_counter_add_multi_snap: the advancing launch files src[0..n) in slot (OLD counter) % ring - of a device buffer and
+    of mapped pinned host memory (what Trainer.step's scalars use); argument errors."""
+    lib = L.lib()
+    ring_n, n = 4, 8
+    for host in (False, True):
+        c = [torch.full((1,), v, dtype=torch.int64, device=DEV) for v in (100, 6)]
+        ring = torch.zeros(ring_n, n).pin_memory() if host else torch.zeros(ring_n, n, device=DEV)
+        ptrs = (C.c_void_p * 2)(*[t.data_ptr() for t in c])
+        for k in range(6):
+            src = torch.arange(n, dtype=torch.float32, device=DEV) + 10.0 * k
+            L.check(lib.dg_counter_add_multi_snap(ptrs, (C.c_uint64 * 2)(5, 1), 2, 1, src.data_ptr(), n, ring.data_ptr(),
+                                                  ring_n, None))
+            torch.cuda.synchronize()
+            assert [int(t) for t in c] == [100 + 5 * (k + 1), 6 + k + 1]
+            assert ring[(6 + k) % ring_n].tolist() == [float(i) + 10.0 * k for i in range(n)], (host, k)
+        assert lib.dg_counter_add_multi_snap(ptrs, (C.c_uint64 * 2)(5, 1), 2, 2, src.data_ptr(), n, ring.data_ptr(), ring_n,
+                                             None) == L.DG_EINVAL
+        assert lib.dg_counter_add_multi_snap(ptrs, (C.c_uint64 * 2)(5, 1), 2, 0, None, n, ring.data_ptr(), ring_n,
+                                             None) == L.DG_EINVAL
+        assert lib.dg_counter_add_multi_snap(ptrs, (C.c_uint64 * 2)(5, 1), 2, 0, src.data_ptr(), 65, ring.data_ptr(), ring_n,
+                                             None) == L.DG_EINVAL
+    # the host-side queue: a snapshot needs its counter's advance in the same flush
+    L.Counters.flush()
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    L.Counters.snapshot(ctr, src.data_ptr(), n, ring.data_ptr(), ring_n)
+    with pytest.raises(RuntimeError):
+        L.Counters.flush()
+    assert L.Counters.snap is None
+
+
 def test_counters_queue_and_multi_add(L):
     from dusty_gan_amd.utils.rng import Philox
     lib = L.lib()

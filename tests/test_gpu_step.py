@@ -401,6 +401,36 @@ def test_eager_draw_between_graph_replays(monkeypatch):
     assert a.rng.offset == b.rng.offset and a.A._rng.offset == b.A._rng.offset
 
 
+@pytest.mark.parametrize("graph", [True, False], ids=["graph", "eager"])
+def test_scalar_ring_equals_device_readback(monkeypatch, graph):
+    """Trainer.step's scalars filed by the step's last launch in the ring of pinned host memory (read behind an event,
+    steps later, out of order) are the values the device copy + blocking read-back returns; a slot read after
+    Trainer.SCALAR_RING further steps raises instead of returning another step's values."""
+    def run(ring, steps, late=False):
+        monkeypatch.setenv("DUSTY_GAN_SCALAR_RING", "1" if ring else "0")
+        monkeypatch.setenv("DUSTY_GAN_GRAPH", "1" if graph else "0")
+        torch.manual_seed(91)
+        tr = make_trainer("dusty2", True, (32, 64), 8, 4, 16, 4)
+        outs = [tr.step(i) for i in range(steps)]                     # nothing read until every step is launched
+        assert (tr._snap_ring is not None) == ring and (tr._graph is not None) == graph
+        if late:
+            return tr, outs
+        return [dict(o.items()) for o in reversed(outs)][::-1]
+    a, b = run(True, 9), run(False, 9)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert list(x) == list(y)
+        for k in x:
+            # (two RUNS: the scalars are sums of atomics - last-bit differences at step 0 grow with the training steps)
+            assert abs(x[k] - y[k]) <= 1e-4 * max(1.0, abs(y[k])), (i, k, x[k], y[k])
+    tr, outs = run(True, tr_steps := 3, late=True)
+    first = outs[0]
+    for i in range(tr.SCALAR_RING):
+        last = tr.step(tr_steps + i)
+    assert len(dict(last.items())) == len(a[0])
+    with pytest.raises(RuntimeError, match="overwritten"):
+        first["loss/D/adversarial"]
+
+
 def test_graph_replay_survives_host_sync():
     """A host-side stream synchronize between two replays of the captured step must not change what the next replay
     computes.  Round 1 / 2 finding: with hipMemsetAsync nodes in the graph (the 32-byte per-sample accumulators of
