@@ -41,7 +41,16 @@ class DgConv(C.Structure):
         ("aux", C.c_void_p), ("dbias", C.c_void_p), ("rowscale", C.c_void_p),
         ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("w_dtype", C.c_int),
         ("nscale", C.c_void_p),
+        ("up_frag", C.c_void_p),
     ]
+
+
+UP_FRAG_BYTES = 3 * 18 * 1024
+
+
+class DgUpFrag(C.Structure):
+    _fields_ = [("off", C.c_longlong), ("frag", C.c_void_p), ("m_st", C.c_longlong), ("m_sn", C.c_longlong),
+                ("m_sk", C.c_longlong), ("N", C.c_int), ("Hc", C.c_int), ("adj", C.c_int)]
 
 
 class DgWgrad(C.Structure):
@@ -143,6 +152,7 @@ PROTOTYPES = {
     "dg_cast": [_P, _P, _I, _L, _P],
     "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
     "dg_transpose_shadow_multi": [_P, _P, _I, _I, _I, _P],
+    "dg_transpose_shadow_multi_frags": [_P, _P, _I, _I, _I, C.POINTER(DgUpFrag), _I, _P],
     "dg_philox_bits": [_U64, _U64, _U64, _L, _P, _P],
     "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],

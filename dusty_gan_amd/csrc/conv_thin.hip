@@ -17,6 +17,7 @@
 // run-time trip count, and a load inside an epilogue brings its own s_waitcnt vmcnt(0).
 #include "common.h"
 #include "mfma_common.h"
+#include "thin_up_frag.h"
 
 #include <stdlib.h>
 
@@ -685,37 +686,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
 // row: planar fp32 outputs are written as float2, 128 contiguous bytes per 16 lanes.
 // The table is one per device: launches that use it must be ordered on one stream (they are: the step is one stream).
 typedef __attribute__((ext_vector_type(4))) float tw_f32x4;
-__device__ __attribute__((aligned(16))) unsigned char g_up_frag[3 * 18 * 1024];  // [class][frag][64 lanes][16 B]
+__device__ __attribute__((aligned(16))) unsigned char g_up_frag[UP_FRAG_BYTES];  // [class][frag][64 lanes][16 B]
 
-// class 0 interior (built at m = 1), 1 first row, 2 last row; frag f = ((dr + 1) * 3 + (dc + 1)) * 2 + half
+// class 0 interior (built at m = 1), 1 first row, 2 last row (thin_up_frag.h)
 __global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
-  const int cls = blockIdx.y;                    // one element per thread: 36 blocks per class
-  const int m = cls == 0 ? 1 : (cls == 1 ? 0 : p.Hc - 1);
-  if (cls == 0 && p.Hc < 3) return;
-  const int N = p.N;
   const bf16* w = (const bf16*)p.w;
-  {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
-    const int half = f & 1, dc = (f >> 1) % 3 - 1, dr = (f >> 1) / 3 - 1;
-    const int mp = l & 15, ci = 32 * half + 8 * (l >> 4) + j;
-    const int px = mp & 1, q = mp >> 1, py = q / N, n = q % N;
-    float v = 0.f;
-    if (py < 2) {
-      // column tap of parity px at offset dc (circular axis): px 0: (dc 0, kx 1), (dc -1, kx 3); px 1: (dc +1, kx 0), (dc 0, kx 2)
-      int kx;
-      if (px == 0) kx = dc == 0 ? 1 : (dc == -1 ? 3 : -1);
-      else kx = dc == 1 ? 0 : (dc == 0 ? 2 : -1);
-      if (kx >= 0) {
-        for (int i = 0; i < 4; ++i) {
-          int r, ky;
-          if (dg_tap1d(MODE_UP, p.adj, 0, 2 * m + py, p.Hc, i, r, ky) && r - m == dr)
-            v += (float)w[(long)(ky * 4 + kx) * p.w_st + (long)n * p.w_sn + ci];
-        }
-      }
-    }
-    *(bf16*)(g_up_frag + (((cls * 18 + f) * 64 + l) * 8 + j) * 2) = (bf16)v;
-  }
+  up_frag_element(blockIdx.y, blockIdx.x * 256 + threadIdx.x, p.N, p.Hc, p.adj,
+                  [&](int tap, int n, int ci) { return (float)w[(long)tap * p.w_st + (long)n * p.w_sn + ci]; }, g_up_frag);
 }
 
 #define TU_PX 64
@@ -785,6 +762,8 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
   }
   int cls = -1;
   tw_bf16x8 fa[18];
+  // the caller's fragments (kept current with its shadows) or the ones thin_up_prep_kernel has just built
+  const unsigned char* frags = p.up_frag ? (const unsigned char*)p.up_frag : g_up_frag;
   __syncthreads();
   const int xl = wave * 16 + col;                                    // this lane's pixel inside the tile
   const int x = xt * TU_PX + xl;
@@ -795,7 +774,7 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
     if (mcls != cls) {                                               // (block-uniform; at most twice per block)
       cls = mcls;
 #pragma unroll
-      for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(g_up_frag + ((cls * 18 + f) * 64 + lane) * 16);
+      for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(frags + ((cls * 18 + f) * 64 + lane) * 16);
     }
     tw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -840,7 +819,8 @@ int dg_conv_up_mfma_supported(const ConvP* p) {
 
 int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_up_mfma_supported(p)) return DG_EUNSUPPORTED;
-  thin_up_prep_kernel<<<dim3(36, 3), 256, 0, s>>>(*p);
+  if (p->up_frag && ((size_t)p->up_frag & 15)) return DG_EINVAL;
+  if (!p->up_frag) thin_up_prep_kernel<<<dim3(UP_FRAG_BLOCKS, 3), 256, 0, s>>>(*p);
   // (a column-walker variant with an LDS-DMA row ring that fetched every input row once instead of three times measured
   //  within noise of this kernel on the step - 0.277 vs 0.282 ms for the family - and was removed in round 2)
   const int tiles_x = p->Wc / TU_PX, nseg = (p->Hc + TU_RS - 1) / TU_RS;

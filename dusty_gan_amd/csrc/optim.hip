@@ -1,6 +1,7 @@
 // Optimizer / parameter-state kernels: fused Adam (+EMA, + low-precision shadow write), the transposed weight
 // shadow used by the MFMA forward kernels, and the Philox4x32-10 generator for z / Gumbel / DiffAugment draws.
 #include "common.h"
+#include "thin_up_frag.h"
 #include <cstdlib>
 
 // torch.optim.Adam (no weight decay / amsgrad) as configured at trainers/dcgan_amp.py:116-125, fused with
@@ -139,10 +140,22 @@ __global__ __launch_bounds__(256) void adam_proj_fused_kernel(float* __restrict_
 
 // all conv segments of a network in one launch: desc[5 i + (0..4)] = (source element offset in `master`, destination
 // pointer, Ci, Co, first tile index); a tile = (tap, 32 x 32 block of [ci][co]) as in transpose_shadow_kernel
+struct UpFrags { DgUpFrag f[4]; int n; int first_block; };   // blocks >= first_block: 3 x UP_FRAG_BLOCKS per fragment set
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_shadow_multi_kernel(const float* __restrict__ master,
-                                                                     const long long* __restrict__ desc, int nseg) {
+                                                                     const long long* __restrict__ desc, int nseg,
+                                                                     UpFrags uf) {
   __shared__ float tile[32][33];
+  if (uf.n > 0 && (int)blockIdx.x >= uf.first_block) {
+    const int job = (int)blockIdx.x - uf.first_block, per = 3 * UP_FRAG_BLOCKS;
+    const DgUpFrag& f = uf.f[job / per];
+    const int cls = (job % per) / UP_FRAG_BLOCKS, e = ((job % per) % UP_FRAG_BLOCKS) * 256 + threadIdx.x;
+    const float* w = master + f.off;
+    up_frag_element(cls, e, f.N, f.Hc, f.adj,
+                    [&](int tap, int n, int k) { return (float)(bf16)w[tap * f.m_st + n * f.m_sn + k * f.m_sk]; },
+                    (unsigned char*)f.frag);
+    return;
+  }
   int sidx = 0;
   for (int i = 1; i < nseg; ++i)
     if ((long long)blockIdx.x >= desc[5 * i + 4]) sidx = i;
@@ -561,8 +574,27 @@ int dg_transpose_shadow_multi(const float* master, const long long* desc_dev, in
                               void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (!master || !desc_dev || nseg <= 0 || total_tiles <= 0) return DG_EINVAL;
-  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg);
-  else transpose_shadow_multi_kernel<float><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg);
+  UpFrags uf{};
+  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg, uf);
+  else transpose_shadow_multi_kernel<float><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg, uf);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_transpose_shadow_multi_frags(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                                    const DgUpFrag* frags, int nfrag, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!master || !desc_dev || nseg <= 0 || total_tiles <= 0 || nfrag < 0 || nfrag > 4 || (nfrag && !frags)) return DG_EINVAL;
+  if (nfrag && dtype != DG_BF16) return DG_EUNSUPPORTED;   // (the kernel that reads them is bf16 only)
+  UpFrags uf{};
+  uf.n = nfrag; uf.first_block = total_tiles;
+  for (int i = 0; i < nfrag; ++i) {
+    if (!frags[i].frag || ((size_t)frags[i].frag & 15) || frags[i].N < 1 || frags[i].N > 4 || frags[i].Hc < 1) return DG_EINVAL;
+    uf.f[i] = frags[i];
+  }
+  const unsigned grid = (unsigned)(total_tiles + nfrag * 3 * UP_FRAG_BLOCKS);
+  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<grid, 256, 0, s>>>(master, desc_dev, nseg, uf);
+  else transpose_shadow_multi_kernel<float><<<grid, 256, 0, s>>>(master, desc_dev, nseg, uf);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

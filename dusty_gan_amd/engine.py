@@ -62,6 +62,7 @@ class ParamStore:
         self._tdesc = None  # device descriptor table of refresh_transposed
         self.shadow_dtype = None
         self._seen_version = -1
+        self.up_frags = {}  # (name, Hc, adj) -> [buffer, DgUpFrag]: weight fragments of the thin matrix-core MODE_UP kernel
 
     # -- views
     def view(self, name, buf=None):
@@ -78,6 +79,7 @@ class ParamStore:
         self.coci = {k: fn(v) for k, v in self.coci.items()}
         self._tdesc = None  # the descriptor table holds the old pointers
         self._seen_version = -1
+        self.up_frags = {}  # (re-registered by the engines, on the new device)
 
     @property
     def device(self):
@@ -89,6 +91,27 @@ class ParamStore:
             self.m = torch.zeros_like(self.flat)
             self.v = torch.zeros_like(self.flat)
 
+    def up_frag(self, name, master_strides, N, Hc, adj):
+        """Device pointer of the thin MODE_UP kernel's weight fragments for segment `name` (DgConv.up_frag), kept current
+        by `refresh_transposed` - i.e. rebuilt by the launch that follows every optimizer step, instead of a preparation
+        launch in front of each of the three convolutions of a step that use them.  master_strides = (tap, n, k) element
+        strides of the weight in the fp32 master.  bf16 shadows only (None otherwise: the kernel prepares its own)."""
+        if self.shadow_dtype != torch.bfloat16:
+            return None
+        key = (name, int(Hc), int(adj))
+        e = self.up_frags.get(key)
+        if e is None:
+            if len(self.up_frags) >= 4:
+                return None
+            buf = torch.empty(L.UP_FRAG_BYTES, dtype=torch.uint8, device=self.flat.device)
+            d = L.DgUpFrag()
+            d.off, d.frag = self.seg[name].off, L.ptr(buf)
+            d.m_st, d.m_sn, d.m_sk = master_strides
+            d.N, d.Hc, d.adj = int(N), int(Hc), int(adj)
+            e = self.up_frags[key] = [buf, d]
+            self.refresh_transposed()  # (first use: build it now; from here on it follows the shadows)
+        return L.ptr(e[0])
+
     def refresh_shadows(self, dtype, force=False):
         """(Re)build the T-typed copies the conv kernels read.  Cheap no-op when nothing changed."""
         ver = self.flat._version
@@ -99,6 +122,7 @@ class ParamStore:
             self.shadow = torch.empty(self.n, dtype=dtype, device=self.flat.device)
             self.coci = {}
             self._tdesc = None
+            self.up_frags = {}
             self.shadow_dtype = dtype
         L.check(lib.dg_cast(L.ptr(self.flat), L.ptr(self.shadow), L.dtype_code(dtype), self.n, st), "dg_cast")
         self.refresh_transposed()
@@ -119,6 +143,12 @@ class ParamStore:
                 tiles += 16 * ((ci + 31) // 32) * ((co + 31) // 32)
             self._tdesc = torch.tensor(desc, dtype=torch.int64).to(self.flat.device)
             self._tdesc_tiles, self._tdesc_dtype = tiles, self.shadow_dtype
+        if self.up_frags and self.shadow_dtype == torch.bfloat16:
+            arr = (L.DgUpFrag * len(self.up_frags))(*[d for _, d in self.up_frags.values()])
+            L.check(lib.dg_transpose_shadow_multi_frags(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
+                                                        L.dtype_code(self.shadow_dtype), arr, len(self.up_frags), st),
+                    "dg_transpose_shadow_multi_frags")
+            return
         L.check(lib.dg_transpose_shadow_multi(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
                                               L.dtype_code(self.shadow_dtype), st), "dg_transpose_shadow_multi")
 
@@ -258,7 +288,7 @@ class Ops:
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
-             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None):
+             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None, up_frag=None):
         p = L.DgConv()
         p.mode, p.adj, p.ring = mode, adj, int(ring)
         p.B, p.Hc, p.Wc, p.K, p.N = B, Hc, Wc, K, N
@@ -281,6 +311,7 @@ class Ops:
         p.dbias, p.rowscale = dbias, L.ptr(rowscale)
         p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, (self.dt if w_dt is None else w_dt)
         p.nscale = L.ptr(nscale)
+        p.up_frag = up_frag
         if TRACE is not None:
             pl = L.DgConvPlan()
             L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
@@ -422,9 +453,12 @@ class GEngine:
                    bias=st.fptr(f"up{i}_b"), bias_mod=co)
         # Head (dcgan_eqlr.py:29-46), all heads in one pass, planar fp32 output
         hc, wc = self.grid[3]
+        # (weight (tap, n = head, k = ci) in the fp32 master [tap][ci][co]: strides (ci co, 1, co))
+        frag = (st.up_frag("head_w", (chs[3] * c.nheads, 1, c.nheads), c.nheads, hc, 0)
+                if (c.ring and chs[3] == 64 and c.nheads <= 3) else None)
         o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.gout,
                (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR,
-               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale)
+               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale, up_frag=frag)
         arch = ARCH_ID[c.arch]
         if arch:
             if noise is None or "pixel" not in noise:
@@ -735,13 +769,16 @@ class DEngine:
         hc, wc = self.grid[i]
         ci, co = self.chs[i - 1], self.chs[i]
         first = i == 1
+        # Down1 (64 -> <= 3 image channels): the thin matrix-core kernel's weight fragments follow the shadows
+        # (weight (tap, n = ci, k = co) in the master [tap][ci][co]: strides (ci co, co, 1))
+        frag = st.up_frag("d1_w", (ci * co, co, 1), ci, hc, 1) if (first and c.ring and co == 64 and ci <= 3) else None
         o.conv(L.MODE_UP, 1, c.ring, n, hc, wc, co, ci, self.e[i], (self.per[i], co, 1), self.e[i - 1],
                (self.per[i - 1], ci, 1), st.sptr(f"d{i}_w"),
                1.0 / math.sqrt(ci * 16), L.EPI_LINEAR if first else L.EPI_MASK,
                aux=None if first else self.h[i - 1],
                dbias=(st.fptr(f"d{i - 1}_b", st.grad) if (want_dbias and not first) else None), bias_mod=ci,
                rowscale=rowscale, x_off=slot * self.per[i], out_off=slot * self.per[i - 1],
-               aux_off=slot * self.per[i - 1])
+               aux_off=slot * self.per[i - 1], up_frag=frag)
 
     def backward_data(self, st, slot, n, up, rowscale, want_dbias):
         """Backward-data chain over batch slots [slot, slot+n): e4 = up*s_f*wf*mask4, then e3, e2, e1 (each the

@@ -60,7 +60,11 @@ typedef struct DgConv {
   const float* rowscale;     /* optional per-sample weight of the dbias sum */
   int in_dtype, out_dtype, w_dtype;
   const float* nscale;       /* optional per-output-channel scale (Head: one EqualLR scale per head) */
+  const void* up_frag;       /* optional, 16-byte aligned, DG_UP_FRAG_BYTES: the weight fragments of the thin matrix-core
+                              * MODE_UP kernel (Head forward, Down1 backward-data) kept current by the caller with
+                              * dg_transpose_shadow_multi_frags; NULL: built by a launch in front of the kernel */
 } DgConv;
+#define DG_UP_FRAG_BYTES (3 * 18 * 1024)
 
 /* Parameter block of dg_wgrad:  dw[tap][ci][co] += scale * sum_b rowscale[b] * sum_pixels a[..][ci] * g[..][co] */
 typedef struct DgWgrad {
@@ -355,6 +359,18 @@ int dg_transpose_shadow(const float* master, void* dst, int dtype, int Ci, int C
  * pointer, Ci, Co, first tile index), tiles = 16 taps x ceil(Ci/32) x ceil(Co/32) per segment (device memory) */
 int dg_transpose_shadow_multi(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
                               void* stream);
+/* the same launch also rebuilds up to 4 DgConv.up_frag buffers from the fp32 master (bf16 only): weight element
+ * (tap, n, k) of fragment set i is master[off + tap * m_st + n * m_sn + k * m_sk], rounded to bf16 like the shadow; K = 64.
+ * One launch per optimizer step keeps every low-precision copy of a network current (Head / Down1 weights change with
+ * optim.step, trainers/dcgan_amp.py:238,314) */
+typedef struct DgUpFrag {
+  long long off;             /* element offset of the layer's weights in `master` */
+  void* frag;                /* DG_UP_FRAG_BYTES */
+  long long m_st, m_sn, m_sk;
+  int N, Hc, adj;            /* output channels (<= 4), coarse rows, DgConv.adj of the launches that use it */
+} DgUpFrag;
+int dg_transpose_shadow_multi_frags(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                                    const DgUpFrag* frags, int nfrag, void* stream);
 
 /* ---- Philox4x32-10 draws (the reference uses torch's device RNG: trainers/dcgan_amp.py:151-152, models/dusty.py:33-34,
  *      utils/diff_augment.py:27-28,59-60,86-87) --------------------------------------------------------------- */

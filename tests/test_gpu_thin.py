@@ -238,3 +238,86 @@ def test_down1_wgrad_one_launch_over_real_fake_tangent(L):
     o.force = 1                                    # the direct kernel has no map: refused, not ignored
     with pytest.raises(L.DgError):
         o.wgrad(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, one.data_ptr(), 0.1, g_mod=2 * n)
+
+
+@pytest.mark.parametrize("case", ["head1", "head2", "head3", "down1"])
+@pytest.mark.parametrize("Hc", [2, 3, 8])
+def test_thin_up_fragments_kept_with_the_shadows(L, case, Hc):
+    """DgConv.up_frag: the thin matrix-core MODE_UP kernel (Head forward, Down1 backward-data) with weight fragments built
+    from the fp32 MASTER by the shadow-refresh launch (dg_transpose_shadow_multi_frags) gives bit for bit what the same
+    kernel gives with the fragments its own preparation launch builds from the bf16 shadow; the ParamStore keeps them
+    current across weight updates."""
+    import ctypes as C
+    from dusty_gan_amd.engine import Ops
+    lib = L.lib()
+    g = torch.Generator().manual_seed(Hc)
+    B, Wc, K = 2, 64, 64
+    N = {"head1": 1, "head2": 2, "head3": 3, "down1": 2}[case]
+    adj = 1 if case == "down1" else 0
+    # fp32 master [tap][ci][co]: head ci = 64, co = N (n = co, k = ci); down1 ci = N, co = 64 (n = ci, k = co)
+    ci, co = (N, K) if adj else (K, N)
+    master = torch.randn(16, ci, co, generator=g).to(DEV)
+    coci = torch.empty(16 * ci * co, dtype=torch.bfloat16, device=DEV)
+    desc = torch.tensor([0, coci.data_ptr(), ci, co, 0], dtype=torch.int64).to(DEV)
+    tiles = 16 * ((ci + 31) // 32) * ((co + 31) // 32)
+    frag = torch.zeros(L.UP_FRAG_BYTES, dtype=torch.uint8, device=DEV)
+    d = L.DgUpFrag()
+    d.off, d.frag = 0, frag.data_ptr()
+    d.m_st, d.m_sn, d.m_sk = (ci * co, co, 1) if adj else (ci * co, 1, co)
+    d.N, d.Hc, d.adj = N, Hc, adj
+    L.check(lib.dg_transpose_shadow_multi_frags(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_BF16,
+                                                (L.DgUpFrag * 1)(d), 1, None))
+    assert torch.equal(coci.view(16, co, ci), master.bfloat16().permute(0, 2, 1).contiguous())   # the transposes still run
+    w = master.bfloat16() if adj else coci                                                       # [tap][n][k] shadow
+    x = torch.randn(B, Hc, Wc, K, generator=g).to(DEV, torch.bfloat16)
+    o = Ops(torch.bfloat16)
+    o.force = 3
+    outs = []
+    from dusty_gan_amd import engine as E
+    E.TRACE = []
+    for use in (False, True):
+        out = torch.full((B, 2 * Hc, 2 * Wc, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        o.conv(L.MODE_UP, adj, True, B, Hc, Wc, K, N, x, (Hc * Wc * K, K, 1), out, (4 * Hc * Wc * N, N, 1), w.data_ptr(),
+               0.125, L.EPI_LINEAR, up_frag=frag.data_ptr() if use else None)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    trace, E.TRACE = E.TRACE, None
+    assert all(t[1] == 3 and t[8] == (2 if Hc >= 2 else 0) for t in trace), trace     # thin_up_mfma (needs two rows)
+    assert float(outs[0].float().abs().mean()) > 0.01
+    assert torch.equal(outs[0], outs[1])
+    # argument checks
+    assert lib.dg_transpose_shadow_multi_frags(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_F32,
+                                               (L.DgUpFrag * 1)(d), 1, None) == L.DG_EUNSUPPORTED
+    assert lib.dg_transpose_shadow_multi_frags(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_BF16,
+                                               (L.DgUpFrag * 1)(d), 5, None) == L.DG_EINVAL
+    d.N = 5
+    assert lib.dg_transpose_shadow_multi_frags(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_BF16,
+                                               (L.DgUpFrag * 1)(d), 1, None) == L.DG_EINVAL
+
+
+def test_param_store_rebuilds_up_fragments_with_every_refresh(L):
+    """engine.ParamStore.up_frag: registered once, rebuilt by every refresh_transposed (the launch behind each optimizer
+    step) - after a weight change the fragments equal those of a freshly registered store."""
+    from dusty_gan_amd import engine as E
+    segs = E.d_segments(1, [64, 128, 256, 512], (64, 256))     # Down1: 2 (BlurVH) -> 64 channels
+    st = E.ParamStore(segs)
+    st.apply(lambda t: t.to(DEV))
+    st.flat.normal_()
+    st.refresh_shadows(torch.bfloat16)
+    p = st.up_frag("d1_w", (2 * 64, 64, 1), 2, 32, 1)
+    assert p is not None and p == st.up_frag("d1_w", (2 * 64, 64, 1), 2, 32, 1)     # registered once
+    before = st.up_frags[("d1_w", 32, 1)][0].clone()
+    st.flat.mul_(-0.5)                                                               # "an optimizer step"
+    st.refresh_shadows(torch.bfloat16)
+    after = st.up_frags[("d1_w", 32, 1)][0].clone()
+    assert not torch.equal(before, after)
+    st2 = E.ParamStore(segs)
+    st2.apply(lambda t: t.to(DEV))
+    st2.flat.copy_(st.flat)
+    st2.refresh_shadows(torch.bfloat16)
+    st2.up_frag("d1_w", (2 * 64, 64, 1), 2, 32, 1)
+    assert torch.equal(after, st2.up_frags[("d1_w", 32, 1)][0])
+    st3 = E.ParamStore(segs)
+    st3.apply(lambda t: t.to(DEV))
+    st3.refresh_shadows(torch.float32)
+    assert st3.up_frag("d1_w", (2 * 64, 64, 1), 2, 32, 1) is None                    # fp32: the kernel prepares its own
