@@ -53,6 +53,14 @@ class DgUpFrag(C.Structure):
                 ("m_sk", C.c_longlong), ("N", C.c_int), ("Hc", C.c_int), ("adj", C.c_int)]
 
 
+class DgDraw(C.Structure):
+    _fields_ = [("kind", C.c_int), ("fill_kind", C.c_int), ("seed", C.c_uint64), ("stream_id", C.c_uint64),
+                ("offset_dev", C.c_void_p), ("base", C.c_ulonglong), ("lo", C.c_float), ("hi", C.c_float),
+                ("eps", C.c_float), ("ilo", C.c_int), ("ihi", C.c_int), ("n", C.c_long), ("out", C.c_void_p),
+                ("out_bf16", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("uf", C.c_void_p),
+                ("qi", C.c_void_p)]
+
+
 class DgWgrad(C.Structure):
     _fields_ = [
         ("wmode", C.c_int), ("ring", C.c_int),
@@ -157,6 +165,7 @@ PROTOTYPES = {
     "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
     "dg_counter_add": [_P, _U64, _P],
+    "dg_step_prologue": [_P, _P, _I, C.POINTER(DgDraw), _I, _P],
     "dg_counter_add_multi": [_P, _P, _I, _P],
     "dg_counter_add_multi_snap": [_P, _P, _I, _I, _P, _I, _P, _I, _P],
     "dg_philox_fill_dev": [_U64, _U64, _P, _I, _F, _F, _I, _I, _L, _P, _P],
@@ -246,6 +255,19 @@ def zero_multi(tensors):
         check(lib().dg_zero_multi(ptrs, cnts, len(chunk), stream_ptr()), "dg_zero_multi")
 
 
+def step_prologue(tensors, draws):
+    """zero-fill up to 4 contiguous fp32 tensors and run up to 6 DgDraw jobs in ONE launch (dg_step_prologue)"""
+    import ctypes as C
+    import torch
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    assert len(ts) <= 4 and len(draws) <= 6
+    assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0 for t in ts)
+    ptrs = (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+    cnts = (C.c_long * max(len(ts), 1))(*[t.numel() for t in ts])
+    arr = (DgDraw * max(len(draws), 1))(*draws)
+    check(lib().dg_step_prologue(ptrs, cnts, len(ts), arr, len(draws), stream_ptr()), "dg_step_prologue")
+
+
 class AccArena:
     """Small fp32 accumulators that must start at zero (per-sample sums, logits, the logged scalars), carved from ONE
     buffer that one kernel zero-fills at the start of a training step - instead of one ~5 us zero-fill node per
@@ -261,13 +283,16 @@ class AccArena:
         return dev.type == want.type and (want.index is None or dev.index == want.index)
 
     @classmethod
-    def begin(cls, device, also=()):
+    def begin(cls, device, also=(), draws=()):
         """open a new epoch: the arena - and the fp32 buffers in `also` (the step's gradient buffers) - zero-filled by
-        one launch"""
+        one launch, which also runs the DgDraw jobs in `draws` (the step's parameter draws)"""
         import torch
         if cls.buf is None or not cls._same(cls.buf.device, device):
             cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
-        zero_multi([cls.buf] + list(also))
+        if draws:
+            step_prologue([cls.buf] + list(also), list(draws))
+        else:
+            zero_multi([cls.buf] + list(also))
         cls.pos = 0
         cls.epoch += 1
 

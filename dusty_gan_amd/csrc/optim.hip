@@ -322,10 +322,10 @@ __global__ void counter_add_multi_kernel(CounterAdds a) {
     __threadfence_system();                      // (dst may be mapped host memory)
   }
 }
-__global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
-                                       int kind, float lo, float hi, int ilo, int ihi, long n, void* __restrict__ out) {
-  const uint64_t offset = *offp;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// (the bodies are device functions: dg_step_prologue's kernel runs the same draws as extra blocks of one launch)
+__device__ __forceinline__ void philox_fill_body(uint64_t seed, uint64_t stream, uint64_t offset, int kind, float lo, float hi,
+                                                 int ilo, int ihi, long n, void* __restrict__ out, bf16* __restrict__ out_bf16,
+                                                 long i) {
   if (4 * i >= n) return;
   uint32_t r[4];
   philox4x32_10(seed, offset + (uint64_t)i, stream, r);
@@ -340,20 +340,26 @@ __global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const uns
       const int a = j & ~1;
       const float u1 = 1.f - (float)(r[a] >> 8) * s24, u2 = (float)(r[a + 1] >> 8) * s24;
       const float rad = sqrtf(-2.f * logf(u1));
-      ((float*)out)[o] = (j & 1) ? rad * sinf(6.283185307179586f * u2) : rad * cosf(6.283185307179586f * u2);
+      const float v = (j & 1) ? rad * sinf(6.283185307179586f * u2) : rad * cosf(6.283185307179586f * u2);
+      ((float*)out)[o] = v;
+      if (out_bf16) out_bf16[o] = (bf16)v;
     } else {
       const float u = (float)(r[j] >> 8) * s24;
-      ((float*)out)[o] = kind == 2 ? lo + (hi - lo) * u : u;
+      const float v = kind == 2 ? lo + (hi - lo) * u : u;
+      ((float*)out)[o] = v;
+      if (out_bf16) out_bf16[o] = (bf16)v;
     }
   }
+}
+__global__ void philox_fill_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
+                                       int kind, float lo, float hi, int ilo, int ihi, long n, void* __restrict__ out) {
+  philox_fill_body(seed, stream, *offp, kind, lo, hi, ilo, ihi, n, out, nullptr, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 // GumbelSigmoid.logistic_noise (models/dusty.py:30-36) straight from the generator: element o of U1 is word o & 3 of Philox
 // counter offset + o / 4, U2 the same (n + 3) / 4 counters further - exactly what two uniform fills of n elements followed
 // by dg_logistic_noise produce, in one launch and without the two 4 n-byte round trips
-__global__ void philox_logistic_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
-                                           float eps, long n, float* __restrict__ out) {
-  const uint64_t offset = *offp;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void philox_logistic_body(uint64_t seed, uint64_t stream, uint64_t offset, float eps, long n,
+                                                     float* __restrict__ out, long i) {
   if (4 * i >= n) return;
   const uint64_t n4 = (uint64_t)((n + 3) / 4);
   uint32_t r1[4], r2[4];
@@ -368,10 +374,12 @@ __global__ void philox_logistic_dev_kernel(uint64_t seed, uint64_t stream, const
     out[o] = -logf(logf(u1 + eps) / logf(u2 + eps) + eps);
   }
 }
-__global__ void aug_draw_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp, int B,
-                                    int sh, int sw, int nx, int ny, float* __restrict__ uf, int* __restrict__ qi) {
-  const uint64_t offset = *offp;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void philox_logistic_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp,
+                                           float eps, long n, float* __restrict__ out) {
+  philox_logistic_body(seed, stream, *offp, eps, n, out, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__device__ __forceinline__ void aug_draw_body(uint64_t seed, uint64_t stream, uint64_t offset, int B, int sh, int sw, int nx,
+                                              int ny, float* __restrict__ uf, int* __restrict__ qi, int b) {
   if (b >= B) return;
   uint32_t r0[4], r1[4];
   philox4x32_10(seed, offset + 2 * (uint64_t)b, stream, r0);
@@ -382,6 +390,46 @@ __global__ void aug_draw_dev_kernel(uint64_t seed, uint64_t stream, const unsign
   qi[1 * B + b] = -sw + (int)(r1[1] % (uint32_t)(2 * sw + 1));
   qi[2 * B + b] = (int)(r1[2] % (uint32_t)nx);
   qi[3 * B + b] = (int)(r1[3] % (uint32_t)ny);
+}
+__global__ void aug_draw_dev_kernel(uint64_t seed, uint64_t stream, const unsigned long long* __restrict__ offp, int B,
+                                    int sh, int sw, int nx, int ny, float* __restrict__ uf, int* __restrict__ qi) {
+  aug_draw_body(seed, stream, *offp, B, sh, sw, nx, ny, uf, qi, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// One launch for what a training step needs before its first real kernel: the zero-fill of the accumulator arena and the
+// gradient buffers (dg_zero_multi) and every parameter draw of the step - latents (with their bfloat16 copy), Gumbel
+// logistic noise, DiffAugment parameters - as extra blocks.  Four dependent launches of 4-8 us each otherwise.
+struct PrologueZero { float* p[4]; long first[5]; int k; int blocks; };
+struct PrologueDraws { DgDraw d[6]; int first_block[7]; int n; };
+__global__ __launch_bounds__(256) void step_prologue_kernel(PrologueZero z, PrologueDraws dr) {
+  if ((int)blockIdx.x < z.blocks) {
+    const long stride = (long)z.blocks * 256, total = z.first[z.k];
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; 4 * i4 < total; i4 += stride) {
+      const long i = 4 * i4;
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (q < z.k && i >= z.first[q]) j = q;
+      *(float4*)(z.p[j] + (i - z.first[j])) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int blk = (int)blockIdx.x - z.blocks;
+  int j = 0;
+  for (int q = 1; q < dr.n; ++q)
+    if (blk >= dr.first_block[q]) j = q;
+  const DgDraw& d = dr.d[j];
+  const long i = (long)(blk - dr.first_block[j]) * 256 + threadIdx.x;
+  const uint64_t offset = *d.offset_dev + d.base;
+  if (d.kind == 0) {
+    philox_fill_body(d.seed, d.stream_id, offset, d.fill_kind, d.lo, d.hi, d.ilo, d.ihi, d.n, d.out, (bf16*)d.out_bf16, i);
+  } else if (d.kind == 1) {
+    philox_logistic_body(d.seed, d.stream_id, offset, d.eps, d.n, (float*)d.out, i);
+  } else {
+    const int sh = (int)(d.H * (1.0 / 8.0) / 2 + 0.5), sw = (int)(d.W * (1.0 / 8.0) / 2 + 0.5);
+    const int ch = (int)(d.H * 0.5 + 0.5), cw = (int)(d.W * 0.5 + 0.5);
+    aug_draw_body(d.seed, d.stream_id, offset, d.B, sh, sw, d.H + (1 - ch % 2), d.W + (1 - cw % 2), d.uf, d.qi, (int)i);
+  }
 }
 
 static inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
@@ -504,6 +552,53 @@ int dg_philox_logistic_dev(uint64_t seed, uint64_t stream, const unsigned long l
                            float* out, void* s_) {
   if (!offset_dev || !out || n <= 0) return DG_EINVAL;
   philox_logistic_dev_kernel<<<nblk((n + 3) / 4), 256, 0, (hipStream_t)s_>>>(seed, stream, offset_dev, eps, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// zero-fill of k <= 4 fp32 buffers (as dg_zero_multi; k may be 0) + ndraw <= 6 draws (DgDraw) in one launch
+int dg_step_prologue(float* const* ptrs, const long* counts, int k, const DgDraw* draws, int ndraw, void* s_) {
+  if (k < 0 || k > 4 || ndraw < 0 || ndraw > 6 || (k && (!ptrs || !counts)) || (ndraw && !draws)) return DG_EINVAL;
+  PrologueZero z{};
+  long tot = 0;
+  for (int i = 0; i < k; ++i) {
+    if (!ptrs[i] || counts[i] < 0 || counts[i] % 4 != 0 || ((size_t)ptrs[i] & 15) != 0) return DG_EINVAL;
+    z.p[i] = ptrs[i]; z.first[i] = tot;
+    tot += counts[i];
+  }
+  z.first[k] = tot;
+  z.k = k;
+  unsigned zb = nblk(tot / 4);
+  if (zb > 2048) zb = 2048;
+  z.blocks = (int)zb;
+  PrologueDraws dr{};
+  long blocks = 0;
+  for (int i = 0; i < ndraw; ++i) {
+    const DgDraw& d = draws[i];
+    if (!d.offset_dev) return DG_EINVAL;
+    long threads;
+    if (d.kind == 0) {
+      if (!d.out || d.n <= 0 || d.fill_kind < 0 || d.fill_kind > 3 || (d.fill_kind == 3 && (d.ihi <= d.ilo || d.out_bf16)))
+        return DG_EINVAL;
+      threads = (d.n + 3) / 4;
+    } else if (d.kind == 1) {
+      if (!d.out || d.n <= 0) return DG_EINVAL;
+      threads = (d.n + 3) / 4;
+    } else if (d.kind == 2) {
+      if (!d.uf || !d.qi || d.B <= 0 || d.H <= 0 || d.W <= 0) return DG_EINVAL;
+      threads = d.B;
+    } else {
+      return DG_EINVAL;
+    }
+    dr.d[i] = d;
+    dr.first_block[i] = (int)blocks;
+    blocks += (threads + 255) / 256;
+    if (blocks > (1L << 30)) return DG_EUNSUPPORTED;
+  }
+  dr.first_block[ndraw] = (int)blocks;
+  dr.n = ndraw;
+  if (zb + blocks == 0) return DG_OK;
+  step_prologue_kernel<<<(unsigned)(zb + blocks), 256, 0, (hipStream_t)s_>>>(z, dr);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

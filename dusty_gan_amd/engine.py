@@ -429,8 +429,9 @@ class GEngine:
         self.HW = HW
         self.ws_B = B
 
-    def forward(self, st: ParamStore, z, noise=None, training=True):
+    def forward(self, st: ParamStore, z, noise=None, training=True, z_ready=False):
         """z [B,nz] fp32; noise: dict(pixel [B,1,H,W], image [B,1,1,1]) logistic noise (dusty archs).
+        z_ready: self.zT already holds z in the compute dtype (written by the launch that drew z: dg_step_prologue).
         Returns the reference's output dict (views of engine workspaces)."""
         c, o, lib = self.cfg, self.ops, L.lib()
         B = z.shape[0]
@@ -438,8 +439,9 @@ class GEngine:
         st.refresh_shadows(self.dtype)
         sp = L.stream_ptr()
         chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
-        z = z.contiguous().float()
-        L.check(lib.dg_cast(L.ptr(z), L.ptr(self.zT), o.dt, B * c.nz, sp), "dg_cast")
+        if not z_ready:
+            z = z.contiguous().float()
+            L.check(lib.dg_cast(L.ptr(z), L.ptr(self.zT), o.dt, B * c.nz, sp), "dg_cast")
         # Proj (dcgan_eqlr.py:6-16): GEMM [B,nz] x [N',nz]^T, N' = h0*w0*C3 in (y,x,c) order
         Np = c.h0 * c.w0 * chs[0]
         o.conv(L.MODE_GEMM, 0, 1, B, 1, 1, c.nz, Np, self.zT, (c.nz, 0, 1), self.a[0], (Np, 0, 1), st.sptr("proj_w"),

@@ -370,18 +370,60 @@ class Trainer:
         mask = raw_batch["mask"].to(self.device, non_blocking=True).float()
         return self.lidar.fetch_reals(pol, mask, float(self.cfg.model.gen.drop_const))
 
-    def _begin_step(self):
+    def _begin_step(self, draw_B=None):
         """Open the step's accumulator arena and zero both networks' gradient buffers (optim.zero_grad, reference :177 and
         :246) with ONE launch; `optimize_D` / `optimize_G` then skip their own fills (a single micro-batch overwrites
-        Proj.weight's 268 MB gradient, or never forms it, so that segment is not filled)."""
+        Proj.weight's 268 MB gradient, or never forms it, so that segment is not filled).  draw_B: the same launch also
+        makes the first micro-batch's draws - latents (+ their bfloat16 copy in the generator workspace), Gumbel noise,
+        DiffAugment parameters: the numbers `_draw_rand` draws, from the same counters - kept for `_prep_rand`."""
         Gst, Dst = _backbone(self.G).store, self.D.store
         g = Gst.grad
         if self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w":
             g = Gst.grad[Gst.seg["proj_b"].off:]
         ok = g.numel() % 4 == 0 and Dst.grad.numel() % 4 == 0 and g.data_ptr() % 16 == 0
-        L.AccArena.begin(self.device, also=(Dst.grad, g) if ok else ())
+        draws, adv = (), None
+        if draw_B is not None:
+            draws, adv = self._draw_jobs(int(draw_B))
+        L.AccArena.begin(self.device, also=(Dst.grad, g) if ok else (), draws=draws)
+        if adv is not None:
+            adv()
         self._arena_ready = True
         self._grads_zeroed = {"D", "G"} if ok else set()
+
+    def _draw_jobs(self, B):
+        """the DgDraw jobs of `_draw_rand(B)` (same generators, same counter ranges, same order) and the function that
+        advances the counters behind the launch; the results wait in self._predrawn"""
+        dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
+        nz = int(self.cfg.model.gen.in_ch)
+        geng = self._g_engines()[0]
+        geng.alloc(B, dev)
+        r, ra = self.rng, self.A.rng(dev)
+        r.sync()
+        ra.sync()
+        z = torch.empty(B, nz, **f32)
+        z_ready = geng.dtype == torch.bfloat16
+        base = 0
+        jobs = [r.job(0, base, fill_kind=1, n=B * nz, out=L.ptr(z), out_bf16=L.ptr(geng.zT) if z_ready else None)]
+        base += (B * nz + 3) // 4
+        noise, arch = None, _backbone(self.G).masker
+        if arch != "none":
+            shapes = [("pixel", (B, 1, self.H, self.W))] + ([("image", (B, 1, 1, 1))] if arch == "dusty2" else [])
+            noise = {}
+            for k, shp in shapes:
+                n = shp[0] * shp[1] * shp[2] * shp[3]
+                noise[k] = torch.empty(shp, **f32)
+                jobs.append(r.job(1, base, eps=1e-10, n=n, out=L.ptr(noise[k])))
+                base += 2 * ((n + 3) // 4)
+        n_sets = 4
+        uf = torch.empty(3, n_sets * B, **f32)
+        qi = torch.empty(4, n_sets * B, dtype=torch.int32, device=dev)
+        jobs.append(ra.job(2, 0, B=n_sets * B, H=self.H, W=self.W, uf=L.ptr(uf), qi=L.ptr(qi)))
+        self._predrawn = {"z": z, "noise": noise, "aug": self.A.sets_of(uf, qi, n_sets, B), "z_ready": z_ready, "B": B}
+
+        def advance(total=base):
+            r.advance(total)
+            ra.advance(2 * n_sets * B)
+        return jobs, advance
 
     def _pooled(self):
         """the loader is the device-resident synthetic pool and its batches can be picked by a device-side index"""
@@ -394,7 +436,7 @@ class Trainer:
         the kernel produces beside x_real survive until DiffAugment reads them.  pooled: `raw_batch` is the batch the
         synthetic loader just yielded (number batches_drawn - 1); the kernel picks that same batch ON THE DEVICE from the
         pool by a counter the step advances (dg_fetch_reals_pool_sum), so a hipGraph replay needs no copy of it."""
-        self._begin_step()
+        self._begin_step(draw_B=self.local_batch)   # (a step that fetches its own batch also draws its own parameters)
         if pooled:
             ds = self.dataset
             if self._pool_ctr is None:
@@ -430,6 +472,10 @@ class Trainer:
 
     def _prep_rand(self, rand, B):
         if rand is None:
+            pre, self._predrawn = getattr(self, "_predrawn", None), None
+            if pre is not None and pre["B"] == B:
+                return pre                # drawn by the step's first launch (`_begin_step`)
+            assert pre is None, "pre-drawn parameters for another batch size"
             return self._draw_rand(B)
         out = {"z": torch.as_tensor(rand["z"]).to(self.device, torch.float32)}
         nz = rand.get("noise")
@@ -552,7 +598,7 @@ class Trainer:
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
         # every small accumulator of the step (these scalars, per-sample sums, logits) comes zeroed out of ONE arena
         if not getattr(self, "_arena_ready", False):   # (the graph path opens it before its fetch_reals)
-            self._begin_step()
+            self._begin_step(draw_B=B if rands is None else None)
         self._arena_ready = False
         if "D" in self._grads_zeroed:
             self._grads_zeroed.discard("D")
@@ -566,7 +612,8 @@ class Trainer:
             else:
                 x_real, m_real = self.fetch_reals(self._next_batch())
             rand = self._prep_rand(rands[j] if rands is not None else None, B)
-            synth = gengs[j].forward(Gst, rand["z"], rand["noise"], training=True)  # :195 (graph kept = workspaces)
+            synth = gengs[j].forward(Gst, rand["z"], rand["noise"], training=True,   # :195 (graph kept = workspaces)
+                                     z_ready=bool(rand.get("z_ready")) and j == 0)
             # :199-204  A(real) | A(fake) -> D, one pass; DiffAugment fused into BlurVH's pass where the sums exist
             y = deng.forward_aug(Dst, self.A, [(x_real, rand["aug"][0]), (synth["depth"], rand["aug"][1])], 0)
             # loss + dLoss/dy + the R1 schedule's per-sample vectors + scalar sums + final-bias gradient: one launch

@@ -55,6 +55,11 @@ class DiffAugment(nn.Module):
         L.check(L.lib().dg_aug_draw_dev(r.seed, r.stream_id, L.ptr(r.ctr), n * B, H, W, L.ptr(uf), L.ptr(qi),
                                         L.stream_ptr()), "dg_aug_draw_dev")
         r.advance(2 * n * B)
+        return self.sets_of(uf, qi, n, B)
+
+    @staticmethod
+    def sets_of(uf, qi, n, B):
+        """the `n` parameter sets held by one draw's output buffers uf [3][n B], qi [4][n B]"""
         sets = []
         for k in range(n):
             sl = slice(k * B, (k + 1) * B)

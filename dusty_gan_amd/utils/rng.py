@@ -37,6 +37,15 @@ class Philox:
         self.advance((n + 3) // 4)
         return out
 
+    def job(self, kind, base, **kw):
+        """a DgDraw for dg_step_prologue reading this generator's device counter at +`base` (what the earlier jobs of the
+        same launch take); the caller syncs before the launch and advances afterwards, as the single draws do"""
+        d = L.DgDraw()
+        d.kind, d.seed, d.stream_id, d.offset_dev, d.base = kind, self.seed, self.stream_id, L.ptr(self.ctr), int(base)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
     def uniform(self, n, lo=0.0, hi=1.0):
         return self._fill(2 if (lo != 0.0 or hi != 1.0) else 0, n, lo, hi)
 

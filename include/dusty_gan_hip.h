@@ -401,6 +401,27 @@ int dg_philox_fill_dev(uint64_t seed, uint64_t stream_id, const unsigned long lo
  * fills of n elements (U1, then U2) followed by dg_logistic_noise; the caller advances the counter by 2 ((n + 3) / 4) */
 int dg_philox_logistic_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, float eps, long n,
                            float* out, void* stream);
+/* One launch in front of a training step: the zero-fill of k <= 4 fp32 buffers (dg_zero_multi: the accumulator arena and
+ * the gradient buffers, optim.zero_grad at trainers/dcgan_amp.py:177,246) plus up to 6 draws - the numbers
+ * dg_philox_fill_dev / dg_philox_logistic_dev / dg_aug_draw_dev produce for the same (seed, stream_id, *offset_dev + base):
+ * sample_latents (trainers/dcgan_amp.py:151-152), GumbelSigmoid.logistic_noise (models/dusty.py:30-36) and DiffAugment's
+ * parameters (utils/diff_augment.py:27-28,59-60,86-87).  The caller advances the counters as for the single draws. */
+typedef struct DgDraw {
+  int kind;                  /* 0 dg_philox_fill_dev, 1 dg_philox_logistic_dev, 2 dg_aug_draw_dev */
+  int fill_kind;             /* kind 0: 0 U[0,1), 1 N(0,1), 2 U[lo,hi), 3 integers in [ilo, ihi) */
+  uint64_t seed, stream_id;
+  const unsigned long long* offset_dev;
+  unsigned long long base;   /* added to *offset_dev: what earlier draws of this launch take from the same generator */
+  float lo, hi, eps;
+  int ilo, ihi;
+  long n;                    /* kind 0 / 1: elements */
+  void* out;                 /* kind 0 / 1 */
+  void* out_bf16;            /* kind 0, optional: a bfloat16 copy of a float fill (the generator's latent operand) */
+  int B, H, W;               /* kind 2 */
+  float* uf;                 /* kind 2: [3][B] */
+  int* qi;                   /* kind 2: [4][B] */
+} DgDraw;
+int dg_step_prologue(float* const* zero_ptrs, const long* zero_counts, int k, const DgDraw* draws, int ndraw, void* stream);
 int dg_aug_draw_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int B, int H, int W,
                     float* uf, int* qi, void* stream);
 /* Adam with the (0-based, already-completed) step count in device memory: this call is step *step_dev + 1 */

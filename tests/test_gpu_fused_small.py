@@ -359,3 +359,58 @@ def test_logistic_noise_in_one_launch(L, shape):
     assert got.shape == tuple(shape) and torch.equal(got.flatten(), want)
     assert a.offset == b.offset
     assert rel_l2(got.flatten().cpu(), O.logistic_noise(u1.cpu(), u2.cpu())) < 1e-5
+
+
+def test_step_prologue_equals_the_single_launches(L):
+    """dg_step_prologue: zero-fill + latents (fp32 and the bfloat16 copy) + two logistic-noise tensors + DiffAugment
+    parameters in one launch are bit for bit what dg_zero_multi and the single draws (Philox.normal / logistic_noise /
+    DiffAugment.draw_sets) produce from the same counters, and the counters end where the single draws leave them."""
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    from dusty_gan_amd.utils.rng import Philox
+    B, nz, H, W = 6, 20, 16, 64            # (nz B not a multiple of 4 x 256: partial last block)
+    def gens():
+        r, A = Philox(4242, DEV, stream_id=1), DiffAugment(seed=99)
+        r.normal(7)                        # a non-zero starting offset
+        A.draw(3, H, W, torch.device(DEV))
+        return r, A
+    r1, A1 = gens()
+    z1 = r1.normal(B * nz)
+    px1 = r1.logistic_noise((B, 1, H, W))
+    im1 = r1.logistic_noise((B, 1, 1, 1))
+    sets1 = A1.draw_sets(4, B, H, W, torch.device(DEV))
+    r2, A2 = gens()
+    ra = A2.rng(torch.device(DEV))
+    r2.sync(); ra.sync()
+    z2 = torch.empty(B * nz, device=DEV)
+    zb = torch.empty(B * nz, device=DEV, dtype=torch.bfloat16)
+    px2, im2 = torch.empty(B, 1, H, W, device=DEV), torch.empty(B, 1, 1, 1, device=DEV)
+    uf, qi = torch.empty(3, 4 * B, device=DEV), torch.empty(4, 4 * B, device=DEV, dtype=torch.int32)
+    base = 0
+    jobs = [r2.job(0, base, fill_kind=1, n=B * nz, out=z2.data_ptr(), out_bf16=zb.data_ptr())]
+    base += (B * nz + 3) // 4
+    jobs.append(r2.job(1, base, eps=1e-10, n=B * H * W, out=px2.data_ptr()))
+    base += 2 * ((B * H * W + 3) // 4)
+    jobs.append(r2.job(1, base, eps=1e-10, n=B, out=im2.data_ptr()))
+    base += 2 * ((B + 3) // 4)
+    jobs.append(ra.job(2, 0, B=4 * B, H=H, W=W, uf=uf.data_ptr(), qi=qi.data_ptr()))
+    a, b = torch.full((4096,), 3.0, device=DEV), torch.full((260,), 5.0, device=DEV)
+    L.step_prologue([a, b], jobs)
+    r2.advance(base); ra.advance(2 * 4 * B)
+    torch.cuda.synchronize()
+    assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+    assert torch.equal(z1, z2) and torch.equal(zb, z1.bfloat16())
+    assert torch.equal(px1, px2) and torch.equal(im1, im2)
+    for s1, s2 in zip(sets1, DiffAugment.sets_of(uf, qi, 4, B)):
+        for k in s1:
+            assert torch.equal(s1[k], s2[k]), k
+    assert r1.offset == r2.offset and A1.rng(torch.device(DEV)).offset == ra.offset
+    # draws only / zero only / argument errors
+    L.step_prologue([], [r2.job(0, 0, fill_kind=0, n=5, out=z2.data_ptr())])
+    torch.cuda.synchronize()
+    assert float(z2[:5].min()) >= 0.0 and float(z2[:5].max()) < 1.0 and torch.equal(z2[5:], z1[5:])
+    a.fill_(1.0)
+    L.step_prologue([a], [])
+    assert float(a.abs().max()) == 0.0
+    bad = r2.job(3, 0, n=4, out=z2.data_ptr())
+    assert L.lib().dg_step_prologue(None, None, 0, (L.DgDraw * 1)(bad), 1, None) == L.DG_EINVAL
+    assert L.lib().dg_step_prologue(None, None, 0, (L.DgDraw * 1)(bad), 7, None) == L.DG_EINVAL
