@@ -508,13 +508,18 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p, int
 // Memory schedule: the `a` tiles come in groups of WGU_GS K steps, the next group's loads in flight while the current
 // one is computed, and the gradient dwords of WGU_TB im2col tasks per thread are requested in one batch (the first
 // version made one global round trip per K step and per task: load, s_waitcnt vmcnt(0), ds_write).
+// NP = 2 (gradient padded to four channels, Co = 3 or 4: the dusty2 head): both channel pairs in one pass - the 64-channel
+// operand, its staging and its transposing reads are shared by the two pairs' MFMAs (a second pass read it again: 54 + 34 us
+// for the three-head gradient against 39 us for one pair).
+template <int NP>
 __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int gpair) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TB = NP == 2 ? WGU_TB / 2 : WGU_TB;                  // (the same dwords in flight per thread)
   const int Wc = p.Wc, Wf = 2 * p.Wc;
   const int RSB = Wc * 2 + 16;                                       // im2col row stride (bytes), +16 B: bank spread
-  unsigned char* s_b = smem;                                         // [32 n][RSB]
-  unsigned char* s_t = smem + (size_t)32 * RSB;                      // [4 waves][16 px][144 B]
-  float* s_red = (float*)smem;                                       // [4 waves][32][64] fp32 (aliases s_b at the end)
+  unsigned char* s_b = smem;                                         // [NP][32 n][RSB]
+  unsigned char* s_t = smem + (size_t)NP * 32 * RSB;                 // [4 waves][16 px][144 B]
+  float* s_red = (float*)smem;                                       // [4 waves][NP 32][64] fp32 (aliases s_b at the end)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long u0 = (long)blockIdx.x * WGU_ROWS_PB;
@@ -525,11 +530,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
   const int g16 = lane >> 4, i16 = lane & 15;
   const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pp = i16 & 3; // transposing-read roles (see wgrad_mfma.hip)
   unsigned char* my_t = s_t + wave * 16 * 144;
-  tw_f32x16 acc[2];
+  tw_f32x16 acc[NP][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[pr][j][e] = 0.f;
   const int nchunk = Wc / 8;
   const int b = (int)(u0 / p.Hc);
   // the K steps of the block's rows in groups of WGU_GS: a wave's step k of a row is the 16 pixels at wave * 16 + 64 k
@@ -555,13 +562,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
     const int r = (int)((u0 + gq / gpr) % p.Hc), s0 = (gq % gpr) * WGU_GS;
     if (gq % gpr == 0) {
       __syncthreads();
-      // ---- im2col rows of input row r: task = (tap, chunk of 8 input pixels), both co at once; WGU_TB tasks per thread
+      // ---- im2col rows of input row r: task = (tap, chunk of 8 input pixels), both co at once; TB tasks per thread
       //      and batch: all their gradient dwords are requested before the first is packed
       const unsigned* Gb = G + (long)b * (p.g_sb / 2);
-      for (int tb = tid; tb < 16 * nchunk; tb += 256 * WGU_TB) {
-        unsigned gv[WGU_TB][8];
+      for (int tb = tid; tb < 16 * nchunk; tb += 256 * TB) {
+        unsigned gv[TB][8][NP];
 #pragma unroll
-        for (int k = 0; k < WGU_TB; ++k) {
+        for (int k = 0; k < TB; ++k) {
           const int t = tb + 256 * k;
           if (t < 16 * nchunk) {
             const int tap = t / nchunk, xi0 = (t % nchunk) * 8;
@@ -579,12 +586,17 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
             for (int j = 0; j < 8; ++j) {
               int x = xi0 + j - dkx;
               if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
-              gv[k][j] = g0[(2 * x + pkx) * gsd];
+              if (NP == 1) {
+                gv[k][j][0] = g0[(2 * x + pkx) * gsd];
+              } else {                                                   // (gsd == 2: the pixel's four channels in 8 bytes)
+                const uint2 t2 = *(const uint2*)(g0 + (2 * x + pkx) * 2);
+                gv[k][j][0] = t2.x; gv[k][j][NP - 1] = t2.y;
+              }
             }
           }
         }
 #pragma unroll
-        for (int k = 0; k < WGU_TB; ++k) {
+        for (int k = 0; k < TB; ++k) {
           const int t = tb + 256 * k;
           if (t < 16 * nchunk) {
             const int tap = t / nchunk, xi0 = (t % nchunk) * 8;
@@ -598,28 +610,31 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
             if (ky == 0 && r == p.Hc - 2) fr1 = 2 * p.Hc - 1;
             const bool any = reg_ok || fr1 >= 0;
             if (!reg_ok) fr1 = -1;                                       // (the mirror row then IS gv)
-            unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};         // co0 / co1, 8 bf16 each
-            if (any) {
-              const unsigned* g1 = fr1 >= 0 ? Gb + (long)fr1 * Wf * gsd : nullptr;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                unsigned v = gv[k][j];
-                if (g1) {                                                // sum of two gradient rows, rounded once to bf16
-                  int x = xi0 + j - dkx;
-                  if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
-                  const unsigned w2 = g1[(2 * x + pkx) * gsd];
-                  const float s0f = __builtin_bit_cast(float, v << 16) + __builtin_bit_cast(float, w2 << 16);
-                  const float s1f = __builtin_bit_cast(float, v & 0xffff0000u) + __builtin_bit_cast(float, w2 & 0xffff0000u);
-                  const bf16 h0 = (bf16)s0f, h1 = (bf16)s1f;
-                  v = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            for (int pr = 0; pr < NP; ++pr) {
+              unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};       // co0 / co1 of the pair, 8 bf16 each
+              if (any) {
+                const unsigned* g1 = fr1 >= 0 ? Gb + (long)fr1 * Wf * gsd + pr : nullptr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  unsigned v = gv[k][j][pr];
+                  if (g1) {                                              // sum of two gradient rows, rounded once to bf16
+                    int x = xi0 + j - dkx;
+                    if (x < 0) x += Wc; else if (x >= Wc) x -= Wc;
+                    const unsigned w2 = g1[(2 * x + pkx) * gsd];
+                    const float s0f = __builtin_bit_cast(float, v << 16) + __builtin_bit_cast(float, w2 << 16);
+                    const float s1f = __builtin_bit_cast(float, v & 0xffff0000u) + __builtin_bit_cast(float, w2 & 0xffff0000u);
+                    const bf16 h0 = (bf16)s0f, h1 = (bf16)s1f;
+                    v = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                  }
+                  const unsigned c0 = v & 0xffffu, c1 = v >> 16;
+                  if (j & 1) { lo[j >> 1] |= c0 << 16; hi[j >> 1] |= c1 << 16; }
+                  else { lo[j >> 1] = c0; hi[j >> 1] = c1; }
                 }
-                const unsigned c0 = v & 0xffffu, c1 = v >> 16;
-                if (j & 1) { lo[j >> 1] |= c0 << 16; hi[j >> 1] |= c1 << 16; }
-                else { lo[j >> 1] = c0; hi[j >> 1] = c1; }
               }
+              *(uint4*)(s_b + (size_t)(pr * 32 + tap * 2 + 0) * RSB + xi0 * 2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+              *(uint4*)(s_b + (size_t)(pr * 32 + tap * 2 + 1) * RSB + xi0 * 2) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             }
-            *(uint4*)(s_b + (size_t)(tap * 2 + 0) * RSB + xi0 * 2) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            *(uint4*)(s_b + (size_t)(tap * 2 + 1) * RSB + xi0 * 2) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
           }
         }
       }
@@ -640,32 +655,38 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
         const int c = lane + 64 * v, row = c >> 3, part = c & 7;
         *(tw_u32x4*)(my_t + row * 144 + part * 16) = cur[st][v];
       }
-      const tw_bf16x8 fa = *(const tw_bf16x8*)(s_b + (size_t)lr * RSB + (xb + 8 * lh) * 2);
+      tw_bf16x8 fa[NP];
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) fa[pr] = *(const tw_bf16x8*)(s_b + (size_t)(pr * 32 + lr) * RSB + (xb + 8 * lh) * 2);
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         const unsigned char* ptr = my_t + (8 * kh + q) * 144 + (jt * 32 + 16 * cb + 4 * pp) * 2;
         const tw_bf16x4 l4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tw_bf16x4 __attribute__((address_space(3)))*)(ptr));
         const tw_bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tw_bf16x4 __attribute__((address_space(3)))*)(ptr + 4 * 144));
         const tw_bf16x8 fg = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fg, acc[jt], 0, 0, 0);
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) acc[pr][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pr], fg, acc[pr][jt], 0, 0, 0);
       }
     }
   }
   // reduce the 4 waves, then one atomic per element.  D layout: col = lane & 31 (ci), row = (e&3)+8(e>>2)+4 lh (n)
   const float sc = p.scale * (p.rowscale ? p.rowscale[b] : 1.f);
   __syncthreads();
+  constexpr int WS = NP * 32 * 64;                                   // a wave's partial tile
 #pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
+  for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int nrow = (e & 3) + 8 * (e >> 2) + 4 * lh;
-      s_red[(wave * 32 + nrow) * 64 + jt * 32 + lr] = acc[jt][e];
-    }
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nrow = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        s_red[wave * WS + (pr * 32 + nrow) * 64 + jt * 32 + lr] = acc[pr][jt][e];
+      }
   __syncthreads();
-  for (int i = tid; i < 32 * 64; i += 256) {
-    const int n = i >> 6, ci = i & 63, tap = n >> 1, co = 2 * gpair + (n & 1);
+  for (int i = tid; i < WS; i += 256) {
+    const int n = i >> 6, ci = i & 63, tap = (n & 31) >> 1, co = 2 * (gpair + (n >> 5)) + (n & 1);
     if (co >= p.Co) continue;
-    const float v = s_red[i] + s_red[2048 + i] + s_red[4096 + i] + s_red[6144 + i];
+    const float v = s_red[i] + s_red[WS + i] + s_red[2 * WS + i] + s_red[3 * WS + i];
     atomicAdd(&p.dw[((long)tap * p.Ci + ci) * p.Co + co], v * sc);
   }
 }
@@ -906,10 +927,15 @@ static bool wgrad_down_mfma_ok(const WgradP* p) {
   return wgrad_down_mfma_lds(p) <= 160 * 1024 && 2 * p->Wc <= 4096 && p->a_sb % 8 == 0 && ((size_t)p->a & 15) == 0 &&
          p->g_sb % 8 == 0 && ((size_t)p->g & 15) == 0;
 }
-static size_t wgrad_up_mfma_lds(const WgradP* p) {
-  size_t lds = (size_t)32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
-  if (lds < (size_t)4 * 32 * 64 * 4) lds = (size_t)4 * 32 * 64 * 4;
+static int wgrad_up_pairs(const WgradP* p) { return (p->Co > 2 && p->g_sp == 4) ? 2 : 1; }   // channel pairs per pass
+static size_t wgrad_up_mfma_lds_np(const WgradP* p, int np) {
+  size_t lds = (size_t)np * 32 * (p->Wc * 2 + 16) + 4 * 16 * 144;
+  if (lds < (size_t)4 * np * 32 * 64 * 4) lds = (size_t)4 * np * 32 * 64 * 4;
   return lds;
+}
+static size_t wgrad_up_mfma_lds(const WgradP* p) {
+  const size_t two = wgrad_up_mfma_lds_np(p, wgrad_up_pairs(p));
+  return two <= 160 * 1024 ? two : wgrad_up_mfma_lds_np(p, 1);       // (very wide maps: one pair per pass)
 }
 static bool wgrad_up_mfma_ok(const WgradP* p) {
   if (!(p->wmode == 1 && p->a_dtype == DG_BF16 && p->g_dtype == DG_BF16 && p->Ci == 64 && p->a_sc == 1 &&
@@ -950,11 +976,16 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (wgrad_up_mfma_ok(p)) {
     const size_t lds = wgrad_up_mfma_lds(p);
     {
+      const bool both = wgrad_up_pairs(p) == 2 && lds == wgrad_up_mfma_lds_np(p, 2);
       if (lds > 64 * 1024)
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)thin_wgrad_up_mfma_kernel,
+        HIP_CHECK_RET(hipFuncSetAttribute(both ? (const void*)thin_wgrad_up_mfma_kernel<2> : (const void*)thin_wgrad_up_mfma_kernel<1>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      for (int gpair = 0; 2 * gpair < p->Co; ++gpair)  // one pass per pair of gradient channels
-        thin_wgrad_up_mfma_kernel<<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p, gpair);
+      if (both) {                                      // Co = 3 / 4 on the four-channel copy: both channel pairs in one pass
+        thin_wgrad_up_mfma_kernel<2><<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p, 0);
+      } else {
+        for (int gpair = 0; 2 * gpair < p->Co; ++gpair)  // one pass per pair of gradient channels
+          thin_wgrad_up_mfma_kernel<1><<<(unsigned)(units / WGU_ROWS_PB), 256, lds, s>>>(*p, gpair);
+      }
       HIP_CHECK_RET(hipGetLastError());
       return DG_OK;
     }

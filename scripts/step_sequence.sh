@@ -1,17 +1,17 @@
 #!/bin/bash
 # The launches of ONE replayed training step in stream order with their durations (rocprofv3 --kernel-trace): the run of
-# kernels between the last two step-begin launches (dg_zero_multi_kernel).   usage: scripts/step_sequence.sh <outdir>
+# kernels between the last two step-begin launches (step_prologue_kernel or dg_zero_multi_kernel).   usage: scripts/step_sequence.sh <outdir>
 out=${1:-gpurun_out/seq}
 root=$(pwd)
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $root/$out/kt -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 6 --warmup 3 $BENCH_ARGS > $root/$out/bench.json 2> $root/$out/kt.log
+rocprofv3 --kernel-trace --output-format csv -d $root/$out/kt -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 8 --warmup 4 $BENCH_ARGS > $root/$out/bench.json 2> $root/$out/kt.log
 cd $root
 f=$(find $out/kt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "dg_zero_multi" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "dg_zero_multi" in r["Kernel_Name"] or "step_prologue" in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0

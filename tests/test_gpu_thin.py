@@ -176,6 +176,8 @@ def test_head_bwd_data_pixel_major_mfma(L, nh):
 
 
 @pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2), (3, 4, 64, 2),
+                                         (3, 32, 512, 2),   # the dusty2 head of the benchmark: both channel pairs, one pass
+                                         (3, 2, 128, 3), (3, 2, 2048, 1),   # reflected rows only; too wide for one pass: two
                                          (2, 2, 1024, 1)])  # 2048-wide images: > 64 KiB of dynamic LDS
 def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
     """Head weight gradient through thin_wgrad_up_mfma (input-pixel-indexed im2col of the pixel-major bf16 head
