@@ -42,10 +42,12 @@ class DgConv(C.Structure):
         ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("w_dtype", C.c_int),
         ("nscale", C.c_void_p),
         ("up_frag", C.c_void_p),
+        ("dbias_ws", C.c_void_p),
     ]
 
 
 UP_FRAG_BYTES = 3 * 18 * 1024
+DBIAS_WS_FLOATS = 32 * 1024
 
 
 class DgUpFrag(C.Structure):

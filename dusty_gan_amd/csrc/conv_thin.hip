@@ -1208,7 +1208,28 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
       if (lane < 8) atomicAdd(&s_db[lane * 8 + e], v);
     }
     __syncthreads();
-    if (tid < 64) atomicAdd(&p.dbias[tid % p.bias_mod], s_db[tid]);
+    if (tid < 64) {
+      if (p.dbias_ws && gridDim.x > DG_DBIAS_SLOTS) {
+        // 768 blocks adding one 256-byte row each into the SAME two lines retire one after the other (memory-side, ~10-20 ns
+        // each: 16 us behind the Head backward-data).  Staged: block j adds into slot j % 32 of the caller's scratch (4 KB
+        // apart, zero on entry), the last block to arrive at a slot (ticket behind the row, lane 0) folds it into dbias
+        // and leaves the slot zero: 24 adds per slot, 32 per dbias line.
+        const int slot = blockIdx.x % DG_DBIAS_SLOTS;
+        const unsigned mine = (gridDim.x - slot + DG_DBIAS_SLOTS - 1) / DG_DBIAS_SLOTS;   // blocks that use this slot
+        float* w = p.dbias_ws + slot * DG_DBIAS_SLOT_FLOATS;
+        atomicAdd(&w[tid], s_db[tid]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (acknowledged memory-side; a fence would write back L2)
+        unsigned t = 0;
+        if (tid == 0) t = atomicAdd((unsigned*)&w[64], 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t == mine - 1) {
+          atomicAdd(&p.dbias[tid % p.bias_mod], atomicExch(&w[tid], 0.f));
+          if (tid == 0) atomicExch((unsigned*)&w[64], 0u);
+        }
+      } else {
+        atomicAdd(&p.dbias[tid % p.bias_mod], s_db[tid]);
+      }
+    }
   }
 }
 

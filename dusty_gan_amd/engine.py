@@ -275,6 +275,7 @@ WGRAD_WS = WgradWorkspace()
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
     default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
+    _dbias_ws = {}      # device -> DgConv.dbias_ws scratch (launches of one stream share it: each leaves it zero)
 
     def __init__(self, dtype):
         self.lib = L.lib()
@@ -312,6 +313,11 @@ class Ops:
         p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, (self.dt if w_dt is None else w_dt)
         p.nscale = L.ptr(nscale)
         p.up_frag = up_frag
+        if dbias is not None:  # staging scratch of the bias-gradient rows (zero between launches; one per process and device)
+            ws = Ops._dbias_ws.get(str(x.device))
+            if ws is None:
+                ws = Ops._dbias_ws[str(x.device)] = torch.zeros(L.DBIAS_WS_FLOATS, dtype=torch.float32, device=x.device)
+            p.dbias_ws = L.ptr(ws)
         if TRACE is not None:
             pl = L.DgConvPlan()
             L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")

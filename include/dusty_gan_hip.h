@@ -63,8 +63,13 @@ typedef struct DgConv {
   const void* up_frag;       /* optional, 16-byte aligned, DG_UP_FRAG_BYTES: the weight fragments of the thin matrix-core
                               * MODE_UP kernel (Head forward, Down1 backward-data) kept current by the caller with
                               * dg_transpose_shadow_multi_frags; NULL: built by a launch in front of the kernel */
+  float* dbias_ws;           /* optional scratch of DG_DBIAS_SLOTS x DG_DBIAS_SLOT_FLOATS floats, zero on entry and left zero:
+                              * per-slot staging of the bias-gradient rows of the thin matrix-core MODE_S2 kernel (hundreds of
+                              * atomic rows on the same two lines serialise memory-side; other kernels ignore it) */
 } DgConv;
 #define DG_UP_FRAG_BYTES (3 * 18 * 1024)
+#define DG_DBIAS_SLOTS 32
+#define DG_DBIAS_SLOT_FLOATS 1024
 
 /* Parameter block of dg_wgrad:  dw[tap][ci][co] += scale * sum_b rowscale[b] * sum_pixels a[..][ci] * g[..][co] */
 typedef struct DgWgrad {

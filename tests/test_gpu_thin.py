@@ -141,13 +141,15 @@ def test_head_thin(L, dtype, nh, Hc, Wc):                                 # part
     assert rel_l2(got, torch.cat(list(gws), dim=1)) < tol
 
 
+@pytest.mark.parametrize("Hc,Wc", [(8, 64), (32, 256)])      # 8 blocks: direct bias-gradient rows; 128: staged per slot
 @pytest.mark.parametrize("nh", [1, 2, 3])
-def test_head_bwd_data_pixel_major_mfma(L, nh):
+def test_head_bwd_data_pixel_major_mfma(L, nh, Hc, Wc):
     """Head backward-data through the direct-fragment MFMA kernel (thin_s2_mfma, adjoint boundary incl. the
-    reflect-adjoint extra taps at rows 1 and H-2) from the pixel-major bf16 copy of the head gradient."""
+    reflect-adjoint extra taps at rows 1 and H-2) from the pixel-major bf16 copy of the head gradient; the bias-gradient
+    rows added directly (few blocks) and staged through DgConv.dbias_ws, which every launch leaves zero."""
     from dusty_gan_amd.engine import Ops
     g = torch.Generator().manual_seed(40 + nh)
-    B, Hc, Wc, C0 = 2, 8, 64, 64
+    B, C0 = 2, 64
     dtype = torch.bfloat16
     x = torch.randn(B, C0, Hc, Wc, generator=g).requires_grad_()
     ws = [torch.randn(C0, 1, 4, 4, generator=g).bfloat16().float()] + \
@@ -173,6 +175,13 @@ def test_head_bwd_data_pixel_major_mfma(L, nh):
     torch.cuda.synchronize()
     assert rel_l2(from_nhwc(dp.float().cpu(), B, C0, Hc, Wc), ref) < 1e-2
     assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < 2e-2
+    scratch = Ops._dbias_ws[str(draw_pm.device)]
+    assert float(scratch.abs().max()) == 0.0
+    # a second launch adds onto db again (accumulating entry point): twice the sums, scratch zero again
+    o.conv(L.MODE_S2, 1, True, B, Hc, Wc, nh, C0, draw_pm, (HW * cp, cp, 1), dp, (Hc * Wc * C0, C0, 1),
+           shadow.data_ptr(), 1.0, L.EPI_MASK, aux=prevd, dbias=db.data_ptr(), bias_mod=C0)
+    torch.cuda.synchronize()
+    assert rel_l2(db.cpu(), 2 * ref.sum(dim=[0, 2, 3])) < 2e-2 and float(scratch.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("nh,Hc,Wc,B", [(1, 8, 64, 2), (2, 4, 128, 3), (2, 2, 64, 2), (3, 4, 64, 2),
