@@ -136,6 +136,7 @@ PROTOTYPES = {
     "dg_nsgan_g_step": [_P, _I, _F, _P, _P, _P],
     "dg_gan_d_step": [_I, _F, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
     "dg_gan_g_step": [_I, _P, _P, _I, _F, _P, _P, _P],
+    "dg_final_gan_bwd": [_I, _I, _F, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _I, _P, _F, _L, _I, _P, _P, _P, _P],
     "dg_mean_acc": [_P, _I, _P, _P],
     "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
     "dg_fetch_reals_sum": [_P, _P, _F, _F, _F, _I, _L, _P, _P, _P],

@@ -1143,19 +1143,18 @@ static int gan_form(int metric, int mode_g, float smoothing, GanForm* f) {
 // One block.  D mode (mode_g = 0): dy = [d/dy_real | d/dy_fake] of w_gan * loss, up / rs / dfinal_b / acc[0..2] as in
 // nsgan_d_step_kernel.  G mode: only the fake half carries a gradient (D(real) is data, trainers/dcgan_amp.py:259);
 // dy = d(w_gan * loss)/dy_fake, acc[0] += loss; y_real may be null unless the metric is relativistic.
-__global__ __launch_bounds__(256) void gan_step_kernel(GanForm fm, int mode_g, const float* __restrict__ y_real,
-                                                       const float* __restrict__ y_fake, int B, float w_gan,
-                                                       float* __restrict__ dy, float* __restrict__ up,
-                                                       float* __restrict__ rs, float* __restrict__ acc,
-                                                       float* __restrict__ dfinal_b) {
-  __shared__ float red[16];
-  __shared__ float bc;
+// `red` >= 17 floats of LDS.  dy / up / rs may be LDS (the fused final-layer kernel: every block evaluates the step for
+// itself) or global memory; `write_acc`: add the scalars / the final bias gradient (one block only).
+__device__ __forceinline__ void gan_step_body(const GanForm& fm, int mode_g, const float* __restrict__ y_real,
+                                              const float* __restrict__ y_fake, int B, float w_gan, float* dy, float* up,
+                                              float* rs, bool write_acc, float* __restrict__ acc,
+                                              float* __restrict__ dfinal_b, float* red) {
   auto bsum = [&](float v) {  // block sum, broadcast to every thread
     const float r = dg_block_sum(v, red);
     __syncthreads();
-    if (threadIdx.x == 0) bc = r;
+    if (threadIdx.x == 0) red[16] = r;
     __syncthreads();
-    return bc;
+    return red[16];
   };
   const bool has_r = (fm.kr != PHI_NONE) || !mode_g;
   float sr = 0.f, sf = 0.f;
@@ -1197,12 +1196,99 @@ __global__ __launch_bounds__(256) void gan_step_kernel(GanForm fm, int mode_g, c
     }
   }
   const float e = dg_block_sum(sd, red);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && write_acc) {
     if (mode_g) {
       acc[0] += loss;
     } else {
       acc[0] += mr; acc[1] += mf; acc[2] += loss;
       if (dfinal_b) dfinal_b[0] += e;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void gan_step_kernel(GanForm fm, int mode_g, const float* __restrict__ y_real,
+                                                       const float* __restrict__ y_fake, int B, float w_gan,
+                                                       float* __restrict__ dy, float* __restrict__ up,
+                                                       float* __restrict__ rs, float* __restrict__ acc,
+                                                       float* __restrict__ dfinal_b) {
+  __shared__ float red[17];
+  gan_step_body(fm, mode_g, y_real, y_fake, B, w_gan, dy, up, rs, true, acc, dfinal_b, red);
+}
+
+// The loss step and the final conv's backward in ONE launch (three in the D phase, two in the G phase otherwise): every
+// block evaluates the loss step on the 2B (or B) logits for itself - a few hundred flops - and keeps the per-sample
+// vectors in LDS; block 0 also writes them out (later launches read dy / rs) and adds the scalars.  Then the block's
+// element range of the final conv's backward-data pass (final_bwd_data_kernel) and, in the same sweep over the samples,
+// of its weight gradient dwf[i] += scale * sum_b dy[b] d4[b][i] (dg_batch_wsum) - d4 is read once for both.
+// D mode: ns = 2B samples [real | fake]; r1: chain upstream [1 | dy_fake], bias-gradient weights [dy_real | 1] (the R1
+// schedule), else upstream dy, weights 1.  G mode: ns = B samples (the fake batch), upstream dy.
+template <typename T>
+__global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode_g, const float* __restrict__ y_real,
+                                                            const float* __restrict__ y_fake, int B, float w_gan, int r1,
+                                                            float* __restrict__ dy, float* __restrict__ up,
+                                                            float* __restrict__ rs, float* __restrict__ acc,
+                                                            float* __restrict__ dfinal_b, const T* __restrict__ d4,
+                                                            const float* __restrict__ wf, float scale, long n, int C,
+                                                            T* __restrict__ dd4, float* __restrict__ dbias,
+                                                            float* __restrict__ dwf) {
+  constexpr int V = Vec16<T>::V;
+  __shared__ float part[4][64 * V];
+  __shared__ float s_dy[256], s_u[256], s_r[256], red[17];
+  const int ns = mode_g ? B : 2 * B;
+  gan_step_body(fm, mode_g, y_real, y_fake, B, w_gan, s_dy, r1 ? s_u : nullptr, r1 ? s_r : nullptr, blockIdx.x == 0, acc,
+                dfinal_b, red);
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b < ns; b += 256) {
+      dy[b] = s_dy[b];
+      if (up && r1) up[b] = s_u[b];
+      if (rs && r1) rs[b] = s_r[b];
+    }
+  if (!r1) {
+    for (int b = threadIdx.x; b < ns; b += 256) { s_u[b] = s_dy[b]; s_r[b] = 1.f; }
+    __syncthreads();
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * 64 + lane) * V;
+  float w[V], db[V], dw[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { w[k] = 0.f; db[k] = 0.f; dw[k] = 0.f; }
+  if (i < n) {
+#pragma unroll
+    for (int k4 = 0; k4 < V; k4 += 4) {
+      const float4 r = *(const float4*)(wf + i + k4);
+      w[k4] = r.x * scale; w[k4 + 1] = r.y * scale; w[k4 + 2] = r.z * scale; w[k4 + 3] = r.w * scale;
+    }
+#pragma unroll 4
+    for (int b = wave; b < ns; b += 4) {
+      float a[V], g[V];
+      Vec16<T>::load(d4 + (long)b * n + i, a);
+      const float u = s_u[b], rsb = s_r[b], c = s_dy[b];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        g[k] = u * w[k] * (a[k] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+        db[k] += rsb * g[k];
+        dw[k] += c * a[k];
+      }
+      Vec16<T>::store(dd4 + (long)b * n + i, g);
+    }
+  }
+  if (dbias) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) part[wave][lane * V + k] = db[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * V; e += 256) {
+      const long ie = (long)blockIdx.x * 64 * V + e;
+      if (ie < n) atomicAdd(&dbias[ie % C], part[0][e] + part[1][e] + part[2][e] + part[3][e]);
+    }
+  }
+  if (dwf) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k) part[wave][lane * V + k] = dw[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * V; e += 256) {
+      const long ie = (long)blockIdx.x * 64 * V + e;
+      if (ie < n) dwf[ie] += (part[0][e] + part[1][e] + part[2][e] + part[3][e]) * scale;
     }
   }
 }
@@ -1765,6 +1851,36 @@ int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, f
   if (fm.kr != PHI_NONE && !y_real) return DG_EINVAL;  // relativistic metrics read D(real) (models/loss.py:76-85)
   gan_step_kernel<<<1, 256, 0, (hipStream_t)s_>>>(fm, 1, y_real, y_fake, B, w_gan, dy, nullptr, nullptr, acc,
                                                   nullptr);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+// dg_gan_d_step / dg_gan_g_step + dg_final_bwd_data (+ dg_batch_wsum with coef = dy when dwf is given) in one launch.
+// DG_EUNSUPPORTED (nothing launched) unless the 16-byte forms apply and the samples fit the kernel's per-sample tables:
+// the caller then issues the separate calls.
+int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_real, const float* y_fake, int B, float w_gan,
+                     int r1, float* dy, float* up, float* rs, float* acc, float* dfinal_b, const void* d4, int dtype,
+                     const float* wf, float scale, long n, int C, void* dd4, float* dbias, float* dwf, void* s_) {
+  if (!y_fake || !dy || !acc || !d4 || !wf || !dd4 || B <= 0 || n <= 0) return DG_EINVAL;
+  if (!mode_g && !y_real) return DG_EINVAL;
+  GanForm fm;
+  const int rc = gan_form(metric, mode_g ? 1 : 0, mode_g ? 1.f : smoothing, &fm);
+  if (rc != DG_OK) return rc;
+  if (mode_g && fm.kr != PHI_NONE && !y_real) return DG_EINVAL;
+  if (mode_g && r1) return DG_EINVAL;
+  const int ns = mode_g ? B : 2 * B;
+  const int V = dtype == DG_BF16 ? 8 : 4;
+  if (!(vec_ok(d4, n, dtype) && vec_ok(dd4, n, dtype) && C % V == 0 && ns <= 256 && ((size_t)wf & 15) == 0 &&
+        (!dwf || ((size_t)dwf & 15) == 0)))
+    return DG_EUNSUPPORTED;
+  const unsigned grid = nblk(n / V, 64);
+  hipStream_t s = (hipStream_t)s_;
+  if (dtype == DG_BF16)
+    final_gan_bwd_kernel<bf16><<<grid, 256, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
+                                                    (const bf16*)d4, wf, scale, n, C, (bf16*)dd4, dbias, dwf);
+  else
+    final_gan_bwd_kernel<float><<<grid, 256, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
+                                                     (const float*)d4, wf, scale, n, C, (float*)dd4, dbias, dwf);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -788,19 +788,43 @@ class DEngine:
                rowscale=rowscale, x_off=slot * self.per[i], out_off=slot * self.per[i - 1],
                aux_off=slot * self.per[i - 1], up_frag=frag)
 
-    def backward_data(self, st, slot, n, up, rowscale, want_dbias):
+    def backward_data(self, st, slot, n, up, rowscale, want_dbias, skip_final=False):
         """Backward-data chain over batch slots [slot, slot+n): e4 = up*s_f*wf*mask4, then e3, e2, e1 (each the
         gradient w.r.t. a layer's pre-activation).  up: per-sample upstream gradient or None (= 1, the R1 chain);
-        rowscale: per-sample weight of the bias-gradient sums (dLoss/dy_real for the shared real chain)."""
+        rowscale: per-sample weight of the bias-gradient sums (dLoss/dy_real for the shared real chain).
+        skip_final: e4 is there already (`final_gan_bwd`)."""
         o, lib = self.ops, L.lib()
         nf = self.per[4]
-        L.check(lib.dg_final_bwd_data(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), L.ptr(up),
-                                      L.ptr(rowscale), 1.0 / math.sqrt(nf), n, nf, self.chs[4],
-                                      L.ptr(self.e[4]) + o.es * slot * nf,
-                                      st.fptr("d4_b", st.grad) if want_dbias else None, L.stream_ptr()),
-                "dg_final_bwd_data")
+        if not skip_final:
+            L.check(lib.dg_final_bwd_data(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), L.ptr(up),
+                                          L.ptr(rowscale), 1.0 / math.sqrt(nf), n, nf, self.chs[4],
+                                          L.ptr(self.e[4]) + o.es * slot * nf,
+                                          st.fptr("d4_b", st.grad) if want_dbias else None, L.stream_ptr()),
+                    "dg_final_bwd_data")
         for i in (4, 3, 2):
             self._bwd_layer(st, i, slot, n, rowscale, want_dbias)
+
+    def final_gan_bwd(self, st, slot, B, metric, mode_g, smoothing, w_gan, y_real, y_fake, r1, dy, up, rs, acc_ptr,
+                      want_dbias, want_wgrad):
+        """The loss step + the final conv's backward-data (+ its weight gradient with coefficients dy) over the 2B (D
+        phase, [real | fake] from `slot`) or B (G phase) samples as ONE launch (dg_final_gan_bwd).  y_real / y_fake:
+        device pointers of the logits.  False - nothing launched - when the kernel does not take the shape: the caller
+        then issues dg_gan_*_step, backward_data and final_wgrad."""
+        if PROFILE is not None:
+            return False
+        o, lib = self.ops, L.lib()
+        nf = self.per[4]
+        rc = lib.dg_final_gan_bwd(metric, int(mode_g), float(smoothing), y_real, y_fake, B, w_gan, int(r1), L.ptr(dy),
+                                  L.ptr(up), L.ptr(rs), acc_ptr,
+                                  st.fptr("final_b", st.grad) if not mode_g else None,
+                                  L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), 1.0 / math.sqrt(nf), nf,
+                                  self.chs[4], L.ptr(self.e[4]) + o.es * slot * nf,
+                                  st.fptr("d4_b", st.grad) if want_dbias else None,
+                                  st.fptr("final_w", st.grad) if want_wgrad else None, L.stream_ptr())
+        if rc == L.DG_EUNSUPPORTED:
+            return False
+        L.check(rc, "dg_final_gan_bwd")
+        return True
 
     def r1_fused_ok(self):
         """whether dg_blur_bwd_r1 (BlurVH adjoint + R1 tangent + |g|^2 in one pass) takes this image shape

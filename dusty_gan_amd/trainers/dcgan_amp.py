@@ -628,16 +628,21 @@ class Trainer:
                 if getattr(self, "_rs3", None) is None or self._rs3.numel() != 3 * B or self._rs3.device != self.device:
                     self._rs3 = torch.ones(3 * B, **f32)
                 rs = self._rs3
-            L.check(lib.dg_gan_d_step(self.gan_code, float(self.criterion["gan"].smoothing), L.ptr(y),
-                                      L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs), L.ptr(scal),
-                                      Dst.fptr("final_b", Dst.grad), sp), "dg_gan_d_step")
+            # the loss step, the final conv's backward-data and its weight gradient as one launch; three where the
+            # kernel does not take the shape
+            fused = deng.final_gan_bwd(Dst, 0, B, self.gan_code, False, float(self.criterion["gan"].smoothing), w_gan,
+                                       L.ptr(y), L.ptr(y) + 4 * B, gp > 0, dy, up, rs, L.ptr(scal), True, True)
+            if not fused:
+                L.check(lib.dg_gan_d_step(self.gan_code, float(self.criterion["gan"].smoothing), L.ptr(y),
+                                          L.ptr(y) + 4 * B, B, w_gan, L.ptr(dy), L.ptr(up), L.ptr(rs), L.ptr(scal),
+                                          Dst.fptr("final_b", Dst.grad), sp), "dg_gan_d_step")
             # data-parallel runs (one micro-batch): the gradient exchange is cut into two buckets at d4_w (73 % of D's
             # bytes live in [d4_w, end)) and the weight gradients are formed last layer first, so the large bucket
             # travels while the three smaller layers' gradients are still being computed
             bucketed = self._bucketed()
             cut = Dst.seg["d4_w"].off
             if gp > 0:
-                deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True)
+                deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True, skip_final=fused)
                 g = torch.empty(B, 1, self.H, self.W, **f32)
                 # R1 (:218-235): g = d sum(y_real) / dx_real, penalty = gp / 2 * mean_b |g_b|^2, and its double backward's
                 # tangent v = d penalty / dg = (gp / B) g, pushed forward through D below
@@ -661,18 +666,21 @@ class Trainer:
                 for layers in (((4,), (3, 2, 1)) if bucketed else ((4, 3, 2, 1),)):
                     deng.wgrad_r1(Dst, B, rs, layers=layers)
                     if 4 in layers:
-                        deng.final_wgrad(Dst, 0, 2 * B, dy)
+                        if not fused:
+                            deng.final_wgrad(Dst, 0, 2 * B, dy)
                         deng.final_wgrad(Dst, 2 * B, B, None)
                         if bucketed:
                             self._allreduce_async("D.hi", Dst.grad[cut:])
             else:
-                deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True)
+                deng.backward_data(Dst, 0, 2 * B, dy, None, want_dbias=True, skip_final=fused)
                 if not bucketed:
                     deng.wgrad(Dst, 0, 0, 2 * B, None)
-                    deng.final_wgrad(Dst, 0, 2 * B, dy)
+                    if not fused:
+                        deng.final_wgrad(Dst, 0, 2 * B, dy)
                 else:
                     deng.wgrad(Dst, 0, 0, 2 * B, None, layers=(4,))
-                    deng.final_wgrad(Dst, 0, 2 * B, dy)
+                    if not fused:
+                        deng.final_wgrad(Dst, 0, 2 * B, dy)
                     self._allreduce_async("D.hi", Dst.grad[cut:])
                     deng.wgrad(Dst, 0, 0, 2 * B, None, layers=(3, 2, 1))
             self._mb.append({"x_real": x_real, "m_real": m_real, "rand": rand, "synth": synth, "geng": gengs[j]})
@@ -722,9 +730,12 @@ class Trainer:
             else:
                 y = deng.forward_aug(Dst, self.A, [(mb["synth"]["depth"], rand["aug"][3])], 0)  # :256, :260, updated D
                 y_real = None
-            L.check(lib.dg_gan_g_step(self.gan_code, y_real, L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp),
-                    "dg_gan_g_step")
-            deng.backward_data(Dst, 0, B, dy, None, want_dbias=False)
+            fused = deng.final_gan_bwd(Dst, 0, B, self.gan_code, True, 1.0, w_gan, y_real, L.ptr(y), False, dy, None, None,
+                                       L.ptr(scal) + 16, False, False)
+            if not fused:
+                L.check(lib.dg_gan_g_step(self.gan_code, y_real, L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp),
+                        "dg_gan_g_step")
+            deng.backward_data(Dst, 0, B, dy, None, want_dbias=False, skip_final=fused)
             ddepth = deng.backward_input_aug(Dst, 0, B, self.A, rand["aug"][3])
             overlap = gather_proj and not pl_on  # (the path-length block adds to every gradient after this pass)
             if overlap:

@@ -261,6 +261,15 @@ int dg_gan_d_step(int metric, float smoothing, const float* y_real, const float*
                   float* up, float* rs, float* acc, float* dfinal_b, void* stream);
 int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, float w_gan, float* dy, float* acc,
                   void* stream);
+/* The loss step and the final conv's backward as ONE launch: dg_gan_d_step (mode_g = 0; r1 = 1: the R1 schedule's up / rs
+ * vectors drive the chain, r1 = 0: upstream dy, unit weights) or dg_gan_g_step (mode_g = 1), then dg_final_bwd_data over
+ * the 2B (B) samples with those vectors, and - when dwf is given - the final conv's weight gradient
+ * dwf[i] += scale * sum_b dy[b] d4[b][i] (dg_batch_wsum) from the same read of d4: `loss.backward()`'s first links,
+ * trainers/dcgan_amp.py:203-235 and :259-309.  DG_EUNSUPPORTED (nothing launched) when the vector forms do not apply or
+ * more than 256 samples are in the pass. */
+int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_real, const float* y_fake, int B, float w_gan,
+                     int r1, float* dy, float* up, float* rs, float* acc, float* dfinal_b, const void* d4, int dtype,
+                     const float* wf, float scale, long n, int C, void* dd4, float* dbias, float* dwf, void* stream);
 int dg_mean_acc(const float* x, int n, float* acc, void* stream);
 
 /* ---- path-length regularisation  trainers/dcgan_amp.py:268-306 (the parts that are not convolutions) ------------

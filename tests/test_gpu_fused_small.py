@@ -414,3 +414,63 @@ def test_step_prologue_equals_the_single_launches(L):
     bad = r2.job(3, 0, n=4, out=z2.data_ptr())
     assert L.lib().dg_step_prologue(None, None, 0, (L.DgDraw * 1)(bad), 1, None) == L.DG_EINVAL
     assert L.lib().dg_step_prologue(None, None, 0, (L.DgDraw * 1)(bad), 7, None) == L.DG_EINVAL
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("metric,mode_g,r1", [(0, 0, 1), (0, 0, 0), (2, 0, 1), (4, 0, 0), (0, 1, 0), (5, 1, 0)])
+def test_final_gan_bwd_equals_the_separate_launches(L, dtype, metric, mode_g, r1):
+    """dg_final_gan_bwd (loss step + final conv backward-data + its weight gradient in one launch, every block evaluating
+    the loss step for itself) against dg_gan_d_step / dg_gan_g_step + dg_final_bwd_data + dg_batch_wsum: the per-sample
+    vectors, scalars and the data gradient bit for bit, the atomically summed bias gradient to rounding."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(metric * 7 + mode_g)
+    B, C, n = 12, 32, 32 * 4 * 16                       # n = C h0 w0
+    ns = B if mode_g else 2 * B
+    dt = L.dtype_code(dtype)
+    y = torch.randn(2 * B, generator=g).to(DEV)
+    d4 = torch.randn(ns, n, generator=g).to(DEV, dtype)
+    wf = torch.randn(n, generator=g).to(DEV)
+    scale, w_gan, smoothing = 1.0 / math.sqrt(n), 0.7, 0.9
+    rel = metric >= 4
+
+    def bufs():
+        return dict(dy=torch.zeros(ns, device=DEV), up=torch.zeros(ns, device=DEV), rs=torch.zeros(ns, device=DEV),
+                    acc=torch.zeros(4, device=DEV), fb=torch.zeros(1, device=DEV), dd4=torch.zeros(ns, n, device=DEV, dtype=dtype),
+                    db=torch.zeros(C, device=DEV), dwf=torch.zeros(n, device=DEV))
+    a, b = bufs(), bufs()
+    y_real, y_fake = (y.data_ptr() + 4 * B if (mode_g and rel) else (None if mode_g else y.data_ptr()),
+                      y.data_ptr() if mode_g else y.data_ptr() + 4 * B)
+    # separate launches
+    if mode_g:
+        L.check(lib.dg_gan_g_step(metric, y_real, y_fake, B, w_gan, a["dy"].data_ptr(), a["acc"].data_ptr(), None))
+        L.check(lib.dg_final_bwd_data(d4.data_ptr(), dt, wf.data_ptr(), a["dy"].data_ptr(), None, scale, ns, n, C,
+                                      a["dd4"].data_ptr(), None, None))
+    else:
+        L.check(lib.dg_gan_d_step(metric, smoothing, y_real, y_fake, B, w_gan, a["dy"].data_ptr(),
+                                  a["up"].data_ptr() if r1 else None, a["rs"].data_ptr() if r1 else None,
+                                  a["acc"].data_ptr(), a["fb"].data_ptr(), None))
+        L.check(lib.dg_final_bwd_data(d4.data_ptr(), dt, wf.data_ptr(), (a["up"] if r1 else a["dy"]).data_ptr(),
+                                      a["rs"].data_ptr() if r1 else None, scale, ns, n, C, a["dd4"].data_ptr(),
+                                      a["db"].data_ptr(), None))
+        L.check(lib.dg_batch_wsum(d4.data_ptr(), dt, a["dy"].data_ptr(), scale, ns, n, a["dwf"].data_ptr(), None))
+    # one launch
+    L.check(lib.dg_final_gan_bwd(metric, mode_g, smoothing, y_real, y_fake, B, w_gan, r1, b["dy"].data_ptr(),
+                                 b["up"].data_ptr() if r1 else None, b["rs"].data_ptr() if r1 else None, b["acc"].data_ptr(),
+                                 None if mode_g else b["fb"].data_ptr(), d4.data_ptr(), dt, wf.data_ptr(), scale, n, C,
+                                 b["dd4"].data_ptr(), None if mode_g else b["db"].data_ptr(),
+                                 None if mode_g else b["dwf"].data_ptr(), None))
+    torch.cuda.synchronize()
+    for k in ("dy", "up", "rs", "acc", "fb", "dd4", "dwf"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["dd4"].float().abs().mean()) > 0 and (mode_g or float(a["dwf"].abs().mean()) > 0)
+    assert rel_l2(b["db"].cpu(), a["db"].cpu()) < 1e-5 or mode_g
+    # shapes the kernel refuses: nothing launched
+    big = 200
+    yb = torch.randn(2 * big, device=DEV)
+    rc = lib.dg_final_gan_bwd(0, 0, 1.0, yb.data_ptr(), yb.data_ptr() + 4 * big, big, 1.0, 0, b["dy"].data_ptr(), None, None,
+                              b["acc"].data_ptr(), None, d4.data_ptr(), dt, wf.data_ptr(), scale, n, C, b["dd4"].data_ptr(),
+                              None, None, None)
+    assert rc == L.DG_EUNSUPPORTED
+    assert lib.dg_final_gan_bwd(0, 1, 1.0, None, y_fake, B, 1.0, 1, b["dy"].data_ptr(), None, None, b["acc"].data_ptr(), None,
+                                d4.data_ptr(), dt, wf.data_ptr(), scale, n, C, b["dd4"].data_ptr(), None, None,
+                                None) == L.DG_EINVAL
