@@ -13,6 +13,7 @@ int dg_proj_stream_supported(const ConvP* p);
 int dg_proj_stream_launch(const ConvP* p, hipStream_t stream, DgConvPlan* plan);
 int dg_conv_thin_mfma_variant(const ConvP* p);
 int dg_wgrad_thin_mfma_variant(const WgradP* p);
+int dg_wgrad_thin_ws_splits(const WgradP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream);
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
@@ -82,14 +83,20 @@ static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force, hipStream
   if ((force == 0 || force == 2 || force == 7 || force == 8) && mfma_ok && dg_wgrad_mfma_dma_supported(p))
     return dg_wgrad_mfma_dma_launch(p, accumulate, force == 7 ? 1 : (force == 8 ? 2 : 0), s, plan);
   if (force == 7 || force == 8) return DG_EUNSUPPORTED;
-  if (plan) return plan->variant ? DG_OK : DG_EUNSUPPORTED;
-  if (p->ws) return DG_EUNSUPPORTED;                // only the LDS-DMA kernel has the workspace form ...
+  // the thin matrix-core kernels (Down1, Head) also have the workspace form: one partial tile per block
+  const bool thin_runs = thin_ok && (force == 3 || (force == 0 && !mfma_ok));
+  const int thin_splits = thin_runs ? dg_wgrad_thin_ws_splits(p) : 0;
+  if (plan) {
+    if (thin_splits) { plan->splits = thin_splits; plan->ws_floats = (long)thin_splits * 16 * p->Ci * p->Co; }
+    return plan->variant ? DG_OK : DG_EUNSUPPORTED;
+  }
+  if (p->ws && !thin_splits) return DG_EUNSUPPORTED;   // (the LDS-DMA kernel and those two: nobody else)
   // ... and the gradient-sample map exists there and in the thin matrix-core kernel of Down1 (checked by its launcher)
   const bool thin_map = p->g_mod && thin_ok && !mfma_ok && (force == 0 || force == 3);
   if (p->g_mod && !thin_map) return DG_EUNSUPPORTED;
   if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
-  if (!accumulate) {
+  if (!accumulate && !p->ws) {                       // (workspace form: the reduce launch overwrites dw)
     const long n = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
     { const int zrc = dg_zero_f32(p->dw, n, s); if (zrc) return zrc; }
   }

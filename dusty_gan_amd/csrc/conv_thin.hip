@@ -484,9 +484,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_mfma_kernel(WgradP p, int
       s_red[(wave * 32 + mrow) * 64 + jt * 32 + lr] = acc[jt][e];
     }
   __syncthreads();
+  // p.ws: the block's partial tile with plain stores (summed by dg_wgrad_reduce, fixed order) instead of 2048 atomics on
+  // the 8 KB every block of the launch adds into
+  float* wsb = p.ws ? p.ws + (long)blockIdx.x * 2048 : nullptr;
   for (int i = tid; i < 32 * 64; i += 256) {
     const float v = s_red[i] + s_red[2048 + i] + s_red[4096 + i] + s_red[6144 + i];
-    atomicAdd(&p.dw[i], v * sc);
+    if (wsb) wsb[i] = v * sc; else atomicAdd(&p.dw[i], v * sc);
   }
 }
 
@@ -683,11 +686,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
         s_red[wave * WS + (pr * 32 + nrow) * 64 + jt * 32 + lr] = acc[pr][jt][e];
       }
   __syncthreads();
+  float* wsb = p.ws ? p.ws + (long)blockIdx.x * 16 * 64 * p.Co : nullptr;   // (single-pass launches only: the partial tile)
   for (int i = tid; i < WS; i += 256) {
     const int n = i >> 6, ci = i & 63, tap = (n & 31) >> 1, co = 2 * (gpair + (n >> 5)) + (n & 1);
     if (co >= p.Co) continue;
     const float v = s_red[i] + s_red[WS + i] + s_red[2 * WS + i] + s_red[3 * WS + i];
-    atomicAdd(&p.dw[((long)tap * p.Ci + ci) * p.Co + co], v * sc);
+    const long o = ((long)tap * p.Ci + ci) * p.Co + co;
+    if (wsb) wsb[o] = v * sc; else atomicAdd(&p.dw[o], v * sc);
   }
 }
 
@@ -950,9 +955,28 @@ int dg_wgrad_thin_mfma_variant(const WgradP* p) {
   return wgrad_down_mfma_ok(p) ? 1 : (wgrad_up_mfma_ok(p) ? 2 : 0);
 }
 
+static int wgrad_down_rows_pb(const WgradP* p) {
+  // rows per block: every block ends in 2048 partial sums for the same 8 KB; 4 rows once 2 rows give >= 1024 blocks
+  return ((long)p->B * p->Hc >= 2048 && p->Hc % 4 == 0) ? 4 : WG_ROWS_PB;
+}
+// Partial tiles (= blocks) of the launch when the kernel that runs has the workspace form (DgWgrad.ws: plain-store partials
+// of 16 Ci Co floats each, summed by dg_wgrad_reduce): the two matrix-core kernels, single-pass launches.  0: no such form.
+int dg_wgrad_thin_ws_splits(const WgradP* p) {
+  if (!dg_wgrad_thin_supported(p)) return 0;
+  const long units = (long)p->B * p->Hc;
+  long nb = 0;
+  if (wgrad_down_mfma_ok(p)) nb = units / wgrad_down_rows_pb(p);
+  else if (wgrad_up_mfma_ok(p)) {
+    const bool one_pass = p->Co <= 2 || (wgrad_up_pairs(p) == 2 && wgrad_up_mfma_lds(p) == wgrad_up_mfma_lds_np(p, 2));
+    if (one_pass) nb = units / WGU_ROWS_PB;
+  }
+  return nb > 0 && nb <= 65536 ? (int)nb : 0;
+}
+
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (!dg_wgrad_thin_supported(p)) return DG_EUNSUPPORTED;
-  if (p->ws || (p->g_mod && !wgrad_down_mfma_ok(p))) return DG_EUNSUPPORTED;   // only thin_wgrad_down_mfma has the sample map
+  if (p->ws && !dg_wgrad_thin_ws_splits(p)) return DG_EUNSUPPORTED;
+  if (p->g_mod && !wgrad_down_mfma_ok(p)) return DG_EUNSUPPORTED;   // only thin_wgrad_down_mfma has the sample map
   const long units = (long)p->B * p->Hc;
   unsigned grid = units < 1024 ? (unsigned)units : 1024u;
   if (wgrad_down_mfma_ok(p)) {
@@ -963,8 +987,7 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
                                  : (Wf <= 1024 ? (const void*)thin_wgrad_down_mfma_kernel<4> : (const void*)thin_wgrad_down_mfma_kernel<16>);
       if (lds > 64 * 1024)  // opt in to more than the default 64 KiB of dynamic LDS
         HIP_CHECK_RET(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      // rows per block: every block ends in 2048 fp32 atomics on the same 8 KB; 4 rows once 2 rows give >= 1024 blocks
-      const int rows_pb = (units >= 2048 && p->Hc % 4 == 0) ? 4 : WG_ROWS_PB;
+      const int rows_pb = wgrad_down_rows_pb(p);
       const unsigned nb = (unsigned)(units / rows_pb);
       if (Wf <= 256) thin_wgrad_down_mfma_kernel<1><<<nb, 256, lds, s>>>(*p, rows_pb);
       else if (Wf <= 1024) thin_wgrad_down_mfma_kernel<4><<<nb, 256, lds, s>>>(*p, rows_pb);

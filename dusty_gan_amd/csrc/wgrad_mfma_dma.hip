@@ -354,13 +354,47 @@ int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, D
 }
 
 // dw[i] (+)= sum_s ws[s * numel + i]: one thread per 16 bytes of each layer, the splits' loads in flight eight at a time
+// Layers with more than RED_WIDE partial tiles (the thin matrix-core kernels: one tile per block, 512-768 of them over a few
+// KB): a block owns 16 elements and its 16 thread groups split the partials, met in LDS in a fixed order - 32-48 loads per
+// thread instead of 768 dependent batches for one.
+constexpr int RED_WIDE = 64;
 struct ReduceItems { DgWgradReduce it[8]; int first_block[9]; int n; };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceItems r) {
+  __shared__ f32x4 s_part[16][17];
   int k = 0;
 #pragma unroll
   for (int i = 1; i < 8; ++i)
     if (i < r.n && (int)blockIdx.x >= r.first_block[i]) k = i;
   const DgWgradReduce it = r.it[k];
+  if (it.splits > RED_WIDE) {
+    const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;          // element of the block, split group
+    const long i4 = (long)(blockIdx.x - r.first_block[k]) * 16 + el;
+    const long stride = it.numel / 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (4 * i4 < it.numel) {
+      const f32x4* src = (const f32x4*)it.ws + i4;
+      int sp = sg;
+      for (; sp + 7 * 16 < it.splits; sp += 8 * 16) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + (long)(sp + 16 * j) * stride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+      }
+      for (; sp < it.splits; sp += 16) acc += __builtin_nontemporal_load(src + (long)sp * stride);
+    }
+    s_part[sg][el] = acc;
+    __syncthreads();
+    if (sg == 0 && 4 * i4 < it.numel) {
+      f32x4 t = s_part[0][el];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) t += s_part[j][el];
+      f32x4* dst = (f32x4*)it.dw + i4;
+      if (it.accumulate) t += *dst;
+      *dst = t;
+    }
+    return;
+  }
   const long i4 = (long)(blockIdx.x - r.first_block[k]) * 256 + threadIdx.x;
   if (4 * i4 >= it.numel) return;
   const f32x4* src = (const f32x4*)it.ws + i4;
@@ -429,7 +463,7 @@ extern "C" int dg_wgrad_reduce(const DgWgradReduce* items, int n, void* stream) 
     if (((size_t)it.ws & 15) != 0 || ((size_t)it.dw & 15) != 0) return DG_EINVAL;
     r.it[i] = it;
     r.first_block[i] = blocks;
-    blocks += (int)((it.numel / 4 + 255) / 256);
+    blocks += (int)((it.numel / 4 + (it.splits > RED_WIDE ? 15 : 255)) / (it.splits > RED_WIDE ? 16 : 256));
   }
   r.first_block[n] = blocks;
   r.n = n;

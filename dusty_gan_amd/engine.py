@@ -253,8 +253,18 @@ class WgradWorkspace:
     def flush(self):
         """sum every pending layer's partials into its gradient (stream order after the launches that wrote them)"""
         items, self.items, self.pos = self.items, [], 0
-        for i in range(0, len(items), 8):
-            chunk = items[i:i + 8]
+        # one launch per <= 8 layers, and never two items with the same destination in one launch (micro-batches, the
+        # path-length terms: their blocks would read-modify-write the same dW concurrently) - those follow in stream order
+        chunks, cur, seen = [], [], set()
+        for it in items:
+            if len(cur) == 8 or it[1] in seen:
+                chunks.append(cur)
+                cur, seen = [], set()
+            cur.append(it)
+            seen.add(it[1])
+        if cur:
+            chunks.append(cur)
+        for chunk in chunks:
             arr = (L.DgWgradReduce * len(chunk))()
             for a, (ws, dw, numel, splits, acc) in zip(arr, chunk):
                 a.ws, a.dw, a.numel, a.splits, a.accumulate = ws, dw, numel, splits, acc
@@ -534,7 +544,7 @@ class GEngine:
         def head_wgrad():
             hc, wc = self.grid[3]
             o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), hsrc, hstr,
-                    st.fptr("head_w", st.grad), 1.0, **hkw_w)
+                    st.fptr("head_w", st.grad), 1.0, defer=True, **hkw_w)
 
         def head_bwd_data():  # gradient w.r.t. Up3's pre-activation, fused lrelu' mask + bias grad
             hc, wc = self.grid[3]
@@ -615,7 +625,7 @@ class GEngine:
             for a_src, (gs, gst, gd) in ((self.a[3], (gsrc, gstr, gdt)), (acts[3], g1)):
                 kw = {} if gd is None else {"g_dt": gd}
                 o.wgrad(1, c.ring, B, hc, wc, chs[3], c.nheads, a_src, (hc * wc * chs[3], chs[3], 1), gs, gst,
-                        st.fptr("head_w", g), 1.0, **kw)
+                        st.fptr("head_w", g), 1.0, defer=True, **kw)
         kw = {} if gdt is None else {"in_dt": gdt}
         o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], gsrc, gstr, dp[3], (hc * wc * chs[3], chs[3], 1),
                st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3], dbias=st.fptr("up3_b", g) if full else None,

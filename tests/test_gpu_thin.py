@@ -213,20 +213,41 @@ def test_head_wgrad_pixel_major_mfma(L, nh, Hc, Wc, B):
     draw_pm = draw_pm.to(DEV, dtype).contiguous()
     xd = nhwc(x).to(DEV, dtype)
     dw = torch.zeros(16, C0, nh, device=DEV)
+    from dusty_gan_amd import engine as E
+    E.TRACE = []
     o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw_pm, (HW * cp, cp, 1), dw.data_ptr(), 1.0,
             rowscale=rs.to(DEV))
     torch.cuda.synchronize()
+    trace, E.TRACE = E.TRACE, None
     got = dw.cpu().view(4, 4, C0, nh).permute(2, 3, 0, 1)
     assert rel_l2(got, ref) < 1e-2
+    # the launch above stored one partial tile per block in the workspace (summed by dg_wgrad_reduce's wide form when there
+    # are more than 64 of them) unless the map is too wide for a single pass; with fp32 atomics onto dW instead: the same
+    one_pass = not (nh == 3 and Wc == 2048)
+    assert trace[0][1] == 7 and trace[0][5] == one_pass and (trace[0][3] == B * Hc // 2 if one_pass else True), trace
+    o.use_ws = False
+    dw2 = torch.zeros(16, C0, nh, device=DEV)
+    o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw_pm, (HW * cp, cp, 1), dw2.data_ptr(), 1.0,
+            rowscale=rs.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(dw2.cpu(), dw.cpu()) < 1e-5
+    # accumulate = 0 overwrites whatever dW held (the reduce launch does it in the workspace form)
+    o.use_ws = True
+    dw3 = torch.full((16, C0, nh), 5.0, device=DEV)
+    o.wgrad(1, True, B, Hc, Wc, C0, nh, xd, (Hc * Wc * C0, C0, 1), draw_pm, (HW * cp, cp, 1), dw3.data_ptr(), 1.0,
+            rowscale=rs.to(DEV), accumulate=0)
+    torch.cuda.synchronize()
+    assert rel_l2(dw3.cpu(), dw.cpu()) < 1e-5
 
 
-def test_down1_wgrad_one_launch_over_real_fake_tangent(L):
+@pytest.mark.parametrize("n,Hc", [(2, 8), (12, 32)])       # 24 partial tiles per launch; 576: dg_wgrad_reduce's wide form
+def test_down1_wgrad_one_launch_over_real_fake_tangent(L, n, Hc):
     """thin_wgrad_down_mfma with the gradient-sample map (DgWgrad.g_mod): one launch over 3n input samples real | fake |
     tangent against the 2n-sample gradient chain (g sample = b % 2n, per-sample weights) == the two launches it replaces in
     the D phase (ordinary + R1 weight gradient of Down1, trainers/dcgan_amp.py:229-235)"""
     from dusty_gan_amd import engine as E
     g = torch.Generator().manual_seed(3)
-    n, Hc, Wc, Ci, Co = 2, 8, 64, 2, 64
+    Wc, Ci, Co = 64, 2, 64
     a = torch.randn(3 * n * 4 * Hc * Wc * Ci, generator=g).to(DEV, torch.bfloat16)
     e = torch.randn(2 * n * Hc * Wc * Co, generator=g).to(DEV, torch.bfloat16)
     rs = (torch.rand(3 * n, generator=g) + 0.5).to(DEV)
@@ -241,11 +262,26 @@ def test_down1_wgrad_one_launch_over_real_fake_tangent(L):
         assert o.wgrad_takes_map(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, two.data_ptr())
         one = torch.zeros(16, Ci, Co, device=DEV)
         o.wgrad(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, one.data_ptr(), 0.1, rowscale=rs, g_mod=2 * n)
-        assert all(t[1] == 7 for t in E.TRACE if t[0] == "wgrad"), E.TRACE     # the thin matrix-core kernel
+        assert all(t[1] == 7 and t[5] for t in E.TRACE if t[0] == "wgrad"), E.TRACE   # the thin matrix-core kernel, partial
+        assert E.TRACE[-1][3] == 3 * n * Hc // 2                                       # tiles in the workspace: one per block
+        o.use_ws = False                                                               # fp32 atomics onto dW: the same sums
+        atom = torch.zeros(16, Ci, Co, device=DEV)
+        o.wgrad(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, atom.data_ptr(), 0.1, rowscale=rs, g_mod=2 * n)
+        o.use_ws = True
     finally:
         E.TRACE = None
     torch.cuda.synchronize()
-    assert rel_l2(one.cpu(), two.cpu()) < 1e-5
+    assert rel_l2(one.cpu(), two.cpu()) < 1e-5 and rel_l2(atom.cpu(), one.cpu()) < 1e-5
+    ref = torch.zeros(16, Ci, Co)                  # and against the definition, sample by sample on the host
+    a_h = a.float().cpu().view(3 * n, 2 * Hc, 2 * Wc, Ci)
+    e_h = e.float().cpu().view(2 * n, Hc, Wc, Co)
+    ap = O.pad_ring(a_h.permute(0, 3, 1, 2), True)                                    # [3n, Ci, 2Hc + 2, 2Wc + 2]
+    for ky in range(4):
+        for kx in range(4):
+            win = ap[:, :, ky:ky + 2 * Hc:2, kx:kx + 2 * Wc:2]                         # [3n, Ci, Hc, Wc]
+            for b in range(3 * n):
+                ref[ky * 4 + kx] += 0.1 * float(rs[b]) * torch.einsum("chw,hwo->co", win[b], e_h[b % (2 * n)])
+    assert rel_l2(one.cpu(), ref) < 1e-2
     o.force = 1                                    # the direct kernel has no map: refused, not ignored
     with pytest.raises(L.DgError):
         o.wgrad(0, True, 3 * n, Hc, Wc, Ci, Co, a, sa, e, sg, one.data_ptr(), 0.1, g_mod=2 * n)
