@@ -477,6 +477,7 @@ class Trainer:
                 return pre                # drawn by the step's first launch (`_begin_step`)
             assert pre is None, "pre-drawn parameters for another batch size"
             return self._draw_rand(B)
+        self._predrawn = None             # (injected draws: whatever the step's first launch drew is not this step's)
         out = {"z": torch.as_tensor(rand["z"]).to(self.device, torch.float32)}
         nz = rand.get("noise")
         out["noise"] = None if not nz else {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in nz.items()}
