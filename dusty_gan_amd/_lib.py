@@ -164,6 +164,7 @@ PROTOTYPES = {
     "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
     "dg_transpose_shadow_multi": [_P, _P, _I, _I, _I, _P],
     "dg_transpose_shadow_multi_frags": [_P, _P, _I, _I, _I, C.POINTER(DgUpFrag), _I, _P],
+    "dg_transpose_shadow_multi_tail": [_P, _P, _I, _I, _I, C.POINTER(DgUpFrag), _I, _P, _P, _I, _I, _P, _I, _P, _I, _P],
     "dg_philox_bits": [_U64, _U64, _U64, _L, _P, _P],
     "dg_philox_fill": [_U64, _U64, _U64, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
@@ -331,14 +332,47 @@ class Counters:
     @classmethod
     def flush_if(cls, t):
         if t is not None and t.data_ptr() in cls.pending:
-            cls.flush()
+            cls.flush(mid_step=True)
+
+    ride = False  # the next ParamStore.refresh_transposed carries the pending advances (and the snapshot) in its launch
 
     @classmethod
-    def flush(cls):
+    def take_for_ride(cls):
+        """(counter pointers, deltas, k, snap_idx, src, n, ring_ptr, ring) of everything pending, for a launch that applies
+        them itself (dg_transpose_shadow_multi_tail); None when nothing rides (no flag, nothing pending, more than 8)"""
         import ctypes as C
+        if not cls.ride or not cls.pending or len(cls.pending) > 8:
+            return None
+        cls.ride = False
+        items = list(cls.pending.values())
+        snap, cls.snap = cls.snap, None
+        at = [j for j, (t, _) in enumerate(items) if snap is not None and t.data_ptr() == snap[0].data_ptr()]
+        if snap is not None and not at:
+            raise RuntimeError("Counters.snapshot: the snapshot's counter has no queued advance")
+        cls.pending.clear()
+        ptrs = (C.c_void_p * len(items))(*[t.data_ptr() for t, _ in items])
+        dels = (C.c_uint64 * len(items))(*[d for _, d in items])
+        if snap is None:
+            return ptrs, dels, len(items), -1, None, 0, None, 1
+        return ptrs, dels, len(items), at[0], snap[1], snap[2], snap[3], snap[4]
+
+    @classmethod
+    def flush(cls, mid_step=False):
+        """apply everything pending.  mid_step (a consumer needs its counter current while a step with a riding snapshot is
+        still running): the snapshot and its counter stay queued - the scalars are not complete yet."""
+        import ctypes as C
+        held = None
+        if mid_step and cls.ride and cls.snap is not None:
+            held = cls.pending.pop(cls.snap[0].data_ptr(), None)
+        else:
+            cls.ride = False
         items = list(cls.pending.values())
         cls.pending.clear()
-        snap, cls.snap = cls.snap, None
+        if held is not None:
+            cls.pending[cls.snap[0].data_ptr()] = held
+            snap = None
+        else:
+            snap, cls.snap = cls.snap, None
         if snap is not None and snap[0].data_ptr() not in [t.data_ptr() for t, _ in items]:
             raise RuntimeError("Counters.snapshot: the snapshot's counter has no queued advance")
         for i in range(0, len(items), 8):

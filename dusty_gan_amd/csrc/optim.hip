@@ -140,12 +140,28 @@ __global__ __launch_bounds__(256) void adam_proj_fused_kernel(float* __restrict_
 
 // all conv segments of a network in one launch: desc[5 i + (0..4)] = (source element offset in `master`, destination
 // pointer, Ci, Co, first tile index); a tile = (tap, 32 x 32 block of [ci][co]) as in transpose_shadow_kernel
+struct CounterAdds {
+  unsigned long long* c[8]; unsigned long long d[8]; int k;
+  int snap_idx, snap_n, snap_ring; const float* snap_src; float* snap_dst;   // snap_idx < 0: no snapshot
+};
+__device__ __forceinline__ void counter_adds_body(const CounterAdds& a) {   // (one block's threads 0 .. k-1)
+  if ((int)threadIdx.x >= a.k) return;
+  const unsigned long long v = *a.c[threadIdx.x];
+  *a.c[threadIdx.x] = v + a.d[threadIdx.x];
+  if ((int)threadIdx.x == a.snap_idx) {          // the thread that advances the counter also files the snapshot under its old value
+    float* dst = a.snap_dst + (long)(v % (unsigned long long)a.snap_ring) * a.snap_n;
+    for (int i = 0; i < a.snap_n; ++i) dst[i] = a.snap_src[i];
+    __threadfence_system();                      // (dst may be mapped host memory)
+  }
+}
 struct UpFrags { DgUpFrag f[4]; int n; int first_block; };   // blocks >= first_block: 3 x UP_FRAG_BLOCKS per fragment set
+// (+ optionally one last block that advances the step's counters and files its scalars: dg_transpose_shadow_multi_tail)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_shadow_multi_kernel(const float* __restrict__ master,
                                                                      const long long* __restrict__ desc, int nseg,
-                                                                     UpFrags uf) {
+                                                                     UpFrags uf, CounterAdds ca, int ca_block) {
   __shared__ float tile[32][33];
+  if ((int)blockIdx.x == ca_block) { counter_adds_body(ca); return; }
   if (uf.n > 0 && (int)blockIdx.x >= uf.first_block) {
     const int job = (int)blockIdx.x - uf.first_block, per = 3 * UP_FRAG_BLOCKS;
     const DgUpFrag& f = uf.f[job / per];
@@ -308,19 +324,8 @@ __global__ void aug_draw_kernel(uint64_t seed, uint64_t stream, uint64_t offset,
 __global__ void counter_add_kernel(unsigned long long* c, unsigned long long delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
 }
-struct CounterAdds {
-  unsigned long long* c[8]; unsigned long long d[8]; int k;
-  int snap_idx, snap_n, snap_ring; const float* snap_src; float* snap_dst;   // snap_idx < 0: no snapshot
-};
 __global__ void counter_add_multi_kernel(CounterAdds a) {
-  if (blockIdx.x != 0 || (int)threadIdx.x >= a.k) return;
-  const unsigned long long v = *a.c[threadIdx.x];
-  *a.c[threadIdx.x] = v + a.d[threadIdx.x];
-  if ((int)threadIdx.x == a.snap_idx) {          // the thread that advances the counter also files the snapshot under its old value
-    float* dst = a.snap_dst + (long)(v % (unsigned long long)a.snap_ring) * a.snap_n;
-    for (int i = 0; i < a.snap_n; ++i) dst[i] = a.snap_src[i];
-    __threadfence_system();                      // (dst may be mapped host memory)
-  }
+  if (blockIdx.x == 0) counter_adds_body(a);
 }
 // (the bodies are device functions: dg_step_prologue's kernel runs the same draws as extra blocks of one launch)
 __device__ __forceinline__ void philox_fill_body(uint64_t seed, uint64_t stream, uint64_t offset, int kind, float lo, float hi,
@@ -508,11 +513,11 @@ int dg_counter_add(unsigned long long* counter, unsigned long long delta, void* 
 
 // k <= 8 DISTINCT counters advanced by one launch (a step's Philox offsets and Adam step counts, queued by the caller
 // behind their consumers: one graph node instead of one per counter)
-static int counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, int snap_idx,
-                             const float* src, int n, float* dst_ring, int ring, void* s_) {
+static int fill_counter_adds(CounterAdds& a, unsigned long long* const* counters, const unsigned long long* deltas, int k,
+                             int snap_idx, const float* src, int n, float* dst_ring, int ring) {
   if (k < 1 || k > 8 || !counters || !deltas) return DG_EINVAL;
   if (snap_idx >= 0 && (snap_idx >= k || !src || !dst_ring || n < 1 || n > 64 || ring < 1)) return DG_EINVAL;
-  CounterAdds a{};
+  a = CounterAdds{};
   a.snap_idx = snap_idx; a.snap_n = n; a.snap_ring = ring; a.snap_src = src; a.snap_dst = dst_ring;
   for (int i = 0; i < k; ++i) {
     if (!counters[i]) return DG_EINVAL;
@@ -521,6 +526,13 @@ static int counter_add_multi(unsigned long long* const* counters, const unsigned
     a.c[i] = counters[i]; a.d[i] = deltas[i];
   }
   a.k = k;
+  return DG_OK;
+}
+static int counter_add_multi(unsigned long long* const* counters, const unsigned long long* deltas, int k, int snap_idx,
+                             const float* src, int n, float* dst_ring, int ring, void* s_) {
+  CounterAdds a{};
+  const int rc = fill_counter_adds(a, counters, deltas, k, snap_idx, src, n, dst_ring, ring);
+  if (rc != DG_OK) return rc;
   counter_add_multi_kernel<<<1, 64, 0, (hipStream_t)s_>>>(a);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
@@ -670,14 +682,14 @@ int dg_transpose_shadow_multi(const float* master, const long long* desc_dev, in
   hipStream_t s = (hipStream_t)s_;
   if (!master || !desc_dev || nseg <= 0 || total_tiles <= 0) return DG_EINVAL;
   UpFrags uf{};
-  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg, uf);
-  else transpose_shadow_multi_kernel<float><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg, uf);
+  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg, uf, CounterAdds{}, -1);
+  else transpose_shadow_multi_kernel<float><<<total_tiles, 256, 0, s>>>(master, desc_dev, nseg, uf, CounterAdds{}, -1);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
 
-int dg_transpose_shadow_multi_frags(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
-                                    const DgUpFrag* frags, int nfrag, void* s_) {
+static int transpose_multi(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                           const DgUpFrag* frags, int nfrag, const CounterAdds* ca, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (!master || !desc_dev || nseg <= 0 || total_tiles <= 0 || nfrag < 0 || nfrag > 4 || (nfrag && !frags)) return DG_EINVAL;
   if (nfrag && dtype != DG_BF16) return DG_EUNSUPPORTED;   // (the kernel that reads them is bf16 only)
@@ -687,11 +699,29 @@ int dg_transpose_shadow_multi_frags(const float* master, const long long* desc_d
     if (!frags[i].frag || ((size_t)frags[i].frag & 15) || frags[i].N < 1 || frags[i].N > 4 || frags[i].Hc < 1) return DG_EINVAL;
     uf.f[i] = frags[i];
   }
-  const unsigned grid = (unsigned)(total_tiles + nfrag * 3 * UP_FRAG_BLOCKS);
-  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<grid, 256, 0, s>>>(master, desc_dev, nseg, uf);
-  else transpose_shadow_multi_kernel<float><<<grid, 256, 0, s>>>(master, desc_dev, nseg, uf);
+  const int work = total_tiles + nfrag * 3 * UP_FRAG_BLOCKS;
+  const unsigned grid = (unsigned)(work + (ca ? 1 : 0));
+  const CounterAdds cav = ca ? *ca : CounterAdds{};
+  if (dtype == DG_BF16) transpose_shadow_multi_kernel<bf16><<<grid, 256, 0, s>>>(master, desc_dev, nseg, uf, cav, ca ? work : -1);
+  else transpose_shadow_multi_kernel<float><<<grid, 256, 0, s>>>(master, desc_dev, nseg, uf, cav, ca ? work : -1);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+int dg_transpose_shadow_multi_frags(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                                    const DgUpFrag* frags, int nfrag, void* s_) {
+  return transpose_multi(master, desc_dev, nseg, total_tiles, dtype, frags, nfrag, nullptr, s_);
+}
+// ... and one more block does what dg_counter_add_multi[_snap] does (snap_idx < 0: no snapshot): the LAST launch of a training
+// step - the shadow refresh behind the generator's optimizer - also advances the step's counters and files its scalars,
+// instead of a launch of five threads behind it
+int dg_transpose_shadow_multi_tail(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                                   const DgUpFrag* frags, int nfrag, unsigned long long* const* counters,
+                                   const unsigned long long* deltas, int k, int snap_idx, const float* src, int n,
+                                   float* dst_ring, int ring, void* s_) {
+  CounterAdds a{};
+  const int rc = fill_counter_adds(a, counters, deltas, k, snap_idx, src, n, dst_ring, ring);
+  if (rc != DG_OK) return rc;
+  return transpose_multi(master, desc_dev, nseg, total_tiles, dtype, frags, nfrag, &a, s_);
 }
 
 }  // extern "C"

@@ -128,8 +128,10 @@ class ParamStore:
         self.refresh_transposed()
         self._seen_version = ver
 
-    def refresh_transposed(self):
-        """[tap][ci][co] fp32 master -> [tap][co][ci] T shadow of every conv segment, one launch per network"""
+    def refresh_transposed(self, tail=False):
+        """[tap][ci][co] fp32 master -> [tap][co][ci] T shadow of every conv segment, one launch per network.  tail: the call
+        behind an optimizer step - when the trainer has flagged it (`_lib.Counters.ride`) this is the step's last launch
+        and carries the pending counter advances and the scalar snapshot."""
         lib, st = L.lib(), L.stream_ptr()
         convs = [(name, s) for name, s in self.seg.items() if s.kind == "conv"]
         if not convs:
@@ -143,10 +145,17 @@ class ParamStore:
                 tiles += 16 * ((ci + 31) // 32) * ((co + 31) // 32)
             self._tdesc = torch.tensor(desc, dtype=torch.int64).to(self.flat.device)
             self._tdesc_tiles, self._tdesc_dtype = tiles, self.shadow_dtype
-        if self.up_frags and self.shadow_dtype == torch.bfloat16:
-            arr = (L.DgUpFrag * len(self.up_frags))(*[d for _, d in self.up_frags.values()])
+        nf = len(self.up_frags) if self.shadow_dtype == torch.bfloat16 else 0
+        arr = (L.DgUpFrag * max(nf, 1))(*[d for _, d in self.up_frags.values()][:nf])
+        ride = L.Counters.take_for_ride() if tail else None
+        if ride is not None:
+            L.check(lib.dg_transpose_shadow_multi_tail(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
+                                                       L.dtype_code(self.shadow_dtype), arr, nf, *ride, st),
+                    "dg_transpose_shadow_multi_tail")
+            return
+        if nf:
             L.check(lib.dg_transpose_shadow_multi_frags(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
-                                                        L.dtype_code(self.shadow_dtype), arr, len(self.up_frags), st),
+                                                        L.dtype_code(self.shadow_dtype), arr, nf, st),
                     "dg_transpose_shadow_multi_frags")
             return
         L.check(lib.dg_transpose_shadow_multi(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,

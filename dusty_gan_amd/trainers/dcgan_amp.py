@@ -218,7 +218,7 @@ class FlatAdam:
                                          self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
                 "dg_adam_ema_step_dev")
         L.Counters.add(self._step_dev, 1)  # (queued: one launch advances all of the step's counters)
-        st.refresh_transposed()
+        st.refresh_transposed(tail=True)
         if ema_store is not None:
             ema_store._seen_version = -1  # its shadows are rebuilt lazily when G_ema is used
         return True
@@ -939,16 +939,21 @@ class Trainer:
     def _step_eager(self, reals=None, rands=None):
         """the launch sequence of one iteration; returns the (locally averaged) scalars: a device tensor, or - single
         process, one micro-batch - the RingSlot they are filed in by the step's last launch (None while capturing)"""
-        self.optimize_D(reals, rands)
-        scal = self.optimize_G()
+        scal = self.optimize_D(reals, rands)
         if self._use_ring():
+            # queued now, applied by the step's LAST launch: the shadow refresh behind the generator's optimizer carries
+            # every pending counter advance and the scalar snapshot (the scalars live in `scal`, the step's arena slice,
+            # for both phases); whatever is still pending afterwards goes out with the flush below
             if self._snap_ring is None:
                 self._snap_ring = torch.zeros(self.SCALAR_RING, 8, dtype=torch.float32).pin_memory()
                 self._snap_ctr = torch.full((1,), self._snap_pos, dtype=torch.int64, device=self.device)
             L.Counters.add(self._snap_ctr, 1)
             L.Counters.snapshot(self._snap_ctr, scal.data_ptr(), 8, self._snap_ring.data_ptr(), self.SCALAR_RING)
-            L.Counters.flush()  # Philox offsets, Adam step counts, the scalar snapshot: one launch
+            L.Counters.ride = True
+            self.optimize_G()
+            L.Counters.flush()  # (nothing left when the generator's refresh took them)
             return None if self._cap is not None else self._ring_slot()
+        scal = self.optimize_G()
         L.Counters.flush()  # Philox offsets and Adam step counts of this step: one launch
         if self.n_acc > 1:
             scal = scal / self.n_acc

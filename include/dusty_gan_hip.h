@@ -385,6 +385,13 @@ typedef struct DgUpFrag {
 } DgUpFrag;
 int dg_transpose_shadow_multi_frags(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
                                     const DgUpFrag* frags, int nfrag, void* stream);
+/* the same launch with one more block doing what dg_counter_add_multi / dg_counter_add_multi_snap do (snap_idx < 0: no
+ * snapshot): the last launch of a training step - the shadow refresh behind the generator's optimizer - also advances the
+ * step's counters and files its scalars */
+int dg_transpose_shadow_multi_tail(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
+                                   const DgUpFrag* frags, int nfrag, unsigned long long* const* counters,
+                                   const unsigned long long* deltas, int k, int snap_idx, const float* src, int n,
+                                   float* dst_ring, int ring, void* stream);
 
 /* ---- Philox4x32-10 draws (the reference uses torch's device RNG: trainers/dcgan_amp.py:151-152, models/dusty.py:33-34,
  *      utils/diff_augment.py:27-28,59-60,86-87) --------------------------------------------------------------- */

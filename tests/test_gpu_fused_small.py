@@ -474,3 +474,54 @@ def test_final_gan_bwd_equals_the_separate_launches(L, dtype, metric, mode_g, r1
     assert lib.dg_final_gan_bwd(0, 1, 1.0, None, y_fake, B, 1.0, 1, b["dy"].data_ptr(), None, None, b["acc"].data_ptr(), None,
                                 d4.data_ptr(), dt, wf.data_ptr(), scale, n, C, b["dd4"].data_ptr(), None, None,
                                 None) == L.DG_EINVAL
+
+
+def test_transpose_shadow_multi_tail_carries_the_counters(L):
+    """dg_transpose_shadow_multi_tail: the shadow-refresh launch with one more block that advances counters and files a
+    snapshot exactly as dg_counter_add_multi_snap does; and the host-side queue: a flagged ride is taken by the refresh
+    behind an optimizer step, a mid-step flush (a consumer syncing its counter) leaves the riding snapshot queued."""
+    lib = L.lib()
+    ci, co = 48, 40
+    master = torch.randn(16, ci, co, device=DEV)
+    coci = torch.empty(16 * ci * co, dtype=torch.bfloat16, device=DEV)
+    desc = torch.tensor([0, coci.data_ptr(), ci, co, 0], dtype=torch.int64).to(DEV)
+    tiles = 16 * ((ci + 31) // 32) * ((co + 31) // 32)
+    c = [torch.full((1,), v, dtype=torch.int64, device=DEV) for v in (7, 100)]
+    ptrs = (C.c_void_p * 2)(*[t.data_ptr() for t in c])
+    ring = torch.zeros(4, 8).pin_memory()
+    src = torch.arange(8, dtype=torch.float32, device=DEV) + 1.0
+    L.check(lib.dg_transpose_shadow_multi_tail(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_BF16, None, 0, ptrs,
+                                               (C.c_uint64 * 2)(1, 5), 2, 0, src.data_ptr(), 8, ring.data_ptr(), 4, None))
+    torch.cuda.synchronize()
+    assert torch.equal(coci.view(16, co, ci), master.bfloat16().permute(0, 2, 1).contiguous())
+    assert [int(t) for t in c] == [8, 105] and ring[7 % 4].tolist() == [float(i + 1) for i in range(8)]
+    L.check(lib.dg_transpose_shadow_multi_tail(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_BF16, None, 0, ptrs,
+                                               (C.c_uint64 * 2)(1, 5), 2, -1, None, 0, None, 1, None))      # no snapshot
+    torch.cuda.synchronize()
+    assert [int(t) for t in c] == [9, 110]
+    assert lib.dg_transpose_shadow_multi_tail(master.data_ptr(), desc.data_ptr(), 1, tiles, L.DG_BF16, None, 0, ptrs,
+                                              (C.c_uint64 * 2)(1, 5), 9, -1, None, 0, None, 1, None) == L.DG_EINVAL
+    # host-side queue
+    from dusty_gan_amd import engine as E
+    L.Counters.flush()
+    st = E.ParamStore(E.d_segments(1, [64, 128, 256, 512], (64, 256)))
+    st.apply(lambda t: t.to(DEV))
+    st.flat.normal_()
+    st.refresh_shadows(torch.bfloat16)
+    other, snapc = torch.zeros(1, dtype=torch.int64, device=DEV), torch.full((1,), 2, dtype=torch.int64, device=DEV)
+    L.Counters.add(other, 3)
+    L.Counters.add(snapc, 1)
+    L.Counters.snapshot(snapc, src.data_ptr(), 8, ring.data_ptr(), 4)
+    L.Counters.ride = True
+    ring.zero_()
+    L.Counters.flush_if(other)                    # a consumer of `other` in the middle of the step
+    torch.cuda.synchronize()
+    assert int(other) == 3 and int(snapc) == 2 and float(ring.abs().max()) == 0.0 and L.Counters.ride
+    L.Counters.add(other, 1)
+    st.refresh_transposed()                       # not the optimizer's refresh: nothing rides
+    torch.cuda.synchronize()
+    assert int(snapc) == 2 and L.Counters.ride
+    st.refresh_transposed(tail=True)
+    torch.cuda.synchronize()
+    assert int(other) == 4 and int(snapc) == 3 and ring[2].tolist() == [float(i + 1) for i in range(8)]
+    assert not L.Counters.pending and L.Counters.snap is None and not L.Counters.ride
