@@ -111,6 +111,7 @@ PROTOTYPES = {
     "dg_wgrad_kernel_variant": [C.POINTER(DgWgrad), _I],
     "dg_wgrad_has_sample_map": [C.POINTER(DgWgrad), _I],
     "dg_blur_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dg_blur_fwd_mean": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "dg_blur_bwd_r1": [_P, _I, _P, _F, _P, _I, _I, _I, _I, _P],
     "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
@@ -129,6 +130,8 @@ PROTOTYPES = {
     "dg_diffaug_blur_fwd": [C.POINTER(DgAugSet), _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "dg_blur_bwd_augsum": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "dg_diffaug_bwd_pre": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "dg_head_post_bwd_aug": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _F, _F, _I, _I, _I, _F, _F, _P, _P, _P,
+                             _I, _P, _P],
     "dg_fetch_reals_pool_sum": [_P, _P, _P, _I, _F, _F, _F, _I, _L, _P, _P, _P],
     "dg_nsgan_d": [_P, _P, _I, _F, _P, _P, _P, _P],
     "dg_nsgan_g": [_P, _I, _F, _P, _P, _P],

@@ -88,7 +88,15 @@ __global__ void blur_bwd_kernel(const T* __restrict__ d, float* __restrict__ dx,
 // condition - one global round trip after the other).
 template <typename T>
 __global__ __launch_bounds__(256) void blur_fwd4_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int H,
-                                                        int W, int ring) {
+                                                        int W, int ring, const float* __restrict__ mean_src, int mean_n,
+                                                        float* __restrict__ mean_acc) {
+  if (mean_src && blockIdx.x == 0 && blockIdx.y == 0) {          // rider of block (0, 0): mean_acc[0] += mean(mean_src[0..n))
+    __shared__ float red[16];                                    // (dg_mean_acc: the R1 penalty of the micro-batch)
+    float sm = 0.f;
+    for (int i = threadIdx.x; i < mean_n; i += 256) sm += mean_src[i];
+    const float t = dg_block_sum(sm, red);
+    if (threadIdx.x == 0) mean_acc[0] += t / mean_n;
+  }
   const int y = blockIdx.x, W4 = W >> 2;
   const long base = (long)blockIdx.y * H * W;                    // b*H*W
   const int yu = y == 0 ? 1 : y - 1, yd = y == H - 1 ? H - 2 : y + 1;
@@ -563,12 +571,75 @@ __global__ __launch_bounds__(256) void head_post_bwd_kernel(const float* __restr
   }
 }
 
+struct AugP {
+  const float *u_b, *u_c;
+  const int *t_h, *t_w, *o_x, *o_y;
+  int policy, B, H, W, cut_h, cut_w;
+};
+
+// Where head_post_bwd4_kernel gets d loss / d depth of a pixel quad from: the tensor itself, or - HeadGradAug - DiffAugment's
+// adjoint gather applied on the fly to the BlurVH adjoint's output gy (diffaug_bwd_kernel's arithmetic for the four
+// columns of a quad; W % 4 == 0, so a quad lies in one row): the generator's upstream gradient is then never written.
+struct HeadGradPlain {
+  const float* ddepth;
+  __device__ __forceinline__ float4 operator()(int b, long p, long HW) const { return *(const float4*)(ddepth + (long)b * HW + p); }
+};
+struct HeadGradAug {
+  AugP a;
+  const float* gy;
+  const float* gsum;
+  __device__ __forceinline__ float4 operator()(int b, long p, long HW) const {
+    const int W = a.W, Wm1 = a.W - 1;
+    const int r = (int)(p / W), q0 = (int)(p - (long)r * W);
+    int yy = r, tw = 0;
+    if (a.policy & 8) {
+      yy = r - a.t_h[b];
+      tw = a.t_w[b] % Wm1;
+      if (tw < 0) tw += Wm1;
+    }
+    const bool row_ok = yy >= 0 && yy < a.H;
+    int c0 = 0, c1 = 0;
+    if ((a.policy & 16) && row_ok) {
+      const int r0 = a.o_x[b] - a.cut_h / 2;
+      if (yy >= r0 && yy < r0 + a.cut_h) { c0 = a.o_y[b] - a.cut_w / 2; c1 = c0 + a.cut_w; }
+    }
+    float cc = 1.f, gm = 0.f;
+    if (a.policy & 4) {
+      const float u = a.u_c[b];
+      cc = 1.f + 0.5f * u * u;
+      gm = (1.f - cc) * gsum[b] / (float)HW;
+    }
+    const float* grow = gy + (long)b * HW + (long)(row_ok ? yy : 0) * W;
+    float o[4];
+    const float gb = grow[W - 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = q0 + k;
+      float g2 = 0.f;
+      if (a.policy & 8) {
+        int w1 = c - tw;
+        if (w1 < 0) w1 += Wm1;
+        const float ga = grow[w1];
+        if (row_ok && c <= W - 2) {
+          if (!(w1 >= c0 && w1 < c1)) g2 += ga;
+          if (w1 == 0 && !(W - 1 >= c0 && W - 1 < c1)) g2 += gb;
+        }
+      } else {
+        const float ga = grow[c];
+        if (!(c >= c0 && c < c1)) g2 = ga;
+      }
+      o[k] = (a.policy & 4) ? cc * g2 + gm : g2;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+
 // Four consecutive pixels per thread (HW % 4 == 0): 16-byte loads of every plane, 16-byte stores; `draw` (the planar fp32
 // copy) may be null - the bf16 path consumes only the pixel-major copy, and three 8 MB planes were written for nobody.
-template <int arch, int CP>   // CP: 2 / 4 padded channel count of the pixel-major copy, 0 none
+template <int arch, int CP, typename DD>   // CP: 2 / 4 padded channel count of the pixel-major copy, 0 none
 __global__ __launch_bounds__(256) void head_post_bwd4_kernel(const float* __restrict__ gout, const float* __restrict__ noise_pixel,
                                       const float* __restrict__ noise_image, const float* __restrict__ mask,
-                                      const float* __restrict__ ddepth, float inv_tau, float drop_const, int B, long HW,
+                                      DD ddepth, float inv_tau, float drop_const, int B, long HW,
                                       float s_depth, float s_conf, float* __restrict__ draw, float* __restrict__ dbias,
                                       bf16* __restrict__ draw_pm, float* __restrict__ bias_ws) {
   __shared__ float red[16];
@@ -580,7 +651,7 @@ __global__ __launch_bounds__(256) void head_post_bwd4_kernel(const float* __rest
   auto ld = [](const float* q) { const float4 v = *(const float4*)q; return v; };
   for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; p < HW; p += (long)gridDim.x * blockDim.x * 4) {
     const long idx = (long)b * HW + p;
-    const float4 t4 = ld(g + p), go4 = ld(ddepth + idx);
+    const float4 t4 = ld(g + p), go4 = ddepth(b, p, HW);
     const float t[4] = {t4.x, t4.y, t4.z, t4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
     float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
     if (arch == 0) {
@@ -814,11 +885,6 @@ __global__ __launch_bounds__(256) void sample_sum_kernel(const float* __restrict
 // policy bits: 1 brightness, 2 saturation (identity for one channel), 4 contrast, 8 translation, 16 cutout.
 // Per-sample parameters: u_b,u_c (the uniform(-1,1) draws; the applied factor is u*u),
 // t_h,t_w,o_x,o_y ints.  xsum[b] = sum of x[b] (needed by contrast: mean of x + brightness).
-struct AugP {
-  const float *u_b, *u_c;
-  const int *t_h, *t_w, *o_x, *o_y;
-  int policy, B, H, W, cut_h, cut_w;
-};
 
 __device__ __forceinline__ bool aug_cut(const AugP& a, int b, int y, int x) {
   if (!(a.policy & 16)) return false;
@@ -1394,6 +1460,26 @@ int dg_zero_f32(float* p, long n, hipStream_t s) {
   return DG_OK;
 }
 
+template <typename DD>
+static int head_post_bwd4_launch(DD dd, const float* gout, const float* noise_pixel, const float* noise_image,
+                                 const float* mask, int arch, float tau, float drop_const, int B, long HW, float s_depth,
+                                 float s_conf, float* draw, float* dbias, void* draw_pm, int cpk, float* bias_ws,
+                                 hipStream_t s) {
+  const unsigned per = B >= 1024 ? 1u : (unsigned)(1024 / B);
+  unsigned hb4 = nblk(HW / 4);
+  if (hb4 > per) hb4 = per;
+  const dim3 grid4(hb4, B);
+#define DG_HPB4(A, C)                                                                                                    \
+  head_post_bwd4_kernel<A, C, DD><<<grid4, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, dd, 1.f / tau, drop_const,   \
+                                                        B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, bias_ws)
+#define DG_HPB4_A(A) do { if (cpk == 0) DG_HPB4(A, 0); else if (cpk == 2) DG_HPB4(A, 2); else DG_HPB4(A, 4); } while (0)
+  if (arch == 0) DG_HPB4_A(0); else if (arch == 1) DG_HPB4_A(1); else DG_HPB4_A(2);
+#undef DG_HPB4_A
+#undef DG_HPB4
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 extern "C" {
 
 // k <= 4 fp32 buffers (16-byte aligned, counts multiples of 4) zero-filled by one launch
@@ -1416,12 +1502,26 @@ int dg_zero_multi(float* const* ptrs, const long* counts, int k, void* s_) {
   return DG_OK;
 }
 
+// dg_blur_fwd + dg_mean_acc(mean_src, mean_n, mean_acc) as one launch (the R1 block: the tangent's BlurVH pass follows the
+// kernel that produced the per-sample |g|^2 sums whose mean is logged).  DG_EUNSUPPORTED - nothing launched - unless the
+// four-pixel form applies.
+int dg_blur_fwd_mean(const float* x, void* out, int dtype, int B, int H, int W, int ring, const float* mean_src, int mean_n,
+                     float* mean_acc, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!mean_src || !mean_acc || mean_n < 1) return DG_EINVAL;
+  if (!(W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)x & 15) == 0 && ((size_t)out & 15) == 0)) return DG_EUNSUPPORTED;
+  if (dtype == DG_BF16) blur_fwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring, mean_src, mean_n, mean_acc);
+  else blur_fwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>(x, (float*)out, B, H, W, ring, mean_src, mean_n, mean_acc);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   const long n = (long)B * H * W;
   if (W % 4 == 0 && W >= 8 && H >= 2 && ((size_t)x & 15) == 0 && ((size_t)out & 15) == 0) {
-    if (dtype == DG_BF16) blur_fwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
-    else blur_fwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
+    if (dtype == DG_BF16) blur_fwd4_kernel<bf16><<<dim3(H, B), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring, nullptr, 0, nullptr);
+    else blur_fwd4_kernel<float><<<dim3(H, B), 256, 0, s>>>(x, (float*)out, B, H, W, ring, nullptr, 0, nullptr);
   } else if (dtype == DG_BF16) blur_fwd_kernel<bf16><<<nblk(n), 256, 0, s>>>(x, (bf16*)out, B, H, W, ring);
   else blur_fwd_kernel<float><<<nblk(n), 256, 0, s>>>(x, (float*)out, B, H, W, ring);
   HIP_CHECK_RET(hipGetLastError());
@@ -1579,20 +1679,9 @@ int dg_head_post_bwd(const float* gout, const float* noise_pixel, const float* n
   const int cpk = !draw_pm ? 0 : (cp == 2 ? 2 : (cp == 4 ? 4 : 1));
   if (!draw && !draw_pm) return DG_EINVAL;
   auto al = [](const void* q) { return ((size_t)q & 15) == 0; };
-  if (HW % 4 == 0 && cpk != 1 && al(gout) && al(ddepth) && al(draw) && al(draw_pm) && al(noise_pixel) && al(mask)) {
-    unsigned hb4 = nblk(HW / 4);
-    if (hb4 > per) hb4 = per;
-    const dim3 grid4(hb4, B);
-#define DG_HPB4(A, C)                                                                                                    \
-    head_post_bwd4_kernel<A, C><<<grid4, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, 1.f / tau, drop_const, \
-                                                      B, HW, s_depth, s_conf, draw, dbias, (bf16*)draw_pm, bias_ws)
-#define DG_HPB4_A(A) do { if (cpk == 0) DG_HPB4(A, 0); else if (cpk == 2) DG_HPB4(A, 2); else DG_HPB4(A, 4); } while (0)
-    if (arch == 0) DG_HPB4_A(0); else if (arch == 1) DG_HPB4_A(1); else DG_HPB4_A(2);
-#undef DG_HPB4_A
-#undef DG_HPB4
-    HIP_CHECK_RET(hipGetLastError());
-    return DG_OK;
-  }
+  if (HW % 4 == 0 && cpk != 1 && al(gout) && al(ddepth) && al(draw) && al(draw_pm) && al(noise_pixel) && al(mask))
+    return head_post_bwd4_launch(HeadGradPlain{ddepth}, gout, noise_pixel, noise_image, mask, arch, tau, drop_const, B, HW,
+                                 s_depth, s_conf, draw, dbias, draw_pm, cpk, bias_ws, s);
   if (!draw) return DG_EUNSUPPORTED;   // (the scalar kernel always writes the planar copy)
 #define DG_HPB(A, C)                                                                                                   \
   head_post_bwd_kernel<A, C><<<grid, 256, 0, s>>>(gout, noise_pixel, noise_image, mask, ddepth, 1.f / tau, drop_const, \
@@ -1726,6 +1815,26 @@ int dg_diffaug_bwd_pre(const float* gy, const float* u_b, const float* u_c, cons
   diffaug_bwd_kernel<<<dim3(H, B), 256, 0, s>>>(a, gy, gsum, gx);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+
+// dg_diffaug_bwd_pre + dg_head_post_bwd in one launch: d loss / d depth is DiffAugment's adjoint gather of gy (the BlurVH
+// adjoint's output; gsum from dg_blur_bwd_augsum), evaluated per pixel quad where the head post-processing's backward
+// needs it - the generator's upstream gradient [B,1,H,W] is never written.  DG_EUNSUPPORTED (nothing launched) unless the
+// four-pixel form applies (W % 4 == 0, 16-byte aligned planes, cp 2 / 4 or no pixel-major copy).
+int dg_head_post_bwd_aug(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
+                         const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                         const int* o_x, const int* o_y, int policy, const float* gsum, int arch, float tau,
+                         float drop_const, int B, int H, int W, float s_depth, float s_conf, float* draw, float* dbias,
+                         void* draw_pm, int cp, float* bias_ws, void* s_) {
+  if (arch < 0 || arch > 2 || !gy || B <= 0 || H <= 0 || W <= 1) return DG_EINVAL;
+  if (!draw && !draw_pm) return DG_EINVAL;
+  if ((policy & 4) && !gsum) return DG_EINVAL;
+  const int cpk = !draw_pm ? 0 : (cp == 2 ? 2 : (cp == 4 ? 4 : 1));
+  auto al = [](const void* q) { return ((size_t)q & 15) == 0; };
+  if (!(W % 4 == 0 && cpk != 1 && al(gout) && al(draw) && al(draw_pm) && al(noise_pixel) && al(mask))) return DG_EUNSUPPORTED;
+  HeadGradAug dd{make_aug(u_b, u_c, t_h, t_w, o_x, o_y, policy, B, H, W), gy, gsum};
+  return head_post_bwd4_launch(dd, gout, noise_pixel, noise_image, mask, arch, tau, drop_const, B, (long)H * W, s_depth,
+                               s_conf, draw, dbias, draw_pm, cpk, bias_ws, (hipStream_t)s_);
 }
 
 static int diffaug_bwd_impl(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,

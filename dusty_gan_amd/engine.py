@@ -538,12 +538,21 @@ class GEngine:
         chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
         arch = ARCH_ID[c.arch]
         s_depth, s_conf = self.head_scales
-        L.check(lib.dg_head_post_bwd(L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None,
-                                     L.ptr(self.noise_image) if arch == 2 else None,
-                                     L.ptr(self.mask) if arch else None, L.ptr(ddepth), arch, c.tau, c.drop_const, B,
-                                     self.HW, s_depth, s_conf, None if self.draw_pm is not None else L.ptr(self.draw),
-                                     st.fptr("head_b", st.grad), L.ptr(self.draw_pm), self.cp, L.ptr(self.hp_ws), sp),
-                "dg_head_post_bwd")
+        head = (L.ptr(self.gout), L.ptr(self.noise_pixel) if arch else None, L.ptr(self.noise_image) if arch == 2 else None,
+                L.ptr(self.mask) if arch else None)
+        tail = (s_depth, s_conf, None if self.draw_pm is not None else L.ptr(self.draw), st.fptr("head_b", st.grad),
+                L.ptr(self.draw_pm), self.cp, L.ptr(self.hp_ws), sp)
+        if isinstance(ddepth, AugGrad):  # DiffAugment's adjoint gather inside this launch: the upstream gradient is never written
+            g = ddepth
+            rc = lib.dg_head_post_bwd_aug(*head, L.ptr(g.gy), *g.args, g.A.mask, L.ptr(g.gsum), arch, c.tau, c.drop_const, B,
+                                          c.H, c.W, *tail)
+            if rc == L.DG_EUNSUPPORTED:
+                ddepth = g.materialize()
+            else:
+                L.check(rc, "dg_head_post_bwd_aug")
+                ddepth = None
+        if ddepth is not None:
+            L.check(lib.dg_head_post_bwd(*head, L.ptr(ddepth), arch, c.tau, c.drop_const, B, self.HW, *tail), "dg_head_post_bwd")
         pl = (c.nheads * self.HW, 1, self.HW)
         pm = self.draw_pm is not None  # bf16: the pixel-major copy of the head gradient feeds the two thin MFMA kernels
         cp = self.cp
@@ -712,6 +721,19 @@ class GEngine:
                              chain=(self.draw, self.draw_pm, self.dp), second_of=proj_terms, thead=self.tout)
 
 
+class AugGrad:
+    """d loss / d (generator output) not yet formed: DiffAugment's adjoint gather of `gy` (the BlurVH adjoint's output, with
+    the window sums `gsum`), which GEngine.backward evaluates inside the head post-processing's backward
+    (dg_head_post_bwd_aug) - or `materialize()`s where that form does not apply."""
+
+    def __init__(self, A, gy, rp, gsum, args, keep):
+        self.A, self.gy, self.rp, self.gsum, self.args, self.keep = A, gy, rp, gsum, args, keep
+        self.shape = gy.shape
+
+    def materialize(self):
+        return self.A.backward_pre(self.gy, self.rp, self.gsum)
+
+
 class DEngine:
     """Discriminator passes (models/gans/dcgan_eqlr.py:85-96): forward, the shared backward-data chain, the R1
     tangent pass and the weight gradients."""
@@ -734,13 +756,24 @@ class DEngine:
         self.y = torch.empty(nb, dtype=torch.float32, device=device)
         self.ws_B = nb
 
-    def forward(self, st, x, slot, tangent_of=None):
+    def forward(self, st, x, slot, tangent_of=None, mean=None):
         """x [n,1,H,W] fp32 written to batch slots [slot, slot+n).  tangent_of = slot of the saved activations whose
-        lrelu masks gate the R1 tangent pass (then no bias, no activation: the Jacobian-vector product)."""
+        lrelu masks gate the R1 tangent pass (then no bias, no activation: the Jacobian-vector product).
+        mean = (src tensor, n, accumulator pointer): acc[0] += mean(src[0..n)) rides on the BlurVH launch (dg_mean_acc
+        otherwise: the R1 penalty's logged value)."""
         c, o, lib = self.cfg, self.ops, L.lib()
         n = x.shape[0]
-        L.check(lib.dg_blur_fwd(L.ptr(x), L.ptr(self.h[0]) + o.es * slot * self.per[0], o.dt, n, c.H, c.W, int(c.ring),
-                                L.stream_ptr()), "dg_blur_fwd")
+        dst = L.ptr(self.h[0]) + o.es * slot * self.per[0]
+        if mean is not None:
+            rc = lib.dg_blur_fwd_mean(L.ptr(x), dst, o.dt, n, c.H, c.W, int(c.ring), L.ptr(mean[0]), int(mean[1]), mean[2],
+                                      L.stream_ptr())
+            if rc == L.DG_EUNSUPPORTED:
+                L.check(lib.dg_mean_acc(L.ptr(mean[0]), int(mean[1]), mean[2], L.stream_ptr()), "dg_mean_acc")
+                mean = None
+            else:
+                L.check(rc, "dg_blur_fwd_mean")
+        if mean is None:
+            L.check(lib.dg_blur_fwd(L.ptr(x), dst, o.dt, n, c.H, c.W, int(c.ring), L.stream_ptr()), "dg_blur_fwd")
         return self._layers(st, n, slot, tangent_of)
 
     def forward_aug(self, st, A, sources, slot):
@@ -868,7 +901,7 @@ class DEngine:
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")
         return True
 
-    def backward_input_aug(self, st, slot, n, A, rp):
+    def backward_input_aug(self, st, slot, n, A, rp, lazy=False):
         """d loss / d x for D(A(x)): Down1 backward-data, then BlurVH's adjoint and DiffAugment's adjoint - two launches:
         the BlurVH adjoint also accumulates the masked per-sample sums DiffAugment's contrast term needs
         (dg_blur_bwd_augsum + dg_diffaug_bwd_pre); three (adjoint, sum, gather) where that form does not apply."""
@@ -882,6 +915,8 @@ class DEngine:
                                         args[5], A.mask, L.ptr(gsum), n, c.H, c.W, int(c.ring), L.stream_ptr())
             if rc != L.DG_EUNSUPPORTED:
                 L.check(rc, "dg_blur_bwd_augsum")
+                if lazy:  # the gather runs inside the consumer (GEngine.backward: dg_head_post_bwd_aug)
+                    return AugGrad(A, dx, rp, gsum, args, keep)
                 return A.backward_pre(dx, rp, gsum)
         L.check(lib.dg_blur_bwd(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt, L.ptr(dx), n, c.H, c.W,
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")

@@ -660,8 +660,8 @@ class Trainer:
                     else:
                         L.check(lib.dg_sample_sum_acc(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum_acc")
                     L.check(lib.dg_scale(L.ptr(g), vscale, g.numel(), L.ptr(vg), sp), "dg_scale")
-                L.check(lib.dg_mean_acc(L.ptr(ssq), B, L.ptr(scal) + 12, sp), "dg_mean_acc")  # :229
-                deng.forward(Dst, vg, 2 * B, tangent_of=0)
+                # (:229: the penalty's logged mean rides on the tangent's BlurVH launch)
+                deng.forward(Dst, vg, 2 * B, tangent_of=0, mean=(ssq, B, L.ptr(scal) + 12))
                 # weight gradients: real (weighted by dLoss/dy_real) + fake halves and tangent (x) real chain, one launch
                 # per fat layer (engine.DEngine.wgrad_r1)
                 for layers in (((4,), (3, 2, 1)) if bucketed else ((4, 3, 2, 1),)):
@@ -737,7 +737,7 @@ class Trainer:
                 L.check(lib.dg_gan_g_step(self.gan_code, y_real, L.ptr(y), B, w_gan, L.ptr(dy), L.ptr(scal) + 16, sp),
                         "dg_gan_g_step")
             deng.backward_data(Dst, 0, B, dy, None, want_dbias=False, skip_final=fused)
-            ddepth = deng.backward_input_aug(Dst, 0, B, self.A, rand["aug"][3])
+            ddepth = deng.backward_input_aug(Dst, 0, B, self.A, rand["aug"][3], lazy=True)
             overlap = gather_proj and not pl_on  # (the path-length block adds to every gradient after this pass)
             if overlap:
                 geng = mb["geng"]

@@ -159,6 +159,10 @@ int dg_wgrad_has_sample_map(const DgWgrad* p, int force);
 
 /* ---- BlurVH  models/ops/common.py:74-88 (forward) and its adjoint --------------------------------------- */
 int dg_blur_fwd(const float* x, void* out, int dtype, int B, int H, int W, int ring, void* stream);
+/* + mean_acc[0] += mean(mean_src[0..mean_n)) (dg_mean_acc) in the same launch: the R1 penalty's logged value
+ * (trainers/dcgan_amp.py:229) rides on the tangent's BlurVH pass.  DG_EUNSUPPORTED unless W % 4 == 0 and 16-byte aligned */
+int dg_blur_fwd_mean(const float* x, void* out, int dtype, int B, int H, int W, int ring, const float* mean_src, int mean_n,
+                     float* mean_acc, void* stream);
 int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ring, void* stream);
 /* the same adjoint at the end of the R1 chain (trainers/dcgan_amp.py:218-235): dx = oscale * g and ssq[b] += sum of g_b^2
  * (ssq zeroed by the caller) in one pass instead of dg_blur_bwd + dg_sample_sum + dg_scale; DG_EUNSUPPORTED unless W % 4 == 0
@@ -234,6 +238,15 @@ int dg_blur_bwd_augsum(const void* d, int dtype, float* dx, const int* t_h, cons
                        float* gsum, int B, int H, int W, int ring, void* stream);
 int dg_diffaug_bwd_pre(const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w, const int* o_x,
                        const int* o_y, int policy, int B, int H, int W, const float* gsum, float* gx, void* stream);
+/* dg_diffaug_bwd_pre + dg_head_post_bwd as one launch: the generator's upstream gradient (DiffAugment's adjoint gather of
+ * gy) is evaluated per pixel quad inside the head post-processing's backward and never written
+ * (loss_G.backward() through utils/diff_augment.py:114-132 into models/dusty.py:77-91,107-127).  DG_EUNSUPPORTED - nothing
+ * launched - unless W % 4 == 0, the planes are 16-byte aligned and cp is 2 / 4 (or draw_pm is NULL). */
+int dg_head_post_bwd_aug(const float* gout, const float* noise_pixel, const float* noise_image, const float* mask,
+                         const float* gy, const float* u_b, const float* u_c, const int* t_h, const int* t_w,
+                         const int* o_x, const int* o_y, int policy, const float* gsum, int arch, float tau,
+                         float drop_const, int B, int H, int W, float s_depth, float s_conf, float* draw, float* dbias,
+                         void* draw_pm, int cp, float* bias_ws, void* stream);
 
 /* ---- GANLoss(nsgan)  models/loss.py:39-41,68-69 + gradient w.r.t. the logits ----------------------------- */
 /* scal[0]=mean(y_real) scal[1]=mean(y_fake) scal[2]=loss_D */

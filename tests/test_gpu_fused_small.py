@@ -525,3 +525,55 @@ def test_transpose_shadow_multi_tail_carries_the_counters(L):
     torch.cuda.synchronize()
     assert int(other) == 4 and int(snapc) == 3 and ring[2].tolist() == [float(i + 1) for i in range(8)]
     assert not L.Counters.pending and L.Counters.snap is None and not L.Counters.ride
+
+
+@pytest.mark.parametrize("arch", [0, 1, 2])
+def test_head_post_bwd_aug_equals_gather_then_head_post_bwd(L, arch):
+    """dg_head_post_bwd_aug (DiffAugment's adjoint gather evaluated inside the head post-processing's backward) against
+    dg_diffaug_bwd_pre followed by dg_head_post_bwd, incl. extreme draws (clamped cut-out boxes, maximal shifts, rows
+    shifted out of the image) and the column the reference's `% (W - 1)` reads twice."""
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5 + arch)
+    B, H, W = 4, 16, 64
+    A = DiffAugment()
+    gy = torch.randn(B, 1, H, W, generator=g).to(DEV)
+    gsum = torch.randn(B, generator=g).to(DEV)
+    gout = torch.randn(B, 1 + arch, H, W, generator=g).to(DEV)
+    gout[:, 0] = torch.tanh(gout[:, 0])
+    npx, nim = torch.randn(B, 1, H, W, generator=g).to(DEV), torch.randn(B, generator=g).to(DEV)
+    mask = (torch.rand(B, max(arch, 1), H, W, generator=g) > 0.4).float().to(DEV)
+    cp = 2 if arch <= 1 else 4
+    for trial in range(3):
+        rp = O.draw_augment_params(B, H, W, g)
+        if trial == 0:
+            sh, sw = O.translation_shift(H, W)
+            rp["o_x"][:] = torch.tensor([0, H, 0, H])
+            rp["o_y"][:] = torch.tensor([0, W, W, 0])
+            rp["t_h"][:] = torch.tensor([-sh, sh, 0, 1])
+            rp["t_w"][:] = torch.tensor([-sw, sw, 1, 0])
+        rpd = DiffAugment.params_to_device(rp, DEV)
+        ddepth = A.backward_pre(gy, rpd, gsum)
+        args, keep = A._args(rpd, B, gy.device)
+        outs = []
+        for fused in (False, True):
+            pm = torch.full((B, H, W, cp), 3.0, device=DEV, dtype=torch.bfloat16)
+            draw = torch.full((B, 1 + arch, H, W), 3.0, device=DEV)
+            db = torch.zeros(3, device=DEV)
+            ws = torch.zeros(B * 1024, device=DEV)
+            head = (gout.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr())
+            tail = (0.25, 0.125, draw.data_ptr(), db.data_ptr(), pm.data_ptr(), cp, ws.data_ptr(), None)
+            if fused:
+                L.check(lib.dg_head_post_bwd_aug(*head, gy.data_ptr(), *args, A.mask, gsum.data_ptr(), arch, 1.0, -1.0, B, H, W,
+                                                 *tail))
+            else:
+                L.check(lib.dg_head_post_bwd(*head, ddepth.data_ptr(), arch, 1.0, -1.0, B, H * W, *tail))
+            torch.cuda.synchronize()
+            outs.append((pm.float().cpu(), draw.cpu(), db.cpu()))
+        assert float(outs[0][1].abs().mean()) > 0
+        assert rel_l2(outs[1][1], outs[0][1]) < 1e-6 and rel_l2(outs[1][0], outs[0][0]) < 1e-3
+        assert rel_l2(outs[1][2][:1 + arch], outs[0][2][:1 + arch]) < 1e-5
+    # the scalar form's shapes are refused, nothing launched
+    assert lib.dg_head_post_bwd_aug(gout.data_ptr(), npx.data_ptr(), nim.data_ptr(), mask.data_ptr(), gy.data_ptr(), *args,
+                                    A.mask, gsum.data_ptr(), arch, 1.0, -1.0, B, H, W - 2, 0.25, 0.125, draw.data_ptr(),
+                                    db.data_ptr(), None, 0, None, None) == L.DG_EUNSUPPORTED
