@@ -232,9 +232,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
         if (ci < p.Ci && co < p.Co) {
           const long i4 = ((long)ci * p.Co + co) / 4;
           const float4 g4 = *(const float4*)(stage + row * BN + c4 * 4);
-          const float4 v4 = ((const float4*)ad.v)[i4];
-          const float4 p4 = ((const float4*)ad.p)[i4];
-          const float4 e4 = ad.ema ? ((const float4*)ad.ema)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          // (every stream of the optimizer is touched once per step: non-temporal, so the 1.7 GB do not sweep L2 / the
+          //  Infinity Cache of what the next kernels read)
+          typedef __attribute__((ext_vector_type(4))) float nt4;
+          const nt4 v4 = __builtin_nontemporal_load((const nt4*)ad.v + i4);
+          const nt4 p4 = __builtin_nontemporal_load((const nt4*)ad.p + i4);
+          const nt4 e4 = ad.ema ? __builtin_nontemporal_load((const nt4*)ad.ema + i4) : nt4{0.f, 0.f, 0.f, 0.f};
           float gv[4] = {g4.x, g4.y, g4.z, g4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w};
           float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
@@ -245,9 +248,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
             pv[k] = pv[k] - ad.lr * (g / (sqrtf(vi) * inv_sqrt_bc2 + ad.eps));
             ev[k] = ad.ema_decay * ev[k] + (1.f - ad.ema_decay) * pv[k];
           }
-          ((float4*)ad.p)[i4] = make_float4(pv[0], pv[1], pv[2], pv[3]);
-          ((float4*)ad.v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-          if (ad.ema) ((float4*)ad.ema)[i4] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+          __builtin_nontemporal_store(nt4{pv[0], pv[1], pv[2], pv[3]}, (nt4*)ad.p + i4);
+          __builtin_nontemporal_store(nt4{vv[0], vv[1], vv[2], vv[3]}, (nt4*)ad.v + i4);
+          if (ad.ema) __builtin_nontemporal_store(nt4{ev[0], ev[1], ev[2], ev[3]}, (nt4*)ad.ema + i4);
           if (ad.shadow) {
             if (ad.shadow_bf16) {
               const bf16 h[4] = {(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
