@@ -254,3 +254,77 @@ def test_algorithmic_work_model_matches_the_survey():
     f_d = 2 * (393216 + 33554432 + 3 * 536870912 + 131072)
     assert sf == 32 * (3 * f_g + 10 * f_d) and 5.5e9 < sb < 6.2e9
 
+
+
+def test_wgrad_workspace_never_reduces_two_items_into_one_destination_per_launch(monkeypatch):
+    """engine.WgradWorkspace.flush: at most 8 layers per dg_wgrad_reduce launch and never two items with the same dW in one
+    launch (micro-batches and the path-length terms queue several partial sets for one gradient: their blocks would
+    read-modify-write it concurrently) - the repeats follow in later launches, in queue order."""
+    from dusty_gan_amd import _lib as L
+    from dusty_gan_amd import engine as E
+    launches = []
+
+    class FakeLib:
+        def dg_wgrad_reduce(self, arr, n, stream):
+            launches.append([(arr[i].ws, arr[i].dw, arr[i].numel, arr[i].splits, arr[i].accumulate) for i in range(n)])
+            return 0
+    monkeypatch.setattr(L, "lib", lambda: FakeLib())
+    monkeypatch.setattr(L, "stream_ptr", lambda: None)
+    ws = E.WgradWorkspace()
+    items = [(1000 + i, dw, 64, 4, 1) for i, dw in enumerate([10, 20, 30, 10, 40, 20, 10, 50, 60, 70, 80, 90, 100, 110])]
+    for it in items:
+        ws.add(*it)
+    ws.flush()
+    assert ws.items == [] and ws.pos == 0
+    assert [it for chunk in launches for it in chunk] == items                 # everything, in order
+    for chunk in launches:
+        assert len(chunk) <= 8 and len({it[1] for it in chunk}) == len(chunk)   # no destination twice in a launch
+    assert len(launches) == 3                                                   # [10 20 30] [10 40 20] [10 50 ... 110]
+
+
+def test_counters_ride_and_mid_step_flush_without_gpu(monkeypatch):
+    """_lib.Counters: a riding snapshot stays queued through a mid-step flush (a consumer syncing its counter) and leaves
+    with `take_for_ride`; a final flush takes everything; a snapshot without its counter's advance is refused."""
+    from dusty_gan_amd import _lib as L
+    calls = []
+
+    class T:                       # stands in for a device counter tensor
+        def __init__(self, p):
+            self.p = p
+
+        def data_ptr(self):
+            return self.p
+
+    class FakeLib:
+        def dg_counter_add_multi(self, ptrs, dels, k, stream):
+            calls.append(("add", [ptrs[i] for i in range(k)], [dels[i] for i in range(k)]))
+            return 0
+
+        def dg_counter_add_multi_snap(self, ptrs, dels, k, idx, src, n, ring, slots, stream):
+            calls.append(("snap", [ptrs[i] for i in range(k)], [dels[i] for i in range(k)], idx, src, n, ring, slots))
+            return 0
+    monkeypatch.setattr(L, "lib", lambda: FakeLib())
+    monkeypatch.setattr(L, "stream_ptr", lambda: None)
+    C = L.Counters
+    C.pending.clear(); C.snap = None; C.ride = False
+    a, b, s = T(0x100), T(0x200), T(0x300)
+    C.add(a, 3); C.add(b, 1); C.add(s, 1)
+    C.snapshot(s, 0xAAA0, 8, 0xBBB0, 64)
+    C.ride = True
+    C.flush_if(a)                                    # mid-step: a and b go out, the snapshot and its counter stay
+    assert calls == [("add", [0x100, 0x200], [3, 1])] and C.ride and C.snap is not None and list(C.pending) == [0x300]
+    C.add(a, 2)
+    ride = C.take_for_ride()
+    assert ride is not None and not C.ride and C.snap is None and not C.pending
+    ptrs, dels, k, idx, src, n, ring, slots = ride
+    assert k == 2 and sorted(ptrs[i] for i in range(k)) == [0x100, 0x300] and ptrs[idx] == 0x300
+    assert (src, n, ring, slots) == (0xAAA0, 8, 0xBBB0, 64)
+    assert C.take_for_ride() is None                 # nothing flagged any more
+    C.add(s, 1); C.snapshot(s, 0xAAA0, 8, 0xBBB0, 64)
+    C.flush()                                        # a final flush files the snapshot itself
+    assert calls[-1][0] == "snap" and calls[-1][3] == 0 and not C.pending and C.snap is None
+    C.snapshot(s, 0xAAA0, 8, 0xBBB0, 64)             # no advance queued for its counter
+    C.add(a, 1)
+    with pytest.raises(RuntimeError):
+        C.flush()
+    C.pending.clear(); C.snap = None; C.ride = False
