@@ -1015,6 +1015,7 @@ class Trainer:
                         pass
                 self._cap, self._cap_cur = None, None
                 L.Counters.pending.clear()  # (advances queued by the aborted capture were never going to run)
+                L.Counters.snap, L.Counters.ride = None, False
                 E.WGRAD_WS.items, E.WGRAD_WS.pos = [], 0
                 if self.world == 1:
                     raise
