@@ -527,8 +527,10 @@ def test_transpose_shadow_multi_tail_carries_the_counters(L):
     assert not L.Counters.pending and L.Counters.snap is None and not L.Counters.ride
 
 
+@pytest.mark.parametrize("policy", [None, [], ["translation"], ["brightness", "contrast", "cutout"]],
+                         ids=["default", "none", "translation", "no-translation"])
 @pytest.mark.parametrize("arch", [0, 1, 2])
-def test_head_post_bwd_aug_equals_gather_then_head_post_bwd(L, arch):
+def test_head_post_bwd_aug_equals_gather_then_head_post_bwd(L, arch, policy):
     """dg_head_post_bwd_aug (DiffAugment's adjoint gather evaluated inside the head post-processing's backward) against
     dg_diffaug_bwd_pre followed by dg_head_post_bwd, incl. extreme draws (clamped cut-out boxes, maximal shifts, rows
     shifted out of the image) and the column the reference's `% (W - 1)` reads twice."""
@@ -536,7 +538,7 @@ def test_head_post_bwd_aug_equals_gather_then_head_post_bwd(L, arch):
     lib = L.lib()
     g = torch.Generator().manual_seed(5 + arch)
     B, H, W = 4, 16, 64
-    A = DiffAugment()
+    A = DiffAugment() if policy is None else DiffAugment(policy=policy)
     gy = torch.randn(B, 1, H, W, generator=g).to(DEV)
     gsum = torch.randn(B, generator=g).to(DEV)
     gout = torch.randn(B, 1 + arch, H, W, generator=g).to(DEV)
