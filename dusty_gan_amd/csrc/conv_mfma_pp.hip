@@ -93,8 +93,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int NPAIR = MODE == MODE_S2 ? 2 : 1;   // pairs per (H tap, 64-channel chunk)
   constexpr bool STRIP = BN == 128;            // output stores through a per-wave LDS transpose strip (below)
   constexpr int SCR = STRIP ? 16 * WC * 2 : 0; // 16 pixels x the wave's channels
-  static_assert(IB >= 1 && NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR];
+  constexpr int NHT = 256;                     // rows of the H-tap table (the launcher checks rows <= NHT)
+  constexpr int LDS_HT = NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR;
+  static_assert(IB >= 1 && LDS_HT + NHT * 8 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_HT + NHT * 8];
 #ifdef DG_PP_DIAG
   constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
 #else
@@ -138,6 +140,31 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     return r;
   };
   const Tile first = tile_at(t0);
+  // The walk from tile t to tile t + nwx as a carry chain over (N tile, column tile, parity, row, sample group): the
+  // stride's digits are worked out once; per tile a dozen scalar instructions instead of three integer divisions.  (Round-4
+  // stamps: the per-tile prologue - tile_at, the H-tap list, the per-lane offsets - cost 900-2400 cycles per tile and group, and
+  // because a group that is not in its LOAD / MFMA pairing holds up its partner at the next barrier, twice that per tile on
+  // the kernel's critical path: 8-19 % of the launch.)
+  Tile dstep;
+  {
+    int r = nwx;
+    dstep.nt = r % tiles_n; r /= tiles_n;
+    dstep.xt = r % tiles_x; r /= tiles_x;
+    dstep.px = 0;
+    if (MODE == MODE_UP && !DUAL) { dstep.px = r & 1; r >>= 1; }
+    dstep.Y = r % rows; dstep.bt = r / rows;
+    dstep.nt = __builtin_amdgcn_readfirstlane(dstep.nt); dstep.xt = __builtin_amdgcn_readfirstlane(dstep.xt);
+    dstep.px = __builtin_amdgcn_readfirstlane(dstep.px); dstep.Y = __builtin_amdgcn_readfirstlane(dstep.Y);
+    dstep.bt = __builtin_amdgcn_readfirstlane(dstep.bt);
+  }
+  auto tile_next = [&](Tile& t) __attribute__((always_inline)) {
+    int c;
+    t.nt += dstep.nt; c = t.nt >= tiles_n; if (c) t.nt -= tiles_n;
+    t.xt += dstep.xt + c; c = t.xt >= tiles_x; if (c) t.xt -= tiles_x;
+    if (MODE == MODE_UP && !DUAL) { t.px += dstep.px + c; c = t.px >> 1; t.px &= 1; }
+    t.Y += dstep.Y + c; c = t.Y >= rows; if (c) t.Y -= rows;
+    t.bt += dstep.bt + c;
+  };
 
   const bf16* in = (const bf16*)p.in;
   const bf16* w = (const bf16*)p.w;
@@ -208,6 +235,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     s_bias[i] = (!MASK && p.bias && i < p.N) ? p.bias[i % p.bias_mod] * (p.epi == EPI_LRELU ? SQRT2 : 1.f) : 0.f;
     s_db[i] = 0.f;
     s_rs[i] = (p.rowscale && i < p.B) ? p.rowscale[i] : 1.f;
+  }
+  // H-tap lists of every output row, built once (up to 6 taps of 10 bits, the count in bits 60-62): a tile reads its
+  // row's entry instead of running the tap enumeration (six rounds of boundary cases) again
+  const unsigned sht0 = lds0 + LDS_HT;
+  for (int y = tid; y < rows; y += 64 * NWV) {
+    unsigned long long hl;
+    const int nh = persist::pack_htaps<MODE>(p.adj, y, p.Hc, hl);
+    ((unsigned long long*)(lds + LDS_HT))[y] = hl | ((unsigned long long)nh << 60);
   }
   __syncthreads();
 
@@ -481,8 +516,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       if (!ISS) PP_WAIT(0);
       else if (t == 0) { if (wave == 0) PP_WAIT(IA + IB + 1); else PP_WAIT(IA + IB); }
       else PP_WAIT(IB);
-      if (t == 0 && pending) {                   // the finished tile's epilogue: behind the wait (mask source landed),
-        if (!(dbg & 4)) epilogue(tprev);         // in front of the MFMA half that restarts the accumulators
+      // The finished tile's epilogue: behind the wait (mask source landed), in front of the MFMA half that restarts the
+      // accumulators.  Both groups run theirs in the SAME barrier interval: the lagging group (waves 4-7) at the end of its
+      // LOAD half, the leading group one barrier later at the head of its MFMA half.  (Round 3 had each group's epilogue
+      // in its own LOAD half, i.e. in consecutive intervals: the partner's 32 MFMAs covered a fifth of it and the partner
+      // then sat at the barrier - MFMA + epilogue + skeleton added up exactly in the ablations.  Two waves of a SIMD doing
+      // VALU work together each still issue at their single-wave rate, so one epilogue time per tile is gone.)
+      auto finish_tile = [&]() __attribute__((always_inline)) {
+        if (!(dbg & 4)) epilogue(tprev);
         else {                                   // (ablation: keep the MFMAs alive without their consumer)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
@@ -491,10 +532,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           zero_acc();
         }
         pending = false;
-      }
+      };
+      if (t == 0 && pending && wave >= 4) finish_tile();
       if (stamps) t2 = pp_stamp();
       __builtin_amdgcn_s_barrier();
       if (stamps) t3 = pp_stamp();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t == 0 && pending) finish_tile();      // (waves 0-3)
       __builtin_amdgcn_sched_barrier(0);
       if (comp) {
 #pragma unroll
@@ -531,7 +575,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   Tile ti = first;
   for (int c = 0; c < tcount; ++c) {
     unsigned long long hl;
-    const int nh = persist::pack_htaps<MODE>(p.adj, ti.Y, p.Hc, hl);
+    int nh;
+    {
+      // (inline asm, like every LDS read of the loop: the compiler must not see an LDS access it would order against the
+      //  LDS-DMA pieces in flight with a vmcnt(0))
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+      u32x2_t e;
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(sht0 + (unsigned)ti.Y * 8u) : "memory");
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)e.y);
+      nh = (int)(hi >> 28) & 7;
+      hl = ((unsigned long long)(hi & 0x0fffffffu) << 32) | lo;
+    }
     const char* in_t = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb);
     const char* w_t = (const char*)(w + (long)(ti.nt * NCH) * p.w_sn);
     const int x0 = cmul * ti.xt * BM;
@@ -563,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       }
     }
     tprev = ti;
-    ti = tile_at(t0 + (c + 1) * nwx);
+    tile_next(ti);
   }
   pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (pending && !(dbg & 4)) {
@@ -625,6 +679,7 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
   if (p->dbias && p->bias_mod < p->N) return DG_EUNSUPPORTED;
   const int Ws = p->mode == MODE_S2 ? 2 * p->Wc : p->Wc;
   if ((Ws & (Ws - 1)) != 0 || p->in_sp * 2 >= (1 << 24)) return DG_EUNSUPPORTED;  // column wrap by mask, 24-bit multiply
+  if ((p->mode == MODE_S2 ? p->Hc : 2 * p->Hc) > 256) return DG_EUNSUPPORTED;       // rows of the kernel's H-tap table
   const bool mask = p->epi == EPI_MASK;
   if (mask ? p->bias != nullptr : p->dbias != nullptr) return DG_EUNSUPPORTED;   // combinations no layer uses
   if (p->rowscale && p->B > 512) return DG_EUNSUPPORTED;

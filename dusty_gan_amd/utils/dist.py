@@ -91,13 +91,20 @@ def all_gather_pair(outs, ins):
             o.view(torch.uint8).copy_(t.contiguous().view(torch.uint8))
         return Works([])
     if dist.get_backend() == "nccl" and hasattr(dist, "_coalescing_manager"):
+        # the documented fast path (no `device`): the two calls are recorded and issued as ONE
+        # allgather_into_tensor_coalesced whose work handle the manager keeps.  (With `device` torch 2.10 replaces that
+        # handle by group._end_coalescing(device), which may be None - a wait() that orders nothing.)
+        cm = None
         try:
-            with dist._coalescing_manager(device=ins[0].device, async_ops=True) as cm:
+            with dist._coalescing_manager(async_ops=True) as cm:
                 for o, t in zip(outs, ins):
                     dist.all_gather_into_tensor(o.view(torch.uint8), t.contiguous().view(torch.uint8))
+        except (TypeError, AttributeError, AssertionError):   # a torch without coalesced all-gathers
+            cm = None
+            dist.distributed_c10d._world.pg_coalesce_state.pop(dist.distributed_c10d._get_default_group(), None)
+        if cm is not None and len(cm.works) > 0:
             return cm
-        except (RuntimeError, TypeError, AttributeError):  # a torch without coalesced all-gathers: two exchanges
-            pass
+        # no handle to wait on: issue the two exchanges one by one (idempotent if the coalesced one did run)
     return Works([all_gather_into(o, t, async_op=True) for o, t in zip(outs, ins)])
 
 

@@ -33,10 +33,11 @@ def test_library_exports_every_declared_symbol(built):
     assert lib.dg_version().decode().startswith("dusty_gan_hip")
 
 
-def test_ctypes_structs_match_header(built):
+def _header_structs():
+    """{struct name: [field names in order]} of every `typedef struct X {...} X;` in the header"""
     h = open(os.path.join(ROOT, "include", "dusty_gan_hip.h")).read()
-    for cname, cls in (("DgConv", built.DgConv), ("DgWgrad", built.DgWgrad)):
-        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), h, flags=re.S).group(1)
+    out = {}
+    for cname, body in re.findall(r"typedef struct (\w+) \{(.*?)\} \1;", h, flags=re.S):
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
         for decl in body.split(";"):
@@ -45,9 +46,72 @@ def test_ctypes_structs_match_header(built):
                 continue
             names = [n.strip().lstrip("*").strip() for n in decl.split(",")]
             names[0] = names[0].split()[-1].lstrip("*")
-            fields += names
-        mine = [f[0].rstrip("_") for f in cls._fields_]
-        assert mine == fields, (cname, mine, fields)
+            fields += [re.sub(r"\[.*\]", "", n) for n in names]
+        out[cname] = fields
+    return out
+
+
+def _c_layout(tmp_path):
+    """sizeof / offsetof of every struct of the header as the C compiler lays them out (gcc, the ABI the library was built to)"""
+    import subprocess
+    structs = _header_structs()
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "dusty_gan_hip.h"', 'int main(void) {']
+    for cname, fields in structs.items():
+        src.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for f in fields:
+            src.append(f'  printf("{cname} {f} %zu\\n", offsetof({cname}, {f}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    lay = {}
+    for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, f, v = line.split()
+        lay.setdefault(cname, {})[f] = int(v)
+    return structs, lay
+
+
+def _check_against_c(cname, cls, structs, lay, where):
+    mine = [f[0].rstrip("_") for f in cls._fields_]
+    assert mine == structs[cname], (where, cname, mine, structs[cname])
+    assert C.sizeof(cls) == lay[cname]["sizeof"], (where, cname, C.sizeof(cls), lay[cname]["sizeof"])
+    for (fname, _t), hname in zip(cls._fields_, structs[cname]):
+        assert getattr(cls, fname).offset == lay[cname][hname], (where, cname, fname)
+
+
+def test_ctypes_structs_match_header(built, tmp_path):
+    """every struct of include/dusty_gan_hip.h has a ctypes mirror in _lib.py with the same field names, order, offsets
+    and size as the C compiler's layout"""
+    structs, lay = _c_layout(tmp_path)
+    assert set(structs) >= {"DgConv", "DgWgrad", "DgConvPlan", "DgWgradPlan", "DgWgradReduce", "DgAugSet", "DgUpFrag", "DgDraw"}
+    for cname in structs:
+        assert hasattr(built, cname), f"{cname} is declared in the header but _lib.py has no ctypes mirror"
+        _check_against_c(cname, getattr(built, cname), structs, lay, "_lib.py")
+
+
+def test_integration_md_stubs_match_header(built, tmp_path):
+    """INTEGRATION.md is the binding a maintainer copies: every ctypes Structure it shows must have the header's field
+    names, order, offsets and sizeof (round 3 shipped a DgConv stub two fields short), and every `lib.dg_*` call it shows
+    must be an exported symbol."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    classes = {}
+    for b in blocks:
+        for m in re.finditer(r"^class (\w+)\(C\.Structure\):.*?\n(?=\S|\Z)", b, flags=re.S | re.M):
+            ns = {"C": C}
+            exec(m.group(0), ns)  # a class statement with a literal _fields_ list
+            classes[m.group(1)] = ns[m.group(1)]
+    assert "DgConv" in classes and "DgWgrad" in classes, sorted(classes)
+    structs, lay = _c_layout(tmp_path)
+    for cname, cls in classes.items():
+        assert cname in structs, f"INTEGRATION.md shows a struct the header does not declare: {cname}"
+        _check_against_c(cname, cls, structs, lay, "INTEGRATION.md")
+        ref = getattr(built, cname)
+        assert [(n.rstrip("_"), t) for n, t in cls._fields_] == [(n.rstrip("_"), t) for n, t in ref._fields_], cname
+    lib = built.lib()
+    for name in set(re.findall(r"\blib\.(dg_\w+)", md)):
+        assert hasattr(lib, name), f"INTEGRATION.md calls {name}, which the library does not export"
 
 
 def test_error_codes_without_gpu(built):
