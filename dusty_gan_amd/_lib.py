@@ -43,6 +43,8 @@ class DgConv(C.Structure):
         ("nscale", C.c_void_p),
         ("up_frag", C.c_void_p),
         ("dbias_ws", C.c_void_p),
+        ("mask_out", C.c_void_p),
+        ("mask_in", C.c_void_p),
     ]
 
 
@@ -91,7 +93,7 @@ class DgWgradReduce(C.Structure):
 
 class DgConvPlan(C.Structure):
     _fields_ = [("family", C.c_int), ("bm", C.c_int), ("bn", C.c_int), ("tiles", C.c_int), ("workgroups", C.c_int),
-                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int)]
+                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int), ("mask_bits", C.c_int)]
 
 
 _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64

@@ -3,6 +3,7 @@
 
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
+int dg_lrelu_bits_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
@@ -27,7 +28,7 @@ const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 //        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error (9: without its
 //        both-parities tile for 64-channel MODE_UP layers), 10 the weight-streaming Proj forward or error.
 //        plan != NULL: describe the launch instead of making it.
-static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
+static int conv_dispatch0(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
   if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
   if (p->mode != MODE_GEMM && (p->Hc < 2 || p->Wc < 2)) return DG_EINVAL;
@@ -36,7 +37,7 @@ static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, 
   if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
-  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; }
+  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; plan->mask_bits = 0; }
   // Proj forward (bf16, K = 512, B <= 32): the weight-streaming kernel (proj_stream.hip); force 10 asks for it, 2 for the
   // general MFMA kernel it replaces
   if ((force == 0 || force == 10) && dg_proj_stream_supported(p)) return dg_proj_stream_launch(p, s, plan);
@@ -46,11 +47,29 @@ static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, 
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {
-    if (plan) { plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); return DG_OK; }
+    if (plan) { plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); plan->mask_bits = plan->thin_mfma == 1 ? 3 : 0; return DG_OK; }
     return dg_conv_thin_launch(p, s);
   }
   if (plan) { plan->family = 1; return DG_OK; }
   return dg_conv_direct_launch(p, s);
+}
+
+// The saved-mask fields around the dispatch: mask_out is honoured behind EVERY kernel (natively by the ping-pong conv and the
+// thin matrix-core MODE_S2 kernel - DgConvPlan.mask_bits & 1 - otherwise by one packing launch over the output), mask_in
+// only by kernels that take bits (the others read aux, which stays mandatory).
+static int conv_dispatch(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
+  if (p && (p->mask_out || p->mask_in)) {
+    if (p->mask_out && p->epi != EPI_LRELU) return DG_EINVAL;
+    if (p->mask_in && p->epi != EPI_MASK) return DG_EINVAL;
+    if (p->out_sn != 1 || p->N % 8 != 0 || p->out_sp % 8 != 0 || p->out_sb % 8 != 0) return DG_EUNSUPPORTED;
+  }
+  if (plan || !p || !p->mask_out) return conv_dispatch0(p, force, wg_cap, s, plan);
+  DgConvPlan pl;
+  int rc = conv_dispatch0(p, force, wg_cap, nullptr, &pl);
+  if (rc) return rc;
+  rc = conv_dispatch0(p, force, wg_cap, s, nullptr);
+  if (rc == DG_OK && !(pl.mask_bits & 1)) rc = dg_lrelu_bits_launch(p, s);
+  return rc;
 }
 
 int dg_conv(const DgConv* p, int force, void* stream) { return conv_dispatch(p, force, 0, (hipStream_t)stream, nullptr); }

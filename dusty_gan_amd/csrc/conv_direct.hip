@@ -163,3 +163,43 @@ int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream) {
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
+
+
+// ---- DgConv.mask_out behind kernels that do not write it themselves: one pass over the output just written.
+// Bit e of the mask = (out element at offset e) > 0, the test the EPI_MASK epilogues make on the saved activation
+// (models/ops/common.py:99-106 under autograd).  One thread per 8 consecutive channels of one pixel = one mask byte.
+__global__ __launch_bounds__(256) void lrelu_bits_kernel(const void* out, unsigned char* bits, int dtype, long total, int n8,
+                                                         long pixels, long out_sb, long out_sp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % n8);
+  const long pix = idx / n8;
+  const long o = (pix / pixels) * out_sb + (pix % pixels) * out_sp + (long)g * 8;
+  unsigned m = 0;
+  if (dtype == DG_BF16) {
+    const uint4 raw = *(const uint4*)((const bf16*)out + o);
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m |= (unsigned)((short)(w[e] & 0xffffu) > 0) << (2 * e);
+      m |= (unsigned)((int)w[e] > 0xffff) << (2 * e + 1);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m |= (unsigned)(((const float*)out)[o + e] > 0.f) << e;
+  }
+  bits[o >> 3] = (unsigned char)m;
+}
+
+int dg_lrelu_bits_launch(const ConvP* p, hipStream_t s) {
+  long pixels = 1;
+  if (p->mode == MODE_S2) pixels = (long)p->Hc * p->Wc;
+  else if (p->mode == MODE_UP) pixels = 4L * p->Hc * p->Wc;
+  const int n8 = p->N / 8;
+  const long total = (long)p->B * pixels * n8;
+  const long blocks = (total + 255) / 256;
+  lrelu_bits_kernel<<<(unsigned)blocks, 256, 0, s>>>(p->out, (unsigned char*)p->mask_out, p->out_dtype, total, n8, pixels,
+                                                     p->out_sb, p->out_sp);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}

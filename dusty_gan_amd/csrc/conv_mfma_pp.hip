@@ -69,8 +69,11 @@ __device__ __forceinline__ float row_add(float v) {  // v + (v of the lane CTRL 
 // wave column wn IS the parity (its pixel fragments sit one image row further).  One pixel image of SW + 2 columns then
 // feeds four W taps instead of two: the 64-channel MODE_UP layers (Down2 backward-data, Up3 forward) were bound by the
 // LDS-DMA issue of their LOAD halves - 6 pieces per wave and pair for 32 MFMAs against 8 for 64 in the 128-channel tile.
-template <int BN, int MODE, bool MASK, bool DUAL = false>
+// BITS (MASK only): the slope comes from the saved 1-bit masks (DgConv.mask_in, 2 bytes per lane and block row) instead of the
+// saved activation itself (aux, 32 bytes per lane and block row, and 32 VGPRs to hold a tile's worth of it).
+template <int BN, int MODE, bool MASK, bool DUAL = false, bool BITS = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
+  static_assert(MASK || !BITS, "BITS: a flavour of the EPI_MASK epilogue");
   static_assert(!DUAL || (MODE == MODE_UP && BN == 128), "DUAL: both column parities of a 64-channel MODE_UP layer");
   constexpr int NCH = DUAL ? BN / 2 : BN;      // real output channels per tile
   constexpr int BM = 256, NWV = 8, WN = 2;
@@ -302,14 +305,26 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // pieces).  (Round-2 finding: with the mask source aliased onto fragment registers the epilogue had to run FIRST in
   // the half behind a vmcnt(0), i.e. drain every LDS-DMA piece in flight once per tile - the EPI_MASK layers stayed at
   // 720-740 TFLOP/s while the others reached 830-1150.)
-  i32x4 axr[MASK ? NST : 1];
+  i32x4 axr[(MASK && !BITS) ? NST : 1];
+  unsigned mbits[BITS ? TM : 1];               // BITS: the lane's CPL mask bits of block row i
+  const unsigned pix_off_m = pix_off >> 4;     // the lane's byte offset inside a mask buffer (1 bit per element)
   auto load_aux = [&](const Tile& t) __attribute__((always_inline)) {
-    const char* ab = (const char*)((const bf16*)p.aux + tile_off(t));
+    if constexpr (BITS) {
+      const char* mb = (const char*)p.mask_in + (tile_off(t) >> 3);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {             // wave-uniform base of block row i + the lane's 32-bit offset
-      const char* src = ab + (long)(i * 16) * px_b;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(axr[(NST / TM) * i]) : "v"(pix_off), "s"(src) : "memory");
-      if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(axr[2 * i + 1]) : "v"(pix_off), "s"(src) : "memory");
+      for (int i = 0; i < TM; ++i) {
+        const char* src = mb + (long)i * px_b;   // 16 tile rows further: 16 px_b bytes of the tensor = px_b bytes of bits
+        if (CPL == 16) asm volatile("global_load_ushort %0, %1, %2" : "=v"(mbits[i]) : "v"(pix_off_m), "s"(src) : "memory");
+        else asm volatile("global_load_ubyte %0, %1, %2" : "=v"(mbits[i]) : "v"(pix_off_m), "s"(src) : "memory");
+      }
+    } else {
+      const char* ab = (const char*)((const bf16*)p.aux + tile_off(t));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {             // wave-uniform base of block row i + the lane's 32-bit offset
+        const char* src = ab + (long)(i * 16) * px_b;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(axr[(NST / TM) * i]) : "v"(pix_off), "s"(src) : "memory");
+        if (NST / TM == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(axr[2 * i + 1]) : "v"(pix_off), "s"(src) : "memory");
+      }
     }
   };
   // Bias-gradient sums (EPI_MASK with dbias): per lane 4 TN channel sums over its pixels, weighted per sample, of the
@@ -335,10 +350,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   };
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
     char* ob = (char*)(out + tile_off(t));
-    if (MASK) {                                // (the caller's wait covered the loads: pin the uses behind it)
+    if (MASK && !BITS) {                       // (the caller's wait covered the loads: pin the uses behind it)
 #pragma unroll
       for (int i = 0; i < NST; ++i) asm volatile("" : "+v"(axr[i]));
     }
+    if (BITS) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(mbits[i]));
+    }
+    char* mob = nullptr;                         // mask_out: this tile's bits (producer side, EPI_LRELU)
+    if (!MASK && p.mask_out) mob = (char*)p.mask_out + (tile_off(t) >> 3);
     f32x4_t bias[TN];
     float rs = 0.f;
     if (want_db) {  // the wave's 64 pixels belong to one sample (SW >= 64): one per-sample weight per tile
@@ -370,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     const float c_lin = p.epi == EPI_LRELU ? c_pos : p.scale;
     const float slope = p.epi == EPI_LRELU ? LRELU_SLOPE : 1.f;          // max(v, 1 v) = v: no select per element
     i32x4 rd[NRD];                               // block row i - 1, read back pixel-major, waiting for its stores
+    unsigned mrow = 0;                           // (mask_out) the CPL bits of the block row being made
     auto store_row = [&](int i) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       // arithmetic of block row i + 1 (which runs under the read latency)
 #pragma unroll
       for (int h = 0; h < NST / TM; ++h) {
-        const i32x4 ax = axr[MASK ? (NST / TM) * i + h : 0];   // mask source of channels 8h .. 8h+7 (MASK only)
+        const i32x4 ax = axr[(MASK && !BITS) ? (NST / TM) * i + h : 0];   // mask source of channels 8h .. 8h+7 (MASK, aux form)
         i32x4 pk;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {                 // two channels per 32-bit word
@@ -394,7 +416,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           for (int q = 0; q < 2; ++q) {
             const int c = 8 * h + 2 * e2 + q, j = c >> 2, r = c & 3;
             float v;
-            if (MASK) {
+            if (MASK && BITS) {
+              // bit c of the row's mask word -> 0 / -1 (v_bfe_i32) -> one of the two factors (v_bfi_b32) -> multiply
+              // (inline asm: from the C form hipcc makes v_and + v_cmp + two wait states + v_cndmask)
+              int sel;
+              float kf;
+              asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(mbits[i]), "n"(c));
+              asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(kf) : "v"(sel), "v"(c_pos), "v"(c_neg));
+              v = acc[i][j][r] * kf;
+              dbacc[c] = fmaf(v, rs, dbacc[c]);
+            } else if (MASK) {
               // bf16 a > 0  <=>  its 16 bits as a signed integer > 0: the halves are compared in place (low half: 16-bit
               // compare of the word's low bits, high half: the word above 0xffff), no unpacking
               const int w32 = ax[e2];
@@ -410,6 +441,24 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
           unsigned pw;                                   // both halves in one conversion (RNE, as (bf16)v)
           asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw) : "v"(v2[0]), "v"(v2[1]));
           pk[e2] = (int)pw;
+        }
+        if (!MASK && mob) {
+          // the saved mask of these 8 channels from the ROUNDED values (what an EPI_MASK pass would test on the stored
+          // activation): per packed pair clamp the halves to [0, 1] (negative -> 0, positive -> 1: v_pk_max_i16, v_pk_min_u16),
+          // then shift-or the four words together - plain VALU, ~2 instructions per channel.  (v_cmp into VCC + v_addc would
+          // be 2 as well, but a VALU write of VCC needs two wait states before a VALU reads it as carry or mask on gfx950.)
+          unsigned tb[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2)
+            asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(tb[e2]) : "v"(pk[e2]));
+          const unsigned mm = tb[0] | (tb[1] << 2) | (tb[2] << 4) | (tb[3] << 6);   // low halves at bits 0,2,4,6, high at 16,18,..
+          const unsigned gb = (mm & 0x55u) | ((mm >> 15) & 0xAAu);
+          if (h == 0) mrow = gb; else mrow |= gb << 8;
+          if (h == NST / TM - 1) {
+            char* dstm = mob + (long)i * px_b;
+            if (CPL == 16) asm volatile("global_store_short %0, %1, %2" ::"v"(pix_off_m), "v"(mrow), "s"(dstm) : "memory");
+            else asm volatile("global_store_byte %0, %1, %2" ::"v"(pix_off_m), "v"(mrow), "s"(dstm) : "memory");
+          }
         }
         if (!STRIP) {                                    // N tile 64: the four lanes of a pixel already write one 64 B run
           char* dstp = ob + (long)(i * 16) * px_b + pix_off;
@@ -639,6 +688,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 
 template <int BN, int MODE, bool MASK, bool DUAL = false>
 int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
+  constexpr int CPL_ = (BN / 2 / 16) * 4;      // bits per lane and block row: whole bytes / 16-bit words of the mask buffers
+  const bool bits_ok = p->out_sn == 1 && p->out_sb % 8 == 0 && p->out_sp % CPL_ == 0 && p->N % CPL_ == 0;
+  if (!MASK && p->mask_out && !bits_ok) return DG_EUNSUPPORTED;
+  const bool bits = MASK && p->mask_in && bits_ok;
   Geo g = g0;
   static int resident = 0;
   if (!resident) {
@@ -653,9 +706,13 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
   if (plan) {
     plan->family = 5; plan->bm = DUAL ? 512 : 256; plan->bn = DUAL ? BN / 2 : BN; plan->tiles = g.ntiles; plan->workgroups = G;
     plan->tiles_per_wg = (g.ntiles + G - 1) / G;
+    plan->mask_bits = MASK ? (bits ? 2 : 0) : 1;
     return DG_OK;
   }
-  conv_pp_kernel<BN, MODE, MASK, DUAL><<<(unsigned)G, 512, 0, stream>>>(*p, g);
+  if constexpr (MASK) {
+    if (bits) conv_pp_kernel<BN, MODE, true, DUAL, true><<<(unsigned)G, 512, 0, stream>>>(*p, g);
+    else conv_pp_kernel<BN, MODE, true, DUAL, false><<<(unsigned)G, 512, 0, stream>>>(*p, g);
+  } else conv_pp_kernel<BN, MODE, false, DUAL><<<(unsigned)G, 512, 0, stream>>>(*p, g);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -1043,7 +1043,10 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
 //   CP = 4: 4 MFMA k-steps, step s <-> ky, lane half h <-> kx in {2h, 2h+1}, j <-> (kx = 2h + (j >> 2), c = j & 3)
 // One wave = one 32-pixel x 64-channel tile at a time (grid-stride), weights live in 16 / 32 VGPRs for the whole
 // kernel, the result tile is transposed through a wave-private 4.5 KB LDS patch and written as whole 128-byte rows.
-template <int CP>
+// MB: the saved 1-bit leaky-relu masks (DgConv.mask_out / mask_in) as a compile-time flavour - 0 none, 1 the EPI_LRELU launch
+// also writes them, 2 the EPI_MASK launch reads them instead of aux (a run-time choice kept both forms' registers live:
+// 134 -> 172 VGPRs, 3 -> 2 waves per SIMD, Down1 forward 40 -> 64 us)
+template <int CP, int MB>
 __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x, long ntiles) {
   constexpr int NS = CP == 2 ? 2 : 4;            // MFMA k-steps per kernel (without adjoint extras)
   __shared__ __attribute__((aligned(16))) unsigned char s_t[4][32 * 144];
@@ -1184,12 +1187,20 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
     // ---- epilogue: D[row = pixel][col = channel]; transpose through the wave's LDS patch.  The leaky-relu mask
     //      source of the tile is requested first so that its latency hides behind the transposition.
     const long obase = (long)b * p.out_sb + ((long)Y * p.Wc + xt * 32) * p.out_sp;
-    uint4 araw[4];
-    if (p.epi == EPI_MASK) {
+    uint4 araw[MB == 2 ? 1 : 4];
+    unsigned abit[MB == 2 ? 4 : 1];              // DgConv.mask_in: one byte = the 8 channels this lane finishes per pass
+    constexpr bool use_bits = MB == 2;
+    if (use_bits) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = lane + 64 * u, row = c >> 3, part = c & 7;
-        araw[u] = *(const uint4*)((const bf16*)p.aux + obase + (long)row * p.out_sp + part * 8);
+        abit[u] = ((const unsigned char*)p.mask_in)[(obase + (long)row * p.out_sp + part * 8) >> 3];
+      }
+    } else if (p.epi == EPI_MASK) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * u, row = c >> 3, part = c & 7;
+        araw[use_bits ? 0 : u] = *(const uint4*)((const bf16*)p.aux + obase + (long)row * p.out_sp + part * 8);
       }
     }
 #pragma unroll
@@ -1210,10 +1221,22 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
       const long o = obase + (long)row * p.out_sp + part * 8;
       uint4 raw = *(const uint4*)(my + row * 144 + part * 16);
       bf16* v = (bf16*)&raw;
-      if (p.epi == EPI_MASK) {
-        const bf16* av = (const bf16*)&araw[u];
+      if (use_bits) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * (((abit[use_bits ? u : 0] >> e) & 1u) ? SQRT2 : LRELU_SLOPE * SQRT2));
+      } else if (p.epi == EPI_MASK) {
+        const bf16* av = (const bf16*)&araw[use_bits ? 0 : u];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2));
+      }
+      if (MB == 1) {                             // (EPI_LRELU) the saved mask of these 8 channels, from the rounded values:
+        const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};   // halves clamped to [0, 1], then shifted together (conv_mfma_pp.hip)
+        unsigned tb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(tb[e]) : "v"(w4[e]));
+        const unsigned mm = tb[0] | (tb[1] << 2) | (tb[2] << 4) | (tb[3] << 6);
+        ((unsigned char*)p.mask_out)[o >> 3] = (unsigned char)((mm & 0x55u) | ((mm >> 15) & 0xAAu));
       }
       if (p.dbias) {
 #pragma unroll
@@ -1274,8 +1297,11 @@ int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
   const long cap = 768;  // 3 blocks per CU = what 164 VGPRs allow resident (measured: 256 -> 50 us, 512 -> 34 us, 768 -> 31 us,
                          // 1024 -> 38 us for Down1 forward at batch 32; the per-wave weight preload amortises over the tiles)
   if (blocks > cap) blocks = cap;
-  if (p->in_sp == 2) thin_s2_mfma_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
-  else thin_s2_mfma_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles);
+  const int mb = (p->epi == EPI_LRELU && p->mask_out) ? 1 : ((p->epi == EPI_MASK && p->mask_in) ? 2 : 0);
+#define DG_S2_LAUNCH(CP_, MB_) thin_s2_mfma_kernel<CP_, MB_><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles)
+  if (p->in_sp == 2) { if (mb == 1) DG_S2_LAUNCH(2, 1); else if (mb == 2) DG_S2_LAUNCH(2, 2); else DG_S2_LAUNCH(2, 0); }
+  else { if (mb == 1) DG_S2_LAUNCH(4, 1); else if (mb == 2) DG_S2_LAUNCH(4, 2); else DG_S2_LAUNCH(4, 0); }
+#undef DG_S2_LAUNCH
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -203,12 +203,13 @@ class NetCfg:
             raise NotImplementedError("discriminator in_ch != 1 (the range-image path is single channel)")
 
 
-def conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, reads_aux):
+def conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, reads_aux, mask_bits=0):
     """(FLOPs, bytes) one conv-like launch needs at minimum: 2 MAC per tap, every operand moved once.
     MODE_S2: output on the coarse grid (Hc x Wc, N channels), input on the fine grid (2Hc x 2Wc, K channels), 16 taps per
     output pixel; MODE_UP: output on the fine grid, input on the coarse grid, 4 taps per output pixel (16 weight taps over
     the four sub-pixel parities); MODE_GEMM: B rows.  `reads_aux`: EPI_MASK also reads the saved activation at every
-    output element."""
+    output element - or, with `mask_bits` & 2 (DgConvPlan.mask_bits), one saved BIT per output element; `mask_bits` & 1:
+    an EPI_LRELU launch also writes one bit per output element."""
     if mode == L.MODE_GEMM:
         pin, pout, taps_px, wtaps = B, B, 1, 1
     elif mode == L.MODE_S2:
@@ -216,7 +217,11 @@ def conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, reads_aux):
     else:
         pin, pout, taps_px, wtaps = B * Hc * Wc, B * 4 * Hc * Wc, 4, 16
     flops = 2.0 * pout * N * K * taps_px
-    nbytes = pin * K * ies + pout * N * oes * (2 if reads_aux else 1) + wtaps * N * K * wes
+    nbytes = pin * K * ies + pout * N * oes + wtaps * N * K * wes
+    if reads_aux:
+        nbytes += pout * N // 8 if (mask_bits & 2) else pout * N * oes
+    elif mask_bits & 1:
+        nbytes += pout * N // 8
     return flops, nbytes
 
 
@@ -242,18 +247,24 @@ class WgradWorkspace:
 
     def __init__(self):
         self.buf, self.pos, self.items = None, 0, []
+        # what the tests of the large-batch plans read: the most floats ever pending, reduces forced by a full buffer,
+        # requests larger than the whole buffer (those launches fall back to fp32 atomics onto dW)
+        self.hwm, self.early_flushes, self.refused = 0, 0, 0
 
     def take(self, nfloats, device):
-        if self.buf is None or self.buf.device != device:
+        if self.buf is None or self.buf.device != device or self.buf.numel() != self.FLOATS:
             self.flush()
             self.buf = torch.empty(self.FLOATS, dtype=torch.float32, device=device)
             self.pos = 0
         if nfloats > self.FLOATS:
+            self.refused += 1
             return None
         if self.pos + nfloats > self.FLOATS:
+            self.early_flushes += 1
             self.flush()        # (stream order: the reduce has read the partials before the next launch overwrites them)
         off = self.pos
         self.pos = (off + nfloats + 63) // 64 * 64
+        self.hwm = max(self.hwm, self.pos)
         return L.ptr(self.buf) + 4 * off
 
     def add(self, ws_ptr, dw_ptr, numel, splits, accumulate):
@@ -289,6 +300,31 @@ class WgradWorkspace:
 
 
 WGRAD_WS = WgradWorkspace()
+
+
+class MaskBits:
+    """Saved leaky-relu masks at 1 bit per element (DgConv.mask_out / mask_in; the reference's autograd keeps the sign of
+    every FusedLeakyReLU pre-activation, models/ops/common.py:99-106).  An engine registers one uint8 buffer of numel / 8
+    bytes per activation buffer; `Ops.conv` then hands its slice to every EPI_LRELU launch that WRITES the activation
+    (mask_out) and to every EPI_MASK launch whose `aux` it is (mask_in), so the backward / tangent passes read 1/16 of the
+    bytes.  bf16 feature maps with >= 16 channels only; everything else keeps reading `aux`."""
+    enabled = os.environ.get("DUSTY_GAN_MASK_BITS", "1") != "0"   # (A/B switch, exercised by tests/test_gpu_ops.py)
+
+    @classmethod
+    def register(cls, act):
+        """give the activation buffer `act` a bit buffer (kept as an attribute of the tensor object the engine passes around)"""
+        if not cls.enabled or act.dtype != torch.bfloat16 or act.numel() % 128:
+            return None
+        act._dg_bits = torch.zeros(act.numel() // 8, dtype=torch.uint8, device=act.device)
+        return act._dg_bits
+
+    @staticmethod
+    def slice_ptr(act, off, N, strides):
+        """device pointer of the bits of `act` from element `off`, or None (no bits for this tensor / geometry)"""
+        bits = getattr(act, "_dg_bits", None)
+        if bits is None or N % 16 or strides[0] % 16 or strides[1] % 16 or strides[2] != 1 or off % 16:
+            return None
+        return L.ptr(bits) + off // 8
 
 
 class Ops:
@@ -332,6 +368,10 @@ class Ops:
         p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, (self.dt if w_dt is None else w_dt)
         p.nscale = L.ptr(nscale)
         p.up_frag = up_frag
+        if epi == L.EPI_LRELU and out_dt == L.DG_BF16:
+            p.mask_out = MaskBits.slice_ptr(out, out_off, N, out_strides)
+        elif epi == L.EPI_MASK and aux is not None and out_dt == L.DG_BF16:
+            p.mask_in = MaskBits.slice_ptr(aux, aux_off, N, out_strides)
         if dbias is not None:  # staging scratch of the bias-gradient rows (zero between launches; one per process and device)
             ws = Ops._dbias_ws.get(str(x.device))
             if ws is None:
@@ -341,14 +381,20 @@ class Ops:
             pl = L.DgConvPlan()
             L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
             TRACE.append(("conv", pl.family, pl.bm, pl.bn, pl.tiles, pl.workgroups, pl.tiles_per_wg,
-                          f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}", pl.thin_mfma))
+                          f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}", pl.thin_mfma,
+                          (1 if p.mask_out else 0) | (pl.mask_bits & 2 if p.mask_in else 0)))
         if PROFILE is None:
             L.check(self.lib.dg_conv_ex(C.byref(p), self.force, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
         wes = 2 if p.w_dtype == L.DG_BF16 else 4
-        flops, nbytes = conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, epi == L.EPI_MASK)
+        mb = 0
+        if p.mask_out or p.mask_in:
+            pl = L.DgConvPlan()
+            L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
+            mb = pl.mask_bits if p.mask_in else 1  # (mask_out behind a kernel without it: the packing launch writes the same bytes)
+        flops, nbytes = conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, epi == L.EPI_MASK, mb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
@@ -434,6 +480,11 @@ class GEngine:
         self.grid = hw
         self.a = [torch.empty(B * hw[i][0] * hw[i][1] * chs[i], dtype=T, device=device) for i in range(4)]
         self.dp = [torch.empty_like(t) for t in self.a]  # gradients w.r.t. the pre-activations of a0..a3
+        # 1-bit leaky-relu mask of a3 only: its consumer (the Head's backward-data) is HBM-bound and a3 is 57 % of the
+        # generator's activation bytes.  Measured per layer (scripts/bench_conv.py, batch 32): writing the bits costs the Up
+        # forward passes 3.6-5.5 us each (the MODE_UP tiles write every other pixel: 2-byte pieces 64 bytes apart) and
+        # saves Up2 / Up3 backward-data 0-1 us - a1 and a2 keep reading the activation itself (a0 = Proj's output: 2 % of the bytes)
+        self.abits = [MaskBits.register(self.a[3])]
         HW = c.H * c.W
         self.gout = torch.empty(B, c.nheads, c.H, c.W, dtype=torch.float32, device=device)
         self.draw = torch.empty_like(self.gout)
@@ -753,6 +804,9 @@ class DEngine:
         self.per = [self.grid[i][0] * self.grid[i][1] * self.chs[i] for i in range(5)]
         self.h = [torch.empty(nb * self.per[i], dtype=T, device=device) for i in range(5)]
         self.e = [torch.empty(nb * self.per[i], dtype=T, device=device) for i in range(5)]
+        # 1-bit leaky-relu masks of h1..h3 (h4's only reader of bits is the R1 tangent's last layer: measured in the step,
+        # writing them cost the two Down4 forward launches +6 us and saved that pass 0.8 us)
+        self.hbits = [MaskBits.register(t) for t in self.h[1:4]]
         self.y = torch.empty(nb, dtype=torch.float32, device=device)
         self.ws_B = nb
 

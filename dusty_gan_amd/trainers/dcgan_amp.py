@@ -354,6 +354,13 @@ class Trainer:
         self._multi = D_.through_backend()  # exchanges go through torch.distributed (utils/dist.py)
         self._works, self._comm_events = {}, None
         self._fuse_proj_ok = os.environ.get("DUSTY_GAN_FUSE_PROJ", "1") != "0"
+        # Collectives INSIDE the captured step (nccl = RCCL only): the process group enqueues a captured collective on its
+        # own stream behind an event of the capture stream, and work.wait() joins it back - fork / join edges of ONE hipGraph,
+        # no host call and no stream hand-off between graph segments at replay.  "1": try it first and fall back to the
+        # segmented replay if the runtime refuses the capture; "0": segments (round-3 behaviour; gloo always)
+        self._comm_in_graph = (self._multi and dist.is_initialized() and dist.get_backend() == "nccl"
+                               and os.environ.get("DUSTY_GAN_GRAPH_COMM", "1") != "0")
+        self._comm_captured = False   # True once a step with captured collectives is being replayed
 
     # ------------------------------------------------------------------ helpers
     def sample_latents(self, B):
@@ -508,6 +515,9 @@ class Trainer:
                 e1.record()
                 self._comm_events.append((name, e0, e1))
         if self._cap is None:
+            fn()
+            return
+        if self._comm_in_graph:      # the collective / the wait become nodes of the graph being captured
             fn()
             return
         self._cap_close()
@@ -828,7 +838,9 @@ class Trainer:
         if self._graph is None:
             return "eager launches"
         n = sum(isinstance(g, torch.cuda.CUDAGraph) for g in self._graph)
-        return "one hipGraph per step" if n == 1 else f"{n} hipGraph segments per step, collectives between them"
+        if n == 1:
+            return "one hipGraph per step" + (", collectives captured inside it" if self._comm_captured else "")
+        return f"{n} hipGraph segments per step, collectives between them"
 
     def comm_bytes(self):
         """bytes each rank contributes to the step's exchanges (the multi-rank schedule at one micro-batch): D's gradient
@@ -985,7 +997,9 @@ class Trainer:
         # they are, and an advance still pending when the capture starts would be baked into the graph and re-added
         # on every replay
         L.Counters.flush()
-        batch = self._next_batch()
+        batch = getattr(self, "_retry_batch", None)
+        if batch is None:
+            batch = self._next_batch()
         pooled = self._pooled()
         if self._graph is None:
             if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
@@ -1007,7 +1021,8 @@ class Trainer:
                 src = batch if pooled else {"depth": self._g_pol, "mask": self._g_mask}
                 self._g_out = self._step_eager(reals=[self._fetch_reals_in_step(src, pooled)])
                 self._cap_close()
-            except BaseException:
+                self._comm_captured = self._comm_in_graph
+            except BaseException as exc:
                 if self._cap_cur is not None:
                     try:
                         self._cap_cur[1].__exit__(None, None, None)
@@ -1017,6 +1032,18 @@ class Trainer:
                 L.Counters.pending.clear()  # (advances queued by the aborted capture were never going to run)
                 L.Counters.snap, L.Counters.ride = None, False
                 E.WGRAD_WS.items, E.WGRAD_WS.pos = [], 0
+                self._works.clear()
+                if self._comm_in_graph:
+                    # the runtime refused collectives inside the capture: nothing was executed - restore the host mirrors
+                    # and capture again as segments with the collectives between them
+                    import warnings
+                    warnings.warn(f"capturing the step with its collectives failed ({type(exc).__name__}: {exc}); "
+                                  "falling back to hipGraph segments")
+                    self._comm_in_graph = False
+                    self.optim_D.step_count, self.optim_G.step_count = counts
+                    self._mb = []
+                    torch.cuda.synchronize()
+                    return self._step_graph_retry(batch, pooled)
                 if self.world == 1:
                     raise
                 # multi-rank: a runtime that refuses the capture must not take the job down - nothing was executed,
@@ -1045,6 +1072,14 @@ class Trainer:
         # shadows (built lazily, only when G_ema is evaluated) are stale now
         _backbone(self.G_ema).store._seen_version = -1
         return self._ring_slot() if self._g_out is None else self._g_out.clone()
+
+    def _step_graph_retry(self, batch, pooled):
+        """second capture attempt of `_step_graph` (segments) on the batch the first one drew"""
+        self._retry_batch = batch
+        try:
+            return self._step_graph()
+        finally:
+            self._retry_batch = None
 
     def step(self, i=0, reals=None, rands=None):
         """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""

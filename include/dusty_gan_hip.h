@@ -66,6 +66,16 @@ typedef struct DgConv {
   float* dbias_ws;           /* optional scratch of DG_DBIAS_SLOTS x DG_DBIAS_SLOT_FLOATS floats, zero on entry and left zero:
                               * per-slot staging of the bias-gradient rows of the thin matrix-core MODE_S2 kernel (hundreds of
                               * atomic rows on the same two lines serialise memory-side; other kernels ignore it) */
+  /* Saved leaky-relu masks, 1 bit per element (models/ops/common.py:99-106 under autograd saves the sign of the
+   * pre-activation; the backward / R1 tangent passes only ever need that sign).  Bit e of a mask buffer belongs to the
+   * element at offset e of the tensor it describes (bit e % 8 of byte e / 8): the mask of `out` is indexed like `out`, the
+   * mask of `aux` like `aux`.  Needs out_sn == 1 and N, out_sp, out_sb multiples of 8 (16 for the matrix-core kernels). */
+  void* mask_out;            /* optional, DG_EPI_LRELU: also store bit = (out element > 0) for every element written.  The
+                              * ping-pong conv and the thin matrix-core MODE_S2 kernel write it from their epilogues, behind any
+                              * other kernel the library adds one packing launch: the bits are there when dg_conv returns OK */
+  const void* mask_in;       /* optional, DG_EPI_MASK: the bits of `aux` (written through mask_out by the launch that produced
+                              * aux); kernels that take bits (DgConvPlan.mask_bits & 2) read 1/16 of the bytes, the others use aux,
+                              * which stays mandatory */
 } DgConv;
 #define DG_UP_FRAG_BYTES (3 * 18 * 1024)
 #define DG_DBIAS_SLOTS 32
@@ -121,6 +131,7 @@ typedef struct DgConvPlan {
   int workgroups;    /* grid size */
   int tiles_per_wg;  /* most tiles any workgroup walks */
   int thin_mfma;     /* family 3: 1 = thin_s2_mfma, 2 = thin_up_mfma (matrix cores), 0 = the VALU kernels */
+  int mask_bits;     /* 1: the kernel writes DgConv.mask_out itself (else a packing launch follows it), 2: it reads mask_in */
 } DgConvPlan;
 int dg_conv_ex(const DgConv* p, int force, int wg_cap, void* stream);
 int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan);

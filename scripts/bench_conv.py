@@ -60,6 +60,12 @@ for name, mode, adj, Hc, Wc, K, N, bm in CONV:
     bias = torch.randn(N, device=dev)
     db = torch.zeros(N, device=dev)
     epi = L.EPI_MASK if adj else L.EPI_LRELU
+    if dtype == torch.bfloat16 and os.environ.get("BENCH_BITS", "1") != "0":   # the step's form: saved 1-bit leaky-relu masks
+        from dusty_gan_amd.engine import MaskBits
+        if adj:
+            aux._dg_bits = torch.randint(0, 256, (aux.numel() // 8,), device=dev, dtype=torch.uint8)
+        else:
+            MaskBits.register(out)
 
     def run():
         o.conv(mode, adj, True, n, Hc, Wc, K, N, x, (hin * win * K, K, 1), out, (ho * wo * N, N, 1), w.data_ptr(),

@@ -200,13 +200,27 @@ def test_forced_segments_single_process_match_one_graph(monkeypatch):
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
-def rccl_worker(rank, world, init_file, out_dir):
+def rccl_worker(rank, world, init_file, out_dir, in_graph=True):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_FORCE_SEG"] = "1"
+    os.environ["DUSTY_GAN_GRAPH_COMM"] = "1" if in_graph else "0"
     dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=rank, world_size=world,
                             device_id=torch.device("cuda", 0), timeout=PG_TIMEOUT)
     from dusty_gan_amd.utils import dist as DD
     assert DD.through_backend()
+    # the coalesced Proj-operand gather against two plain gathers (advisor, round 3): same bytes, and a handle whose wait
+    # really orders the consumer behind RCCL's stream
+    a = torch.randn(1 << 20, device="cuda").bfloat16()
+    b = torch.randn(3 << 18, device="cuda")
+    oa, ob = torch.empty_like(a), torch.empty_like(b)
+    w = DD.all_gather_pair((oa, ob), (a, b))
+    assert len(getattr(w, "works", [1])) > 0, "no work handle behind the coalesced gather"
+    w.wait()
+    pa, pb = torch.empty_like(a), torch.empty_like(b)
+    DD.all_gather_into(pa, a)
+    DD.all_gather_into(pb, b)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, pa) and torch.equal(ob, pb)
     torch.manual_seed(77)
     tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
     assert tr._multi
@@ -217,30 +231,51 @@ def rccl_worker(rank, world, init_file, out_dir):
             torch.cuda.synchronize()  # host-side synchronisation between replays (bench.py's sync / barrier pattern)
             dist.barrier()
     segs = sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
-    res = {"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": sc, "segs": segs}
+    res = {"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": sc, "segs": segs,
+           "mode": tr.launch_mode(), "captured": tr._comm_captured}
+    # steady-state step time of this schedule (device events over 20 replays)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(3):
+        tr.step(i)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(20):
+        tr.step(i)
+    e1.record()
+    torch.cuda.synchronize()
+    res["ms"] = e0.elapsed_time(e1) / 20
     res["prof"] = tr.comm_profile(2)
     torch.save(res, os.path.join(out_dir, "rccl.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_single_rank_rccl_runs_the_multi_rank_schedule(monkeypatch):
+@pytest.mark.parametrize("in_graph", [True, False])
+def test_single_rank_rccl_runs_the_multi_rank_schedule(monkeypatch, in_graph):
     """The one thing the gloo tests above cannot show on a one-GPU box: the multi-rank schedule on the "nccl" backend
     (RCCL).  A process group of ONE rank with DUSTY_GAN_FORCE_SEG=1 sends every exchange of the step through RCCL -
     asynchronous bucketed all-reduces on RCCL's stream, the Proj operand all-gathers (`all_gather_into_tensor` on byte
-    views), work handles waited between hipGraph segments, thread-local capture beside the RCCL watchdog - at the
-    benchmark's size (bf16, B = 32).  With one rank every collective is an identity, so the run must train like the
-    single-graph replay."""
+    views, coalesced), work handles, thread-local capture beside the RCCL watchdog - at the benchmark's size (bf16,
+    B = 32).  in_graph: the collectives and their waits are captured INSIDE the step's one hipGraph (round 4; the default
+    on nccl); otherwise they are host calls between hipGraph segments (round 3).  With one rank every collective is an
+    identity, so either run must train like the single-graph replay."""
     from tests.test_gpu_step import make_trainer
     with tempfile.TemporaryDirectory() as td:
-        mp.spawn(rccl_worker, args=(1, os.path.join(td, "init"), td), nprocs=1, join=True)
+        mp.spawn(rccl_worker, args=(1, os.path.join(td, "init"), td, in_graph), nprocs=1, join=True)
         a = torch.load(os.path.join(td, "rccl.pt"))
     monkeypatch.setenv("DUSTY_GAN_FORCE_SEG", "0")
     torch.manual_seed(77)
     b = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
     sb = [dict(b.step(i).items()) for i in range(5)]
-    assert a["segs"] >= 4
-    assert any("wait" in k for k in a["prof"]), a["prof"]
+    if in_graph and a["captured"]:
+        assert a["segs"] == 1, a["mode"]
+    else:
+        if in_graph:   # the runtime refused collectives inside the capture: the fallback must still be the segmented replay
+            import warnings
+            warnings.warn("collectives were not captured inside the graph on this box: " + a["mode"])
+        assert a["segs"] >= 4
+        assert any("wait" in k for k in a["prof"]), a["prof"]
+    print(f"single-rank RCCL schedule, in_graph={in_graph}: {a['mode']}, {a['ms']:.3f} ms per step")
     for x, y in zip(a["scal"], sb):
         for k in x:
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])

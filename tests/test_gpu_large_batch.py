@@ -1,0 +1,153 @@
+"""The LARGE-batch plans under a checker: `bench.py` times BASELINE configs[4]'s per-GPU share at
+B = 64 (dusty2, 128x2048) and the 64x1024 net at up to B = 64, but tile counts per workgroup, split-K plans and the
+split-K workspace of the weight gradients all depend on B, and the oracle only covers B <= 4 at those widths (a CPU step
+at B = 64, 128x2048 takes minutes and ~40 GB).  So the B = 64 plans are held to the B = 4 plans the oracle does cover:
+
+ (i)   the generator / discriminator outputs of the first 4 samples of a B = 64 step equal those of a B = 4 step on the
+       same parameters and randomness;
+ (ii)  the B = 64 gradients equal the gradients accumulated over 16 micro-batches of 4 (reference:
+       utils/context_manager.py:21-35, loss / num_accumulation at trainers/dcgan_amp.py:234,308);
+ (iii) a B = 4 micro-batch is checked against the oracle in tests/test_gpu_timed_path.py::test_config5_shapes_whole_step;
+ (iv)  the split-K workspace never fills at these sizes, and when it is made to (forced small) both fall-backs - an early
+       reduce, fp32 atomics - give the same gradients.
+"""
+import pytest
+import torch
+
+from oracle import dusty_oracle as O
+from tests.golden_util import rel_l2
+from tests.test_gpu_step import _cos, grads_by_name, make_trainer
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+DEV = "cuda"
+
+
+def _rand(B, nz, H, W, arch, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 1, H, W, generator=gen) * 2 - 1
+    noise = {"pixel": O.logistic_noise(torch.rand(B, 1, H, W, generator=gen), torch.rand(B, 1, H, W, generator=gen))}
+    if arch == "dusty2":
+        noise["image"] = O.logistic_noise(torch.rand(B, 1, 1, 1, generator=gen), torch.rand(B, 1, 1, 1, generator=gen))
+    rand = {"z": torch.randn(B, nz, generator=gen), "noise": noise,
+            "aug": [O.draw_augment_params(B, H, W, gen) for _ in range(4)]}
+    return x, rand
+
+
+def _slice(r, s):
+    return {"z": r["z"][s], "noise": {k: v[s] for k, v in r["noise"].items()},
+            "aug": [{k: v[s] for k, v in rp.items()} for rp in r["aug"]]}
+
+
+def _pair(arch, shape, B, mb):
+    torch.manual_seed(2024)
+    big = make_trainer(arch, True, shape, 512, 64, 512, B, amp=True)
+    acc = make_trainer(arch, True, shape, 512, 64, 512, mb, amp=True, n_acc=B // mb)
+    acc.G.load_state_dict(big.G.state_dict())
+    acc.D.load_state_dict(big.D.state_dict())
+    acc.G_ema.load_state_dict(big.G_ema.state_dict())
+    return big, acc
+
+
+@pytest.mark.parametrize("arch,shape,B", [("dusty2", (128, 2048), 64), ("none", (64, 1024), 64)],
+                         ids=["config5-share-128x2048-b64", "64x1024-b64"])
+def test_large_batch_plan_equals_accumulated_micro_batches(arch, shape, B):
+    from dusty_gan_amd import engine as E
+    mb = 4
+    H, W = shape
+    big, acc = _pair(arch, shape, B, mb)
+    x, rand = _rand(B, 512, H, W, arch, seed=11)
+    xd, md = x.to(DEV), torch.ones(B, 1, H, W, device=DEV)
+    E.WGRAD_WS.hwm = E.WGRAD_WS.early_flushes = E.WGRAD_WS.refused = 0
+    E.TRACE = []
+    try:
+        big.optimize_D(reals=[(xd, md)], rands=[rand])
+        tr_big = list(E.TRACE)
+    finally:
+        E.TRACE = None
+    # the B = 64 plan really is a different one: persistent conv with several tiles per workgroup, split-K workspace in use
+    pc = [t for t in tr_big if t[0] == "conv" and t[1] == 5]
+    assert pc and max(t[6] for t in pc) >= 8, pc
+    assert any(t[0] == "wgrad" and t[1] == 5 and t[5] for t in tr_big)
+    chunks = [slice(k * mb, (k + 1) * mb) for k in range(B // mb)]
+    acc.optimize_D(reals=[(xd[c].contiguous(), md[c]) for c in chunks], rands=[_slice(rand, c) for c in chunks])
+    # (i) per-sample results do not depend on the batch they were computed in
+    sb, sa = big._mb[0]["synth"], acc._mb[0]["synth"]
+    for k in sa:
+        a, b = sa[k].float().cpu(), sb[k][:mb].float().cpu()
+        if k == "mask":
+            assert (a != b).float().mean() < 1e-3, k
+        else:
+            assert rel_l2(b, a) < 2e-3, (k, rel_l2(b, a))
+    # (ii) gradients: one launch over 64 (3 x 64 for D's merged R1 launches) samples == 16 launches over 4, summed
+    gb, ga = grads_by_name(big.optim_D), grads_by_name(acc.optim_D)
+    for k in gb:
+        if float(gb[k].abs().max()) > 0:
+            assert rel_l2(ga[k], gb[k]) < 2e-2 and _cos(ga[k], gb[k]) > 0.9995, ("D", k, rel_l2(ga[k], gb[k]))
+    big.optimize_G()
+    acc.optimize_G()
+    gb, ga = grads_by_name(big.optim_G), grads_by_name(acc.optim_G)
+    for k in gb:
+        if float(gb[k].abs().max()) > 0:
+            # (G's gradients pass through the UPDATED discriminators, which differ by the rounding of the D step)
+            assert rel_l2(ga[k], gb[k]) < 8e-2 and _cos(ga[k], gb[k]) > 0.995, ("G", k, rel_l2(ga[k], gb[k]))
+    # (iv) the split-K workspace at this size: below capacity, no reduce forced early, nothing pushed to atomics
+    ws = E.WGRAD_WS
+    assert 0 < ws.hwm < ws.FLOATS and ws.early_flushes == 0 and ws.refused == 0, (ws.hwm, ws.FLOATS, ws.early_flushes, ws.refused)
+    print(f"{arch} {shape} B={B}: WGRAD_WS high-water mark {4 * ws.hwm / 2**20:.0f} MB of {4 * ws.FLOATS / 2**20:.0f} MB")
+
+
+@pytest.mark.parametrize("floats,what", [(24 << 20, "early reduce"), (1 << 20, "atomics")])
+def test_split_k_workspace_overflow_paths_give_the_same_gradients(monkeypatch, floats, what):
+    """WGRAD_WS made too small for the step at 64x1024, B = 32: 96 MB forces reduces in mid-phase (`take` flushes when the
+    next request does not fit), 4 MB is smaller than any fat layer's request (`take` -> None -> the launch adds its split-K
+    partials onto dW with fp32 atomics).  Either way the gradients must equal the normal run's."""
+    from dusty_gan_amd import engine as E
+    H, W, B = 64, 1024, 32
+    x, rand = _rand(B, 512, H, W, "none", seed=5)
+    xd, md = x.to(DEV), torch.ones(B, 1, H, W, device=DEV)
+
+    def run(n):
+        monkeypatch.setattr(E.WgradWorkspace, "FLOATS", n)
+        E.WGRAD_WS.hwm = E.WGRAD_WS.early_flushes = E.WGRAD_WS.refused = 0
+        torch.manual_seed(2025)
+        tr = make_trainer("none", True, (H, W), 512, 64, 512, B, amp=True)
+        tr.optimize_D(reals=[(xd, md)], rands=[rand])
+        gD = grads_by_name(tr.optim_D)
+        tr.optimize_G()
+        return gD, grads_by_name(tr.optim_G), (E.WGRAD_WS.early_flushes, E.WGRAD_WS.refused)
+    gD0, gG0, st0 = run(96 << 20)
+    gD1, gG1, st1 = run(floats)
+    assert st0 == (0, 0)
+    assert (st1[0] > 0) if what == "early reduce" else (st1[1] > 0), st1
+    for k in gD0:
+        if float(gD0[k].abs().max()) > 0:
+            assert rel_l2(gD1[k], gD0[k]) < 1e-4, ("D", k, rel_l2(gD1[k], gD0[k]))
+    for k in gG0:
+        if float(gG0[k].abs().max()) > 0:
+            assert rel_l2(gG1[k], gG0[k]) < 2e-2 and _cos(gG1[k], gG0[k]) > 0.999, ("G", k, rel_l2(gG1[k], gG0[k]))
+
+
+def test_bf16_training_tracks_fp32_over_50_steps(monkeypatch):
+    """The timed mode's TRAINING, not one step: the same mid-size net (64x512, 64..256 channels, B = 16,
+    R1 + DiffAugment on, device RNG with the same seeds) trained 50 steps in the fp32 parity mode and in the bf16 mode.
+    GAN training amplifies rounding differences, so the two runs are compared as loss CURVES: per logged scalar, the mean
+    over steps 1-10, 11-30 and 31-50 must agree within the stated band, and both runs must stay finite and keep the
+    discriminator's outputs separated the same way."""
+    def run(amp):
+        torch.manual_seed(31)
+        tr = make_trainer("dusty2", True, (64, 512), 128, 64, 256, 16, amp=amp)
+        return [dict(tr.step(i).items()) for i in range(50)]
+    a, b = run(False), run(True)
+    keys = list(a[0].keys())
+    worst = {}
+    for lo, hi in ((0, 10), (10, 30), (30, 50)):
+        for k in keys:
+            ma = sum(s[k] for s in a[lo:hi]) / (hi - lo)
+            mb_ = sum(s[k] for s in b[lo:hi]) / (hi - lo)
+            assert ma == ma and mb_ == mb_, (k, lo, hi)
+            dev = abs(ma - mb_) / max(1.0, abs(ma))
+            worst[k] = max(worst.get(k, 0.0), dev)
+            # band: 0.25 of max(1, |fp32 mean|) on every window (measured: see the printed line; a mis-scaled layer or a
+            # broken optimizer moves these means by O(1) within ten steps)
+            assert dev < 0.25, (k, lo, hi, ma, mb_)
+    print("bf16 vs fp32 over 50 steps, worst window deviation per scalar:", {k: round(v, 4) for k, v in worst.items()})

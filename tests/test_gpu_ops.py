@@ -36,10 +36,20 @@ def from_nhwc(flat, B, C_, H, W):
     return flat.view(B, H, W, C_).permute(0, 3, 1, 2).contiguous()
 
 
+def pack_bits(t):
+    """1 bit per element, bit e % 8 of byte e / 8 = (element e > 0): the layout of DgConv.mask_out / mask_in"""
+    b = (t.float().reshape(-1, 8) > 0).to(torch.int32)
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=t.device)
+    return (b * w).sum(dim=1).to(torch.uint8)
+
+
 def run_conv(L, mode, adj, ring, x, wpacked_nk, N, scale, epi, dtype, force, bias=None, aux=None, want_db=False,
              rowscale=None):
-    """x [B,K,Hin,Win] torch cpu; wpacked_nk [16][N][K]; returns out [B,N,Ho,Wo] float cpu (+ dbias)"""
-    from dusty_gan_amd.engine import Ops
+    """x [B,K,Hin,Win] torch cpu; wpacked_nk [16][N][K]; returns out [B,N,Ho,Wo] float cpu (+ dbias).
+    bf16 feature maps with >= 16 channels also go through the saved 1-bit masks (DgConv.mask_out / mask_in), whatever kernel
+    `force` puts them on: an EPI_LRELU launch must leave exactly the bits of (out > 0), and an EPI_MASK launch must give the
+    SAME bytes from the bits of `aux` as from `aux` itself."""
+    from dusty_gan_amd.engine import MaskBits, Ops
     o = Ops(dtype)
     o.force = force
     B, K, Hin, Win = x.shape
@@ -54,10 +64,30 @@ def run_conv(L, mode, adj, ring, x, wpacked_nk, N, scale, epi, dtype, force, bia
     biasd = None if bias is None else bias.to(DEV, torch.float32)
     db = torch.zeros(N, device=DEV) if want_db else None
     rs = None if rowscale is None else rowscale.to(DEV, torch.float32)
-    o.conv(mode, adj, ring, B, Hc, Wc, K, N, xd, (Hin * Win * K, K, 1), out, (Ho * Wo * N, N, 1), wd.data_ptr(), scale,
-           epi, bias=None if biasd is None else biasd.data_ptr(), bias_mod=N, aux=auxd,
-           dbias=None if db is None else db.data_ptr(), rowscale=rs)
-    torch.cuda.synchronize()
+    use_bits = dtype == torch.bfloat16 and N % 16 == 0 and MaskBits.enabled
+    obits = None
+    if use_bits and epi == L.EPI_LRELU:
+        obits = MaskBits.register(out)
+        obits.fill_(0xA5)
+    if use_bits and epi == L.EPI_MASK:
+        auxd._dg_bits = pack_bits(auxd)
+
+    def launch(dst, dbp):
+        o.conv(mode, adj, ring, B, Hc, Wc, K, N, xd, (Hin * Win * K, K, 1), dst, (Ho * Wo * N, N, 1), wd.data_ptr(), scale,
+               epi, bias=None if biasd is None else biasd.data_ptr(), bias_mod=N, aux=auxd,
+               dbias=None if dbp is None else dbp.data_ptr(), rowscale=rs)
+        torch.cuda.synchronize()
+    launch(out, db)
+    if obits is not None:
+        assert torch.equal(obits, pack_bits(out)), "mask_out differs from (out > 0)"
+    if use_bits and epi == L.EPI_MASK:   # the same launch from the saved activation itself: bit-identical
+        del auxd._dg_bits
+        out2 = torch.empty_like(out)
+        db2 = None if db is None else torch.zeros_like(db)
+        launch(out2, db2)
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "mask_in and aux give different outputs"
+        if db is not None:
+            assert rel_l2(db.cpu(), db2.cpu()) < 1e-5   # (atomic adds: the order of the partial sums differs run to run)
     res = from_nhwc(out.float().cpu(), B, N, Ho, Wo)
     return (res, db.cpu()) if want_db else res
 

@@ -43,9 +43,14 @@ def test_down1_thin(L, dtype, Hc, Wc, B):
     coci = w.permute(2, 3, 0, 1).contiguous().to(DEV, dtype)  # [tap][co][ci] shadow
     out = torch.empty(B * Hc * Wc * Co, device=DEV, dtype=dtype)
     bd = b.to(DEV)
+    from dusty_gan_amd.engine import MaskBits
+    from tests.test_gpu_ops import pack_bits
+    obits = MaskBits.register(out)               # bf16: the launch also leaves the saved 1-bit leaky-relu mask (DgConv.mask_out)
     o.conv(L.MODE_S2, 0, True, B, Hc, Wc, Ci, Co, xd, (4 * Hc * Wc * Ci, Ci, 1), out, (Hc * Wc * Co, Co, 1),
            coci.data_ptr(), s, L.EPI_LRELU, bias=bd.data_ptr(), bias_mod=Co)
     torch.cuda.synchronize()
+    if obits is not None:
+        assert torch.equal(obits, pack_bits(out)), "mask_out differs from (out > 0)"
     assert rel_l2(from_nhwc(out.float().cpu(), B, Co, Hc, Wc), y) < tol
     # backward-data (MODE_UP adjoint, N = 2) straight from the fp32 master weights
     y32 = O.down(xr, wr, br, True)
@@ -175,6 +180,16 @@ def test_head_bwd_data_pixel_major_mfma(L, nh, Hc, Wc):
     torch.cuda.synchronize()
     assert rel_l2(from_nhwc(dp.float().cpu(), B, C0, Hc, Wc), ref) < 1e-2
     assert rel_l2(db.cpu(), ref.sum(dim=[0, 2, 3])) < 2e-2
+    if dtype == torch.bfloat16:   # the same launch from the saved 1-bit mask of `prev` (DgConv.mask_in): identical bytes
+        from tests.test_gpu_ops import pack_bits
+        prevd._dg_bits = pack_bits(prevd)
+        dp_b, db_b = torch.empty_like(dp), torch.zeros_like(db)
+        o.conv(L.MODE_S2, 1, True, B, Hc, Wc, nh, C0, draw_pm, (HW * cp, cp, 1), dp_b, (Hc * Wc * C0, C0, 1),
+               shadow.data_ptr(), 1.0, L.EPI_MASK, aux=prevd, dbias=db_b.data_ptr(), bias_mod=C0)
+        torch.cuda.synchronize()
+        del prevd._dg_bits
+        assert torch.equal(dp.view(torch.int16), dp_b.view(torch.int16))
+        assert rel_l2(db.cpu(), db_b.cpu()) < 1e-4   # (atomic adds: the order of the block sums differs run to run)
     scratch = Ops._dbias_ws[str(draw_pm.device)]
     assert float(scratch.abs().max()) == 0.0
     # a second launch adds onto db again (accumulating entry point): twice the sums, scratch zero again

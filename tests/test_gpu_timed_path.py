@@ -58,7 +58,9 @@ def test_persistent_conv_several_tiles_per_workgroup(monkeypatch, trace, which, 
     fn = OPS.test_down_fwd_bwd_wgrad if which == "down" else OPS.test_up_fwd_bwd_wgrad
     fn(L, Ci, Co, H, W, B, True, dtype, family)
     pc = [t for t in trace if t[0] == "conv" and t[1] == family]   # dg_conv force 4 / 5 -> plan family 4 / 5
-    assert len(pc) == 2, trace                      # forward + backward-data both on the persistent kernel
+    # forward + backward-data both on the persistent kernel (bf16: run_conv repeats the backward-data launch without the
+    # saved mask bits to compare the two forms)
+    assert len(pc) == (3 if dtype == torch.bfloat16 else 2), trace
     for t in pc:
         assert t[5] <= cap and t[6] >= 4, t         # workgroups <= cap, >= 4 tiles per workgroup
 
