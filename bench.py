@@ -23,7 +23,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  fp32x3: fp32 operands split into bf16 hi + lo, two
+# v_mfma_f32_32x32x16_bf16 per 4 k of an fp32 fragment (8 of their 32 k-slots carry distinct products... 4 useful k per 2 x 16):
+# 1/8 of the bf16 rate in fp32-equivalent FLOPs
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 312.5}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -32,7 +35,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp32", "fp32x3"], default="bf16",
+                    help="bf16: the timed mode; fp32: exact parity mode; fp32x3: fp32 storage, split-bf16 matrix instructions")
     ap.add_argument("--arch", choices=["none", "dusty1", "dusty2"], default=None,
                     help="default: BASELINE configs[1] (dcgan_eqlr baseline) at N=1, configs[3] (dusty2) at N>1")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
@@ -65,6 +69,7 @@ def make_trainer(args, rank, local_rank, world):
         ov.append("solver.augment=[]")
     cfg = load_config(ov)
     torch.manual_seed(1234 + rank)
+    os.environ["DUSTY_GAN_FP32_SPLIT"] = "1" if args.precision == "fp32x3" else "0"   # (read by the Trainer's constructor)
     tr = Trainer(cfg, {"gpu": local_rank, "ngpus": world, "batch_size": args.batch, "num_workers": 0})
     return tr, arch
 
@@ -216,11 +221,13 @@ def other_config_lines(args):
     an out-of-memory kill or a hang in an appended configuration costs its own entry, never the headline record."""
     import subprocess
     out = {}
-    for tag, arch, shape, batch in (("config3_dusty1_64x1024_b32", "dusty1", [64, 1024], 32),
-                                    ("config4_share_dusty2_64x1024_b32", "dusty2", [64, 1024], 32),
-                                    ("config5_share_dusty2_128x2048_b64", "dusty2", [128, 2048], 64)):
+    for tag, arch, shape, batch, prec in (("config3_dusty1_64x1024_b32", "dusty1", [64, 1024], 32, args.precision),
+                                          ("config4_share_dusty2_64x1024_b32", "dusty2", [64, 1024], 32, args.precision),
+                                          ("config5_share_dusty2_128x2048_b64", "dusty2", [128, 2048], 64, args.precision),
+                                          # the headline workload in the fast parity mode (<= 1e-3 tolerance class)
+                                          ("config2_none_64x1024_b32_fp32x3", "none", [64, 1024], 32, "fp32x3")):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--arch", arch, "--shape", str(shape[0]), str(shape[1]),
-               "--batch", str(batch), "--steps", str(args.other_steps), "--warmup", "5", "--precision", args.precision,
+               "--batch", str(batch), "--steps", str(args.other_steps), "--warmup", "5", "--precision", prec,
                "--gp", str(args.gp), "--pl", str(args.pl), "--no-roofline", "--no-cpu-baseline", "--no-other-configs"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
         try:
@@ -419,7 +426,10 @@ def main():
             "bf16 storage, fp32 accumulate: outputs <= 5e-3, losses <= 2e-3, D gradients <= 2.5e-2 and G gradients <= 8e-2 "
             "rel-L2 against the bf16-emulating oracle (measured 1.1e-3 / 8e-5 / 1.3e-2 / 5.3e-2); the <= 1e-3 north-star "
             "tolerance is met by --precision fp32 (tests/test_gpu_configs.py)"
-            if args.precision == "bf16" else "fp32 parity mode: <= 1e-3 against the oracle / reference fixtures")
+            if args.precision == "bf16" else
+            ("fp32x3: fp32 storage, operands split into bf16 hi + lo on the bf16 matrix instructions, fp32 accumulation: held to "
+             "the fp32 mode's bounds against the reference digests at full width (tests/test_gpu_configs.py)"
+             if args.precision == "fp32x3" else "fp32 parity mode: <= 1e-3 against the oracle / reference fixtures"))
     if (rank == 0 and world == 1 and not args.no_other_configs and args.arch is None and args.shape == [64, 1024]
             and args.batch == 32 and args.precision == "bf16" and args.pl == 0.0 and args.gp == 1.0 and not args.no_augment):
         del tr

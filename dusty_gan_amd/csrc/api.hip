@@ -20,9 +20,17 @@ int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream);
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_thin_supported(const WgradP* p);
 
+int g_dg_fp32_split = 0;   // dg_set_fp32_split: fp32 operands through split-bf16 matrix instructions (mfma_common.h)
+
 extern "C" {
 
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
+
+int dg_set_fp32_split(int on) {
+  const int prev = g_dg_fp32_split;
+  g_dg_fp32_split = on ? 1 : 0;
+  return prev;
+}
 
 // force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
 //        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error (9: without its

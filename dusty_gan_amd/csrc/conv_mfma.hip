@@ -28,8 +28,11 @@
 #define DG_CONV_SETPRIO 1
 #endif
 
-template <typename T, int BM, int BN, int SB, int NS>
+// X3 (T = float only): the fp32x3 form - fp32 storage and LDS images, operands split into bf16 hi / lo in registers, bf16
+// matrix instructions (mfma_common.h)
+template <typename T, int BM, int BN, int SB, int NS, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n, int tiles_x, int dbg) {
+  static_assert(!X3 || sizeof(T) == 4, "fp32x3: fp32 operands");
   // SB = bytes of K per row per pipeline stage (64 or 128), NS = LDS stages (prefetch distance NS-1)
   constexpr int ES = sizeof(T);
   constexpr bool PRIO = DG_CONV_SETPRIO;
@@ -185,11 +188,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n,
       }
       __builtin_amdgcn_sched_barrier(0);
       if (PRIO && !(dbg & 8)) __builtin_amdgcn_s_setprio(1);
+      if constexpr (X3) {
+        SplitA sa[TM];
+        SplitB sb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) sa[i] = split_a(__builtin_bit_cast(f32x4, fa[ks & 1][i]));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          mma_tile((const T*)nullptr, fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) sb[j] = split_b(__builtin_bit_cast(f32x4, fb[ks & 1][j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_tile_x3(sa[i], sb[j], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            mma_tile((const T*)nullptr, fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      }
       if (PRIO && !(dbg & 8)) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n,
   }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool X3 = false>
 static int launch_cfg(const ConvP* p, hipStream_t stream, DgConvPlan* plan) {
   const int tiles_n = (p->N + BN - 1) / BN;
   int tiles_x = 1;
@@ -340,7 +356,7 @@ static int launch_cfg(const ConvP* p, hipStream_t stream, DgConvPlan* plan) {
     return DG_OK;
   }
   // 128-byte stages x 2 (64-byte stages x 3 / x 4 measured slower on every layer and are not instantiated)
-  conv_mfma_kernel<T, BM, BN, 128, 2><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, 0);
+  conv_mfma_kernel<T, BM, BN, 128, 2, X3><<<(unsigned)nwg, 256, 0, stream>>>(*p, tiles_n, tiles_x, 0);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -374,13 +390,20 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
     const int rc = dg_conv_mfma_pp_launch(p, stream, 256, wg_cap, plan, 1);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
-  {
+  const bool x3 = p->in_dtype == DG_F32 && g_dg_fp32_split;
+  if (!x3) {   // (fp32x3: the one-tile-per-workgroup kernel below - the lock-step persistent fp32 kernel sits at 256 VGPRs)
     const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 1, wg_cap, plan)
                                           : dg_conv_mfma_persist_launch_f32(p, stream, 1, wg_cap, plan);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
   const bool m128 = p->mode == MODE_GEMM ? false : (p->Wc % 128 == 0);
   const bool n128 = p->N % 128 == 0;
+  if (x3) {
+    if (m128 && n128) return launch_cfg<float, 128, 128, true>(p, stream, plan);
+    if (m128) return launch_cfg<float, 128, 64, true>(p, stream, plan);
+    if (n128) return launch_cfg<float, 64, 128, true>(p, stream, plan);
+    return launch_cfg<float, 64, 64, true>(p, stream, plan);
+  }
   if (p->in_dtype == DG_BF16) {
     if (m128 && n128) return launch_cfg<bf16, 128, 128>(p, stream, plan);
     if (m128) return launch_cfg<bf16, 128, 64>(p, stream, plan);

@@ -11,7 +11,7 @@
 //     full-rate shape), or stored when there is a single split and nothing to accumulate onto.
 //   * the per-sample weight (dy_b for the real batch) costs no second accumulator set: the running sum is
 //     kept divided by the current sample's weight and rescaled by rs_old / rs_new when the sample changes.
-#include "common.h"
+#include "mfma_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -21,8 +21,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define BKP_OF(es) ((es) == 2 ? 64 : 32)
 
 // AdamEpi (common.h): optional optimizer epilogue, ADAM = true (Proj.weight in data-parallel runs)
-template <typename T, int BM, int BN, bool ADAM = false>
+// X3 (T = float only): fp32x3 - fp32 tiles in LDS, operands split into bf16 hi / lo in registers (mfma_common.h)
+template <typename T, int BM, int BN, bool ADAM = false, bool X3 = false>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, int accumulate, AdamEpi ad = AdamEpi{}) {
+  static_assert(!X3 || sizeof(T) == 4, "fp32x3: fp32 operands");
   constexpr int ES = sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int BKP = BKP_OF(ES);
@@ -159,6 +161,31 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);
         }
+      } else if constexpr (X3) {
+        // four pixel-row pairs per step: this lane's rows 2 (k8 + m) + lh, m = 0..3, are the 4 k values of its fragments
+#pragma unroll 2
+        for (int k8 = 0; k8 < BKP / 2; k8 += 4) {
+          SplitA sa[TM];
+          SplitB sg[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            f32x4 f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) f[m] = *(const float*)(ldsA + (2 * (k8 + m) + lh) * RSA + (wm * (BM / 2) + i * 32 + lr) * 4);
+            sa[i] = split_a(f);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            f32x4 f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) f[m] = *(const float*)(ldsG + (2 * (k8 + m) + lh) * RSG + (wn * (BN / 2) + j * 32 + lr) * 4);
+            sg[j] = split_b(f);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma_tile_x3(sa[i], sg[j], acc[i][j]);
+        }
       } else {
 #pragma unroll 4
         for (int k2 = 0; k2 < BKP / 2; ++k2) {
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
       }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool X3 = false>
 static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
   const int tiles_m = (p->Ci + BM - 1) / BM, tiles_n = (p->Co + BN - 1) / BN;
   const int ntap = p->wmode == 2 ? 1 : 16;
@@ -299,7 +326,7 @@ static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
     if (split < 1) split = 1;
   }
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ntap, (unsigned)split);
-  wgrad_mfma_kernel<T, BM, BN><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+  wgrad_mfma_kernel<T, BM, BN, false, X3><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -337,6 +364,12 @@ int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream) {
     if (m128) return launch_cfg<bf16, 128, 64>(p, accumulate, stream);
     if (n128) return launch_cfg<bf16, 64, 128>(p, accumulate, stream);
     return launch_cfg<bf16, 64, 64>(p, accumulate, stream);
+  }
+  if (g_dg_fp32_split) {
+    if (m128 && n128) return launch_cfg<float, 128, 128, true>(p, accumulate, stream);
+    if (m128) return launch_cfg<float, 128, 64, true>(p, accumulate, stream);
+    if (n128) return launch_cfg<float, 64, 128, true>(p, accumulate, stream);
+    return launch_cfg<float, 64, 64, true>(p, accumulate, stream);
   }
   if (m128 && n128) return launch_cfg<float, 128, 128>(p, accumulate, stream);
   if (m128) return launch_cfg<float, 128, 64>(p, accumulate, stream);

@@ -243,25 +243,36 @@ class WgradWorkspace:
     (8x dW's bytes per launch: VERDICT r02).  A bump allocator over one caller-owned buffer; the reduce is deferred to
     the point where the gradient is first needed (before an exchange / the optimizer), so one launch serves a whole
     network.  Fixed summation order: the gradients are bit-reproducible."""
-    FLOATS = 96 << 20   # 384 MB: D's three fat layers at 3B rows + G's three (80 MB each) with room for the path-length terms
+    FLOATS = 96 << 20   # cap, 384 MB: D's three fat layers at 3B rows + G's three (80 MB each) with room for the path-length terms
+    START = 4 << 20     # first allocation (16 MB): tiny nets never need more; the buffer doubles up to the cap on demand
 
     def __init__(self):
         self.buf, self.pos, self.items = None, 0, []
         # what the tests of the large-batch plans read: the most floats ever pending, reduces forced by a full buffer,
-        # requests larger than the whole buffer (those launches fall back to fp32 atomics onto dW)
+        # requests larger than the cap (those launches fall back to fp32 atomics onto dW)
         self.hwm, self.early_flushes, self.refused = 0, 0, 0
 
     def take(self, nfloats, device):
-        if self.buf is None or self.buf.device != device or self.buf.numel() != self.FLOATS:
-            self.flush()
-            self.buf = torch.empty(self.FLOATS, dtype=torch.float32, device=device)
-            self.pos = 0
         if nfloats > self.FLOATS:
             self.refused += 1
             return None
-        if self.pos + nfloats > self.FLOATS:
-            self.early_flushes += 1
-            self.flush()        # (stream order: the reduce has read the partials before the next launch overwrites them)
+        if self.buf is not None and (self.buf.device != device or self.buf.numel() > self.FLOATS):
+            self.flush()
+            self.buf = None
+        need = self.pos + nfloats
+        if self.buf is None or need > self.buf.numel():
+            size = self.START if self.buf is None else self.buf.numel()
+            while size < min(need, self.FLOATS):
+                size *= 2
+            size = min(size, self.FLOATS)
+            if self.buf is None or size > self.buf.numel():
+                # grow: the pending partials are summed first (stream order keeps the old buffer alive until that reduce has
+                # run: the caching allocator hands its memory out again only to later work of this stream)
+                self.flush()
+                self.buf = torch.empty(size, dtype=torch.float32, device=device)
+            if self.pos + nfloats > self.buf.numel():   # at the cap and still full: reduce early, start over
+                self.early_flushes += 1
+                self.flush()    # (stream order: the reduce has read the partials before the next launch overwrites them)
         off = self.pos
         self.pos = (off + nfloats + 63) // 64 * 64
         self.hwm = max(self.hwm, self.pos)
@@ -299,7 +310,33 @@ class WgradWorkspace:
             PROFILE.append(("wgrad_reduce_kernel", 0.0, nbytes, e0, e1, f"{len(chunk)} layers"))
 
 
-WGRAD_WS = WgradWorkspace()
+class _PerStreamWorkspace:
+    """`engine.WGRAD_WS`: one WgradWorkspace per (device, HIP stream).  Launches of one stream are ordered, so engines that
+    share a stream may share the bump allocator (a reduce always precedes the reuse of its partials); engines on DIFFERENT
+    streams - a second trainer, a validation model on a side stream - get buffers of their own instead of interleaving
+    allocations in one (round-3 review: a process-global singleton)."""
+
+    def __init__(self):
+        self._by_stream = {}
+
+    def _cur(self):
+        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else (-1, 0)
+        ws = self._by_stream.get(key)
+        if ws is None:
+            ws = self._by_stream[key] = WgradWorkspace()
+        return ws
+
+    def __getattr__(self, name):          # take / add / flush / items / pos / hwm ... of the current stream's workspace
+        return getattr(self._cur(), name)
+
+    def __setattr__(self, name, value):
+        if name == "_by_stream":
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self._cur(), name, value)
+
+
+WGRAD_WS = _PerStreamWorkspace()
 
 
 class MaskBits:

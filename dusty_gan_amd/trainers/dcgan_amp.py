@@ -14,6 +14,7 @@ What differs underneath:
   * scalars are gathered with ONE packed all-reduce and read back lazily.
 """
 import math
+import os
 import os.path as osp
 from collections import OrderedDict
 from collections.abc import Mapping
@@ -316,6 +317,11 @@ class Trainer:
         self.optim_G = FlatAdam(self.G, self.cfg.solver.lr.alpha.gen, betas)
         self.optim_D = FlatAdam(self.D, self.cfg.solver.lr.alpha.dis, betas)
         self.enable_amp = bool(cfg.enable_amp)
+        # fp32x3 (DUSTY_GAN_FP32_SPLIT=1 with enable_amp: false): fp32 storage everywhere, the fat layers' contractions on the
+        # bf16 matrix instructions with each operand split into bf16 hi + lo (dg_set_fp32_split; process-wide, so every
+        # trainer construction sets it to what ITS configuration asks for)
+        self.fp32_split = (not self.enable_amp) and os.environ.get("DUSTY_GAN_FP32_SPLIT", "0") == "1"
+        L.lib().dg_set_fp32_split(int(self.fp32_split))
 
         # resume (reference :134-144)
         self.start_iteration = 0
@@ -346,7 +352,6 @@ class Trainer:
         # (RingSlot); DUSTY_GAN_SCALAR_RING=0: a device copy + a blocking read-back per step instead
         self._snap_ring, self._snap_ctr, self._snap_pos = None, None, 0
         # hipGraph replay of the step (single GPU, synthetic device-resident data); DUSTY_GAN_GRAPH=0 disables it
-        import os
         self.use_graph = os.environ.get("DUSTY_GAN_GRAPH", "1") != "0"
         self._graph, self._eager_steps = None, 0
         self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
@@ -436,18 +441,22 @@ class Trainer:
         """the loader is the device-resident synthetic pool and its batches can be picked by a device-side index"""
         ds = getattr(self, "dataset", None)
         return (isinstance(ds, SyntheticLiDAR) and getattr(ds, "pool_depth", None) is not None
-                and (self.H * self.W) % 256 == 0 and self.n_acc == 1)
+                and (self.H * self.W) % 256 == 0)
 
-    def _fetch_reals_in_step(self, raw_batch, pooled=False):
+    def _fetch_reals_in_step(self, raw_batch, pooled=False, begin=True):
         """fetch_reals as the first launch of a step: the step's accumulator arena is opened first, so the per-sample sums
         the kernel produces beside x_real survive until DiffAugment reads them.  pooled: `raw_batch` is the batch the
         synthetic loader just yielded (number batches_drawn - 1); the kernel picks that same batch ON THE DEVICE from the
         pool by a counter the step advances (dg_fetch_reals_pool_sum), so a hipGraph replay needs no copy of it."""
-        self._begin_step(draw_B=self.local_batch)   # (a step that fetches its own batch also draws its own parameters)
+        if begin:   # (begin=False: a further micro-batch of an accumulated step - the arena is open, the draws follow per micro-batch)
+            self._begin_step(draw_B=self.local_batch)   # (a step that fetches its own batch also draws its own parameters)
         if pooled:
             ds = self.dataset
             if self._pool_ctr is None:
-                self._pool_ctr = torch.full((1,), self.batches_drawn - 1, dtype=torch.int64, device=self.device)
+                # (the batch this call fetches: the last one drawn, or - an accumulated step draws its num_accumulation batches
+                #  up front - the first of those)
+                first = self.batches_drawn - (getattr(self, "_drawn_ahead", 1) or 1)
+                self._pool_ctr = torch.full((1,), first, dtype=torch.int64, device=self.device)
             L.Counters.flush_if(self._pool_ctr)
             x = self.lidar.fetch_reals_pool(ds.pool_depth, ds.pool_mask, self._pool_ctr,
                                             float(self.cfg.model.gen.drop_const))
@@ -962,7 +971,14 @@ class Trainer:
             L.Counters.add(self._snap_ctr, 1)
             L.Counters.snapshot(self._snap_ctr, scal.data_ptr(), 8, self._snap_ring.data_ptr(), self.SCALAR_RING)
             L.Counters.ride = True
-            self.optimize_G()
+            try:
+                self.optimize_G()
+            except BaseException:
+                # (advisor, round 3) a generator phase that raises must not leave the ride armed: the NEXT step's first
+                # shadow refresh would file a snapshot of half-finished scalars and advance the device serial past the host's
+                L.Counters.ride, L.Counters.snap = False, None
+                L.Counters.pending.pop(self._snap_ctr.data_ptr(), None)
+                raise
             L.Counters.flush()  # (nothing left when the generator's refresh took them)
             return None if self._cap is not None else self._ring_slot()
         scal = self.optimize_G()
@@ -997,16 +1013,22 @@ class Trainer:
         # they are, and an advance still pending when the capture starts would be baked into the graph and re-added
         # on every replay
         L.Counters.flush()
+        pooled = self._pooled()
         batch = getattr(self, "_retry_batch", None)
         if batch is None:
-            batch = self._next_batch()
-        pooled = self._pooled()
+            # num_accumulation micro-batches per step (utils/context_manager.py:21-35): the host loader moves on by as many
+            # batches as the device-side pool index does inside the replay
+            batches = [self._next_batch() for _ in range(self.n_acc)]
+            self._drawn_ahead = self.n_acc
+            batch = batches[0] if self.n_acc == 1 else batches
+        mbs = batch if isinstance(batch, list) else [batch]
+
+        def fetch_all(srcs):   # every micro-batch's fetch_reals at the head of the step (the first one opens the arena)
+            return [self._fetch_reals_in_step(b, pooled, begin=(j == 0)) for j, b in enumerate(srcs)]
         if self._graph is None:
             if self._eager_steps < 2:  # warm-up: workspaces, shadows and counters must exist before the capture
                 self._eager_steps += 1
-                if self.n_acc != 1:
-                    return self._step_eager()
-                return self._step_eager(reals=[self._fetch_reals_in_step(batch, pooled)])
+                return self._step_eager(reals=fetch_all(mbs))
             if not pooled:  # any other fixed-shape device loader: the replay reads static copies of the batch
                 self._g_pol = batch["depth"].to(self.device).clone()
                 self._g_mask = batch["mask"].to(self.device).clone()
@@ -1018,8 +1040,8 @@ class Trainer:
             counts = (self.optim_D.step_count, self.optim_G.step_count)
             try:
                 self._cap_open()
-                src = batch if pooled else {"depth": self._g_pol, "mask": self._g_mask}
-                self._g_out = self._step_eager(reals=[self._fetch_reals_in_step(src, pooled)])
+                src = mbs if pooled else [{"depth": self._g_pol, "mask": self._g_mask}]
+                self._g_out = self._step_eager(reals=fetch_all(src))
                 self._cap_close()
                 self._comm_captured = self._comm_in_graph
             except BaseException as exc:
@@ -1053,7 +1075,7 @@ class Trainer:
                 self.optim_D.step_count, self.optim_G.step_count = counts
                 self.use_graph = False
                 self._mb = []
-                return self._step_eager(reals=[self._fetch_reals_in_step(batch, pooled)])
+                return self._step_eager(reals=fetch_all(mbs))
             self._graph, self._cap = self._cap, None
             # the capture did not execute anything, but the host mirrors of the Adam step counts advanced once
             self.optim_D.step_count -= 1
@@ -1083,7 +1105,7 @@ class Trainer:
 
     def step(self, i=0, reals=None, rands=None):
         """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""
-        if self._graph_eligible(reals, rands) and self.n_acc == 1:
+        if self._graph_eligible(reals, rands) and (self.n_acc == 1 or self._pooled()):
             out = self._step_graph()
         else:
             out = self._step_eager(reals, rands)
@@ -1200,6 +1222,7 @@ class Trainer:
         # the loader: same epoch, same position inside it
         n = int(st["batches_drawn"])
         self.batches_drawn = n
+        self._pool_ctr = None   # the device-side pool index is re-derived from batches_drawn at the next pooled fetch
         src = getattr(self, "dataset", None)
         from ..datasets.scans import ScanLoader
         inner = getattr(self, "_scan_loader", None)

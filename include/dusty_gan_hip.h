@@ -118,6 +118,13 @@ typedef struct DgWgrad {
  * with such tiles - the forced forms let parity tests run either family on small problems).
  */
 int dg_conv(const DgConv* p, int force, void* stream);
+/* "fp32x3" (precision contract: fp32 storage with fp32 or split-bf16 x 3 MFMA): process-wide switch for
+ * DG_F32 operands of dg_conv / dg_wgrad on the matrix-core kernels.  0 (default): exact fp32 products
+ * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate); 1: every operand is split into bf16 hi + lo in registers and a product
+ * is a_hi b_hi + a_lo b_hi + a_hi b_lo on the bf16 matrix instructions with fp32 accumulation (relative error ~2^-16 per
+ * product; the mode autocast-free fp32 training of trainers/dcgan_amp.py would want on this hardware).  Returns the
+ * previous setting. */
+int dg_set_fp32_split(int on);
 /* What a dg_conv call launches (introspection for the parity tests and the benchmark: which kernel family / tile ran,
  * and how many tiles each persistent workgroup walks).  family: 1 direct, 2 one-tile-per-workgroup MFMA, 3 thin,
  * 4 persistent large-tile MFMA (lock step: fp32, small layers), 5 persistent ping-pong MFMA (bf16 fat layers),

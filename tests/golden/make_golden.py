@@ -390,6 +390,44 @@ def make_lidar_golden():
     print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_kitti_golden():
+    """datasets/kitti.py:54-67 - KITTIOdometry.preprocess itself (input side).  The file imports
+    torchvision (absent here) for `transform`; `preprocess` is pure numpy, so the file is loaded by path with an empty
+    torchvision placeholder in sys.modules and only `preprocess` is called (the NEAREST resize of `transform` is
+    torchvision's, a third-party step the restatement replaces by F.interpolate(mode="nearest") - unpinned, as before).
+    Scans: random points plus every threshold case the masks decide on - zeros, |.| just below / at / above min_depth and
+    max_depth."""
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    kitti = _load(os.path.join(REF, "datasets", "kitti.py"), "ref_kitti")
+    import tempfile
+    rng = np.random.default_rng(2026)
+    d = {"meta/min_depth": np.array(0.9), "meta/max_depth": np.array(120.0), "meta/numpy": np.array(np.__version__)}
+    with tempfile.TemporaryDirectory() as tmp:
+        ds = kitti.KITTIOdometry(tmp, "val", shape=(8, 32), min_depth=0.9, max_depth=120.0)   # (no files: an empty datalist)
+        for k, (Hs, Ws, C) in enumerate([(16, 100, 3), (8, 64, 5), (32, 128, 4)]):
+            r = np.exp(rng.uniform(np.log(0.3), np.log(200.0), (Hs, Ws)))
+            dirs = rng.normal(size=(Hs, Ws, 3))
+            dirs /= np.linalg.norm(dirs, axis=2, keepdims=True)
+            xyz = (dirs * r[..., None]).astype(np.float32)
+            u = rng.random((Hs, Ws))
+            xyz[u < 0.05] = 0.0
+            xyz[(u > 0.05) & (u < 0.08)] = (0.9, 0.0, 0.0)            # |.| == min_depth -> invalid (strict >)
+            xyz[(u > 0.08) & (u < 0.11)] = (0.0, np.float32(0.9000001), 0.0)
+            xyz[(u > 0.11) & (u < 0.14)] = (120.0, 0.0, 0.0)          # |.| == max_depth -> invalid (strict <)
+            xyz[(u > 0.14) & (u < 0.17)] = (0.0, 0.0, np.float32(119.99999))
+            pts = np.concatenate([xyz, rng.random((Hs, Ws, C - 3)).astype(np.float32)], -1) if C > 3 else xyz
+            pts = pts.astype(np.float32)
+            out = ds.preprocess({"xyz": pts[..., :3].copy()})          # __getitem__ :79-85 up to transform
+            d[f"s{k}/points"] = pts
+            d[f"s{k}/depth"], d[f"s{k}/mask"], d[f"s{k}/xyz"] = out["depth"], out["mask"], out["xyz"]
+    path = os.path.join(HERE, "kitti_pre.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def make_metrics_golden():
     """utils/metrics/jsd.py (plain torch, importable) on seeded clouds: the occupancy-grid counters of both sets and the
     divergence.  Clouds live in the radius-0.5 ball like trainers/dcgan_amp.py:387 feeds them
@@ -645,6 +683,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["lidar"]:
         make_lidar_golden()
+        sys.exit(0)
+    if sys.argv[1:] == ["kitti"]:
+        make_kitti_golden()
         sys.exit(0)
     if sys.argv[1:] == ["gan_modes"]:  # only the fixtures added after the first set (the others stay byte-identical)
         make_gan_mode_goldens()

@@ -123,11 +123,22 @@ def test_timed_mode_gradients_tight_against_emulating_oracle(trace, arch):
     _check(res[0], tr, state, **BF16_EMU)
 
 
-def test_hip_path_matches_reference_at_full_width():
+@pytest.fixture(autouse=True)
+def _exact_fp32_afterwards():
+    yield
+    from dusty_gan_amd import _lib as L
+    L.lib().dg_set_fp32_split(0)   # (process-wide switch: whatever a test's trainer set, the next test starts exact)
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32", "fp32x3"])
+def test_hip_path_matches_reference_at_full_width(monkeypatch, x3):
     """The HIP fp32 path against what the REFERENCE's own modules computed at 64x1024 / 512 channels (dusty2, B = 2, one
     step): digests from tests/golden/full_dusty2.npz, inputs regenerated from its seed.  Outputs, logits, losses 1e-4;
     gradients 2e-2 on the digests (a unit within fp32 rounding of zero takes the other slope in the two
-    implementations - tests/test_gpu_step.py::test_step_fp32_vs_oracle_full_width_64x1024); updated parameters 1e-3."""
+    implementations - tests/test_gpu_step.py::test_step_fp32_vs_oracle_full_width_64x1024); updated parameters 1e-3.
+    fp32x3: the same bounds with the fat layers' contractions on the bf16 matrix instructions (operands split into bf16
+    hi + lo, dg_set_fp32_split) - the fast parity mode of `bench.py --precision fp32x3`."""
+    monkeypatch.setenv("DUSTY_GAN_FP32_SPLIT", "1" if x3 else "0")
     g = load("full_dusty2")
     if str(g["meta/torch"]) != torch.__version__:
         pytest.skip(f"fixture made with torch {g['meta/torch']}: the regenerated inputs need the same CPU generator")
@@ -136,6 +147,7 @@ def test_hip_path_matches_reference_at_full_width():
     tr = make_trainer(str(g["meta/arch"]), True, shape, int(g["meta/in_ch"]), int(g["meta/ch_base"]),
                       int(g["meta/ch_max"]), int(g["meta/B"]), amp=False)
     assert abs(tr.ema_decay - float(g["meta/ema_decay"])) < 1e-12
+    assert tr.fp32_split == x3
     tr.G.load_state_dict(G)
     tr.G_ema.load_state_dict(G)
     sync_D(tr, D)
@@ -159,7 +171,9 @@ def test_hip_path_matches_reference_at_full_width():
     for k, v in gD.items():
         check_digest(g, f"grad_D/{k}", v, 2e-2, "grad_D")
     for k, v in gG.items():
-        check_digest(g, f"grad_G/{k}", v, 2e-2, "grad_G")
+        # (fp32x3: a head bias gradient is ONE number, the sum of 131 072 signed per-pixel gradients that cancel to ~1e-3 of
+        #  their absolute sum; the split products' 2^-16 relative error shows there first - 3.7e-2 measured, held to 6e-2)
+        check_digest(g, f"grad_G/{k}", v, 6e-2 if (x3 and v.numel() <= 4) else 2e-2, "grad_G")
     for tag, net in (("G", tr.G), ("D", tr.D), ("G_ema", tr.G_ema)):
         for k, v in net.state_dict().items():
             if k == "drop_const" or k.endswith("kernel"):

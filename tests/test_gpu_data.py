@@ -56,6 +56,22 @@ def test_scan_to_polar_matches_oracle(Hs, Ws, C, H, W):
         scan_to_polar(torch.from_numpy(pts), (H, W), 0.9, 120.0)  # host tensor: no CPU fallback
 
 
+def test_scan_to_polar_matches_reference_kitti_preprocess():
+    """the HIP kernel (dg_scan_to_polar) against what the reference's own KITTIOdometry.preprocess returned
+    (tests/golden/kitti_pre.npz, datasets/kitti.py:54-67), at the scans' own size (the NEAREST resize is then the
+    identity): depth, mask and xyz bit-exact, including points exactly on the range limits."""
+    from dusty_gan_amd.datasets.scans import scan_to_polar
+    from tests.golden_util import load
+    g = load("kitti_pre")
+    for k in range(3):
+        pts = torch.from_numpy(g[f"s{k}/points"])[None].to(DEV)
+        Hs, Ws = pts.shape[1:3]
+        out = scan_to_polar(pts, (Hs, Ws), float(g["meta/min_depth"]), float(g["meta/max_depth"]), want_xyz=True)
+        assert torch.equal(out["mask"][0, 0].cpu() > 0, torch.from_numpy(g[f"s{k}/mask"])), k
+        assert torch.equal(out["depth"][0, 0].cpu(), torch.from_numpy(g[f"s{k}/depth"])), k
+        assert torch.equal(out["xyz"][0].cpu(), torch.from_numpy(g[f"s{k}/xyz"]).permute(2, 0, 1)), k
+
+
 def test_inv_to_xyz_and_postprocess_match_reference_golden(tmp_path):
     """Coordinate.inv_to_xyz / utils.postprocess against vectors from the reference's LiDAR class"""
     from dusty_gan_amd.utils.lidar import LiDAR, postprocess

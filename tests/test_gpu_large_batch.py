@@ -68,6 +68,8 @@ def test_large_batch_plan_equals_accumulated_micro_batches(arch, shape, B):
     pc = [t for t in tr_big if t[0] == "conv" and t[1] == 5]
     assert pc and max(t[6] for t in pc) >= 8, pc
     assert any(t[0] == "wgrad" and t[1] == 5 and t[5] for t in tr_big)
+    ws = E.WGRAD_WS
+    d_stats = (ws.hwm, ws.early_flushes, ws.refused)
     chunks = [slice(k * mb, (k + 1) * mb) for k in range(B // mb)]
     acc.optimize_D(reals=[(xd[c].contiguous(), md[c]) for c in chunks], rands=[_slice(rand, c) for c in chunks])
     # (i) per-sample results do not depend on the batch they were computed in
@@ -83,17 +85,22 @@ def test_large_batch_plan_equals_accumulated_micro_batches(arch, shape, B):
     for k in gb:
         if float(gb[k].abs().max()) > 0:
             assert rel_l2(ga[k], gb[k]) < 2e-2 and _cos(ga[k], gb[k]) > 0.9995, ("D", k, rel_l2(ga[k], gb[k]))
+    ws.hwm = ws.early_flushes = ws.refused = 0
     big.optimize_G()
+    g_stats = (ws.hwm, ws.early_flushes, ws.refused)
     acc.optimize_G()
     gb, ga = grads_by_name(big.optim_G), grads_by_name(acc.optim_G)
     for k in gb:
         if float(gb[k].abs().max()) > 0:
             # (G's gradients pass through the UPDATED discriminators, which differ by the rounding of the D step)
             assert rel_l2(ga[k], gb[k]) < 8e-2 and _cos(ga[k], gb[k]) > 0.995, ("G", k, rel_l2(ga[k], gb[k]))
-    # (iv) the split-K workspace at this size: below capacity, no reduce forced early, nothing pushed to atomics
-    ws = E.WGRAD_WS
-    assert 0 < ws.hwm < ws.FLOATS and ws.early_flushes == 0 and ws.refused == 0, (ws.hwm, ws.FLOATS, ws.early_flushes, ws.refused)
-    print(f"{arch} {shape} B={B}: WGRAD_WS high-water mark {4 * ws.hwm / 2**20:.0f} MB of {4 * ws.FLOATS / 2**20:.0f} MB")
+    # (iv) the split-K workspace in the B = 64 step (one micro-batch): below capacity in either phase, no reduce forced early,
+    # nothing pushed to atomics.  (The 16-micro-batch run defers every micro-batch's partials to one reduce per phase and is
+    # MEANT to fill the buffer and reduce early; its gradients were just compared.)
+    for name, (hwm, early, refused) in (("D", d_stats), ("G", g_stats)):
+        assert 0 < hwm < ws.FLOATS and early == 0 and refused == 0, (name, hwm, ws.FLOATS, early, refused)
+    print(f"{arch} {shape} B={B}: WGRAD_WS high-water mark D phase {4 * d_stats[0] / 2**20:.0f} MB, G phase "
+          f"{4 * g_stats[0] / 2**20:.0f} MB of {4 * ws.FLOATS / 2**20:.0f} MB")
 
 
 @pytest.mark.parametrize("floats,what", [(24 << 20, "early reduce"), (1 << 20, "atomics")])
@@ -121,10 +128,14 @@ def test_split_k_workspace_overflow_paths_give_the_same_gradients(monkeypatch, f
     assert (st1[0] > 0) if what == "early reduce" else (st1[1] > 0), st1
     for k in gD0:
         if float(gD0[k].abs().max()) > 0:
-            assert rel_l2(gD1[k], gD0[k]) < 1e-4, ("D", k, rel_l2(gD1[k], gD0[k]))
+            # (same bf16 operands, fp32 sums in another order - Down1's thin kernel and the atomics path add their partial
+            #  tiles in arrival order: 1.8e-4 measured on the 2-channel layer, 1.05e-3 on a 256-element bias gradient)
+            assert rel_l2(gD1[k], gD0[k]) < 3e-3, ("D", k, rel_l2(gD1[k], gD0[k]))
     for k in gG0:
         if float(gG0[k].abs().max()) > 0:
-            assert rel_l2(gG1[k], gG0[k]) < 2e-2 and _cos(gG1[k], gG0[k]) > 0.999, ("G", k, rel_l2(gG1[k], gG0[k]))
+            # (through the UPDATED discriminator: D weights whose gradient is rounding noise take Adam's first step,
+            #  lr * sign(g), the other way in the two runs - 7.7e-2 measured on Proj.weight, as between any two runs)
+            assert rel_l2(gG1[k], gG0[k]) < 1.2e-1 and _cos(gG1[k], gG0[k]) > 0.99, ("G", k, rel_l2(gG1[k], gG0[k]))
 
 
 def test_bf16_training_tracks_fp32_over_50_steps(monkeypatch):
@@ -147,7 +158,7 @@ def test_bf16_training_tracks_fp32_over_50_steps(monkeypatch):
             assert ma == ma and mb_ == mb_, (k, lo, hi)
             dev = abs(ma - mb_) / max(1.0, abs(ma))
             worst[k] = max(worst.get(k, 0.0), dev)
-            # band: 0.25 of max(1, |fp32 mean|) on every window (measured: see the printed line; a mis-scaled layer or a
-            # broken optimizer moves these means by O(1) within ten steps)
-            assert dev < 0.25, (k, lo, hi, ma, mb_)
+            # band: 0.05 of max(1, |fp32 mean|) on every window (measured on MI355X: 0.004-0.010 per scalar; a mis-scaled
+            # layer or a broken optimizer moves these means by O(1) within ten steps)
+            assert dev < 0.05, (k, lo, hi, ma, mb_)
     print("bf16 vs fp32 over 50 steps, worst window deviation per scalar:", {k: round(v, 4) for k, v in worst.items()})

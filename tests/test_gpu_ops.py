@@ -92,6 +92,21 @@ def run_conv(L, mode, adj, ring, x, wpacked_nk, N, scale, epi, dtype, force, bia
     return (res, db.cpu()) if want_db else res
 
 
+@pytest.mark.parametrize("which", ["down", "up"])
+@pytest.mark.parametrize("Ci,Co,H,W,B", [(64, 128, 4, 128, 2), (128, 64, 8, 64, 2), (256, 128, 4, 64, 3)])
+def test_fp32x3_matrix_core_kernels_match_the_fp32_reference(L, which, Ci, Co, H, W, B):
+    """dg_set_fp32_split(1): fp32 operands through split-bf16 matrix instructions (a = a_hi + a_lo in bf16, three of the four
+    partial products, fp32 accumulation) on the one-tile-per-workgroup conv and the register-staged weight-gradient
+    kernel - forward, backward-data and weight gradient of a Down / Up layer against the fp32 oracle at the FP32 tolerance
+    (1e-4; the dropped a_lo b_lo term is ~2^-16 of a product)."""
+    prev = L.lib().dg_set_fp32_split(1)
+    try:
+        fn = test_down_fwd_bwd_wgrad if which == "down" else test_up_fwd_bwd_wgrad
+        fn(L, Ci, Co, H, W, B, True, torch.float32, 2)
+    finally:
+        L.lib().dg_set_fp32_split(prev)
+
+
 def pack_down(w):  # Conv2d weight (Co,Ci,4,4) -> fwd [16][n=co][k=ci], bwd [16][n=ci][k=co]
     fwd = w.permute(2, 3, 0, 1).reshape(16, w.shape[0], w.shape[1])
     bwd = w.permute(2, 3, 1, 0).reshape(16, w.shape[1], w.shape[0])

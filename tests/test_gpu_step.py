@@ -277,6 +277,74 @@ def test_gradient_accumulation_equals_full_batch():
         assert rel_l2(g2[k], g1[k]) < 1e-4, k
 
 
+def test_gradient_accumulation_matches_the_oracle_on_the_full_batch():
+    """num_accumulation = 2 against the ORACLE (not only against the engine's own full-batch step): two micro-batches of
+    B / 2 must give the gradients, losses and updated parameters `O.train_step` gives on the B samples in one batch - the
+    reference's schedule (utils/context_manager.py:21-35 with loss / num_accumulation, trainers/dcgan_amp.py:234,308)."""
+    arch, shape, nz, cb, cm, B = "dusty2", (32, 64), 8, 4, 16, 4
+    torch.manual_seed(808)
+    tr = make_trainer(arch, True, shape, nz, cb, cm, B // 2, n_acc=2)
+    G, D = oracle_state(tr)
+    G_ema = {k: v.clone() for k, v in G.items()}
+    gen = torch.Generator().manual_seed(6)
+    H, W = shape
+    pol = torch.rand(B, 1, H, W, generator=gen)
+    mask = torch.rand(B, 1, H, W, generator=gen) > 0.15
+    pol = pol * mask
+    rand = {"z": torch.randn(B, nz, generator=gen),
+            "noise": {"pixel": O.logistic_noise(torch.rand(B, 1, H, W, generator=gen), torch.rand(B, 1, H, W, generator=gen)),
+                      "image": O.logistic_noise(torch.rand(B, 1, 1, 1, generator=gen), torch.rand(B, 1, 1, 1, generator=gen))},
+            "aug": [O.draw_augment_params(B, H, W, gen) for _ in range(4)]}
+    x_cpu, _ = O.fetch_reals(pol, mask)
+    cfg = O.StepConfig(arch=arch, ema_decay=tr.ema_decay)
+    sc_ref, ex = O.train_step(G, D, G_ema, O.new_optim_state(G), O.new_optim_state(D), 1, cfg, x_cpu, rand, return_grads=True)
+    h = B // 2
+
+    def half(s):
+        return {"z": rand["z"][s], "noise": {k: v[s] for k, v in rand["noise"].items()},
+                "aug": [{k: v[s] for k, v in rp.items()} for rp in rand["aug"]]}
+    reals = []
+    for s in (slice(0, h), slice(h, B)):
+        reals.append(tr.fetch_reals({"depth": pol[s], "mask": mask[s]}))
+    scal = tr.step(1, reals=reals, rands=[half(slice(0, h)), half(slice(h, B))])
+    for k, v in scal.items():
+        assert abs(v - sc_ref[k]) <= 1e-3 * max(1.0, abs(sc_ref[k])), (k, v, sc_ref[k])
+    gG = grads_by_name(tr.optim_G)
+    for k, v in ex["grad_G"].items():
+        assert rel_l2(gG[k], v) < 1e-3, ("grad_G", k, rel_l2(gG[k], v))
+    for tag, net, ref in (("G", tr.G, G), ("D", tr.D, D), ("G_ema", tr.G_ema, G_ema)):
+        sd = net.state_dict()
+        for k, v in ref.items():
+            if k.endswith("kernel"):
+                continue
+            assert rel_l2(sd[k].cpu(), v) < 1e-3, (tag, k, rel_l2(sd[k].cpu(), v))
+
+
+def test_accumulated_step_replays_from_a_graph(monkeypatch):
+    """num_accumulation = 2 on the device-resident synthetic pool: the whole accumulated step (both micro-batches' fetches,
+    draws, D and G phases, one optimizer step each) is captured into ONE hipGraph and replayed - the same parameters after
+    2 eager + 3 replayed steps as 5 eager steps from the same seeds.  (Round 3 launched such steps eagerly: ~5 ms of host
+    time per step.)"""
+    def run(graph):
+        monkeypatch.setenv("DUSTY_GAN_GRAPH", "1" if graph else "0")
+        torch.manual_seed(515)
+        tr = make_trainer("dusty1", True, (64, 256), 128, 64, 256, 8, amp=True, n_acc=2)
+        sc = [dict(tr.step(i).items()) for i in range(5)]
+        assert (tr._graph is not None) == graph
+        if graph:
+            assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph) == 1
+            assert tr.batches_drawn == 10     # the host loader moved on by num_accumulation batches per step
+        return tr, sc
+    a, sa = run(True)
+    b, sb = run(False)
+    for net in ("G", "D", "G_ema"):
+        fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
+        assert rel_l2(fa, fb) < 2.5e-3, (net, rel_l2(fa, fb))
+    for x, y in zip(sa, sb):
+        for k in x:
+            assert abs(x[k] - y[k]) < 2e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+
+
 def test_checkpoint_roundtrip_and_generate(tmp_path):
     tr = make_trainer("dusty2", True, (32, 64), 8, 4, 16, 2)
     s = tr.step(1)

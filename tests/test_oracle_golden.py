@@ -140,6 +140,25 @@ def test_train_step_matches_reference(case):
 # ---------------------------------------------------------------------------------------------------------------
 # data formats either side of the step: oracle/lidar_oracle.py
 # ---------------------------------------------------------------------------------------------------------------
+def test_scan_preprocess_matches_reference_kitti_dataset():
+    """datasets/kitti.py:54-67 (KITTIOdometry.preprocess: norm, the three strict range tests, normalisation, zeroing) -
+    the restatement in oracle/lidar_oracle.py against what the reference's own class returned (tests/golden/kitti_pre.npz,
+    made by `make_golden.py kitti`: the file loaded by path with an empty torchvision placeholder).  Bit-exact, including
+    the points that sit exactly on min_depth / max_depth.  At an identity output size the NEAREST resize of `transform`
+    (torchvision, third party) is the identity, so the whole `scan_to_polar` is pinned there."""
+    from oracle import lidar_oracle as LO
+    g = load("kitti_pre")
+    for k in range(3):
+        pts = g[f"s{k}/points"]
+        Hs, Ws = pts.shape[:2]
+        out = LO.scan_to_polar(pts, (Hs, Ws), float(g["meta/min_depth"]), float(g["meta/max_depth"]))
+        assert torch.equal(out["mask"][0], torch.from_numpy(g[f"s{k}/mask"])), k
+        assert torch.equal(out["depth"][0], torch.from_numpy(g[f"s{k}/depth"])), k
+        assert torch.equal(out["xyz"], torch.from_numpy(g[f"s{k}/xyz"]).permute(2, 0, 1)), k
+        m = g[f"s{k}/mask"]
+        assert 0.1 < m.mean() < 0.95 and (g[f"s{k}/depth"][~m] == 0).all()
+
+
 def test_lidar_oracle_matches_reference():
     """utils/lidar.py restatement against vectors from the reference's LiDAR class (tests/golden/lidar.npz)"""
     from oracle import lidar_oracle as LO
