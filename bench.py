@@ -373,6 +373,9 @@ def main():
             comm = tr.comm_profile(steps=3)
             if comm:
                 out["distributed"]["exposed_ms_per_step"] = comm
+            elif getattr(tr, "_comm_captured", False):
+                out["distributed"]["exposed_ms_per_step"] = ("collectives and their waits are nodes of the step's hipGraph "
+                                                             "(no host-side call to time); DUSTY_GAN_GRAPH_COMM=0 measures the segmented form")
         except Exception as e:  # noqa: BLE001
             out["distributed"]["exposed_ms_per_step"] = f"not measured ({type(e).__name__}: {e})"
     fl, f_g, f_d = flops_per_sample(args.shape, arch, args.gp)
