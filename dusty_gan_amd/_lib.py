@@ -102,6 +102,7 @@ _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double,
 PROTOTYPES = {
     "dg_conv": [C.POINTER(DgConv), _I, _P],
     "dg_set_fp32_split": [_I],
+    "dg_set_conv_bigtile": [_I],
     "dg_conv_ex": [C.POINTER(DgConv), _I, _I, _P],
     "dg_conv_plan": [C.POINTER(DgConv), _I, _I, C.POINTER(DgConvPlan)],
     "dg_conv_mfma_supported": [C.POINTER(DgConv)],

@@ -21,10 +21,17 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_thin_supported(const WgradP* p);
 
 int g_dg_fp32_split = 0;   // dg_set_fp32_split: fp32 operands through split-bf16 matrix instructions (mfma_common.h)
+int g_dg_bigtile = 0;      // dg_set_conv_bigtile: force == 0 may pick the big-tile conv (conv_mfma_bt.hip; measured slower: opt-in)
 
 extern "C" {
 
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
+
+int dg_set_conv_bigtile(int on) {
+  const int prev = g_dg_bigtile;
+  g_dg_bigtile = on ? 1 : 0;
+  return prev;
+}
 
 int dg_set_fp32_split(int on) {
   const int prev = g_dg_fp32_split;
@@ -51,7 +58,7 @@ static int conv_dispatch0(const DgConv* p, int force, int wg_cap, hipStream_t s,
   if ((force == 0 || force == 10) && dg_proj_stream_supported(p)) return dg_proj_stream_launch(p, s, plan);
   if (force == 10) return DG_EUNSUPPORTED;
   if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
-  if (force == 4 || force == 5 || force == 9) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (force == 4 || force == 5 || force == 9 || force == 11) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {

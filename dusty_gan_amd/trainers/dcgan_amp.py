@@ -322,6 +322,9 @@ class Trainer:
         # trainer construction sets it to what ITS configuration asks for)
         self.fp32_split = (not self.enable_amp) and os.environ.get("DUSTY_GAN_FP32_SPLIT", "0") == "1"
         L.lib().dg_set_fp32_split(int(self.fp32_split))
+        # DUSTY_GAN_BIGTILE=1: the fat conv layers on the big-tile kernel (conv_mfma_bt.hip: round-4 experiment, parity-green,
+        # measured SLOWER than the ping-pong kernel - DESIGN.md section 4 - hence opt-in)
+        L.lib().dg_set_conv_bigtile(int(os.environ.get("DUSTY_GAN_BIGTILE", "0") == "1"))
 
         # resume (reference :134-144)
         self.start_iteration = 0

@@ -125,6 +125,12 @@ int dg_conv(const DgConv* p, int force, void* stream);
  * product; the mode autocast-free fp32 training of trainers/dcgan_amp.py would want on this hardware).  Returns the
  * previous setting. */
 int dg_set_fp32_split(int on);
+/* Whether force == 0 may pick the big-tile persistent conv (family 7, conv_mfma_bt.hip: one wave per SIMD, 128 x 64 outputs
+ * per wave, fragment reads and LDS-DMA pipelined under the wave's own matrix instructions) for bf16 layers with >= 256 of
+ * its tiles.  Default 0: the kernel is parity-green but measured slower than the ping-pong kernel (family 5) on every layer
+ * (round 4), so it is opt-in; dg_conv force 11 asks for it by name (parity tests).  Returns the previous
+ * setting. */
+int dg_set_conv_bigtile(int on);
 /* What a dg_conv call launches (introspection for the parity tests and the benchmark: which kernel family / tile ran,
  * and how many tiles each persistent workgroup walks).  family: 1 direct, 2 one-tile-per-workgroup MFMA, 3 thin,
  * 4 persistent large-tile MFMA (lock step: fp32, small layers), 5 persistent ping-pong MFMA (bf16 fat layers),

@@ -15,6 +15,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 dev = "cuda"
 o = Ops(dtype)
 o.force = 2
+if os.environ.get("BENCH_BIGTILE", "0") == "1":   # A/B: the fat layers on the big-tile kernel (conv_mfma_bt.hip, opt-in)
+    L.lib().dg_set_conv_bigtile(1)
 torch.manual_seed(0)
 
 # (name, mode, adj, Hc, Wc, K, N, batch multiplier)

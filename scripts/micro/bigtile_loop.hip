@@ -1,0 +1,180 @@
+// What a LARGER register tile could sustain on MI355X: the K loop of an implicit-GEMM conv with ONE wave per SIMD and a
+// 128 x 128 output tile per wave (accumulators: 256 registers per lane, i.e. the AGPR half of the 512-register file),
+// CU tile 256 x 256, 64-channel K steps of 64 KB (A 32 KB + B 32 KB) moved by LDS-DMA into a two-stage ring, fragment reads
+// of k-step ks + 1 and the next stage's DMA pieces interleaved with the 64 MFMAs of k-step ks - the structure the round-3
+// review asks for in place of the 64 x 64 ping-pong tile.  Only the main loop: operands are whatever
+// lies in a 4 MB buffer, nothing is stored, so the number is the CEILING of that structure on this chip, to be set beside
+// the ping-pong kernel's K loop (conv family without its epilogue: ~1.16 PFLOP/s in the step).
+//   build: hipcc --offload-arch=gfx950 -O3 -o bigtile_loop scripts/micro/bigtile_loop.hip ; run: ./bigtile_loop [ksteps]
+//   variants (template flags): DMA off / fragment reads off, to price the two feeds separately.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+
+constexpr int SB = 128;                 // bytes of K per tile row and stage
+constexpr int ROWS = 256;               // rows of A (pixels) and of B (channels) per stage
+constexpr int STAGE = 2 * ROWS * SB;    // 64 KB
+constexpr int PIECES = STAGE / 1024;    // 64 one-KiB pieces per stage, 16 per wave
+
+template <bool DMA, bool READS, int TM, int TN>
+__global__ __launch_bounds__(256, 1) void bigtile_kernel(const char* __restrict__ src, float* out, int ksteps, unsigned mask) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int a16 = lane & 15, g4 = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // fragment addresses: row r, 16-byte chunk c of a row at c ^ ((r >> 1) & 7) (conflict-free for row offsets that are
+  // multiples of 2: the swizzle the ping-pong conv started from)
+  auto frag = [&](int row, int chunk) { return (unsigned)(row * SB + ((chunk ^ ((row >> 1) & 7)) << 4)); };
+  unsigned pa[2], pb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    pa[ks] = lds0 + frag(wm * (16 * TM) + a16, 4 * ks + g4);
+    pb[ks] = lds0 + ROWS * SB + frag(wn * (16 * TN) + a16, 4 * ks + g4);
+  }
+  // DMA: piece q of a stage = tile rows 8 q .. 8 q + 7; lane l carries chunk l & 7 of row 8 q + (l >> 3) to LDS offset 1024 q + 16 l
+  const int lrow = lane >> 3, pos = lane & 7;
+  unsigned voff[PIECES / 4];
+#pragma unroll
+  for (int u = 0; u < PIECES / 4; ++u) {
+    const int row = (wave + 4 * u) * 8 + lrow;
+    voff[u] = (unsigned)(row * 256 + ((pos ^ ((row >> 1) & 7)) << 4));   // source rows 256 B apart (a 128-channel bf16 map)
+  }
+  const unsigned dst_wave = (unsigned)wave * 1024u;
+  auto piece = [&](int u, const char* base, unsigned stage_off) __attribute__((always_inline)) {
+    if (!DMA) return;
+    const unsigned m0v = lds0 + stage_off + dst_wave + (unsigned)u * 4096u;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff[u]), "s"(base) : "memory");
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[s][i] = i32x4{tid, s, i, 1};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[s][j] = i32x4{tid, s, j, 2};
+  }
+  // reads of one k-step's fragments into buffer `buf` from stage offset `so`; r-th read of the 16 (A first, then B)
+  auto read1 = [&](int buf, int ks, unsigned so, int r) __attribute__((always_inline)) {
+    if (!READS) return;
+    if (r < TM) { if (buf == 0) LDS_READ128(fa[0][r], pa[ks] + so, r * 16 * SB); else LDS_READ128(fa[1][r], pa[ks] + so, r * 16 * SB); }
+    else { const int j = r - TM; if (buf == 0) LDS_READ128(fb[0][j], pb[ks] + so, j * 16 * SB); else LDS_READ128(fb[1][j], pb[ks] + so, j * 16 * SB); }
+  };
+  auto mfma = [&](int buf, int i, int j) __attribute__((always_inline)) {
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[buf][j]), __builtin_bit_cast(bf16x8, fa[buf][i]),
+                                                        acc[i][j], 0, 0, 0);
+  };
+  constexpr int NMF = TM * TN;                  // MFMAs per k-step
+  constexpr int NRD = TM + TN;                  // fragment reads per k-step
+  constexpr int NPC = PIECES / 4 / 2;           // DMA pieces per wave and k-step
+
+  // prologue: stage 0 <- K step 0, first fragments
+  const char* base = src + (size_t)blockIdx.x * 65536;
+#pragma unroll
+  for (int u = 0; u < PIECES / 4; ++u) piece(u, base, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int r = 0; r < NRD; ++r) read1(0, 0, 0, r);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  unsigned so = 0;                              // stage being computed
+  unsigned goff = 65536;
+  for (int s = 0; s < ksteps; ++s) {
+    const char* nb = src + (((size_t)blockIdx.x * 65536 + goff) & mask);
+    goff += 65536;
+    const unsigned sn = so ^ STAGE;             // stage being filled
+    // k-step 0 on buffer 0: 64 MFMAs with the 16 reads of k-step 1 (-> buffer 1) and half of the next stage's pieces between them
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = i * TN + j;
+        mfma(0, i, j);
+        if (n % (NMF / NRD) == NMF / NRD - 1) read1(1, 1, so, n / (NMF / NRD));
+        if (n % (NMF / NPC) == NMF / NPC / 2) piece(n / (NMF / NPC), nb, sn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[1][i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[1][j]));
+    // k-step 1 on buffer 1: the other half of the pieces; the last quarter of its MFMAs runs BEHIND the stage hand-off, over
+    // the latency of the next step's first fragment reads
+    constexpr int HOLD = NMF / 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = i * TN + j;
+        if (n == NMF - HOLD) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage has landed (this wave's share) ...
+          __builtin_amdgcn_s_barrier();                        // ... everyone's, and everyone is done reading the other one
+#pragma unroll
+          for (int r = 0; r < NRD; ++r) read1(0, 0, sn, r);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma(1, i, j);
+        if (n < NMF - HOLD && n % ((NMF - HOLD) / NPC) == (NMF - HOLD) / NPC / 2) piece(NPC + n / ((NMF - HOLD) / NPC), nb, sn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[0][i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[0][j]));
+    so = sn;
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (sum == 123.456f) out[0] = sum;
+}
+
+template <bool DMA, bool READS, int TM, int TN>
+static void run(const char* name, const char* src, float* out, int ksteps, int cus) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0);
+    bigtile_kernel<DMA, READS, TM, TN><<<cus, 256>>>(src, out, ksteps, (4u << 20) - 1);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)cus * 4 * ksteps * 2 * (TM * TN) * 16384.0;
+    if (rep) printf("%-34s %dx%d per wave: %.3f ms, %.1f TFLOP/s (%.3f of 2.5 PFLOP/s)\n", name, 16 * TM, 16 * TN, ms, flops / ms / 1e9,
+                    flops / ms / 1e9 / 2500.0);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int ksteps = argc > 1 ? atoi(argv[1]) : 4000;
+  int cus = 256;
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  char* src;
+  float* out;
+  hipMalloc(&src, (8u << 20) + 65536 * 512);
+  hipMemset(src, 0x3c, (8u << 20) + 65536 * 512);   // bf16 pairs 0x3c3c: ~0.011 (random-ish magnitudes are not needed for timing, but not zeros)
+  hipMalloc(&out, 4);
+  run<true, true, 8, 8>("DMA + fragment reads + MFMA", src, out, ksteps, cus);
+  run<false, true, 8, 8>("fragment reads + MFMA (no DMA)", src, out, ksteps, cus);
+  run<true, false, 8, 8>("DMA + MFMA (no fragment reads)", src, out, ksteps, cus);
+  run<false, false, 8, 8>("MFMA only", src, out, ksteps, cus);
+  return 0;
+}
