@@ -19,10 +19,16 @@ python3 scripts/pmc_traffic.py $out/${tag}_pmc_traffic.json $(find $out/fetch -n
 python3 scripts/pmc_summary.py $out/${tag}_pmc_sq.json $(find $out/sq -name "*counter_collection.csv" | head -1) > $out/${tag}_pmc_sq_summary.txt
 # bench lines: the driver's default, then the other configurations of SURVEY.md §8d
 python3 bench.py > $out/${tag}_bench_config2.json 2> /dev/null
-python3 bench.py --arch dusty1 --no-cpu-baseline > $out/${tag}_bench_config3_dusty1.json 2> /dev/null
-python3 bench.py --arch dusty2 --no-cpu-baseline > $out/${tag}_bench_config4_share_dusty2.json 2> /dev/null
-python3 bench.py --arch dusty2 --shape 128 2048 --batch 64 --no-cpu-baseline --steps 20 --warmup 5 > $out/${tag}_bench_config5_share_128x2048_b64.json 2> /dev/null
-python3 bench.py --precision fp32 --no-cpu-baseline --steps 20 --warmup 5 > $out/${tag}_bench_config2_fp32_parity.json 2> /dev/null
-python3 bench.py --gp 0 --no-augment --no-cpu-baseline > $out/${tag}_bench_config2_nogp_noaug.json 2> /dev/null
+python3 bench.py --arch dusty1 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_config3_dusty1.json 2> /dev/null
+python3 bench.py --arch dusty2 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_config4_share_dusty2.json 2> /dev/null
+python3 bench.py --arch dusty2 --shape 128 2048 --batch 64 --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 > $out/${tag}_bench_config5_share_128x2048_b64.json 2> /dev/null
+python3 bench.py --precision fp32 --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 > $out/${tag}_bench_config2_fp32_parity.json 2> /dev/null
+python3 bench.py --precision fp32x3 --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 > $out/${tag}_bench_config2_fp32x3.json 2> /dev/null
+python3 bench.py --gp 0 --no-augment --no-cpu-baseline --no-other-configs > $out/${tag}_bench_config2_nogp_noaug.json 2> /dev/null
+# the multi-rank schedule on one GPU through RCCL (a process group of one rank): collectives inside the graph / between segments
+DUSTY_GAN_FORCE_SEG=1 DUSTY_BENCH_BACKEND=nccl python3 bench.py --no-cpu-baseline --no-other-configs --no-roofline > $out/${tag}_bench_schedule_rccl_1rank_in_graph.json 2> /dev/null
+DUSTY_GAN_FORCE_SEG=1 DUSTY_BENCH_BACKEND=nccl DUSTY_GAN_GRAPH_COMM=0 python3 bench.py --no-cpu-baseline --no-other-configs --no-roofline > $out/${tag}_bench_schedule_rccl_1rank_segments.json 2> /dev/null
+python3 bench.py --no-cpu-baseline --no-other-configs --no-roofline > $out/${tag}_bench_schedule_one_graph.json 2> /dev/null
+bash scripts/step_sequence.sh $out/seq > $out/${tag}_step_sequence.txt 2>&1
 rm -rf $out/kt $out/fetch $out/write $out/sq
 ls -la $out
