@@ -20,6 +20,7 @@
 #include "thin_up_frag.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------
 // thin_smallk: block = (b, coarse row Y, 64 output columns); thread = 4 pixels x 4 channels (N == 64 per pass).
@@ -1041,23 +1042,31 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
 // an MFMA lane needs, so every A fragment is one 16-byte global load.  K = 4 ky x 4 kx x CP.
 //   CP = 2: 2 MFMA k-steps, lane half h <-> ky = 2 s + h, j <-> (kx = j >> 1, c = j & 1)
 //   CP = 4: 4 MFMA k-steps, step s <-> ky, lane half h <-> kx in {2h, 2h+1}, j <-> (kx = 2h + (j >> 2), c = j & 3)
-// One wave = one 32-pixel x 64-channel tile at a time (grid-stride), weights live in 16 / 32 VGPRs for the whole
-// kernel, the result tile is transposed through a wave-private 4.5 KB LDS patch and written as whole 128-byte rows.
+// One wave = one 32-pixel x 64-channel tile at a time (a contiguous range of tiles per wave), weights live in 16 / 32 VGPRs
+// for the whole kernel.  Round 4: the product is formed as W x A^T (weights as the A operand), so a lane ends up with ONE
+// pixel and runs of four consecutive channels - scale / leaky-relu / saved-mask select / bf16 packing happen on the
+// accumulator layout (3.5 VALU instructions per element, 594 -> ~250 per tile: the kernel was VALU-bound, SQ_INSTS_VALU in
+// profiles/r04a_pmc_sq_summary.txt), the tile goes through a wave-private 4.5 KB LDS patch as eight 8-byte writes and comes
+// back as the 4096 CONTIGUOUS bytes it occupies in the pixel-major output; the bias rides in the accumulators' start value.
+// The tile's inputs are prefetched two tiles ahead with counted vmcnt waits (see `prefetch` below), which lets the output
+// stores of two tiles stay in flight: Down1 forward at batch 32 / 64 30.8 / 47.2 -> 24.9 / 39.3 us, Head backward-data
+// 34.7 -> 30.9 us (same box, eager step).
 // MB: the saved 1-bit leaky-relu masks (DgConv.mask_out / mask_in) as a compile-time flavour - 0 none, 1 the EPI_LRELU launch
 // also writes them, 2 the EPI_MASK launch reads them instead of aux (a run-time choice kept both forms' registers live:
 // 134 -> 172 VGPRs, 3 -> 2 waves per SIMD, Down1 forward 40 -> 64 us)
 template <int CP, int MB>
-__global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x, long ntiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP == 2 ? 3 : 2))) void thin_s2_mfma_kernel(ConvP p, int tiles_x, long ntiles) {
   constexpr int NS = CP == 2 ? 2 : 4;            // MFMA k-steps per kernel (without adjoint extras)
   __shared__ __attribute__((aligned(16))) unsigned char s_t[4][32 * 144];
   __shared__ float s_db[64];
+  __shared__ __attribute__((aligned(16))) float s_binit[64];   // bias / scale: what the accumulators start from
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int Wf = 2 * p.Wc, Hf = 2 * p.Hc;
   const bf16* in = (const bf16*)p.in;
   const bf16* w = (const bf16*)p.w;              // [tap][n][k = c] with strides w_st, w_sn, 1 ; k < p.K real channels
-  if (tid < 64) s_db[tid] = 0.f;
+  if (tid < 64) { s_db[tid] = 0.f; s_binit[tid] = p.bias ? p.bias[tid % p.bias_mod] / p.scale : 0.f; }
   __syncthreads();
 
   // B fragments: element j of step s for output channel n = jt*32 + lr
@@ -1105,51 +1114,166 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
     }
     return make_uint4(d[0], d[1], d[2], d[3]);
   };
-  // the A fragments of tile (xt_, Y_, b_): NS 16-byte loads per lane
-  auto load_frags = [&](int xt_, int Y_, int b_, uint4 (&a)[NS]) {
-    const int X_ = xt_ * 32 + lr;
+  // Everything a tile loads - its NS fragments (16 bytes per lane each), the 64 mask bits of the lane's pixel, the per-sample
+  // weight of the bias-gradient sums - is requested TWO tiles ahead, by inline asm with counted waits.  vmcnt retires in
+  // order: a wait for loads issued ONE tile ahead also waits for the output stores of the tile before (issued in between),
+  // i.e. a store has one tile's time (~1.5 us at three-four waves per SIMD) to be acknowledged, against 2-3 us under a
+  // 3 TB/s write stream; two tiles ahead the stores of tile j only have to be complete at the top of tile j + 3.  (The
+  // same pipeline written in C++ does not survive the compiler's own waitcnt insertion: register copies of prefetched
+  // values and zero-initialisations of conditionally loaded registers each became an s_waitcnt vmcnt(0) per tile.)
+  // A window that wraps around the row (first lane of a row's first tile, last lane of its last) is the clamped window
+  // shifted by one pixel plus that pixel from the other end of the row: a second small load issued for EVERY tile, so that
+  // the number of loads per tile - what the counted waits count - is a constant.
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  constexpr int NPXD = CP / 2;                   // dwords per pixel
+  constexpr int NF = 2 * NS + 1 + (MB == 2 ? 1 : 0);          // loads per prefetch
+  constexpr int NSTO = 4 + (MB == 1 ? 4 : 0);                 // stores per tile
+  v4u pa[2][NS];                               // the two prefetch register sets (indexed by compile-time constants only)
+  typedef typename std::conditional<CP == 2, unsigned, v2u>::type wrap_t;   // the pixel from the other end of the row
+  wrap_t pw[2][NS];
+  v2u pm[2];
+  float prs[2];
+  const int Wd = Wf * NPXD;                      // dwords per input row
+  const float* rs_src = (p.dbias && p.rowscale) ? p.rowscale : (const float*)p.w;   // (always a valid address)
+  const unsigned zero_off = 0u;
+  auto out_base = [&](int xt_, int Y_, int b_) -> long { return (long)b_ * p.out_sb + ((long)Y_ * p.Wc + xt_ * 32) * 64; };
+  auto prefetch = [&](int xt_, int Y_, int b_, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int I = decltype(buf_tag)::value;
+    const char* img = (const char*)(in + (long)b_ * p.in_sb);   // wave-uniform
+    const int d0 = (2 * (xt_ * 32 + lr) - 1 + (CP == 2 ? 0 : 2 * lh)) * NPXD;
+    const int d0c = min(max(d0, 0), Wd - 4);
+    const int dw = d0 < 0 ? Wd - NPXD : 0;       // the pixel from the other end of the row (lanes that do not wrap: any)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int ky = CP == 2 ? 2 * s + lh : s;
       int r = 2 * Y_ - 1 + ky;
-      bool ok = true;
       if (!p.adj) { if (r < 0) r = -r; if (r >= Hf) r = 2 * Hf - 2 - r; }
-      else ok = r >= 0 && r < Hf;
-      const int c0 = 2 * X_ - 1 + (CP == 2 ? 0 : 2 * lh);
-      a[s] = ok ? window_of(b_, r, c0) : make_uint4(0, 0, 0, 0);
+      else r = min(max(r, 0), Hf - 1);           // (rows outside the image: zeroed where the fragment is used)
+      const unsigned ro = (unsigned)(r * Wd);
+      const unsigned oa = (ro + (unsigned)d0c) * 4u, ow = (ro + (unsigned)dw) * 4u;
+      v4u ta;
+      wrap_t tw;                                 // (whole asm outputs only: building a register pair from a loaded dword is a
+                                                 //  v_mov of a register whose load has not landed)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ta) : "v"(oa), "s"(img) : "memory");
+      if (CP == 2) asm volatile("global_load_dword %0, %1, %2" : "=v"(tw) : "v"(ow), "s"(img) : "memory");
+      else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(tw) : "v"(ow), "s"(img) : "memory");
+      pa[I][s] = ta;
+      pw[I][s] = tw;
+    }
+    const float* rsp = rs_src + ((p.dbias && p.rowscale) ? b_ : 0);
+    float trs;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(trs) : "v"(zero_off), "s"(rsp) : "memory");
+    prs[I] = trs;
+    if (MB == 2) {
+      const char* mb = (const char*)p.mask_in + (out_base(xt_, Y_, b_) >> 3);
+      const unsigned om = (unsigned)(lr * 8);
+      v2u tm;
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(tm) : "v"(om), "s"(mb) : "memory");
+      pm[I] = tm;
     }
   };
-  float bias2[2];
+  auto advance = [&](int& xt_, int& Y_, int& b_) __attribute__((always_inline)) {
+    if (++xt_ == tiles_x) { xt_ = 0; if (++Y_ == p.Hc) { Y_ = 0; ++b_; } }
+  };
+  // Two register sets used alternately by a loop unrolled twice, each refilled in place right behind the tile's MFMAs (the
+  // mask bits and the weight are copied out first).
+  prs[0] = prs[1] = 1.f;
+  pm[0] = pm[1] = v2u{0u, 0u};
 #pragma unroll
-  for (int jt = 0; jt < 2; ++jt) bias2[jt] = p.bias ? p.bias[(jt * 32 + lr) % p.bias_mod] : 0.f;
-  uint4 a_next[NS];
-  // per-sample weight of the bias-gradient sums: fetched with the tile's fragments (inside the store loop it cost a
-  // load + s_waitcnt vmcnt(0) per 16-byte store, draining the prefetched fragments four times per tile)
-  const bool want_rs = p.dbias && p.rowscale;
-  float rs_next = 1.f;
-  if (tcnt > 0) { load_frags(xt, Y, b, a_next); if (want_rs) rs_next = p.rowscale[b]; }
-  for (int ti = 0; ti < tcnt; ++ti) {
-    // the fragments of the NEXT tile are requested before this tile's MFMAs and epilogue
-    uint4 a_cur[NS];
+  for (int s = 0; s < NS; ++s) { pa[0][s] = pa[1][s] = v4u{0u, 0u, 0u, 0u}; pw[0][s] = pw[1][s] = wrap_t{}; }
+  int xt2 = xt, Y2 = Y, b2 = b;                  // the tile two ahead of the one being computed
+  if (tcnt > 0) prefetch(xt2, Y2, b2, std::integral_constant<int, 0>{});
+  advance(xt2, Y2, b2);
+  if (tcnt > 1) prefetch(xt2, Y2, b2, std::integral_constant<int, 1>{});
+  advance(xt2, Y2, b2);
+  // Epilogue constants.  D = W x A^T: a lane holds ONE pixel (lr) and the channels jt*32 + 8g + 4lh + r (g, r = 0..3), i.e.
+  // runs of four consecutive channels = 8 bytes of the pixel-major output row.  sqrt(2) is folded into the scale (lrelu
+  // commutes with a positive factor: max(v, 0.2 v)), the bias into the accumulators' start value (s_binit), the saved mask
+  // into ONE select per element (the lane's pixel owns 64 mask bits = one 8-byte load).
+  float c_pos = p.scale * SQRT2, c_neg = p.scale * (LRELU_SLOPE * SQRT2);
+  asm volatile("" : "+v"(c_pos), "+v"(c_neg));   // (opaque: else the select is made between constants + a second multiply)
+  const float c_lin = p.epi == EPI_LRELU ? c_pos : p.scale;
+  const float slope = p.epi == EPI_LRELU ? LRELU_SLOPE : 1.f;          // max(v, 1 v) = v: no select per element
+  unsigned char* my_w = my + lr * 144 + lh * 8;                         // phase 1: + jt*64 + g*16
+  unsigned char* my_r = my + (lane >> 3) * 144 + (lane & 7) * 16;       // phase 2: + u * 8 * 144
+  auto tile = [&](auto buf_tag, const int ti) __attribute__((always_inline)) {
+    constexpr int I = decltype(buf_tag)::value;
+    const bool more = ti + 2 < tcnt;
+    // this tile's loads have landed: everything issued behind them may still be in flight - the stores of the two tiles
+    // before and the next tile's prefetch (tiles 0 and 1: what exists of that)
+#define S2_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    if (ti >= 2) { if (ti + 1 < tcnt) S2_WAIT(2 * NSTO + NF); else S2_WAIT(2 * NSTO); }
+    else if (ti == 1) { if (tcnt > 2) S2_WAIT(NSTO + NF); else S2_WAIT(NSTO); }
+    else { if (tcnt > 1) S2_WAIT(NF); else S2_WAIT(0); }
+#undef S2_WAIT
+    v4u a_cur[NS];
+    wrap_t w_cur[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a_cur[s] = a_next[s];
-    const float rs = rs_next;
-    int nxt = xt + 1, nY = Y, nb = b;
-    if (nxt == tiles_x) { nxt = 0; if (++nY == p.Hc) { nY = 0; ++nb; } }
-    if (ti + 1 < tcnt) { load_frags(nxt, nY, nb, a_next); if (want_rs) rs_next = p.rowscale[nb]; }
-    const int X = xt * 32 + lr;                  // this lane's output pixel (as A-fragment row)
+    for (int s = 0; s < NS; ++s) {
+      v4u ta = pa[I][s];
+      wrap_t tw = pw[I][s];
+      asm volatile("" : "+v"(ta), "+v"(tw));     // (uses pinned behind the wait)
+      a_cur[s] = ta; w_cur[s] = tw;
+    }
+    float rs = prs[I];
+    v2u mword = pm[I];
+    asm volatile("" : "+v"(rs), "+v"(mword));
+    if (!(p.dbias && p.rowscale)) rs = 1.f;      // (the load is issued regardless, from a valid address: constant load count)
+    if (xt == 0 || xt == tiles_x - 1) {          // (wave-uniform) the wrapped windows: shift in the pixel from the other end
+      const bool lo = xt == 0 && lr == 0 && (CP == 2 || lh == 0);
+      const bool hi = xt == tiles_x - 1 && lr == 31 && (CP == 2 || lh == 1);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const v4u a = a_cur[s];
+        if constexpr (CP == 2) {
+          const unsigned w = w_cur[s];
+          if (lo) a_cur[s] = v4u{w, a.x, a.y, a.z};
+          if (hi) a_cur[s] = v4u{a.y, a.z, a.w, w};
+        } else {
+          const v2u w = w_cur[s];
+          if (lo) a_cur[s] = v4u{w.x, w.y, a.x, a.y};
+          if (hi) a_cur[s] = v4u{a.z, a.w, w.x, w.y};
+        }
+      }
+    }
+    if (p.adj && (Y == 0 || Y == p.Hc - 1)) {    // (adjoint: kernel rows outside the image contribute nothing)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int ky = CP == 2 ? 2 * s + lh : s;
+        const int r = 2 * Y - 1 + ky;
+        if (r < 0 || r >= Hf) a_cur[s] = v4u{0u, 0u, 0u, 0u};
+      }
+    }
+    int nxt = xt, nY = Y, nb = b;
+    advance(nxt, nY, nb);
+    const long obase = out_base(xt, Y, b);       // the tile = 4096 contiguous bytes from here
+    // the fallback form of EPI_MASK without saved bits reads the lane's 8 x 4 activations themselves (8-byte pieces, 128 B
+    // apart between lanes, waited for inside the tile: slow, unused by the training step)
+    uint2 araw[(MB != 2) ? 8 : 1];
+    if (MB == 0 && p.epi == EPI_MASK) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        araw[MB != 2 ? q : 0] = *(const uint2*)((const bf16*)p.aux + obase + lr * 64 + (q >> 2) * 32 + (q & 3) * 8 + lh * 4);
+    }
+    const int X = xt * 32 + lr;                  // this lane's output pixel (as fragment column)
     auto window = [&](int r, int c0) -> uint4 { return window_of(b, r, c0); };
-    tw_f32x16 acc[2];
+    tw_f32x16 acc[2];                            // start value: bias / scale of the lane's channels
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *(const float4*)&s_binit[jt * 32 + g * 8 + lh * 4];
+        acc[jt][4 * g] = b4.x; acc[jt][4 * g + 1] = b4.y; acc[jt][4 * g + 2] = b4.z; acc[jt][4 * g + 3] = b4.w;
+      }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a_cur[s]);
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[s][jt], acc[jt], 0, 0, 0);
+      for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s][jt], fa, acc[jt], 0, 0, 0);
     }
+    if (more) prefetch(xt2, Y2, b2, buf_tag);    // (in place: everything of this register set has been copied out or consumed)
+    advance(xt2, Y2, b2);
     if (p.adj && CP == 2 && (Y == 1 || Y == p.Hc - 2)) {
       // reflect-adjoint extras (common.h dg_tap1d, MODE_S2/adj): row 0 through ky = 3 into Y == 1,
       // row Hf-1 through ky = 0 into Y == Hc-2; the tap sits in lane half 0, half 1 multiplies zeros
@@ -1159,14 +1283,14 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
         if (lh == 0) a = window(0, c0);
         const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a);
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbx[jt], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbx[jt], fa, acc[jt], 0, 0, 0);
       }
       if (Y == p.Hc - 2) {
         uint4 a = make_uint4(0, 0, 0, 0);
         if (lh == 0) a = window(Hf - 1, c0);
         const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, a);
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][jt], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][jt], fa, acc[jt], 0, 0, 0);
       }
     }
     if (p.adj && CP == 4 && (Y == 1 || Y == p.Hc - 2)) {
@@ -1176,59 +1300,58 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
       if (Y == 1) {
         const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, window(0, c0));
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[NS - 1][jt], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[NS - 1][jt], fa, acc[jt], 0, 0, 0);
       }
       if (Y == p.Hc - 2) {
         const tw_bf16x8 fa = __builtin_bit_cast(tw_bf16x8, window(Hf - 1, c0));
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][jt], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][jt], fa, acc[jt], 0, 0, 0);
       }
     }
-    // ---- epilogue: D[row = pixel][col = channel]; transpose through the wave's LDS patch.  The leaky-relu mask
-    //      source of the tile is requested first so that its latency hides behind the transposition.
-    const long obase = (long)b * p.out_sb + ((long)Y * p.Wc + xt * 32) * p.out_sp;
-    uint4 araw[MB == 2 ? 1 : 4];
-    unsigned abit[MB == 2 ? 4 : 1];              // DgConv.mask_in: one byte = the 8 channels this lane finishes per pass
-    constexpr bool use_bits = MB == 2;
-    if (use_bits) {
+    // ---- epilogue, phase 1: scale / activation / mask on the accumulator layout, 4 channels -> one 8-byte LDS write.
+    //      The form is chosen once per tile (0 linear / leaky-relu through c_lin and slope, 1 saved bits, 2 the activation
+    //      itself as mask source): a run-time test of p.epi per element became a scalar branch per element.
+    const unsigned msh0 = mword.x >> (4 * lh), msh1 = mword.y >> (4 * lh);   // bit 8g + r = channel jt*32 + 8g + 4lh + r
+    auto phase1 = [&](auto form_tag) __attribute__((always_inline)) {
+      constexpr int FORM = decltype(form_tag)::value;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = lane + 64 * u, row = c >> 3, part = c & 7;
-        abit[u] = ((const unsigned char*)p.mask_in)[(obase + (long)row * p.out_sp + part * 8) >> 3];
-      }
-    } else if (p.epi == EPI_MASK) {
+      for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = lane + 64 * u, row = c >> 3, part = c & 7;
-        araw[use_bits ? 0 : u] = *(const uint4*)((const bf16*)p.aux + obase + (long)row * p.out_sp + part * 8);
-      }
-    }
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      const int n = jt * 32 + lr;
-      const float bias = bias2[jt];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float v = acc[jt][e] * p.scale + bias;
-        if (p.epi == EPI_LRELU) v = (v > 0.f ? v : LRELU_SLOPE * v) * SQRT2;
-        *(bf16*)(my + row * 144 + n * 2) = (bf16)v;
-      }
-    }
+          for (int r = 0; r < 4; ++r) {
+            const float a = acc[jt][4 * g + r];
+            if (FORM == 1) {
+              int sel;
+              float kf;
+              asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(jt ? msh1 : msh0), "n"(8 * g + r));
+              asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(kf) : "v"(sel), "v"(c_pos), "v"(c_neg));
+              v[r] = a * kf;
+            } else if (FORM == 2) {
+              const uint2 aw = araw[MB != 2 ? jt * 4 + g : 0];
+              const int w32 = (int)(r < 2 ? aw.x : aw.y);
+              const bool posv = (r & 1) ? w32 > 0xffff : (short)w32 > 0;    // bf16 > 0 <=> its bits as a signed integer > 0
+              v[r] = a * (posv ? c_pos : c_neg);
+            } else {
+              const float t = a * c_lin;
+              v[r] = fmaxf(t, slope * t);
+            }
+          }
+          uint2 pk;
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk.x) : "v"(v[0]), "v"(v[1]));
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk.y) : "v"(v[2]), "v"(v[3]));
+          *(uint2*)(my_w + jt * 64 + g * 16) = pk;
+        }
+    };
+    if (MB == 2) phase1(std::integral_constant<int, 1>{});
+    else if (MB == 0 && p.epi == EPI_MASK) phase1(std::integral_constant<int, 2>{});
+    else phase1(std::integral_constant<int, 0>{});
+    // ---- phase 2: the patch read back as whole 16-byte pieces of pixel rows = the tile's 4096 contiguous output bytes
+    unsigned char* otile = (unsigned char*)((bf16*)p.out + obase) + lane * 16;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int c = lane + 64 * u, row = c >> 3, part = c & 7;   // part == lane & 7 for every u
-      const long o = obase + (long)row * p.out_sp + part * 8;
-      uint4 raw = *(const uint4*)(my + row * 144 + part * 16);
-      bf16* v = (bf16*)&raw;
-      if (use_bits) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * (((abit[use_bits ? u : 0] >> e) & 1u) ? SQRT2 : LRELU_SLOPE * SQRT2));
-      } else if (p.epi == EPI_MASK) {
-        const bf16* av = (const bf16*)&araw[use_bits ? 0 : u];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * ((float)av[e] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2));
-      }
+      const uint4 raw = *(const uint4*)(my_r + u * (8 * 144));
       if (MB == 1) {                             // (EPI_LRELU) the saved mask of these 8 channels, from the rounded values:
         const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};   // halves clamped to [0, 1], then shifted together (conv_mfma_pp.hip)
         unsigned tb[4];
@@ -1236,15 +1359,20 @@ __global__ __launch_bounds__(256) void thin_s2_mfma_kernel(ConvP p, int tiles_x,
         for (int e = 0; e < 4; ++e)
           asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(tb[e]) : "v"(w4[e]));
         const unsigned mm = tb[0] | (tb[1] << 2) | (tb[2] << 4) | (tb[3] << 6);
-        ((unsigned char*)p.mask_out)[o >> 3] = (unsigned char)((mm & 0x55u) | ((mm >> 15) & 0xAAu));
+        ((unsigned char*)p.mask_out)[(obase >> 3) + lane + 64 * u] = (unsigned char)((mm & 0x55u) | ((mm >> 15) & 0xAAu));
       }
       if (p.dbias) {
+        const bf16* v = (const bf16*)&raw;
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += rs * (float)v[e];
       }
-      *(uint4*)((bf16*)p.out + o) = raw;
+      *(uint4*)(otile + u * 1024) = raw;
     }
     xt = nxt; Y = nY; b = nb;
+  };
+  for (int ti = 0; ti < tcnt; ti += 2) {
+    tile(std::integral_constant<int, 0>{}, ti);
+    if (ti + 1 < tcnt) tile(std::integral_constant<int, 1>{}, ti + 1);
   }
   if (p.dbias) {
 #pragma unroll
@@ -1286,6 +1414,7 @@ int dg_conv_s2_mfma_supported(const ConvP* p) {
   const int cp = p->in_sp;  // padded channel count of the input tensor
   if ((cp != 2 && cp != 4) || p->K > cp || p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1 || p->out_sp != 64) return 0;
   if (p->dbias && p->bias_mod != 64) return 0;
+  if (p->out_sb % 64 != 0) return 0;             // (a tile's output and its mask bits are addressed as whole 64-channel pixels)
   return 1;
 }
 
@@ -1294,7 +1423,10 @@ int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
   const int tiles_x = p->Wc / 32;
   const long ntiles = (long)p->B * p->Hc * tiles_x;
   long blocks = (ntiles + 3) / 4;
-  const long cap = 768;  // 3 blocks per CU = what 164 VGPRs allow resident (measured: 256 -> 50 us, 512 -> 34 us, 768 -> 31 us,
+#ifndef S2_CAP
+#define S2_CAP 768
+#endif
+  const long cap = S2_CAP;  // 3 blocks per CU = what 164 VGPRs allow resident (measured: 256 -> 50 us, 512 -> 34 us, 768 -> 31 us,
                          // 1024 -> 38 us for Down1 forward at batch 32; the per-wave weight preload amortises over the tiles)
   if (blocks > cap) blocks = cap;
   const int mb = (p->epi == EPI_LRELU && p->mask_out) ? 1 : ((p->epi == EPI_MASK && p->mask_in) ? 2 : 0);

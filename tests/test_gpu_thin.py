@@ -21,9 +21,12 @@ def L():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Hc,Wc,B", [(4, 64, 3), (16, 128, 2), (4, 1024, 1)])  # last: 2048-wide images (> 64 KiB LDS in the wgrad)
-def test_down1_thin(L, dtype, Hc, Wc, B):
+@pytest.mark.parametrize("Hc,Wc,B", [(4, 64, 3), (16, 128, 2), (4, 1024, 1),   # 1024: 2048-wide images (> 64 KiB LDS in the wgrad)
+                                     (32, 512, 24)])  # the bench geometry: 5-6 tiles per wave, i.e. the steady state of
+def test_down1_thin(L, dtype, Hc, Wc, B):            # thin_s2_mfma's two-tiles-ahead prefetch (counted vmcnt waits)
     from dusty_gan_amd.engine import Ops
+    if B > 8 and dtype == torch.float32:
+        pytest.skip("the large case is there for the bf16 matrix-core kernel")
     g = torch.Generator().manual_seed(Hc + Wc)
     Ci, Co = 2, 64
     tol = 1e-4 if dtype == torch.float32 else 2e-2
@@ -146,15 +149,16 @@ def test_head_thin(L, dtype, nh, Hc, Wc):                                 # part
     assert rel_l2(got, torch.cat(list(gws), dim=1)) < tol
 
 
-@pytest.mark.parametrize("Hc,Wc", [(8, 64), (32, 256)])      # 8 blocks: direct bias-gradient rows; 128: staged per slot
+@pytest.mark.parametrize("Hc,Wc,B", [(8, 64, 2), (32, 256, 2),  # 8 blocks: direct bias-gradient rows; 128: staged per slot
+                                     (32, 512, 24)])            # the bench geometry: 4 tiles per wave (prefetch steady state)
 @pytest.mark.parametrize("nh", [1, 2, 3])
-def test_head_bwd_data_pixel_major_mfma(L, nh, Hc, Wc):
+def test_head_bwd_data_pixel_major_mfma(L, nh, Hc, Wc, B):
     """Head backward-data through the direct-fragment MFMA kernel (thin_s2_mfma, adjoint boundary incl. the
     reflect-adjoint extra taps at rows 1 and H-2) from the pixel-major bf16 copy of the head gradient; the bias-gradient
     rows added directly (few blocks) and staged through DgConv.dbias_ws, which every launch leaves zero."""
     from dusty_gan_amd.engine import Ops
     g = torch.Generator().manual_seed(40 + nh)
-    B, C0 = 2, 64
+    C0 = 64
     dtype = torch.bfloat16
     x = torch.randn(B, C0, Hc, Wc, generator=g).requires_grad_()
     ws = [torch.randn(C0, 1, 4, 4, generator=g).bfloat16().float()] + \
