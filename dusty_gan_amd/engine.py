@@ -246,33 +246,40 @@ class WgradWorkspace:
     FLOATS = 96 << 20   # cap, 384 MB: D's three fat layers at 3B rows + G's three (80 MB each) with room for the path-length terms
     START = 4 << 20     # first allocation (16 MB): tiny nets never need more; the buffer doubles up to the cap on demand
 
-    def __init__(self):
+    def __init__(self, start=None):
         self.buf, self.pos, self.items = None, 0, []
         # what the tests of the large-batch plans read: the most floats ever pending, reduces forced by a full buffer,
         # requests larger than the cap (those launches fall back to fp32 atomics onto dW)
         self.hwm, self.early_flushes, self.refused = 0, 0, 0
+        # first allocation: another stream's workspace on this device has already found out what a step needs (the step's graph
+        # is captured on a stream of its own: starting small there baked the growth's extra reduce launches into every replay)
+        self.start = max(self.START, min(int(start or 0), self.FLOATS))
+        self.demand = 0     # floats requested since the caller's last flush, growth's own reduces not counted: what to grow to
+        self.grows = 0      # allocations (1 = the first one sufficed)
 
     def take(self, nfloats, device):
         if nfloats > self.FLOATS:
             self.refused += 1
             return None
         if self.buf is not None and (self.buf.device != device or self.buf.numel() > self.FLOATS):
-            self.flush()
+            self._reduce_pending()
             self.buf = None
         need = self.pos + nfloats
+        self.demand += (nfloats + 63) // 64 * 64
         if self.buf is None or need > self.buf.numel():
-            size = self.START if self.buf is None else self.buf.numel()
-            while size < min(need, self.FLOATS):
+            size = self.start if self.buf is None else self.buf.numel()
+            while size < min(max(need, self.demand), self.FLOATS):
                 size *= 2
             size = min(size, self.FLOATS)
             if self.buf is None or size > self.buf.numel():
                 # grow: the pending partials are summed first (stream order keeps the old buffer alive until that reduce has
                 # run: the caching allocator hands its memory out again only to later work of this stream)
-                self.flush()
+                self._reduce_pending()
                 self.buf = torch.empty(size, dtype=torch.float32, device=device)
+                self.grows += 1
             if self.pos + nfloats > self.buf.numel():   # at the cap and still full: reduce early, start over
                 self.early_flushes += 1
-                self.flush()    # (stream order: the reduce has read the partials before the next launch overwrites them)
+                self._reduce_pending()    # (stream order: the reduce has read the partials before the next launch overwrites them)
         off = self.pos
         self.pos = (off + nfloats + 63) // 64 * 64
         self.hwm = max(self.hwm, self.pos)
@@ -283,6 +290,10 @@ class WgradWorkspace:
 
     def flush(self):
         """sum every pending layer's partials into its gradient (stream order after the launches that wrote them)"""
+        self.demand = 0
+        self._reduce_pending()
+
+    def _reduce_pending(self):
         items, self.items, self.pos = self.items, [], 0
         # one launch per <= 8 layers, and never two items with the same destination in one launch (micro-batches, the
         # path-length terms: their blocks would read-modify-write the same dW concurrently) - those follow in stream order
@@ -323,7 +334,8 @@ class _PerStreamWorkspace:
         key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else (-1, 0)
         ws = self._by_stream.get(key)
         if ws is None:
-            ws = self._by_stream[key] = WgradWorkspace()
+            known = [w.buf.numel() for (dev, _), w in self._by_stream.items() if dev == key[0] and w.buf is not None]
+            ws = self._by_stream[key] = WgradWorkspace(start=max(known, default=0))
         return ws
 
     def __getattr__(self, name):          # take / add / flush / items / pos / hwm ... of the current stream's workspace

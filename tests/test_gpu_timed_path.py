@@ -145,7 +145,14 @@ def test_graph_replay_matches_eager_at_bench_size(monkeypatch):
         sc = [dict(tr.step(i).items()) for i in range(5)]
         assert (tr._graph is not None) == graph
         return tr, sc
+    from dusty_gan_amd import engine as E
+    E.WGRAD_WS._by_stream.clear()
     a, sa = run(True)
+    # the split-K workspace of the capture stream started at the size the eager warm-up steps had grown theirs to: a
+    # workspace that grows DURING capture bakes its extra reduce launches into every replay (round 4: 59 launches, not 58)
+    wss = list(E.WGRAD_WS._by_stream.values())
+    assert len(wss) >= 2 and all(w.buf is not None for w in wss), [(w.grows, w.buf is not None) for w in wss]
+    assert wss[0].grows >= 1 and all(w.grows == 1 and w.early_flushes == 0 for w in wss[1:]), [w.grows for w in wss]
     b, sb = run(False)
     for net in ("G", "D", "G_ema"):
         fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
