@@ -319,12 +319,64 @@ class AccArena:
         return cls.buf[a:a + n]
 
 
-class Counters:
+class CounterQueue:
+    """The queued counter advances of one owner (a Trainer; the process-wide default for everything else):
+    pending  {counter pointer: [tensor, delta]}
+    snap     (counter tensor, src pointer, n, ring pointer, ring slots): filed by the next flush (dg_counter_add_multi_snap)
+    ride     the next ParamStore.refresh_transposed carries the pending advances (and the snapshot) in its launch"""
+    _all = None   # weak set of every queue (flush_if looks for a counter's queued advance in all of them)
+
+    def __init__(self):
+        import weakref
+        self.pending, self.snap, self.ride = {}, None, False
+        if CounterQueue._all is None:
+            CounterQueue._all = weakref.WeakSet()
+        CounterQueue._all.add(self)
+
+
+class _CountersMeta(type):
+    """`Counters.pending / .snap / .ride` read and write the CURRENT queue (`Counters.bind`), so the classmethods below and
+    their callers are written as for one queue"""
+    _STATE = ("pending", "snap", "ride")
+
+    def __getattr__(cls, name):
+        if name in _CountersMeta._STATE:
+            return getattr(cls._stack[-1], name)
+        raise AttributeError(name)
+
+    def __setattr__(cls, name, value):
+        if name in _CountersMeta._STATE:
+            setattr(cls._stack[-1], name, value)
+        else:
+            type.__setattr__(cls, name, value)
+
+
+class Counters(metaclass=_CountersMeta):
     """Device counters (Philox offsets, Adam step counts) are advanced behind their consumers.  The advances of a step are
-    queued here and applied by ONE kernel at the end of the step (`flush`); anything that reads a counter with a queued
-    advance - the next draw from the same generator, `Philox.offset`, the next optimizer step - flushes first."""
-    pending = {}
-    snap = None   # (counter tensor, src pointer, n, ring pointer, ring slots): filed by the next flush (dg_counter_add_multi_snap)
+    queued and applied by ONE kernel at the end of the step (`flush`); anything that reads a counter with a queued
+    advance - the next draw from the same generator, `Philox.offset`, the next optimizer step - flushes first.
+    The queue is per owner (round-3 review: it was one process-global): a Trainer binds its own `CounterQueue` around its
+    public entry points, so the flush / the riding launch at the end of ITS step - possibly being captured into ITS graph -
+    never carries advances another trainer of the process has queued."""
+    _stack = [CounterQueue()]   # [-1] = the current queue; [0] = the process-wide default
+
+    @classmethod
+    def current(cls):
+        return cls._stack[-1]
+
+    @classmethod
+    def bind(cls, queue):
+        """context manager: `queue` is the current queue inside the block"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _bound():
+            cls._stack.append(queue)
+            try:
+                yield queue
+            finally:
+                cls._stack.pop()
+        return _bound()
 
     @classmethod
     def snapshot(cls, ctr, src_ptr, n, ring_ptr, ring):
@@ -338,10 +390,15 @@ class Counters:
 
     @classmethod
     def flush_if(cls, t):
-        if t is not None and t.data_ptr() in cls.pending:
+        if t is None:
+            return
+        if t.data_ptr() in cls.pending:
             cls.flush(mid_step=True)
-
-    ride = False  # the next ParamStore.refresh_transposed carries the pending advances (and the snapshot) in its launch
+            return
+        for q in list(CounterQueue._all or ()):   # (a counter read outside its owner's entry points)
+            if q is not cls._stack[-1] and t.data_ptr() in q.pending:
+                with cls.bind(q):
+                    cls.flush(mid_step=True)
 
     @classmethod
     def take_for_ride(cls):

@@ -233,8 +233,24 @@ def _backbone(G):
     return G.backbone if hasattr(G, "backbone") else G
 
 
+def _own_counters(fn):
+    """run a Trainer entry point with the trainer's own queue of counter advances current (`_lib.Counters.bind`)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with L.Counters.bind(self.counters):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class Trainer:
     def __init__(self, cfg, local_cfg, loader=None):
+        self.counters = L.CounterQueue()   # this trainer's queued Philox / Adam / pool counter advances (never another trainer's)
+        with L.Counters.bind(self.counters):
+            self._init(cfg, local_cfg, loader)
+
+    def _init(self, cfg, local_cfg, loader=None):
         self.cfg = cfg
         self.local_cfg = local_cfg
         gpu = local_cfg["gpu"] if isinstance(local_cfg, dict) else local_cfg.gpu
@@ -259,7 +275,8 @@ class Trainer:
         self.world = _world()
         self._job_seed = D_.broadcast_int(torch.initial_seed() & (2**62 - 1), self.device, src=0)
         self.A = DiffAugment(policy=list(self.cfg.solver.augment) if self.cfg.solver.augment is not None else None,
-                             seed=None if self.world == 1 else self._job_seed + 101 + 7919 * _rank())
+                             seed=self._job_seed + 101 + 7919 * _rank())   # (fixed at construction: the lazy default reads
+                                                                            #  torch's GLOBAL seed at the first draw)
         H, W = self.cfg.dataset.shape
         self.H, self.W = int(H), int(W)
         self.lidar = LiDAR(num_ring=H, num_points=W, min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth,
@@ -600,6 +617,7 @@ class Trainer:
             self._coll(lambda: None)
 
     # ------------------------------------------------------------------ D phase (reference :171-238)
+    @_own_counters
     def optimize_D(self, reals=None, rands=None):
         """One discriminator update over `num_accumulation` micro-batches.
         reals: optional list of (x_real, m_real) already through fetch_reals; rands: optional list of randomness
@@ -718,6 +736,7 @@ class Trainer:
         return scal
 
     # ------------------------------------------------------------------ G phase (reference :240-316)
+    @_own_counters
     def optimize_G(self):
         lib, sp = L.lib(), L.stream_ptr()
         B = self.local_batch
@@ -1106,6 +1125,7 @@ class Trainer:
         finally:
             self._retry_batch = None
 
+    @_own_counters
     def step(self, i=0, reals=None, rands=None):
         """One training iteration (reference :162-325).  Returns dict[str,float] of globally averaged scalars."""
         if self._graph_eligible(reals, rands) and (self.n_acc == 1 or self._pooled()):
@@ -1124,6 +1144,7 @@ class Trainer:
         from ..utils.lidar import postprocess
         return postprocess(synth, self.lidar)
 
+    @_own_counters
     @torch.no_grad()
     def generate(self, ema=False):
         """reference :331-340"""
@@ -1144,6 +1165,7 @@ class Trainer:
                                          shuffle=True, drop_last=False)
         return self.val_loader
 
+    @_own_counters
     @torch.no_grad()
     def validation(self, swd_rand=None, return_data=False):
         """reference :342-393: real (validation split) vs synthetic (G_ema) sets of equal size N ->
@@ -1179,6 +1201,7 @@ class Trainer:
         scores.update(compute_cov_mmd_1nna(data["fake-3d"], data["real-3d"], 512, ("cd",)))
         return (scores, data) if return_data else scores
 
+    @_own_counters
     def state(self, step):
         def sd(m):
             return OrderedDict((k, v.detach().cpu().contiguous()) for k, v in m.state_dict().items())
@@ -1236,6 +1259,7 @@ class Trainer:
             for _ in range(n % len(src)):
                 next(self.loader)
 
+    @_own_counters
     def save_models(self, suffix, step, directory="models"):
         """reference :395-409 (same keys, reference-shaped tensors)"""
         import os

@@ -15,6 +15,10 @@ class Philox:
     def __init__(self, seed, device, stream_id=0):
         self.seed, self.device, self.stream_id = int(seed) & (2**64 - 1), device, int(stream_id)
         self.ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        # the queue of counter advances this generator belongs to: its creator's (a Trainer builds its generators with its own
+        # queue current).  Draws made from anywhere - a test, a script calling sample_latents between two steps - queue
+        # THERE, where the owner's next step looks before it launches or replays anything.
+        self.queue = L.Counters.current()
 
     @property
     def offset(self):
@@ -23,7 +27,8 @@ class Philox:
 
     def advance(self, n):
         """queued (L.Counters): applied with the step's other counters, or before this counter is read again"""
-        L.Counters.add(self.ctr, n)
+        with L.Counters.bind(self.queue):
+            L.Counters.add(self.ctr, n)
 
     def sync(self):
         """the device counter is current (call before a kernel reads it)"""

@@ -598,3 +598,32 @@ def test_resume_continues_like_the_uninterrupted_run(tmp_path, arch):
         d.step(i)
     assert rel_l2(params(d), params(a)) >= 2e-3, rel_l2(params(d), params(a))
     assert c.rng.offset == a.rng.offset and c.A._rng.offset == a.A._rng.offset
+
+
+def test_two_trainers_interleaved_train_like_solo_runs(monkeypatch):
+    """Two trainers of one process stepping alternately (graph replay, eager draws in between) end where each ends alone:
+    the counter advances a trainer queues - applied by the last launch of ITS step, i.e. captured into ITS graph - are its
+    own (`_lib.CounterQueue` per trainer), and so is its split-K workspace."""
+    monkeypatch.setenv("DUSTY_GAN_GRAPH", "1")
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return make_trainer("none", True, (32, 64), 8, 4, 16, 4)   # (the dusty maskers seed their generator lazily from torch's
+                                                                    #  GLOBAL seed: not a function of the trainer alone)
+    def solo(seed, n):
+        tr = make(seed)
+        for i in range(n):
+            tr.step(i)
+            tr.generate()                       # an eager draw between replays (queued advance outside the graph)
+        return tr
+    ref_a, ref_b = solo(11, 4), solo(12, 4)
+    a, b = make(11), make(12)
+    for i in range(4):
+        a.step(i); b.step(i)
+        b.generate(); a.generate()
+    assert a._graph is not None and b._graph is not None
+    for tr, ref in ((a, ref_a), (b, ref_b)):
+        for net in ("G", "D", "G_ema"):
+            r = rel_l2(getattr(tr, net).store.flat.cpu(), getattr(ref, net).store.flat.cpu())
+            assert r < 1e-5, (net, r)
+        assert tr.optim_G.step_count == 4 and int(tr.optim_G._step_dev) == int(ref.optim_G._step_dev)

@@ -392,3 +392,22 @@ def test_counters_ride_and_mid_step_flush_without_gpu(monkeypatch):
     with pytest.raises(RuntimeError):
         C.flush()
     C.pending.clear(); C.snap = None; C.ride = False
+
+
+def test_counter_queues_are_per_owner():
+    """`_lib.Counters` (queued Philox / Adam / pool counter advances) reads and writes the CURRENT owner's queue: what one
+    trainer queues is invisible to the flush / the riding launch of another trainer's step (round-3 review, item 10)"""
+    import torch
+    from dusty_gan_amd import _lib as L
+    a, b = L.CounterQueue(), L.CounterQueue()
+    t = torch.zeros(1, dtype=torch.int64)
+    with L.Counters.bind(a):
+        L.Counters.add(t, 3)
+        L.Counters.ride = True
+        with L.Counters.bind(b):
+            assert not L.Counters.pending and not L.Counters.ride and L.Counters.snap is None
+            L.Counters.add(t, 1)
+        assert L.Counters.pending[t.data_ptr()][1] == 3 and L.Counters.ride
+    assert t.data_ptr() not in L.Counters.pending and not L.Counters.ride      # the process-wide default queue: untouched
+    assert b.pending[t.data_ptr()][1] == 1 and a.ride and not b.ride
+    a.pending.clear(); b.pending.clear()
