@@ -351,6 +351,13 @@ class _PerStreamWorkspace:
 WGRAD_WS = _PerStreamWorkspace()
 
 
+def grads_ready():
+    """The engines' backward passes leave the split-K partial tiles of the fat layers' weight gradients in `WGRAD_WS`
+    (`defer=True`): `st.grad` is complete only after this call (what `FlatAdam.step` and the trainer's all-reduce helpers
+    do first).  Anything else that reads a ParamStore's gradient after GEngine.backward / DEngine.wgrad calls it."""
+    WGRAD_WS.flush()
+
+
 class MaskBits:
     """Saved leaky-relu masks at 1 bit per element (DgConv.mask_out / mask_in; the reference's autograd keeps the sign of
     every FusedLeakyReLU pre-activation, models/ops/common.py:99-106).  An engine registers one uint8 buffer of numel / 8

@@ -368,6 +368,7 @@ class Trainer:
         self._pending = None
         self._dev_scal = None
         self._pool_ctr = None   # device-resident loader position of the synthetic pool (dg_fetch_reals_pool_sum)
+        self._pool_host = 0     # its host mirror: checked against batches_drawn before every graph step
         # the logged scalars leave the device with the step's last launch, into a ring of mapped pinned host memory
         # (RingSlot); DUSTY_GAN_SCALAR_RING=0: a device copy + a blocking read-back per step instead
         self._snap_ring, self._snap_ctr, self._snap_pos = None, None, 0
@@ -477,11 +478,16 @@ class Trainer:
                 #  up front - the first of those)
                 first = self.batches_drawn - (getattr(self, "_drawn_ahead", 1) or 1)
                 self._pool_ctr = torch.full((1,), first, dtype=torch.int64, device=self.device)
+                self._pool_host = first
             L.Counters.flush_if(self._pool_ctr)
             x = self.lidar.fetch_reals_pool(ds.pool_depth, ds.pool_mask, self._pool_ctr,
                                             float(self.cfg.model.gen.drop_const))
             L.Counters.add(self._pool_ctr, 1)   # (queued: applied with the step's other counters, inside the graph)
-            return x, raw_batch["mask"]
+            if not torch.cuda.is_current_stream_capturing():
+                self._pool_host += 1            # (host mirror of the device index; a capture executes nothing)
+            # no mask on this path: the loader's host batch is NOT what a replay reads (the device picks the batch), and
+            # nothing downstream uses the reals' mask (reference :154-160 returns it, :162-325 never reads it)
+            return x, None
         return self.fetch_reals(raw_batch)
 
     def _g_engines(self):
@@ -1043,6 +1049,12 @@ class Trainer:
             batches = [self._next_batch() for _ in range(self.n_acc)]
             self._drawn_ahead = self.n_acc
             batch = batches[0] if self.n_acc == 1 else batches
+            if pooled and self._pool_ctr is not None and self._pool_host != self.batches_drawn - self.n_acc:
+                # another consumer of the loader (an eager step with injected draws, a script calling _next_batch) has moved
+                # the host position past the device-side pool index: the step fetches what the loader just yielded
+                L.Counters.flush_if(self._pool_ctr)
+                self._pool_host = self.batches_drawn - self.n_acc
+                self._pool_ctr.fill_(self._pool_host)
         mbs = batch if isinstance(batch, list) else [batch]
 
         def fetch_all(srcs):   # every micro-batch's fetch_reals at the head of the step (the first one opens the arena)
@@ -1112,6 +1124,8 @@ class Trainer:
                 item()
         self.optim_D.step_count += 1
         self.optim_G.step_count += 1
+        if pooled:
+            self._pool_host += self.n_acc   # (the replay advanced the device-side pool index by its micro-batches)
         # the replayed Adam+EMA kernel rewrote G_ema's master through raw pointers: its low-precision / transposed
         # shadows (built lazily, only when G_ema is evaluated) are stale now
         _backbone(self.G_ema).store._seen_version = -1

@@ -627,3 +627,27 @@ def test_two_trainers_interleaved_train_like_solo_runs(monkeypatch):
             r = rel_l2(getattr(tr, net).store.flat.cpu(), getattr(ref, net).store.flat.cpu())
             assert r < 1e-5, (net, r)
         assert tr.optim_G.step_count == 4 and int(tr.optim_G._step_dev) == int(ref.optim_G._step_dev)
+
+
+def test_pool_index_follows_the_loader_when_something_else_draws_a_batch(monkeypatch):
+    """The synthetic pool's batch is picked ON THE DEVICE by a counter the replayed step advances.  Another consumer of the
+    loader between two graph steps (an eager step with injected draws, a script) moves the host position only: the next
+    step re-seeds the device index from `batches_drawn` instead of fetching a batch behind the loader's for ever."""
+    from dusty_gan_amd import _lib as L
+    monkeypatch.setenv("DUSTY_GAN_GRAPH", "1")
+    torch.manual_seed(5)
+    tr = make_trainer("none", True, (32, 64), 8, 4, 16, 4)
+    for i in range(4):
+        tr.step(i)
+    assert tr._graph is not None and tr._pool_ctr is not None
+
+    def device_index():
+        with L.Counters.bind(tr.counters):
+            L.Counters.flush_if(tr._pool_ctr)
+        return int(tr._pool_ctr)
+    assert device_index() == tr.batches_drawn == 4
+    tr._next_batch()                       # somebody else takes a batch
+    tr.step(4)
+    assert device_index() == tr.batches_drawn == 6
+    tr.step(5)
+    assert device_index() == tr.batches_drawn == 7
