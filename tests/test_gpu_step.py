@@ -340,9 +340,12 @@ def test_accumulated_step_replays_from_a_graph(monkeypatch):
     for net in ("G", "D", "G_ema"):
         fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
         assert rel_l2(fa, fb) < 2.5e-3, (net, rel_l2(fa, fb))
+    # (scripts/probes/acc_graph_flake.py, 16 repetitions: graph-vs-eager and eager-vs-eager have the SAME spread - the run-to-run
+    #  noise of a bf16 step with atomics; losses <= 0.015, the mean raw logits `output/*` of 8 samples <= 0.024 in absolute terms)
     for x, y in zip(sa, sb):
         for k in x:
-            assert abs(x[k] - y[k]) < 2e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+            tol = 6e-2 if "/output/" in k else 3e-2
+            assert abs(x[k] - y[k]) < tol * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
 def test_checkpoint_roundtrip_and_generate(tmp_path):

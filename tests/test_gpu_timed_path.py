@@ -160,7 +160,8 @@ def test_graph_replay_matches_eager_at_bench_size(monkeypatch):
         assert float((fa - fb).abs().max()) <= 0.05, net  # (Adam can move an element ~sqrt(k) lr at step k)
     for x, y in zip(sa, sb):
         for k in x:
-            assert abs(x[k] - y[k]) < 2e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+            tol = 4e-2 if "/output/" in k else 2e-2   # (mean raw logits: run-to-run noise of their own, tests/test_gpu_step.py)
+            assert abs(x[k] - y[k]) < tol * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
 @pytest.mark.parametrize("amp,B", [(False, 2), (True, 4)], ids=["fp32-B2", "bf16-B4"])
