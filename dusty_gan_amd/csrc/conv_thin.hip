@@ -1426,8 +1426,9 @@ int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
 #ifndef S2_CAP
 #define S2_CAP 768
 #endif
-  const long cap = S2_CAP;  // 3 blocks per CU = what 164 VGPRs allow resident (measured: 256 -> 50 us, 512 -> 34 us, 768 -> 31 us,
-                         // 1024 -> 38 us for Down1 forward at batch 32; the per-wave weight preload amortises over the tiles)
+  const long cap = S2_CAP;  // 3 blocks per CU.  Round 3 (164 VGPRs, 3 resident): 256 -> 50 us, 512 -> 34 us, 768 -> 31 us, 1024 -> 38 us
+                         // for Down1 forward at batch 32; round 4 (116-120 VGPRs, 4 resident): 512 / 768 / 1024 -> 26.6 / 25.5 / 26.3 us
+                         // (43.0 / 38.3 / 41.9 at batch 64) - the per-wave weight preload amortises over the tiles
   if (blocks > cap) blocks = cap;
   const int mb = (p->epi == EPI_LRELU && p->mask_out) ? 1 : ((p->epi == EPI_MASK && p->mask_in) ? 2 : 0);
 #define DG_S2_LAUNCH(CP_, MB_) thin_s2_mfma_kernel<CP_, MB_><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, ntiles)
