@@ -247,6 +247,149 @@ def other_config_lines(args):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: every rank is a SUPERVISOR that starts the measuring process as a child and never touches the GPU itself.
+# The default multi-rank schedule replays RCCL collectives captured inside the step's hipGraph; no box this repository
+# has been measured on had two GPUs, so a deadlock of that form at replay must cost one attempt, not the record:
+#   attempt 0  collectives inside the one graph          (the trainer's default on the nccl backend)
+#   attempt 1  DUSTY_GAN_GRAPH_COMM=0: hipGraph segments with the collectives as host calls between them
+#   attempt 2  DUSTY_GAN_GRAPH_DDP=0:  eager launches
+# A child that dies, stops making progress for STALL seconds or exceeds CAP seconds fails the attempt for ALL ranks (a flag
+# in the launcher's TCP store); every supervisor then kills its child's process group and starts a NEW child of the next
+# mode on a fresh rendezvous port - never a re-exec or a restart inside a process that has initialised the GPU.
+# Reference: train.py:44-57,185-186 (one worker per GPU, file-store rendezvous, no retry of any kind).
+ATTEMPTS = (("collectives inside the hipGraph", {}),
+            ("hipGraph segments, collectives between them", {"DUSTY_GAN_GRAPH_COMM": "0"}),
+            ("eager launches", {"DUSTY_GAN_GRAPH_COMM": "0", "DUSTY_GAN_GRAPH_DDP": "0"}))
+
+
+def progress(what):
+    """the measuring child tells its supervisor that it is alive (one appended line per phase / step)"""
+    path = os.environ.get("DUSTY_BENCH_PROGRESS")
+    if path:
+        try:
+            with open(path, "a") as fh:
+                fh.write(f"{time.time():.3f} {what}\n")
+        except OSError:
+            pass
+
+
+def _supervisor_store(rank, world):
+    """the key-value store the supervisors coordinate through: the launcher's own TCP store (torch.distributed.run keeps
+    one at MASTER_ADDR:MASTER_PORT and tells its workers to join it as clients), else one hosted by rank 0's supervisor"""
+    import datetime
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    return dist.TCPStore(addr, port, None, (not agent) and rank == 0, timeout=datetime.timedelta(seconds=120),
+                         wait_for_workers=False)
+
+
+def _kill_group(proc):
+    import signal
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        proc.wait(timeout=30)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def supervise(args):
+    """run the measuring child of this rank through ATTEMPTS (see above); rank 0 relays the successful child's JSON line"""
+    import socket
+    import subprocess
+    import tempfile
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    stall = float(os.environ.get("DUSTY_BENCH_STALL_S", "180"))     # no progress line for this long = hung
+    cap = float(os.environ.get("DUSTY_BENCH_CAP_S", "600"))         # wall-clock budget of one attempt
+    first = int(os.environ.get("DUSTY_BENCH_FIRST_ATTEMPT", "0"))
+    child_cmd = os.environ.get("DUSTY_BENCH_CHILD_CMD")             # (tests: a stand-in for the measuring process)
+    store = _supervisor_store(rank, world)
+    pfx = f"dusty_bench/{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+    history = []
+    tmp = tempfile.mkdtemp(prefix=f"dusty_bench_r{rank}_")
+    for a in range(first, len(ATTEMPTS)):
+        name, extra = ATTEMPTS[a]
+        key = f"{pfx}/a{a}"
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                store.set(f"{key}/port", str(sk.getsockname()[1]))
+        port = store.get(f"{key}/port").decode()
+        env = dict(os.environ)
+        env.update(extra)
+        env.update({"DUSTY_BENCH_CHILD": "1", "DUSTY_BENCH_ATTEMPT": str(a), "MASTER_PORT": port,
+                    "DUSTY_BENCH_PROGRESS": os.path.join(tmp, f"progress_a{a}")})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the child's process group meets on its OWN port with rank 0's child as the host (not the launcher's store, where
+        # the keys of a failed attempt would still lie)
+        for k in ("TORCHELASTIC_USE_AGENT_STORE",):
+            env.pop(k, None)
+        out_path = os.path.join(tmp, f"stdout_a{a}")
+        cmd = child_cmd.split() if child_cmd else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.time()
+        with open(out_path, "w") as fout:
+            proc = subprocess.Popen(cmd, env=env, stdout=fout, start_new_session=True)
+        outcome, last_size, last_change = None, -1, t0
+        while outcome is None:
+            time.sleep(0.25)
+            rc = proc.poll()
+            now = time.time()
+            if rc is not None:
+                outcome = "ok" if rc == 0 else f"child exited {rc}"
+                break
+            if store.check([f"{key}/fail"]):
+                outcome = "failed on another rank: " + store.get(f"{key}/fail").decode()
+                break
+            try:
+                size = os.path.getsize(env["DUSTY_BENCH_PROGRESS"])
+            except OSError:
+                size = 0
+            if size != last_size:
+                last_size, last_change = size, now
+            if now - last_change > stall:
+                outcome = f"no progress for {stall:.0f} s (rank {rank})"
+            elif now - t0 > cap:
+                outcome = f"exceeded {cap:.0f} s (rank {rank})"
+        if outcome != "ok":
+            if not store.check([f"{key}/fail"]):
+                store.set(f"{key}/fail", outcome)
+            _kill_group(proc)
+        else:
+            store.set(f"{key}/done/{rank}", "ok")
+            # everyone's child must have finished: a rank whose child is still stuck fails the attempt for all
+            t1 = time.time()
+            keys = [f"{key}/done/{r}" for r in range(world)]
+            while not store.check(keys):
+                if store.check([f"{key}/fail"]):
+                    outcome = "failed on another rank: " + store.get(f"{key}/fail").decode()
+                    break
+                if time.time() - t1 > stall:
+                    outcome = "the other ranks did not finish"
+                    store.set(f"{key}/fail", outcome)
+                    break
+                time.sleep(0.25)
+        history.append({"attempt": a, "mode": name, "outcome": outcome, "seconds": round(time.time() - t0, 1)})
+        if outcome == "ok":
+            if rank == 0:
+                line = None
+                with open(out_path) as fh:
+                    for ln in fh:
+                        if ln.startswith("{"):
+                            line = ln
+                if line is None:
+                    print("bench.py supervisor: the child printed no JSON line", file=sys.stderr)
+                    return 1
+                rec = json.loads(line)
+                rec.setdefault("distributed", {})["launch_attempts"] = history
+                print(json.dumps(rec), flush=True)
+            return 0
+        print(f"bench.py supervisor (rank {rank}): attempt {a} [{name}] failed: {outcome}", file=sys.stderr, flush=True)
+    return 1
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves (the
     reference's train.py:185-186 does mp.spawn(main_worker, nprocs=ngpus)) and relay rank 0's JSON line.  Runs before
@@ -261,13 +404,24 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    # every worker is a supervisor (above) with its own per-attempt budget; this is the belt over those braces
+    budget = len(ATTEMPTS) * float(os.environ.get("DUSTY_BENCH_CAP_S", "600")) + 300
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=budget)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the launcher did not finish within {budget:.0f} s; killing its process group", file=sys.stderr)
+        _kill_group(proc)
+        return 1
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("DUSTY_BENCH_CHILD") != "1" \
+            and os.environ.get("DUSTY_BENCH_SUPERVISE", "1") != "0":
+        sys.exit(supervise(args))     # (before anything touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -303,7 +457,9 @@ def main():
                                 device_id=torch.device("cuda", 0))
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    progress("process group up")
     tr, arch = make_trainer(args, rank, local_rank, world)
+    progress("trainer constructed")
 
     def sync():
         torch.cuda.synchronize()
@@ -314,9 +470,13 @@ def main():
     last = None
     for i in range(args.warmup):
         last = tr.step(i)
+        if world > 1:
+            torch.cuda.synchronize()   # (a hang shows up at the step that hangs, not at the end of the warm-up)
+            progress(f"warm-up step {i}: {tr.launch_mode()}")
     if last is not None:
         _ = list(last.values())
     sync()
+    progress("timed region")
     # per-step device times: one HIP event after every step on the launch stream (the replayed graph / the eager
     # launches of a step run on torch's current stream, so consecutive events bracket exactly one step)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -338,6 +498,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    progress("timed region done")
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,6 +525,8 @@ def main():
     if dist.is_initialized():
         out["distributed"] = {"backend": backend or dist.get_backend(), "world_size": dist.get_world_size(),
                               "devices_visible": torch.cuda.device_count()}
+        out["distributed"]["attempt"] = (ATTEMPTS[int(os.environ["DUSTY_BENCH_ATTEMPT"])][0]
+                                         if "DUSTY_BENCH_ATTEMPT" in os.environ else "unsupervised")
         out["distributed"]["exchanges_per_step"] = 4  # D.hi, D.lo, G.gather (one coalesced pair), G.tail (+ the async scalars)
         try:
             out["distributed"]["bytes_per_step"] = tr.comm_bytes()

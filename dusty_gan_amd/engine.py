@@ -293,6 +293,11 @@ class WgradWorkspace:
         self.demand = 0
         self._reduce_pending()
 
+    def discard(self):
+        """forget the pending partials WITHOUT summing them: the launches that were to write them never ran (an aborted
+        stream capture) - a later flush would add never-written workspace memory onto the gradients"""
+        self.items, self.pos, self.demand = [], 0, 0
+
     def _reduce_pending(self):
         items, self.items, self.pos = self.items, [], 0
         # one launch per <= 8 layers, and never two items with the same destination in one launch (micro-batches, the
@@ -340,6 +345,22 @@ class _PerStreamWorkspace:
 
     def __getattr__(self, name):          # take / add / flush / items / pos / hwm ... of the current stream's workspace
         return getattr(self._cur(), name)
+
+    def pending_elsewhere(self):
+        """layers whose partials wait in ANOTHER stream's workspace of the current device: `grads_ready()` on this stream
+        does not sum them (a reader of `st.grad` on the wrong stream would see incomplete gradients)"""
+        if not torch.cuda.is_available():
+            return 0
+        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        return sum(len(w.items) for k, w in self._by_stream.items() if k[0] == key[0] and k != key)
+
+    def drop_stream(self, stream=None):
+        """release the workspace of `stream` (default: the current one) - called when the graph / trainer that owned the
+        stream goes away, so that a recycled stream handle does not inherit its buffer or its pending list"""
+        if not torch.cuda.is_available():
+            return
+        h = (stream or torch.cuda.current_stream()).cuda_stream
+        self._by_stream.pop((torch.cuda.current_device(), h), None)
 
     def __setattr__(self, name, value):
         if name == "_by_stream":

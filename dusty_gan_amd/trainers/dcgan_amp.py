@@ -1072,44 +1072,57 @@ class Trainer:
             # workspace allocated while capturing one segment stays valid in the next.
             self._cap, self._cap_pool = [], torch.cuda.graph_pool_handle()
             counts = (self.optim_D.step_count, self.optim_G.step_count)
+            in_graph, err = self._comm_in_graph, None
             try:
                 self._cap_open()
                 src = mbs if pooled else [{"depth": self._g_pol, "mask": self._g_mask}]
                 self._g_out = self._step_eager(reals=fetch_all(src))
                 self._cap_close()
-                self._comm_captured = self._comm_in_graph
             except BaseException as exc:
+                err = exc
                 if self._cap_cur is not None:
+                    # the split-K partials queued by the aborted capture were never written: forget them while the CAPTURE
+                    # stream is still current (E.WGRAD_WS is per stream - after __exit__ the default stream's workspace would be
+                    # the one reset, and the retry on this capture stream would reduce never-written memory into the gradients
+                    # on every replay)
+                    E.WGRAD_WS.discard()
                     try:
                         self._cap_cur[1].__exit__(None, None, None)
                     except BaseException:
                         pass
-                self._cap, self._cap_cur = None, None
+                else:
+                    E.WGRAD_WS.discard()
+                self._cap_cur = None
                 L.Counters.pending.clear()  # (advances queued by the aborted capture were never going to run)
                 L.Counters.snap, L.Counters.ride = None, False
-                E.WGRAD_WS.items, E.WGRAD_WS.pos = [], 0
                 self._works.clear()
-                if self._comm_in_graph:
-                    # the runtime refused collectives inside the capture: nothing was executed - restore the host mirrors
-                    # and capture again as segments with the collectives between them
-                    import warnings
-                    warnings.warn(f"capturing the step with its collectives failed ({type(exc).__name__}: {exc}); "
-                                  "falling back to hipGraph segments")
+                if not isinstance(exc, Exception):   # KeyboardInterrupt / SystemExit: not a refused capture
+                    self._cap = None
+                    raise
+            # The ranks take ONE decision about collectives inside the graph: a rank that fell back to segments beside peers
+            # replaying captured collectives would be the only one making host-side calls (and a mixed job has never run
+            # anywhere).  Nothing has executed yet - the capture only recorded - so every rank reaches this exchange.
+            everyone = D_.all_agree(err is None, self.device) if (in_graph and self.world > 1) else err is None
+            what = D_.capture_decision(in_graph, err is None, everyone, self.world)
+            if what != "keep":
+                import warnings
+                self._cap = None
+                self._works.clear()
+                self.optim_D.step_count, self.optim_G.step_count = counts   # nothing was executed: restore the host mirrors
+                self._mb = []
+                if what == "segments":
+                    why = f"{type(err).__name__}: {err}" if err is not None else "a peer rank could not capture them"
+                    warnings.warn(f"capturing the step with its collectives failed ({why}); falling back to hipGraph segments")
                     self._comm_in_graph = False
-                    self.optim_D.step_count, self.optim_G.step_count = counts
-                    self._mb = []
                     torch.cuda.synchronize()
                     return self._step_graph_retry(batch, pooled)
-                if self.world == 1:
-                    raise
-                # multi-rank: a runtime that refuses the capture must not take the job down - nothing was executed,
-                # so restore the host mirrors and keep launching eagerly
-                import warnings
+                if what == "raise":
+                    raise err
+                # multi-rank: a runtime that refuses the capture must not take the job down - keep launching eagerly
                 warnings.warn("hipGraph capture of the training step failed; continuing with eager launches")
-                self.optim_D.step_count, self.optim_G.step_count = counts
                 self.use_graph = False
-                self._mb = []
                 return self._step_eager(reals=fetch_all(mbs))
+            self._comm_captured = in_graph
             self._graph, self._cap = self._cap, None
             # the capture did not execute anything, but the host mirrors of the Adam step counts advanced once
             self.optim_D.step_count -= 1

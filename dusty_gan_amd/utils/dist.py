@@ -56,6 +56,34 @@ def broadcast_int(value, device, src=0):
     return int(t.item())
 
 
+def all_agree(ok, device=None):
+    """True iff `ok` is true on EVERY rank (a blocking MIN all-reduce of one flag; the flag itself without a process
+    group).  The ranks use it to take one decision about something each of them tried alone - whether the step's
+    collectives could be captured inside its hipGraph: a rank that fell back to segments while its peers replay captured
+    collectives would be the only one issuing host-side calls."""
+    if world_size() == 1:
+        return bool(ok)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def capture_decision(in_graph, local_ok, everyone_ok, world):
+    """What a rank does after its attempt to capture the training step (trainers/dcgan_amp.py `_step_graph`):
+      "keep"      replay what was captured
+      "segments"  discard it and capture again as hipGraph segments with the collectives as host calls between them
+      "eager"     keep launching eagerly (a multi-rank job must not die of a refused capture)
+      "raise"     single process: the failure is the caller's to see
+    in_graph: the attempt had the collectives inside the capture; local_ok: this rank's capture went through;
+    everyone_ok: all_agree(local_ok) - only consulted for in-graph attempts, where ONE rank falling back means ALL do."""
+    if in_graph:
+        return "keep" if (local_ok and everyone_ok) else "segments"
+    if local_ok:
+        return "keep"
+    return "raise" if world == 1 else "eager"
+
+
 def allreduce_grads(flat_grad, async_op=False):
     """SUM all-reduce of one network's flat gradient buffer; returns (work handle or None, gscale) where gscale is the
     factor the optimizer applies to turn the sum into DDP's average."""

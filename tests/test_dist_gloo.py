@@ -130,3 +130,36 @@ def test_local_batch_and_accumulation_schedule():
     assert DD.world_size() == 1 and DD.rank() == 0
     g = torch.ones(4)
     assert DD.allreduce_grads(g) == (None, 1.0)
+
+
+def agree_worker(rank, world, init_file, out_dir):
+    from dusty_gan_amd.utils import dist as DD
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
+    # round 0: every rank captured; round 1: rank 1 could not; round 2: nobody could
+    seen = [DD.all_agree(True), DD.all_agree(rank != 1), DD.all_agree(False)]
+    what = [DD.capture_decision(True, ok, ev, world) for ok, ev in zip((True, rank != 1, False), seen)]
+    torch.save({"seen": seen, "what": what}, os.path.join(out_dir, f"agree{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_agree_on_the_capture_outcome():
+    """One rank that cannot capture the collectives inside the step's hipGraph takes every rank to the segmented replay
+    (trainers/dcgan_amp.py `_step_graph`): the flag is MIN-reduced, and the decision table is the same on every rank."""
+    from dusty_gan_amd.utils import dist as DD
+    world = 2
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(agree_worker, args=(world, os.path.join(td, "init"), td), nprocs=world, join=True)
+        outs = [torch.load(os.path.join(td, f"agree{r}.pt")) for r in range(world)]
+    for o in outs:
+        assert o["seen"] == [True, False, False]
+        assert o["what"] == ["keep", "segments", "segments"]   # the rank that DID capture discards its graph too
+    # the table itself (no process group: the flag is the rank's own)
+    assert DD.all_agree(True) is True and DD.all_agree(False) is False
+    assert DD.capture_decision(True, True, True, 8) == "keep"
+    assert DD.capture_decision(True, True, False, 8) == "segments"
+    assert DD.capture_decision(True, False, False, 1) == "segments"
+    assert DD.capture_decision(False, True, True, 8) == "keep"
+    assert DD.capture_decision(False, False, False, 8) == "eager"     # a multi-rank job does not die of a refused capture
+    assert DD.capture_decision(False, False, False, 1) == "raise"

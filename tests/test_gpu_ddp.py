@@ -150,6 +150,57 @@ def test_two_ranks_over_rccl_match_single_process():
     assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
 
 
+def rccl_graph_worker(rank, world, init_file, out_dir, mode):
+    from tests.test_gpu_step import make_trainer
+    os.environ["DUSTY_GAN_GRAPH_COMM"] = "1" if mode == "in_graph" else "0"
+    os.environ["DUSTY_GAN_GRAPH_DDP"] = "0" if mode == "eager" else "1"
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", rank), timeout=PG_TIMEOUT)
+    torch.manual_seed(300)   # one job seed: same initial nets; each rank's device RNG streams derive from it by rank
+    tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 16, amp=True, gpu=rank)
+    scal = []
+    for i in range(6):
+        s = tr.step(i)
+        if i % 2 == 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+        scal.append(dict(s.items()))
+    segs = 0 if tr._graph is None else sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
+    torch.save({"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": scal,
+                "segs": segs, "captured": tr._comm_captured, "mode": tr.launch_mode()}, os.path.join(out_dir, f"{mode}_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: this box has one GPU")
+@pytest.mark.parametrize("mode", ["in_graph", "segments"])
+def test_two_ranks_over_rccl_graph_forms_match_eager(mode):
+    """The two replayed forms of the multi-rank step on the backend and at the size the multi-GPU bench runs (RCCL, two
+    devices, 64x1024, bf16, device RNG): collectives captured INSIDE the one hipGraph (the default) and hipGraph segments
+    with the collectives between them must each train like the eager launch sequence, and leave both ranks with identical
+    parameters.  Skipped on one-GPU boxes (every box this suite has run on so far): bench.py's supervisor is what keeps
+    the first real run from being lost if the in-graph form misbehaves there."""
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for m in (mode, "eager"):
+            mp.spawn(rccl_graph_worker, args=(2, os.path.join(td, "init_" + m), td, m), nprocs=2, join=True)
+            res[m] = [torch.load(os.path.join(td, f"{m}_r{r}.pt")) for r in range(2)]
+    a, e = res[mode], res["eager"]
+    if mode == "in_graph":
+        assert a[0]["captured"] == a[1]["captured"], "the ranks disagree about the capture"
+        assert a[0]["segs"] == (1 if a[0]["captured"] else a[0]["segs"]), a[0]["mode"]
+    else:
+        assert a[0]["segs"] >= 4 and not a[0]["captured"]
+    assert e[0]["segs"] == 0
+    for k in ("G", "D", "E"):
+        assert torch.equal(a[0][k], a[1][k]), k                    # the ranks stay replicas of each other
+        assert rel_l2(a[0][k], e[0][k]) < 2e-3, (k, rel_l2(a[0][k], e[0][k]))
+    for x, y in zip(a[0]["scal"], e[0]["scal"]):
+        for k in x:
+            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+
+
 @pytest.mark.parametrize("full", [False, True], ids=["tiny-fp32", "64x1024-bf16-B8"])
 def test_two_ranks_segmented_graph_matches_eager(full):
     """world > 1 (the default there): the step is replayed as hipGraph segments with the collectives (two D gradient
@@ -195,6 +246,54 @@ def test_forced_segments_single_process_match_one_graph(monkeypatch):
     for net in ("G", "D", "G_ema"):
         fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
         assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb))
+    for x, y in zip(sa, sb):
+        for k in x:
+            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+
+
+def test_aborted_capture_leaves_no_pending_partials(monkeypatch):
+    """A capture that fails while split-K partials are still pending (round-4 advice): the handler must forget them on the
+    CAPTURE stream's workspace - the re-capture as segments runs on that stream, and a stale pending list would be reduced
+    from never-written workspace memory into the gradients on every replay.  One process on the multi-rank schedule
+    (DUSTY_GAN_FORCE_SEG=1) with the in-graph form forced on and the wait for the Proj-operand gather raising once during
+    the capture; the run must then train like one whose capture never failed."""
+    import warnings
+    from dusty_gan_amd import engine as E
+    from tests.test_gpu_step import make_trainer
+
+    def run(fail):
+        monkeypatch.setenv("DUSTY_GAN_FORCE_SEG", "1")
+        torch.manual_seed(91)
+        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8, amp=True)
+        sc = [dict(tr.step(i).items()) for i in range(2)]       # the two eager warm-up steps
+        seen = {"n": 0, "pending": 0}
+        if fail:
+            tr._comm_in_graph = True
+            orig = tr._comm_wait
+
+            def flaky(*keys):
+                if tr._cap is not None and tr._comm_in_graph and "G.gather" in keys and seen["n"] == 0:
+                    seen["n"] += 1
+                    seen["pending"] = len(E.WGRAD_WS.items)
+                    raise RuntimeError("injected capture failure")
+                return orig(*keys)
+            tr._comm_wait = flaky
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            sc += [dict(tr.step(i).items()) for i in range(2, 6)]
+        if fail:
+            assert seen["n"] == 1 and any("falling back" in str(w.message) for w in caught)
+            assert not tr._comm_in_graph and tr._graph is not None
+        torch.cuda.synchronize()
+        for ws in E.WGRAD_WS._by_stream.values():
+            assert not ws.items, "partials of the aborted capture are still pending"
+        return tr, sc, seen
+    a, sa, seen = run(True)
+    b, sb, _ = run(False)
+    for net in ("G", "D", "G_ema"):
+        fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
+        assert torch.isfinite(fa).all()
+        assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb), seen)
     for x, y in zip(sa, sb):
         for k in x:
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
