@@ -192,7 +192,7 @@ def bench_config_key(args, arch):
             "pl": args.pl, "augment": not args.no_augment}
 
 
-PMC_FILE = "profiles/r04_pmc_traffic.json"
+PMC_FILE = "profiles/r05_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, args, arch):
@@ -211,6 +211,21 @@ def pmc_traffic(kernel, args, arch):
         return round(d["kernels"][kernel]["bytes_per_launch"]), f"{PMC_FILE} @ {d.get('git_sha', '?')}"
     except (OSError, KeyError, ValueError) as e:
         return None, f"not collected ({type(e).__name__})"
+
+
+def pmc_step_traffic(args, arch):
+    """measured HBM-side bytes of one whole step (every kernel of the PMC passes, divided by the steps the passes ran) and
+    the three big families' shares - beside `roofline.step.bytes`, the minimal-traffic model; None unless collected on
+    these sources and this workload"""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha") != kernel_source_sha() or d.get("config") != bench_config_key(args, arch):
+            return None
+        return {"bytes": round(d["all_kernels"]["bytes_per_step"]), "steps_in_trace": d["steps"],
+                "families": {k: round(v["bytes_per_step"]) for k, v in d["kernels"].items()}, "source": PMC_FILE}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def other_config_lines(args):
@@ -586,6 +601,11 @@ def main():
                 "bound": "hbm" if t_bytes > t_flop else "mfma", "frac": round(max(t_flop, t_bytes) / ms, 4),
                 "note": "per GPU: executed conv FLOPs / MFMA peak vs minimal parameter + activation bytes / 8 TB/s "
                         "(bench.py step_model), over the measured ms_per_step"}
+        meas = pmc_step_traffic(args, arch)
+        step["measured_bytes"] = meas["bytes"] if meas else None
+        if meas:
+            step["measured"] = meas
+            step["measured_over_model"] = round(meas["bytes"] / sb, 3)
         out.setdefault("roofline", {})["step"] = step
         # the gradient tolerances of the timed mode are its own (tests/test_gpu_configs.py), not north_star's 1e-3
         out["parity_of_this_mode"] = (

@@ -22,12 +22,19 @@ FAMILIES = {  # bench.py family name -> substrings of the kernel symbols it cove
 }
 
 
+STEP_BEGIN = ("step_prologue_kernel", "dg_zero_multi")   # the launch that opens a training step: counts the steps in a trace
+
+
 def load(path, counter):
     tot, n, names = collections.Counter(), collections.Counter(), collections.defaultdict(set)
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
+            tot["_all"] += float(r["Counter_Value"])
+            n["_all"] += 1
+            if any(sb in r["Kernel_Name"] for sb in STEP_BEGIN):
+                n["_steps"] += 1
             for fam, subs in FAMILIES.items():
                 if any(s in r["Kernel_Name"] for s in subs):
                     tot[fam] += float(r["Counter_Value"])
@@ -48,14 +55,26 @@ def main():
     res = {"_note": __doc__.strip().split("usage")[0].strip() + " bytes_per_launch = (2*FETCH_KB + WRITE_KB)*1024 / launches.",
            "kernel_source_sha": kernel_source_sha(), "config": bench_config_key(bench_args, bench_args.arch or "none"),
            "git_sha": sha or "(collected on the GPU box: no .git there)", "kernels": {}}
+    # the traces hold `steps` whole training steps (warm-up included: --steps 4 --warmup 2 = 6): per-step figures divide by it
+    assert fn["_steps"] == wn["_steps"] and fn["_steps"] > 0, (fn["_steps"], wn["_steps"])
+    steps = fn["_steps"]
+    res["steps"] = steps
     for fam in FAMILIES:
         if fn[fam] == 0:
             continue
         assert fn[fam] == wn[fam], (fam, fn[fam], wn[fam])
         res["kernels"][fam] = {"fetch_kb_raw": fk[fam], "write_kb": wk[fam], "launches": fn[fam],
-                               "bytes_per_launch": (2 * fk[fam] + wk[fam]) * 1024 / fn[fam], "symbols": sorted(names[fam])}
+                               "bytes_per_launch": (2 * fk[fam] + wk[fam]) * 1024 / fn[fam],
+                               "bytes_per_step": (2 * fk[fam] + wk[fam]) * 1024 / steps, "symbols": sorted(names[fam])}
+    # every kernel of the trace, same correction (the doubling is calibrated for 16-byte-per-lane streams only: kernels with
+    # narrower reads are over-counted by it - an upper bound on the step's HBM-side traffic)
+    res["all_kernels"] = {"fetch_kb_raw": fk["_all"], "write_kb": wk["_all"], "launches": fn["_all"],
+                          "bytes_per_step": (2 * fk["_all"] + wk["_all"]) * 1024 / steps,
+                          "bytes_per_step_fetch_not_doubled": (fk["_all"] + wk["_all"]) * 1024 / steps}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: round(v["bytes_per_launch"]) for k, v in res["kernels"].items()}))
+    print(json.dumps({"steps": steps, "per_launch": {k: round(v["bytes_per_launch"]) for k, v in res["kernels"].items()},
+                      "per_step": {k: round(v["bytes_per_step"]) for k, v in res["kernels"].items()},
+                      "step_total": round(res["all_kernels"]["bytes_per_step"])}))
 
 
 if __name__ == "__main__":
