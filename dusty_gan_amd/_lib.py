@@ -18,6 +18,7 @@ DG_OK, DG_EINVAL, DG_EUNSUPPORTED, DG_EHIP = 0, 1, 2, 3
 DG_F32, DG_BF16 = 0, 1
 MODE_S2, MODE_UP, MODE_GEMM = 0, 1, 2
 EPI_LINEAR, EPI_LRELU, EPI_MASK = 0, 1, 2
+DG_FORCE_FP32X3 = 0x100   # flag bit of the `force` arguments (include/dusty_gan_hip.h)
 POLICY_BITS = {"brightness": 1, "saturation": 2, "contrast": 4, "translation": 8, "cutout": 16}
 
 _ERR = {1: "DG_EINVAL (bad argument)", 2: "DG_EUNSUPPORTED (shape not supported by the requested kernel)",
@@ -101,8 +102,6 @@ _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double,
 # name -> argtypes (all return int except dg_version); mirrors include/dusty_gan_hip.h one to one
 PROTOTYPES = {
     "dg_conv": [C.POINTER(DgConv), _I, _P],
-    "dg_set_fp32_split": [_I],
-    "dg_set_conv_bigtile": [_I],
     "dg_conv_ex": [C.POINTER(DgConv), _I, _I, _P],
     "dg_conv_plan": [C.POINTER(DgConv), _I, _I, C.POINTER(DgConvPlan)],
     "dg_conv_mfma_supported": [C.POINTER(DgConv)],

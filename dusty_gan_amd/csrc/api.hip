@@ -4,7 +4,7 @@
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream);
 int dg_lrelu_bits_launch(const ConvP* p, hipStream_t stream);
-int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan);
+int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan, int x3);
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
 int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan);
@@ -16,34 +16,25 @@ int dg_conv_thin_mfma_variant(const ConvP* p);
 int dg_wgrad_thin_mfma_variant(const WgradP* p);
 int dg_wgrad_thin_ws_splits(const WgradP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
-int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream);
+int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream, int x3);
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_thin_supported(const WgradP* p);
 
-int g_dg_fp32_split = 0;   // dg_set_fp32_split: fp32 operands through split-bf16 matrix instructions (mfma_common.h)
-int g_dg_bigtile = 0;      // dg_set_conv_bigtile: force == 0 may pick the big-tile conv (conv_mfma_bt.hip; measured slower: opt-in)
+// `force` carries one flag bit beside the kernel-family code: DG_FORCE_FP32X3 (include/dusty_gan_hip.h) - fp32 operands through
+// split-bf16 matrix instructions (mfma_common.h).  Per CALL, so two engines of different precision in one process do not
+// share a setting (rounds 3-4 had a process-wide dg_set_fp32_split).
 
 extern "C" {
 
 const char* dg_version(void) { return "dusty_gan_hip 0.1 (gfx950)"; }
 
-int dg_set_conv_bigtile(int on) {
-  const int prev = g_dg_bigtile;
-  g_dg_bigtile = on ? 1 : 0;
-  return prev;
-}
-
-int dg_set_fp32_split(int on) {
-  const int prev = g_dg_fp32_split;
-  g_dg_fp32_split = on ? 1 : 0;
-  return prev;
-}
-
 // force: 0 auto (MFMA implicit GEMM -> thin LDS/VALU kernel -> direct), 1 direct, 2 MFMA or error, 3 thin or error,
 //        4 lock-step persistent large-tile MFMA kernel or error, 5 ping-pong persistent kernel or error (9: without its
-//        both-parities tile for 64-channel MODE_UP layers), 10 the weight-streaming Proj forward or error.
+//        both-parities tile for 64-channel MODE_UP layers), 10 the weight-streaming Proj forward or error;
+//        | DG_FORCE_FP32X3: DG_F32 operands through split-bf16 matrix instructions (the one-tile-per-workgroup MFMA kernels).
 //        plan != NULL: describe the launch instead of making it.
-static int conv_dispatch0(const DgConv* p, int force, int wg_cap, hipStream_t s, DgConvPlan* plan) {
+static int conv_dispatch0(const DgConv* p, int force_flags, int wg_cap, hipStream_t s, DgConvPlan* plan) {
+  const int force = force_flags & ~DG_FORCE_FP32X3, x3 = (force_flags & DG_FORCE_FP32X3) ? 1 : 0;
   if (!p || !p->in || !p->out || !p->w) return DG_EINVAL;
   if (p->B <= 0 || p->K <= 0 || p->N <= 0) return DG_EINVAL;
   if (p->mode != MODE_GEMM && (p->Hc < 2 || p->Wc < 2)) return DG_EINVAL;
@@ -57,9 +48,9 @@ static int conv_dispatch0(const DgConv* p, int force, int wg_cap, hipStream_t s,
   // general MFMA kernel it replaces
   if ((force == 0 || force == 10) && dg_proj_stream_supported(p)) return dg_proj_stream_launch(p, s, plan);
   if (force == 10) return DG_EUNSUPPORTED;
-  if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan) : DG_EUNSUPPORTED;
-  if (force == 4 || force == 5 || force == 9 || force == 11) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
-  if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan);
+  if (force == 2) return mfma_ok ? dg_conv_mfma_launch(p, s, wg_cap, plan, x3) : DG_EUNSUPPORTED;
+  if (force == 4 || force == 5 || force == 9) return mfma_ok ? dg_conv_mfma_big_launch(p, s, force, wg_cap, plan) : DG_EUNSUPPORTED;
+  if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan, x3);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {
     if (plan) { plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); plan->mask_bits = plan->thin_mfma == 1 ? 3 : 0; return DG_OK; }
@@ -107,7 +98,8 @@ int dg_conv_kernel_choice(const DgConv* p) {  // 2 = MFMA, 3 = thin, 1 = direct 
 
 // force: 0 auto, 1 direct, 2 MFMA (the LDS-DMA kernel where the shape allows), 3 thin, 6 the register-staged MFMA kernel,
 //        7 / 8 the LDS-DMA kernel with / without W-tap pairs
-static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force, hipStream_t s, DgWgradPlan* plan) {
+static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force_flags, hipStream_t s, DgWgradPlan* plan) {
+  const int force = force_flags & ~DG_FORCE_FP32X3, x3 = (force_flags & DG_FORCE_FP32X3) ? 1 : 0;
   if (!p || !p->a || !p->g || !p->dw) return DG_EINVAL;
   if (p->B <= 0 || p->Ci <= 0 || p->Co <= 0 || p->Hc <= 0 || p->Wc <= 0) return DG_EINVAL;
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
@@ -128,8 +120,8 @@ static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force, hipStream
   // ... and the gradient-sample map exists there and in the thin matrix-core kernel of Down1 (checked by its launcher)
   const bool thin_map = p->g_mod && thin_ok && !mfma_ok && (force == 0 || force == 3);
   if (p->g_mod && !thin_map) return DG_EUNSUPPORTED;
-  if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s) : DG_EUNSUPPORTED;
-  if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s);
+  if (force == 2 || force == 6) return mfma_ok ? dg_wgrad_mfma_launch(p, accumulate, s, x3) : DG_EUNSUPPORTED;
+  if (force == 0 && mfma_ok) return dg_wgrad_mfma_launch(p, accumulate, s, x3);
   if (!accumulate && !p->ws) {                       // (workspace form: the reduce launch overwrites dw)
     const long n = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
     { const int zrc = dg_zero_f32(p->dw, n, s); if (zrc) return zrc; }
@@ -150,7 +142,8 @@ int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan
 
 // 5 = MFMA on the LDS-DMA ring (wgrad_mfma_dma.hip), 2 = register-staged MFMA, 7 = thin on the matrix cores, 3 = thin
 // (VALU), 1 = direct: what `force` launches
-int dg_wgrad_kernel_variant(const DgWgrad* p, int force) {
+int dg_wgrad_kernel_variant(const DgWgrad* p, int force_flags) {
+  const int force = force_flags & ~DG_FORCE_FP32X3;
   const bool mfma_ok = dg_wgrad_mfma_supported(p);
   if ((force == 0 || force == 2 || force == 7 || force == 8) && mfma_ok && dg_wgrad_mfma_dma_supported(p)) return 5;
   if (force == 7 || force == 8) return 0;

@@ -379,24 +379,18 @@ int dg_conv_mfma_persist_launch_bf16(const ConvP* p, hipStream_t stream, int aut
 int dg_conv_mfma_persist_launch_f32(const ConvP* p, hipStream_t stream, int auto_rule, int wg_cap, DgConvPlan* plan);
 
 int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan, int dual);
-int dg_conv_mfma_bt_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan);
-extern int g_dg_bigtile;
 
 // plan != NULL: fill it with what would be launched and launch nothing.
 // Auto rule: bf16 layers with >= 256 tiles of 256 pixels -> ping-pong persistent kernel (conv_mfma_pp.hip, family 5);
 // layers the lock-step persistent kernel tiles with every CU busy -> that one (conv_mfma_persist_impl.h, family 4: fp32,
 // 128 x 128 tiles); everything else -> one tile per workgroup (below, family 2).
-int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
+int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan, int fp32x3) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  if (p->in_dtype == DG_BF16 && g_dg_bigtile) {   // layers with >= 256 tiles of 256 x 128 (or 512 x 64): the big-tile kernel
-    const int rc = dg_conv_mfma_bt_launch(p, stream, 256, wg_cap, plan);
-    if (rc != DG_EUNSUPPORTED) return rc;
-  }
   if (p->in_dtype == DG_BF16) {
     const int rc = dg_conv_mfma_pp_launch(p, stream, 256, wg_cap, plan, 1);
     if (rc != DG_EUNSUPPORTED) return rc;
   }
-  const bool x3 = p->in_dtype == DG_F32 && g_dg_fp32_split;
+  const bool x3 = p->in_dtype == DG_F32 && fp32x3;
   if (!x3) {   // (fp32x3: the one-tile-per-workgroup kernel below - the lock-step persistent fp32 kernel sits at 256 VGPRs)
     const int rc = p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 1, wg_cap, plan)
                                           : dg_conv_mfma_persist_launch_f32(p, stream, 1, wg_cap, plan);
@@ -426,7 +420,6 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
 // small problems): dg_conv force == 4 -> the lock-step kernel, force == 5 -> the ping-pong kernel
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
-  if (family == 11) return p->in_dtype == DG_BF16 ? dg_conv_mfma_bt_launch(p, stream, 1, wg_cap, plan) : DG_EUNSUPPORTED;
   if (family == 5 || family == 9)   // 9: the ping-pong kernel without its both-parities tile (A/B, parity tests)
     return p->in_dtype == DG_BF16 ? dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan, family == 5) : DG_EUNSUPPORTED;
   return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0, wg_cap, plan)

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const int tcount = t0 < xe ? (xe - t0 + nwx - 1) / nwx : 0;
   if (tcount == 0) return;
 
+  const unsigned long long tk0 = (dbg & 8) ? pp_stamp() : 0ull;   // (diagnostic build: phases of the workgroup's lifetime)
   const int tid = threadIdx.x;
   const int KC = p.K / 64;
   const int Ws = MODE == MODE_S2 ? 2 * p.Wc : p.Wc, cmul = MODE == MODE_S2 ? 2 : 1;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     ((unsigned long long*)(lds + LDS_HT))[y] = hl | ((unsigned long long)nh << 60);
   }
   __syncthreads();
+  const unsigned long long tk1 = (dbg & 8) ? pp_stamp() : 0ull;
 
   f32x4_t acc[TM][TN];
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // ---- main loop
   const bool stamps = (dbg & 8) != 0;
   unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};  // LOAD work, LOAD waits, barrier 1, MFMA half, barrier 2, between steps
-  unsigned long long tend = 0;
+  unsigned long long tend = 0, tkf = 0;
 
   if (wave >= 4) __builtin_amdgcn_s_barrier(); // group B runs one barrier behind group A
   unsigned so_c = PSTAGE, so_i = 0;            // LDS offsets of the pair stage read / refilled (two stages, swapped per pair)
@@ -590,6 +592,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       if (t == 0 && pending) finish_tile();      // (waves 0-3)
       __builtin_amdgcn_sched_barrier(0);
       if (comp) {
+        if (stamps && tkf == 0) tkf = t3;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           if (!(dbg & 2)) {
@@ -669,14 +672,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     tile_next(ti);
   }
   pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  const unsigned long long tk2 = (dbg & 8) ? pp_stamp() : 0ull;
   if (pending && !(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epilogue(tprev);
   }
   if (stamps && blockIdx.x == 0 && lane == 0) {
     float* sink = (float*)p.out + wave * 8;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the final epilogue's stores acknowledged: part of its phase)
+    const unsigned long long tk3 = pp_stamp();
     for (int k = 0; k < 6; ++k) sink[k] = (float)tsum[k];
+    // phases of the workgroup's lifetime, cycles from kernel entry: prologue end, first matrix half, loop end, stores acknowledged
+    float* ph = (float*)p.out + 64 + wave * 8;
+    ph[0] = (float)(tk1 - tk0); ph[1] = (float)(tkf - tk0); ph[2] = (float)(tk2 - tk0); ph[3] = (float)(tk3 - tk0);
+    ph[4] = (float)tcount;
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // pairs with group B's late start
   if (want_db) {

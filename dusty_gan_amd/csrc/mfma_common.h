@@ -31,8 +31,7 @@ __device__ __forceinline__ void mma_tile(const float*, const i32x4& a, const i32
 //     MFMA 1:  A = [a_hi(4) | a_lo(4)]   B = [b_hi(4) | b_hi(4)]      -> a_hi b_hi + a_lo b_hi
 //     MFMA 2:  A = [a_hi(4) |   0    ]   B = [b_lo(4) |   0    ]      -> a_hi b_lo
 // i.e. 2 x 32 cycles where the exact path (4 x v_mfma_f32_32x32x2_f32) takes 4 x 64, with no change to the LDS images or
-// the fragment reads.  The switch is process-wide: dg_set_fp32_split (api.hip), read by the launchers.
-extern int g_dg_fp32_split;
+// the fragment reads.  Asked for per call: DG_FORCE_FP32X3 in the `force` argument of dg_conv / dg_wgrad (api.hip).
 
 struct SplitA { i32x4 hl, h0; };   // [hi01, hi23, lo01, lo23], [hi01, hi23, 0, 0]
 struct SplitB { i32x4 hh, l0; };   // [hi01, hi23, hi01, hi23], [lo01, lo23, 0, 0]

@@ -356,7 +356,7 @@ extern "C" int dg_wgrad_mfma_supported(const WgradP* p) {
 }
 
 // accumulate = 1: dw += (atomics, K split over workgroups); accumulate = 0: dw = (single pass, plain stores)
-int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream) {
+int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream, int fp32x3) {
   if (!dg_wgrad_mfma_supported(p)) return DG_EUNSUPPORTED;
   const bool m128 = p->Ci % 128 == 0, n128 = p->Co % 128 == 0;
   if (p->a_dtype == DG_BF16) {
@@ -365,7 +365,7 @@ int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream) {
     if (n128) return launch_cfg<bf16, 64, 128>(p, accumulate, stream);
     return launch_cfg<bf16, 64, 64>(p, accumulate, stream);
   }
-  if (g_dg_fp32_split) {
+  if (fp32x3) {
     if (m128 && n128) return launch_cfg<float, 128, 128, true>(p, accumulate, stream);
     if (m128) return launch_cfg<float, 128, 64, true>(p, accumulate, stream);
     if (n128) return launch_cfg<float, 64, 128, true>(p, accumulate, stream);

@@ -409,15 +409,23 @@ class Ops:
     default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
     _dbias_ws = {}      # device -> DgConv.dbias_ws scratch (launches of one stream share it: each leaves it zero)
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, x3=False):
         self.lib = L.lib()
         self.dtype = dtype
+        # fp32x3: DG_F32 operands on the bf16 matrix instructions, split into bf16 hi + lo (DG_FORCE_FP32X3 on every call of
+        # THIS Ops: per engine, nothing process-wide)
+        self.x3 = bool(x3) and dtype == torch.float32
         self.dt = L.dtype_code(dtype)
         self.es = 2 if dtype == torch.bfloat16 else 4
         # dg_conv / dg_wgrad `force` (0 auto; the parity tests set 1 direct, 2 MFMA, 3 thin, 4 / 5 persistent kernels)
         self.force = 0
         self.wg_cap = Ops.default_wg_cap  # dg_conv_ex: cap on the persistent conv's workgroup count (0 = one residency wave)
         self.use_ws = True  # split-K partials through WGRAD_WS + dg_wgrad_reduce (False: fp32 atomics onto dW)
+
+    @property
+    def _f(self):
+        """the `force` argument of the C ABI: kernel-family code | flag bits"""
+        return self.force | (L.DG_FORCE_FP32X3 if self.x3 else 0)
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
@@ -456,12 +464,12 @@ class Ops:
             p.dbias_ws = L.ptr(ws)
         if TRACE is not None:
             pl = L.DgConvPlan()
-            L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
+            L.check(self.lib.dg_conv_plan(C.byref(p), self._f, self.wg_cap, C.byref(pl)), "dg_conv_plan")
             TRACE.append(("conv", pl.family, pl.bm, pl.bn, pl.tiles, pl.workgroups, pl.tiles_per_wg,
                           f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}", pl.thin_mfma,
                           (1 if p.mask_out else 0) | (pl.mask_bits & 2 if p.mask_in else 0)))
         if PROFILE is None:
-            L.check(self.lib.dg_conv_ex(C.byref(p), self.force, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
+            L.check(self.lib.dg_conv_ex(C.byref(p), self._f, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
@@ -469,19 +477,19 @@ class Ops:
         mb = 0
         if p.mask_out or p.mask_in:
             pl = L.DgConvPlan()
-            L.check(self.lib.dg_conv_plan(C.byref(p), self.force, self.wg_cap, C.byref(pl)), "dg_conv_plan")
+            L.check(self.lib.dg_conv_plan(C.byref(p), self._f, self.wg_cap, C.byref(pl)), "dg_conv_plan")
             mb = pl.mask_bits if p.mask_in else 1  # (mask_out behind a kernel without it: the packing launch writes the same bytes)
         flops, nbytes = conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, epi == L.EPI_MASK, mb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(self.lib.dg_conv(C.byref(p), self.force, L.stream_ptr()), "dg_conv")
+        L.check(self.lib.dg_conv(C.byref(p), self._f, L.stream_ptr()), "dg_conv")
         e1.record()
         PROFILE.append(({2: "conv_mfma_kernel", 3: "conv_thin_kernel"}.get(choice, "conv_direct_kernel"), flops, nbytes, e0, e1,
                         f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
 
     def wgrad_plan(self, p, accumulate=1):
         pl = L.DgWgradPlan()
-        L.check(self.lib.dg_wgrad_plan(C.byref(p), accumulate, self.force, C.byref(pl)), "dg_wgrad_plan")
+        L.check(self.lib.dg_wgrad_plan(C.byref(p), accumulate, self._f, C.byref(pl)), "dg_wgrad_plan")
         return pl
 
     def wgrad(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale=None,
@@ -495,18 +503,18 @@ class Ops:
         if pl is not None and pl.ws_floats > 0:
             p.ws = WGRAD_WS.take(pl.ws_floats, a.device)
         if TRACE is not None:
-            TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self.force),
+            TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self._f),
                           f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}", 0 if pl is None else pl.splits,
                           0 if pl is None else pl.tap_pairs, bool(p.ws), g_mod))
         if PROFILE is None:
-            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
+            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self._f, L.stream_ptr()), "dg_wgrad")
         else:
             choice = self.lib.dg_wgrad_kernel_choice(C.byref(p)) if self.force in (0, 7, 8) else self.force
             flops, nbytes = wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4,
                                               2 if p.g_dtype == L.DG_BF16 else 4)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self.force, L.stream_ptr()), "dg_wgrad")
+            L.check(self.lib.dg_wgrad(C.byref(p), accumulate, self._f, L.stream_ptr()), "dg_wgrad")
             e1.record()
             PROFILE.append(({2: "wgrad_mfma_kernel", 3: "wgrad_thin_kernel"}.get(choice, "wgrad_direct_kernel"), flops, nbytes,
                             e0, e1, f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
@@ -520,7 +528,7 @@ class Ops:
         and Down1's thin matrix-core kernel"""
         p = self._wgrad_params(wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, 1.0, None, None, None,
                                0, 0, 0)
-        return self.lib.dg_wgrad_has_sample_map(C.byref(p), self.force) == 1
+        return self.lib.dg_wgrad_has_sample_map(C.byref(p), self._f) == 1
 
     def _wgrad_params(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale, a_dt, g_dt,
                       a_off, g_off, g_mod):
@@ -542,9 +550,9 @@ class Ops:
 class GEngine:
     """Generator forward / backward on one ParamStore (models/gans/dcgan_eqlr.py:49-72 + models/dusty.py)."""
 
-    def __init__(self, cfg: NetCfg, dtype):
+    def __init__(self, cfg: NetCfg, dtype, x3=False):
         self.cfg, self.dtype = cfg, dtype
-        self.ops = Ops(dtype)
+        self.ops = Ops(dtype, x3=x3)
         self.ws_B = 0
 
     def alloc(self, B, device):
@@ -866,9 +874,9 @@ class DEngine:
     """Discriminator passes (models/gans/dcgan_eqlr.py:85-96): forward, the shared backward-data chain, the R1
     tangent pass and the weight gradients."""
 
-    def __init__(self, cfg: NetCfg, dtype):
+    def __init__(self, cfg: NetCfg, dtype, x3=False):
         self.cfg, self.dtype = cfg, dtype
-        self.ops = Ops(dtype)
+        self.ops = Ops(dtype, x3=x3)
         self.ws_B = 0
 
     def alloc(self, nb, device):

@@ -151,9 +151,10 @@ class Generator(_EngineNet):
         return pairs
 
     def engine(self):
-        if self._eng is None or self._eng.dtype != self.compute_dtype:
+        x3 = bool(getattr(self, "fp32_split", False))   # (set by the Trainer on ITS networks: fp32x3 parity mode)
+        if self._eng is None or self._eng.dtype != self.compute_dtype or self._eng.ops.x3 != (x3 and self.compute_dtype == torch.float32):
             cfg = E.NetCfg(self.shape, self.in_ch, self.chs, self.masker, self.ring, self.tau, self.drop_const)
-            self._eng = E.GEngine(cfg, self.compute_dtype)
+            self._eng = E.GEngine(cfg, self.compute_dtype, x3=x3)
         self._eng.cfg.tau, self._eng.cfg.drop_const = float(self.tau), float(self.drop_const)
         return self._eng
 
@@ -203,9 +204,10 @@ class Discriminator(_EngineNet):
         return pairs
 
     def engine(self):
-        if self._eng is None or self._eng.dtype != self.compute_dtype:
+        x3 = bool(getattr(self, "fp32_split", False))
+        if self._eng is None or self._eng.dtype != self.compute_dtype or self._eng.ops.x3 != (x3 and self.compute_dtype == torch.float32):
             cfg = E.NetCfg(self.shape, 1, self.chs, "none", self.ring, dis_in_ch=self.in_ch)
-            self._eng = E.DEngine(cfg, self.compute_dtype)
+            self._eng = E.DEngine(cfg, self.compute_dtype, x3=x3)
         return self._eng
 
     def forward(self, x):

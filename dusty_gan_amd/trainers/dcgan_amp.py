@@ -335,13 +335,12 @@ class Trainer:
         self.optim_D = FlatAdam(self.D, self.cfg.solver.lr.alpha.dis, betas)
         self.enable_amp = bool(cfg.enable_amp)
         # fp32x3 (DUSTY_GAN_FP32_SPLIT=1 with enable_amp: false): fp32 storage everywhere, the fat layers' contractions on the
-        # bf16 matrix instructions with each operand split into bf16 hi + lo (dg_set_fp32_split; process-wide, so every
-        # trainer construction sets it to what ITS configuration asks for)
+        # bf16 matrix instructions with each operand split into bf16 hi + lo.  A property of THIS trainer's networks: their
+        # engines pass DG_FORCE_FP32X3 with every launch (nothing process-wide; a second trainer of another precision in the
+        # same process keeps its own kernels)
         self.fp32_split = (not self.enable_amp) and os.environ.get("DUSTY_GAN_FP32_SPLIT", "0") == "1"
-        L.lib().dg_set_fp32_split(int(self.fp32_split))
-        # DUSTY_GAN_BIGTILE=1: the fat conv layers on the big-tile kernel (conv_mfma_bt.hip: round-4 experiment, parity-green,
-        # measured SLOWER than the ping-pong kernel - DESIGN.md section 4 - hence opt-in)
-        L.lib().dg_set_conv_bigtile(int(os.environ.get("DUSTY_GAN_BIGTILE", "0") == "1"))
+        for net in (_backbone(self.G), self.D, _backbone(self.G_ema)):
+            net.fp32_split = self.fp32_split
 
         # resume (reference :134-144)
         self.start_iteration = 0
@@ -496,7 +495,7 @@ class Trainer:
             from ..engine import GEngine
             bb = _backbone(self.G)
             first = bb.engine()
-            self._geng = [first] + [GEngine(first.cfg, self.dtype) for _ in range(self.n_acc - 1)]
+            self._geng = [first] + [GEngine(first.cfg, self.dtype, x3=self.fp32_split) for _ in range(self.n_acc - 1)]
         return self._geng
 
     def _sample_noise(self, B):
@@ -935,7 +934,7 @@ class Trainer:
         from ..engine import GEngine
         lib, sp = L.lib(), L.stream_ptr()
         if self._geng_pl is None:
-            self._geng_pl = GEngine(self._g_engines()[0].cfg, self.dtype)
+            self._geng_pl = GEngine(self._g_engines()[0].cfg, self.dtype, x3=self.fp32_split)
         geng = self._geng_pl
         nz = int(self.cfg.model.gen.in_ch)
         if inj is not None:

@@ -118,19 +118,14 @@ typedef struct DgWgrad {
  * with such tiles - the forced forms let parity tests run either family on small problems).
  */
 int dg_conv(const DgConv* p, int force, void* stream);
-/* "fp32x3" (precision contract: fp32 storage with fp32 or split-bf16 x 3 MFMA): process-wide switch for
- * DG_F32 operands of dg_conv / dg_wgrad on the matrix-core kernels.  0 (default): exact fp32 products
- * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate); 1: every operand is split into bf16 hi + lo in registers and a product
- * is a_hi b_hi + a_lo b_hi + a_hi b_lo on the bf16 matrix instructions with fp32 accumulation (relative error ~2^-16 per
- * product; the mode autocast-free fp32 training of trainers/dcgan_amp.py would want on this hardware).  Returns the
- * previous setting. */
-int dg_set_fp32_split(int on);
-/* Whether force == 0 may pick the big-tile persistent conv (family 7, conv_mfma_bt.hip: one wave per SIMD, 128 x 64 outputs
- * per wave, fragment reads and LDS-DMA pipelined under the wave's own matrix instructions) for bf16 layers with >= 256 of
- * its tiles.  Default 0: the kernel is parity-green but measured slower than the ping-pong kernel (family 5) on every layer
- * (round 4), so it is opt-in; dg_conv force 11 asks for it by name (parity tests).  Returns the previous
- * setting. */
-int dg_set_conv_bigtile(int on);
+/* "fp32x3" (precision contract: fp32 storage with fp32 or split-bf16 x 3 MFMA): a flag bit in the
+ * `force` argument of dg_conv / dg_conv_ex / dg_conv_plan / dg_wgrad / dg_wgrad_plan, OR-ed onto the kernel-family code, for
+ * DG_F32 operands on the matrix-core kernels.  Clear (default): exact fp32 products (v_mfma_f32_32x32x2_f32, 1/16 of the bf16
+ * rate); set: every operand is split into bf16 hi + lo in registers and a product is a_hi b_hi + a_lo b_hi + a_hi b_lo on
+ * the bf16 matrix instructions with fp32 accumulation (relative error ~2^-16 per product; the mode autocast-free fp32
+ * training of trainers/dcgan_amp.py would want on this hardware).  Per call - nothing process-wide: two engines of
+ * different precision in one process do not share a setting. */
+#define DG_FORCE_FP32X3 0x100
 /* What a dg_conv call launches (introspection for the parity tests and the benchmark: which kernel family / tile ran,
  * and how many tiles each persistent workgroup walks).  family: 1 direct, 2 one-tile-per-workgroup MFMA, 3 thin,
  * 4 persistent large-tile MFMA (lock step: fp32, small layers), 5 persistent ping-pong MFMA (bf16 fat layers),

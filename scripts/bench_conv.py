@@ -15,8 +15,6 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 dev = "cuda"
 o = Ops(dtype)
 o.force = 2
-if os.environ.get("BENCH_BIGTILE", "0") == "1":   # A/B: the fat layers on the big-tile kernel (conv_mfma_bt.hip, opt-in)
-    L.lib().dg_set_conv_bigtile(1)
 torch.manual_seed(0)
 
 # (name, mode, adj, Hc, Wc, K, N, batch multiplier)
@@ -79,7 +77,11 @@ for name, mode, adj, Hc, Wc, K, N, bm in CONV:
     tot_fl += fl
     print(f"{name:10s} B{n:3d} {Hc:2d}x{Wc:3d} K{K:3d} N{N:3d}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TFLOP/s")
     if int(os.environ.get("DG_CONV_DBG", "0")) & 8:  # cycle stamps of workgroup 0 (waves 0 and 4), see conv_mfma_pp.hip
-        st = out[:128].view(torch.float32).tolist()
+        st = out[:256].view(torch.float32).tolist()
+        for k in (0, 4):
+            ph = st[64 + 8 * k:64 + 8 * k + 5]
+            print(f"    wave{k} phases (cycles from entry; {ph[4]:.0f} tiles): prologue done {ph[0]:.0f}, first matrix half {ph[1]:.0f}, "
+                  f"loop done {ph[2]:.0f}, final epilogue + stores acknowledged {ph[3]:.0f}")
         for wv, v in ((f"wave{k}", st[8 * k:8 * k + 6]) for k in (0, 4)):
             tot = sum(v) or 1.0
             print(f"    {wv}: cycles load {v[0]:.0f} ({100 * v[0] / tot:.0f}%) wait {v[1]:.0f} ({100 * v[1] / tot:.0f}%) bar1 {v[2]:.0f} "

@@ -37,6 +37,25 @@ __global__ __launch_bounds__(512) void k_store(i32x4* out, int per_thread, int s
   }
 }
 
+// the ping-pong conv's output pattern: a 256-pixel x 128-channel bf16 tile per workgroup, every wave-instruction writes 8
+// pixels x 128 B (its 64 channels) at the tensor's pixel stride (256 B x N tiles); the N tiles of a pixel block are
+// neighbouring workgroups
+__global__ __launch_bounds__(512) void k_store_tile(char* out, int stride, int spin_us) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = stride / 256;
+  const long base = (long)(blockIdx.x / nt) * 256 * stride + (long)(blockIdx.x % nt) * 256 + wn * 128 + (lane & 7) * 16;
+  if (spin_us > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_us * 100ull) __builtin_amdgcn_s_sleep(8);
+  }
+  const i32x4 v = {(int)threadIdx.x, (int)blockIdx.x, 3, 4};
+  for (int i = 0; i < 8; ++i) {
+    const int px = wm * 64 + i * 8 + (lane >> 3);
+    *(i32x4*)(out + base + (long)px * stride) = v;
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <class F>
@@ -92,6 +111,11 @@ int main() {
     const double b = time_chain(s, N, [&](int i) { k_store<false><<<cus, 512, 0, s>>>(out[i & 1], 8, us, in, 0); });
     const double c = time_chain(s, N, [&](int i) { k_store<true><<<cus, 512, 0, s>>>(out[i & 1], 8, us, in, 0); });
     printf("spin %2d us: no store %7.2f   + 64 KB store at the end %7.2f (nontemporal %7.2f)\n", us, a, b, c);
+  }
+  for (int stride : {256, 512, 1024}) {
+    const double a = time_chain(s, N, [&](int i) { k_store_tile<<<cus, 512, 0, s>>>((char*)out[i & 1], stride, 0); });
+    const double b = time_chain(s, N, [&](int i) { k_store_tile<<<cus, 512, 0, s>>>((char*)out[i & 1], stride, 10); });
+    printf("conv tile pattern, 64 KB per CU, pixel stride %4d B: %7.2f   after a 10 us spin %7.2f\n", stride, a, b);
   }
   // stream launches (no graph) of the empty kernel, for comparison
   {

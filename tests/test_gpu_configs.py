@@ -64,13 +64,18 @@ def _check(res, tr, state, out_tol, loss_tol, grad_tol, cos_min, mask_tol, lr=0.
         else:
             assert rel_l2(synth[k], ex["synth"][k]) <= out_tol, (k, rel_l2(synth[k], ex["synth"][k]))
     worst = {}
+    fails = []
     for name, got, ref in (("grad_D", gD, ex["grad_D"]), ("grad_G", gG, ex["grad_G"])):
         for k, v in ref.items():
             if v.abs().max() > 0:
                 r, c = rel_l2(got[k], v), _cos(got[k], v)
                 worst[name] = max(worst.get(name, 0.0), r)
-                assert r <= grad_tol[name], (name, k, r)
-                assert c >= cos_min, (name, k, c)
+                worst[name + "_cos"] = min(worst.get(name + "_cos", 1.0), c)
+                if r > grad_tol[name] or c < cos_min:
+                    fails.append((name, k, f"rel-L2 {r:.3e} (bound {grad_tol[name]:.1e})", f"cosine {c:.6f} (bound {cos_min})"))
+    # (measured values in the record: `pytest -s` shows how far inside its bounds a run sits)
+    print("PARITY", {k: float(f"{v:.4g}") for k, v in worst.items()}, "bounds", grad_tol, cos_min)
+    assert not fails, (fails, worst)
     # post-Adam parameters: the first step at beta1 = 0 moves every element by ~lr * sign(g), so every element is within
     # 2 lr of the oracle's; D before the sync (the engine's own update), G and G_ema after
     for tag, got_sd, ref in (("G", tr.G.state_dict(), G), ("D", ex["D_engine_after"], D), ("G_ema", tr.G_ema.state_dict(), G_ema)):
@@ -123,13 +128,6 @@ def test_timed_mode_gradients_tight_against_emulating_oracle(trace, arch):
     _check(res[0], tr, state, **BF16_EMU)
 
 
-@pytest.fixture(autouse=True)
-def _exact_fp32_afterwards():
-    yield
-    from dusty_gan_amd import _lib as L
-    L.lib().dg_set_fp32_split(0)   # (process-wide switch: whatever a test's trainer set, the next test starts exact)
-
-
 @pytest.mark.parametrize("x3", [False, True], ids=["fp32", "fp32x3"])
 def test_hip_path_matches_reference_at_full_width(monkeypatch, x3):
     """The HIP fp32 path against what the REFERENCE's own modules computed at 64x1024 / 512 channels (dusty2, B = 2, one
@@ -137,7 +135,7 @@ def test_hip_path_matches_reference_at_full_width(monkeypatch, x3):
     gradients 2e-2 on the digests (a unit within fp32 rounding of zero takes the other slope in the two
     implementations - tests/test_gpu_step.py::test_step_fp32_vs_oracle_full_width_64x1024); updated parameters 1e-3.
     fp32x3: the same bounds with the fat layers' contractions on the bf16 matrix instructions (operands split into bf16
-    hi + lo, dg_set_fp32_split) - the fast parity mode of `bench.py --precision fp32x3`."""
+    hi + lo, DG_FORCE_FP32X3 on every launch of this trainer's engines) - the fast parity mode of `bench.py --precision fp32x3`."""
     monkeypatch.setenv("DUSTY_GAN_FP32_SPLIT", "1" if x3 else "0")
     g = load("full_dusty2")
     if str(g["meta/torch"]) != torch.__version__:
@@ -148,6 +146,7 @@ def test_hip_path_matches_reference_at_full_width(monkeypatch, x3):
                       int(g["meta/ch_max"]), int(g["meta/B"]), amp=False)
     assert abs(tr.ema_decay - float(g["meta/ema_decay"])) < 1e-12
     assert tr.fp32_split == x3
+    assert tr.D.engine().ops.x3 == x3 and tr._g_engines()[0].ops.x3 == x3   # per engine: nothing process-wide to reset
     tr.G.load_state_dict(G)
     tr.G_ema.load_state_dict(G)
     sync_D(tr, D)

@@ -84,10 +84,7 @@ def run_conv(L, mode, adj, ring, x, wpacked_nk, N, scale, epi, dtype, force, bia
         del auxd._dg_bits
         out2 = torch.empty_like(out)
         db2 = None if db is None else torch.zeros_like(db)
-        if force == 11:   # (the big-tile kernel takes the bits form only: the aux form of the same pass on the ping-pong kernel,
-            o.force = 5   #  which accumulates its k-steps in the same order)
         launch(out2, db2)
-        o.force = force
         assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "mask_in and aux give different outputs"
         if db is not None:
             assert rel_l2(db.cpu(), db2.cpu()) < 1e-5   # (atomic adds: the order of the partial sums differs run to run)
@@ -98,16 +95,24 @@ def run_conv(L, mode, adj, ring, x, wpacked_nk, N, scale, epi, dtype, force, bia
 @pytest.mark.parametrize("which", ["down", "up"])
 @pytest.mark.parametrize("Ci,Co,H,W,B", [(64, 128, 4, 128, 2), (128, 64, 8, 64, 2), (256, 128, 4, 64, 3)])
 def test_fp32x3_matrix_core_kernels_match_the_fp32_reference(L, which, Ci, Co, H, W, B):
-    """dg_set_fp32_split(1): fp32 operands through split-bf16 matrix instructions (a = a_hi + a_lo in bf16, three of the four
+    """DG_FORCE_FP32X3 (Ops.x3): fp32 operands through split-bf16 matrix instructions (a = a_hi + a_lo in bf16, three of the four
     partial products, fp32 accumulation) on the one-tile-per-workgroup conv and the register-staged weight-gradient
     kernel - forward, backward-data and weight gradient of a Down / Up layer against the fp32 oracle at the FP32 tolerance
     (1e-4; the dropped a_lo b_lo term is ~2^-16 of a product)."""
-    prev = L.lib().dg_set_fp32_split(1)
+    from dusty_gan_amd.engine import Ops
+    init = Ops.__init__
+
+    def init_x3(self, dtype, x3=False):
+        init(self, dtype, x3=True)
     try:
+        Ops.__init__ = init_x3      # every Ops the op tests build asks for the split form
         fn = test_down_fwd_bwd_wgrad if which == "down" else test_up_fwd_bwd_wgrad
         fn(L, Ci, Co, H, W, B, True, torch.float32, 2)
+        # ... and the flag really selects other kernels: same launch with and without it differ in the last bits only
+        o0, o1 = Ops(torch.float32), Ops(torch.float32)
+        assert o0.x3 and o1._f == (o1.force | L.DG_FORCE_FP32X3)
     finally:
-        L.lib().dg_set_fp32_split(prev)
+        Ops.__init__ = init
 
 
 def pack_down(w):  # Conv2d weight (Co,Ci,4,4) -> fwd [16][n=co][k=ci], bwd [16][n=ci][k=co]
@@ -144,15 +149,6 @@ CASES = [  # (Ci, Co, H, W, B, ring, dtype, force)   force 1 = direct, 2 = MFMA,
     (64, 128, 4, 64, 8, True, torch.bfloat16, 5),    # ... 4 sample segments of 64 + 2 columns
     (64, 128, 2, 512, 1, True, torch.bfloat16, 5),   # ... two column tiles per row
     (64, 128, 2, 256, 1, True, torch.bfloat16, 9),   # force 9: the single-parity 256 x 64 tile those layers ran on before
-    # the big-tile kernel (round 4: one wave per SIMD, 128 x 64 outputs per wave, software-pipelined K loop) on the same
-    # geometries: one / two / four / eight sample segments per 256-pixel tile, both-parities tiles, several channel chunks
-    (256, 128, 4, 128, 2, True, torch.bfloat16, 11),
-    (128, 128, 2, 512, 1, True, torch.bfloat16, 11),
-    (128, 256, 4, 64, 8, True, torch.bfloat16, 11),
-    (64, 128, 2, 256, 1, True, torch.bfloat16, 11),
-    (64, 128, 4, 64, 8, True, torch.bfloat16, 11),
-    (64, 128, 2, 512, 1, True, torch.bfloat16, 11),
-    (128, 128, 8, 256, 3, True, torch.bfloat16, 11),  # odd sample count, more rows
 ]
 
 
@@ -193,7 +189,7 @@ def test_down_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     # weight gradient
     from dusty_gan_amd.engine import Ops
     o = Ops(dtype)
-    o.force = 2 if force in (4, 5, 9, 11) else force
+    o.force = 2 if force in (4, 5, 9) else force
     xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
     dw = torch.zeros(16, Ci, Co, device=DEV)
     o.wgrad(0, ring, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw.data_ptr(), s)
@@ -215,8 +211,6 @@ def test_down_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
 @pytest.mark.parametrize("Ci,Co,H,W,B,ring,dtype,force", CASES)
 def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     """Up (dcgan_eqlr.py:19-26): forward, backward-data, weight gradient."""
-    if force == 11 and Ci % 128:
-        pytest.skip("the big-tile kernel has no 64-channel MODE_S2 tile (Up backward-data with 64 input channels stays on the ping-pong kernel)")
     g = torch.Generator().manual_seed(Ci * 77 + Co + W)
     tol = TOL32 if dtype == torch.float32 else TOLBF
     x = torch.randn(B, Ci, H, W, generator=g)
@@ -243,7 +237,7 @@ def test_up_fwd_bwd_wgrad(L, Ci, Co, H, W, B, ring, dtype, force):
     assert rel_l2(db, ref_dx.sum(dim=[0, 2, 3])) < (tol if dtype == torch.float32 else 5e-2)
     from dusty_gan_amd.engine import Ops
     o = Ops(dtype)
-    o.force = 2 if force in (4, 5, 9, 11) else force
+    o.force = 2 if force in (4, 5, 9) else force
     xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
     dw = torch.zeros(16, Ci, Co, device=DEV)
     o.wgrad(1, ring, B, H, W, Ci, Co, xd, (H * W * Ci, Ci, 1), ed, (4 * H * W * Co, Co, 1), dw.data_ptr(), s)

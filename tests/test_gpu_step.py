@@ -171,6 +171,10 @@ def run_both(arch, shape, in_ch, ch_base, ch_max, B, amp, steps=1, seed=0, pl=0.
     return tr, (G, D, G_ema), res
 
 
+# fp32 parity mode, gradients at full width (see the docstring below): set from measurements on MI355X, 1.25 x the worst seen
+FP32_GRAD_TOL, FP32_GRAD_COS = 2e-2, 0.9999
+
+
 def _cos(a, b):
     a, b = a.flatten().double(), b.flatten().double()
     return float((a @ b) / (a.norm() * b.norm()))
@@ -195,10 +199,15 @@ def test_step_fp32_vs_oracle_full_width_64x1024():
     for k in ("depth", "depth_orig", "confidence"):
         assert rel_l2(synth[k], ex["synth"][k]) < tol, k
     assert (synth["mask"] != ex["synth"]["mask"]).float().mean() < 1e-5
+    worst = {}
     for name, got, ref in (("grad_D", gD, ex["grad_D"]), ("grad_G", gG, ex["grad_G"])):
         for k, v in ref.items():
-            assert rel_l2(got[k], v) < 2e-2, (name, k, rel_l2(got[k], v))
-            assert _cos(got[k], v) > 0.9999, (name, k)
+            r, c = rel_l2(got[k], v), _cos(got[k], v)
+            worst[name] = max(worst.get(name, 0.0), r)
+            worst[name + "_cos"] = min(worst.get(name + "_cos", 1.0), c)
+    print("PARITY full-width fp32 B=2", {k: float(f"{v:.4g}") for k, v in worst.items()})
+    for name in ("grad_D", "grad_G"):
+        assert worst[name] < FP32_GRAD_TOL and worst[name + "_cos"] > FP32_GRAD_COS, (name, worst)
     tol = 1e-3
     sd = tr.G.state_dict()
     for k, v in G.items():

@@ -41,11 +41,6 @@ MULTI = [
     (128, 128, 4, 512, 4, torch.bfloat16, 7, 5),    # two x tiles per row
     (128, 256, 4, 64, 16, torch.bfloat16, 4, 5),    # 4 samples' row segments per tile
     (64, 128, 4, 256, 4, torch.bfloat16, 5, 5),     # 64-channel side: 256 x 64 tiles in the backward-data passes
-    (128, 256, 4, 128, 8, torch.bfloat16, 5, 11),   # the big-tile kernel (dg_conv force 11 -> plan family 7): several tiles
-    (256, 128, 4, 128, 8, torch.bfloat16, 3, 11),   # per workgroup, cross-tile pipeline, epilogue between two pair iterations
-    (128, 128, 4, 512, 4, torch.bfloat16, 7, 11),
-    (128, 256, 4, 64, 16, torch.bfloat16, 4, 11),
-    (64, 128, 4, 256, 4, torch.bfloat16, 5, 11),
     (128, 256, 4, 128, 8, torch.bfloat16, 5, 4),    # the lock-step kernel on the same geometries
     (128, 256, 4, 64, 14, torch.bfloat16, 6, 4),    # 14 % 4 != 0: 128 x 128 tiles from 2 samples' row segments
     (64, 128, 4, 256, 4, torch.bfloat16, 5, 4),
@@ -62,12 +57,10 @@ def test_persistent_conv_several_tiles_per_workgroup(monkeypatch, trace, which, 
     from dusty_gan_amd import _lib as L
     fn = OPS.test_down_fwd_bwd_wgrad if which == "down" else OPS.test_up_fwd_bwd_wgrad
     fn(L, Ci, Co, H, W, B, True, dtype, family)
-    pc = [t for t in trace if t[0] == "conv" and t[1] == {11: 7}.get(family, family)]   # dg_conv force 4 / 5 / 11 -> plan family 4 / 5 / 7
+    pc = [t for t in trace if t[0] == "conv" and t[1] == family]   # dg_conv force 4 / 5 -> plan family 4 / 5
     # forward + backward-data both on the persistent kernel (bf16: run_conv repeats the backward-data launch without the
-    # saved mask bits to compare the two forms; the big-tile kernel has the bits form only, so its repeat runs on family 5)
-    assert len(pc) == (2 if family == 11 or dtype != torch.bfloat16 else 3), trace
-    if family == 11:
-        assert len([t for t in trace if t[0] == "conv" and t[1] == 5]) == 1, trace
+    # saved mask bits to compare the two forms)
+    assert len(pc) == (2 if dtype != torch.bfloat16 else 3), trace
     for t in pc:
         assert t[5] <= cap and t[6] >= 4, t         # workgroups <= cap, >= 4 tiles per workgroup
 
