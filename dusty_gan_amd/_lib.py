@@ -108,6 +108,7 @@ PROTOTYPES = {
     "dg_conv_kernel_choice": [C.POINTER(DgConv)],
     "dg_wgrad": [C.POINTER(DgWgrad), _I, _I, _P],
     "dg_wgrad_plan": [C.POINTER(DgWgrad), _I, _I, C.POINTER(DgWgradPlan)],
+    "dg_wgrad_group": [C.POINTER(DgWgrad), _I, _I, _P],
     "dg_wgrad_reduce": [C.POINTER(DgWgradReduce), _I, _P],
     "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_choice": [C.POINTER(DgWgrad)],

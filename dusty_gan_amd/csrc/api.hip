@@ -8,6 +8,7 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
 int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan);
+int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, hipStream_t stream);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_supported(const ConvP* p);
 int dg_proj_stream_supported(const ConvP* p);
@@ -133,6 +134,18 @@ static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force_flags, hip
 
 int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   return wgrad_dispatch(p, accumulate, force, (hipStream_t)stream, nullptr);
+}
+
+int dg_wgrad_group(const DgWgrad* items, int n, int force_flags, void* stream) {
+  const int force = force_flags & ~DG_FORCE_FP32X3;
+  if (!items || n < 1) return DG_EINVAL;
+  if (force != 0 && force != 2 && force != 7 && force != 8) return DG_EUNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    const DgWgrad* p = &items[i];
+    if (!p->a || !p->g || !p->dw || p->B <= 0 || p->Ci <= 0 || p->Co <= 0 || p->Hc <= 0 || p->Wc <= 0) return DG_EINVAL;
+    if (!dg_wgrad_mfma_supported(p)) return DG_EUNSUPPORTED;
+  }
+  return dg_wgrad_mfma_dma_group_launch(items, n, force == 7 ? 1 : (force == 8 ? 2 : 0), (hipStream_t)stream);
 }
 
 int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan) {

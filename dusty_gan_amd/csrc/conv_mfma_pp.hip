@@ -240,6 +240,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     s_db[i] = 0.f;
     s_rs[i] = (p.rowscale && i < p.B) ? p.rowscale[i] : 1.f;
   }
+  // (round 5: the same tables by LDS-DMA instead of ordinary loads - no dependent global round trip in front of the first
+  //  tile's DMA - measured 400 cycles SLOWER per launch: the loads' latency already sat under the H-tap table's arithmetic,
+  //  and a DMA piece costs ~100 cycles to issue; profiles/r05a_conv_lifetime_phases_b32.txt)
   // H-tap lists of every output row, built once (up to 6 taps of 10 bits, the count in bits 60-62): a tile reads its
   // row's entry instead of running the tap enumeration (six rounds of boundary cases) again
   const unsigned sht0 = lds0 + LDS_HT;
@@ -612,7 +615,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (stamps) t4 = pp_stamp();
-      __builtin_amdgcn_s_barrier();
+      // (the drain pair's very last barrier: group A's pairs with group B's late start; group B has none left to pair with and
+      //  goes straight from its last matrix half into its epilogue - see the end of the kernel)
+      if (ISS || t == 0 || wave < 4) __builtin_amdgcn_s_barrier();
       if (stamps) {
         t5 = pp_stamp();
         tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
@@ -687,7 +692,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     ph[0] = (float)(tk1 - tk0); ph[1] = (float)(tkf - tk0); ph[2] = (float)(tk2 - tk0); ph[3] = (float)(tk3 - tk0);
     ph[4] = (float)tcount;
   }
-  if (wave < 4) __builtin_amdgcn_s_barrier();  // pairs with group B's late start
+  // Both groups' FINAL epilogues run side by side: group A's last barrier (the one that pairs with group B's late start) is
+  // the drain pair's last one, taken BEFORE its epilogue.  (Round 4 had it after group A's epilogue: group B, one barrier
+  // behind, sat in its last barrier until group A had stored its whole tile - round-5 stamps: 4 000 of a one-tile launch's
+  // 70 000 cycles, in every launch.)
   if (want_db) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();

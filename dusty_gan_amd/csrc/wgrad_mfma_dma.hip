@@ -52,28 +52,33 @@ constexpr int wg_dbg = DG_WG_DIAG;   // ablation builds (make wgdiag WGDIAG=bits
 #else
 constexpr int wg_dbg = 0;
 #endif
+template <int BM, int BN, int NT>
+constexpr int stage_bytes() { return BKP * BM * 2 + (NT == 2 ? 1024 : 0) + BKP * BN * 2; }
+
+// One workgroup of the (tile, tap or tap pair, K split) grid gx x gy x gz, linear index `id`; `lds`: NS stages.  The body of
+// wgrad_dma_kernel (one layer per launch) and of wgrad_group_kernel (several layers' workgroups in ONE launch, below).
 template <int WMODE, int BM, int BN, int NT>
-__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n, int accumulate) {
+__device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_n, const int accumulate, const int id,
+                                               const int gx, const int gy, const int gz, unsigned char* lds) {
   constexpr int RA = BM * 2, RG = BN * 2;                 // LDS row bytes (one pixel)
   constexpr int STA = BKP * RA + (NT == 2 ? 1024 : 0), STG = BKP * RG, STAGE = STA + STG;   // pair: 64 + 1 pixels (one more piece of rows)
   constexpr int PA = BKP * RA / 1024 / 4, PG = STG / 1024 / 4;  // DMA pieces per wave per stage (+ the A image's last piece: wave 0)
   constexpr int TM = BM / 64, TN = BN / 64;
   static_assert(PA >= 1 && PG >= 1, "tile too small for the piece distribution");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+  static_assert(STAGE == stage_bytes<BM, BN, NT>(), "stage size");
 
   const int tid = threadIdx.x;
   // XCD-aware, bijective remap of the (tile, tap, split) grid (blocks id and id+8 share an XCD): the 16 taps x tiles of
   // one K split read the same pixel rows, so each XCD gets a contiguous range of splits and fetches their rows once
-  const int nwg = gridDim.x * gridDim.y * gridDim.z;
-  const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int nwg = gx * gy * gz;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-  const int bx = logical % gridDim.x, by = (logical / gridDim.x) % gridDim.y, bz = logical / (gridDim.x * gridDim.y);
+  const int bx = logical % gx, by = (logical / gx) % gy, bz = logical / (gx * gy);
   const int ct = bx % tiles_n, mt = bx / tiles_n;
   const int ci0 = mt * BM, co0 = ct * BN;
   const int ky = NT == 2 ? by >> 1 : by >> 2, kxp = NT == 2 ? by & 1 : by & 3;   // pair: kx = kxp and kxp + 2; single: kx = kxp
   const long units = (long)p.B * p.Hc;
-  const long u0 = units * bz / gridDim.z, u1 = units * (bz + 1) / gridDim.z;
+  const long u0 = units * bz / gz, u1 = units * (bz + 1) / gz;
   const int cpr = p.Wc / BKP;                             // chunks per row
   const long nchunks64 = (u1 - u0) * cpr;
   const int Wa = WMODE == 0 ? 2 * p.Wc : p.Wc;
@@ -311,12 +316,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
   }
 }
 
-// pairs: 0 = by the K range per workgroup, 1 = always, 2 = never.  plan != NULL: describe the launch, launch nothing.
-template <int WMODE, int BM, int BN>
-int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan) {
+template <int WMODE, int BM, int BN, int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n, int accumulate) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * stage_bytes<BM, BN, NT>()];
+  wgrad_dma_body<WMODE, BM, BN, NT>(p, tiles_n, accumulate, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)),
+                                    (int)gridDim.x, (int)gridDim.y, (int)gridDim.z, lds);
+}
+
+// ---- several layers in ONE launch.  A weight-gradient launch is one residency round of ~512 workgroups that start
+// together, fill their rings together (a cold burst of 130 KB per CU) and store their partial tiles together (16-67 MB): at
+// 40-100 us per launch a fifth to a quarter of it is that ramp (round-5 stamps of the conv kernel, same structure; the B-sized
+// launches of the generator ran at 0.31 of the matrix peak against 0.40 for the 3B-sized ones of the discriminator).  The
+// weight gradients of a network's layers are independent of each other - they all read finished activations and gradient
+// chains - so their workgroups go into ONE grid: item k owns the blocks [first_k, first_k + pad8(count_k)), and as the
+// workgroups of one layer drain, the next layer's take their slots: fill and tail of one layer under the matrix work of
+// its neighbours.  Partial tiles, splits and the reduce are exactly those of the single launches (same plan function).
+constexpr int GROUP_MAX = 4;
+struct GroupItem { WgradP p; int tiles_n, gx, gy, gz, first, variant, accumulate; };
+struct GroupP { GroupItem it[GROUP_MAX]; int n; };
+constexpr int variant_code(int wmode, int bm, int bn, int nt) { return wmode * 8 + (bm == 128 ? 4 : 0) + (bn == 128 ? 2 : 0) + (nt == 2 ? 1 : 0); }
+
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(GroupP g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * stage_bytes<128, 128, 2>()];
+  // (the item by unrolled scalar selects: a dynamically indexed kernel argument would be copied to scratch, and values that
+  //  come back from scratch are no longer provably wave-uniform - the "s" operands of the LDS-DMA statements need that)
+  GroupItem it = g.it[0];
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.it[i].first) it = g.it[i];
+  const int id = (int)blockIdx.x - it.first;
+  if (id >= it.gx * it.gy * it.gz) return;       // (items are padded to multiples of 8 blocks: id & 7 stays the XCD label)
+#define DG_GROUP_CASE(W, M, N, T) \
+  case variant_code(W, M, N, T): wgrad_dma_body<W, M, N, T>(it.p, it.tiles_n, it.accumulate, id, it.gx, it.gy, it.gz, lds); break;
+  switch (it.variant) {
+    DG_GROUP_CASE(0, 64, 64, 1) DG_GROUP_CASE(0, 64, 64, 2) DG_GROUP_CASE(0, 64, 128, 1) DG_GROUP_CASE(0, 64, 128, 2)
+    DG_GROUP_CASE(0, 128, 64, 1) DG_GROUP_CASE(0, 128, 64, 2) DG_GROUP_CASE(0, 128, 128, 1) DG_GROUP_CASE(0, 128, 128, 2)
+    DG_GROUP_CASE(1, 64, 64, 1) DG_GROUP_CASE(1, 64, 64, 2) DG_GROUP_CASE(1, 64, 128, 1) DG_GROUP_CASE(1, 64, 128, 2)
+    DG_GROUP_CASE(1, 128, 64, 1) DG_GROUP_CASE(1, 128, 64, 2) DG_GROUP_CASE(1, 128, 128, 1) DG_GROUP_CASE(1, 128, 128, 2)
+    default: break;
+  }
+#undef DG_GROUP_CASE
+}
+
+// the launch geometry of one layer: K split, tap pairs or single taps (pairs: 0 = by the K range per workgroup, 1 = always,
+// 2 = never; ws: partial tiles go to a workspace)
+struct DmaGeo { int tiles_m, tiles_n; long split; bool use_pairs; };
+template <int BM, int BN>
+DmaGeo dma_geo(const WgradP* p, int accumulate, int pairs, bool ws) {
   const int tiles_m = p->Ci / BM, tiles_n = p->Co / BN;
   const long units = (long)p->B * p->Hc;
-  const bool ws = plan ? true : p->ws != nullptr;          // (a plan describes the launch WITH a workspace)
   const bool can_split = accumulate || ws;
   auto split_for = [&](long tiles) {
     long split = 1;
@@ -336,13 +384,23 @@ int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, D
   const long chunks2 = units / split2 * (p->Wc / BKP);
   const bool use_pairs = pairs == 1 ? can_split : (pairs == 2 ? false : (can_split && chunks2 >= (ws ? PAIR_MIN_WS : 48)));
   const long split = use_pairs ? split2 : split_for((long)tiles_m * tiles_n * 16);
+  return DmaGeo{tiles_m, tiles_n, split, use_pairs};
+}
+
+// plan != NULL: describe the launch, launch nothing.
+template <int WMODE, int BM, int BN>
+int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan) {
+  const bool ws = plan ? true : p->ws != nullptr;          // (a plan describes the launch WITH a workspace)
+  const DmaGeo ge = dma_geo<BM, BN>(p, accumulate, pairs, ws);
+  const int tiles_m = ge.tiles_m, tiles_n = ge.tiles_n;
+  const long split = ge.split;
   if (plan) {
     plan->splits = (int)split;
     plan->ws_floats = split * 16L * p->Ci * p->Co;
-    plan->tap_pairs = use_pairs ? 1 : 0;
+    plan->tap_pairs = ge.use_pairs ? 1 : 0;
     return DG_OK;
   }
-  if (use_pairs) {
+  if (ge.use_pairs) {
     dim3 grid((unsigned)(tiles_m * tiles_n), 8u, (unsigned)split);
     wgrad_dma_kernel<WMODE, BM, BN, 2><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   } else {
@@ -442,6 +500,34 @@ int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStre
   if (m128) return launch_dma<1, 128, 64>(p, accumulate, pairs, stream, plan);
   if (n128) return launch_dma<1, 64, 128>(p, accumulate, pairs, stream, plan);
   return launch_dma<1, 64, 64>(p, accumulate, pairs, stream, plan);
+}
+
+// up to GROUP_MAX layers as one launch (see wgrad_group_kernel); every item must take the LDS-DMA kernel and bring its
+// workspace (DgWgrad.ws sized by dg_wgrad_plan: the geometry here is the same function's)
+int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, hipStream_t stream) {
+  if (n < 1 || n > GROUP_MAX) return DG_EINVAL;
+  GroupP g{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradP* p = &items[i];
+    if (!dg_wgrad_mfma_dma_supported(p) || !p->ws) return DG_EUNSUPPORTED;
+    if (p->g_mod < 0 || ((size_t)p->ws & 15) != 0) return DG_EINVAL;
+    const int bm = p->Ci % 128 == 0 ? 128 : 64, bn = p->Co % 128 == 0 ? 128 : 64;
+    const DmaGeo ge = bm == 128 ? (bn == 128 ? dma_geo<128, 128>(p, 1, pairs, true) : dma_geo<128, 64>(p, 1, pairs, true))
+                                : (bn == 128 ? dma_geo<64, 128>(p, 1, pairs, true) : dma_geo<64, 64>(p, 1, pairs, true));
+    GroupItem& it = g.it[i];
+    it.p = *p;
+    it.tiles_n = ge.tiles_n;
+    it.gx = ge.tiles_m * ge.tiles_n; it.gy = ge.use_pairs ? 8 : 16; it.gz = (int)ge.split;
+    it.first = blocks;
+    it.variant = variant_code(p->wmode, bm, bn, ge.use_pairs ? 2 : 1);
+    it.accumulate = 1;
+    blocks += (it.gx * it.gy * it.gz + 7) / 8 * 8;
+  }
+  g.n = n;
+  wgrad_group_kernel<<<(unsigned)blocks, 256, 0, stream>>>(g);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
 }
 
 extern "C" int dg_wgrad_reduce(const DgWgradReduce* items, int n, void* stream) {

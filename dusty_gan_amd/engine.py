@@ -256,6 +256,7 @@ class WgradWorkspace:
         self.start = max(self.START, min(int(start or 0), self.FLOATS))
         self.demand = 0     # floats requested since the caller's last flush, growth's own reduces not counted: what to grow to
         self.grows = 0      # allocations (1 = the first one sufficed)
+        self.pre_reduce = None   # set by an open Ops.grouped() block: issues its queued launches before any reduce
 
     def take(self, nfloats, device):
         if nfloats > self.FLOATS:
@@ -299,6 +300,10 @@ class WgradWorkspace:
         self.items, self.pos, self.demand = [], 0, 0
 
     def _reduce_pending(self):
+        if self.items and self.pre_reduce is not None:
+            # launches whose partials are about to be summed may still be waiting in an open `Ops.grouped()` block (they were
+            # queued, not issued): issue them first - the reduce follows them in stream order
+            self.pre_reduce()
         items, self.items, self.pos = self.items, [], 0
         # one launch per <= 8 layers, and never two items with the same destination in one launch (micro-batches, the
         # path-length terms: their blocks would read-modify-write the same dW concurrently) - those follow in stream order
@@ -404,8 +409,36 @@ class MaskBits:
         return L.ptr(bits) + off // 8
 
 
+class _WgradGroup:
+    def __init__(self, ops):
+        self.ops = ops
+
+    def __enter__(self):
+        self.outer = self.ops._group is not None    # (a block inside a block joins the outer one's launch)
+        if not self.outer:
+            self.ops._group = []
+            self.ws = WGRAD_WS._cur()
+            self.ws.pre_reduce = self._issue_now
+        return self
+
+    def _issue_now(self):
+        """the workspace is about to sum pending partials (it grows, or it is full): the queued launches must run first"""
+        items, self.ops._group = self.ops._group, []
+        self.ops._launch_group(items)
+
+    def __exit__(self, et, ev, tb):
+        if self.outer:
+            return False
+        items, self.ops._group = self.ops._group, None
+        self.ws.pre_reduce = None
+        if et is None:
+            self.ops._launch_group(items)
+        return False
+
+
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
+    group_enabled = os.environ.get("DUSTY_GAN_WGRAD_GROUP", "1") != "0"
     default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
     _dbias_ws = {}      # device -> DgConv.dbias_ws scratch (launches of one stream share it: each leaves it zero)
 
@@ -421,6 +454,7 @@ class Ops:
         self.force = 0
         self.wg_cap = Ops.default_wg_cap  # dg_conv_ex: cap on the persistent conv's workgroup count (0 = one residency wave)
         self.use_ws = True  # split-K partials through WGRAD_WS + dg_wgrad_reduce (False: fp32 atomics onto dW)
+        self._group = None  # the open `grouped()` block's launches
 
     @property
     def _f(self):
@@ -502,6 +536,14 @@ class Ops:
         pl = self.wgrad_plan(p, accumulate) if self.use_ws else None
         if pl is not None and pl.ws_floats > 0:
             p.ws = WGRAD_WS.take(pl.ws_floats, a.device)
+        if self._group is not None and defer and p.ws and pl.variant == 5 and len(self._group) < self.GROUP_MAX:
+            # inside `with ops.grouped():` - the launch joins the group's ONE launch (dg_wgrad_group) at the end of the block;
+            # its partials wait in the workspace like any deferred launch's
+            if TRACE is not None:
+                TRACE.append(("wgrad", 5, f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}", pl.splits, pl.tap_pairs, True, g_mod))
+            self._group.append((p, (wmode, B, Hc, Wc, Ci, Co), (a, g, rowscale)))   # (the tensors: kept alive until the launch)
+            WGRAD_WS.add(p.ws, dw_ptr, 16 * Ci * Co, pl.splits, int(accumulate))
+            return
         if TRACE is not None:
             TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self._f),
                           f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}", 0 if pl is None else pl.splits,
@@ -522,6 +564,49 @@ class Ops:
             WGRAD_WS.add(p.ws, dw_ptr, (1 if wmode == 2 else 16) * Ci * Co, pl.splits, int(accumulate))
             if not defer:
                 WGRAD_WS.flush()
+
+    GROUP_MAX = 4   # (GROUP_MAX of csrc/wgrad_mfma_dma.hip)
+
+    def grouped(self):
+        """`with ops.grouped():` - the deferred weight-gradient launches of the block that run on the MFMA LDS-DMA kernel with a
+        split-K workspace become ONE launch (dg_wgrad_group: the layers of a network are independent of each other, and one
+        grid lets the ring fill / partial-tile stores of one layer overlap the matrix work of the next); anything else in the
+        block launches at once as before.  Nothing reads the partials before the caller's WGRAD_WS.flush(), which comes after
+        the block.  DUSTY_GAN_WGRAD_GROUP=0: single launches (A/B, tests)."""
+        return _WgradGroup(self)
+
+    def _launch_group(self, items):
+        if not items:
+            return
+        if len(items) == 1 or not Ops.group_enabled:
+            for p, (wmode, B, Hc, Wc, Ci, Co), _ in items:
+                if PROFILE is None:
+                    L.check(self.lib.dg_wgrad(C.byref(p), 1, self._f, L.stream_ptr()), "dg_wgrad")
+                    continue
+                f, b = wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4, 2 if p.g_dtype == L.DG_BF16 else 4)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.check(self.lib.dg_wgrad(C.byref(p), 1, self._f, L.stream_ptr()), "dg_wgrad")
+                e1.record()
+                PROFILE.append(("wgrad_mfma_kernel", f, b, e0, e1, f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
+            return
+        arr = (L.DgWgrad * len(items))()
+        for i, (p, _, _) in enumerate(items):
+            C.memmove(C.byref(arr, i * C.sizeof(L.DgWgrad)), C.byref(p), C.sizeof(L.DgWgrad))
+        if TRACE is not None:
+            TRACE.append(("wgrad_group", len(items), [f"wmode{d[0]} B{d[1]} {d[2]}x{d[3]} Ci{d[4]} Co{d[5]}" for _, d, _ in items]))
+        if PROFILE is None:
+            L.check(self.lib.dg_wgrad_group(arr, len(items), self._f, L.stream_ptr()), "dg_wgrad_group")
+            return
+        flops = nbytes = 0.0
+        for p, (wmode, B, Hc, Wc, Ci, Co), _ in items:
+            f, b = wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4, 2 if p.g_dtype == L.DG_BF16 else 4)
+            flops, nbytes = flops + f, nbytes + b
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(self.lib.dg_wgrad_group(arr, len(items), self._f, L.stream_ptr()), "dg_wgrad_group")
+        e1.record()
+        PROFILE.append(("wgrad_mfma_kernel", flops, nbytes, e0, e1, f"group of {len(items)} layers"))
 
     def wgrad_takes_map(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr):
         """whether the kernel that would run this launch has the g-sample index map (DgWgrad.g_mod): the LDS-DMA kernel
@@ -720,24 +805,30 @@ class GEngine:
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), 1.0 / math.sqrt(co * 16), L.EPI_MASK, aux=self.a[i - 1],
                    dbias=st.fptr(prev_b, st.grad), bias_mod=ci)
 
+        # The weight gradients of Up1-3 only read finished buffers (a[i-1], dp[i]: nothing below overwrites them), so they are
+        # collected while the backward-data chain is issued and leave as ONE launch behind it (dg_wgrad_group, round 5: the ring
+        # fill and the partial-tile stores of one layer under the matrix work of the next - the three B-sized launches ran at
+        # 0.31 of the matrix peak, a quarter of each being ramp).
         if chain_first:
             head_bwd_data()
             for i in (3, 2, 1):
                 up_bwd_data(i)
             if after_chain is not None:
                 after_chain()
-            up_wgrad(1)
+            with o.grouped():
+                up_wgrad(1)
+                up_wgrad(2)
+                up_wgrad(3)
             if after_up1 is not None:
                 after_up1()
-            up_wgrad(2)
-            up_wgrad(3)
             head_wgrad()
         else:
-            head_wgrad()
-            head_bwd_data()
-            for i in (3, 2, 1):
-                up_wgrad(i)
-                up_bwd_data(i)
+            with o.grouped():
+                head_wgrad()
+                head_bwd_data()
+                for i in (3, 2, 1):
+                    up_wgrad(i)
+                    up_bwd_data(i)
         if not skip_proj:
             self.proj_wgrad(st, self.dp[0], self.zT, B, accumulate_proj)
 
@@ -1065,12 +1156,13 @@ class DEngine:
         """dW_i += s_i * sum_b rowscale[b] * (h_{i-1}[a_slot+b] (x) e_i[g_slot + b % g_mod]) for the Down layers in `layers`.
         The split-K partials of the fat layers wait in engine.WGRAD_WS: the caller flushes before the gradient is read."""
         c, o = self.cfg, self.ops
-        for i in layers:
-            hc, wc = self.grid[i]
-            ci, co = self.chs[i - 1], self.chs[i]
-            o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
-                    (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
-                    a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i], g_mod=g_mod, defer=True)
+        with o.grouped():   # the fat layers' launches as ONE (dg_wgrad_group)
+            for i in layers:
+                hc, wc = self.grid[i]
+                ci, co = self.chs[i - 1], self.chs[i]
+                o.wgrad(0, c.ring, n, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
+                        (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad), 1.0 / math.sqrt(ci * 16), rowscale=rowscale,
+                        a_off=a_slot * self.per[i - 1], g_off=g_slot * self.per[i], g_mod=g_mod, defer=True)
 
     def wgrad_r1(self, st, B, rs3, layers=(1, 2, 3, 4)):
         """The D phase's weight gradients with R1 on (trainers/dcgan_amp.py:235 through :218-232): per layer
@@ -1079,15 +1171,16 @@ class DEngine:
         kernel that has the gradient-sample index map they are ONE launch over the 3B input slots with g sample = b % 2B
         and per-sample weights rs3 = [dLoss/dy_real | 1 | 1]: half the launches and half the split-K partial tiles."""
         c, o = self.cfg, self.ops
-        for i in layers:
-            hc, wc = self.grid[i]
-            ci, co = self.chs[i - 1], self.chs[i]
-            if o.wgrad_takes_map(0, c.ring, 3 * B, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
-                                 (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad)):
-                self.wgrad(st, 0, 0, 3 * B, rs3, layers=(i,), g_mod=2 * B)
-            else:
-                self.wgrad(st, 0, 0, 2 * B, rs3, layers=(i,))
-                self.wgrad(st, 2 * B, 0, B, None, layers=(i,))
+        with o.grouped():   # Down2-4 at 3B samples: one launch for the three layers (round 5)
+            for i in layers:
+                hc, wc = self.grid[i]
+                ci, co = self.chs[i - 1], self.chs[i]
+                if o.wgrad_takes_map(0, c.ring, 3 * B, hc, wc, ci, co, self.h[i - 1], (self.per[i - 1], ci, 1), self.e[i],
+                                     (self.per[i], co, 1), st.fptr(f"d{i}_w", st.grad)):
+                    self.wgrad(st, 0, 0, 3 * B, rs3, layers=(i,), g_mod=2 * B)
+                else:
+                    self.wgrad(st, 0, 0, 2 * B, rs3, layers=(i,))
+                    self.wgrad(st, 2 * B, 0, B, None, layers=(i,))
 
     def final_wgrad(self, st, slot, n, coef):
         """dwf += s_f * sum_b coef[b] * h4[slot+b]"""

@@ -159,6 +159,13 @@ typedef struct DgWgradPlan {
   int tap_pairs;    /* 1: one workgroup computes the W taps (kx, kx + 2) from one staged image */
 } DgWgradPlan;
 int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan);
+/* Up to 4 weight-gradient GEMMs as ONE launch (the layers of one network: independent of each other, all reading finished
+ * activations and gradient chains - loss.backward() at trainers/dcgan_amp.py:235,309 produces them in one sweep too): every
+ * item must run on the MFMA LDS-DMA kernel (dg_wgrad_plan: variant 5) and bring its split-K workspace (`ws`, ws_floats of its
+ * plan under the same `force`); the partial tiles, the splits and the dg_wgrad_reduce that follows are exactly those of n
+ * single dg_wgrad calls.  One grid instead of n residency rounds: the ring fill and the partial-tile stores of one layer's
+ * workgroups run under the matrix work of its neighbours'.  DG_EUNSUPPORTED (nothing launched) if an item does not qualify. */
+int dg_wgrad_group(const DgWgrad* items, int n, int force, void* stream);
 /* dw[i] (+)= sum_s ws[s * numel + i] for up to 8 layers in one launch (fixed summation order: deterministic gradients) */
 typedef struct DgWgradReduce {
   const float* ws;

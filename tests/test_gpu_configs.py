@@ -48,8 +48,15 @@ def trace():
     E.TRACE = None
 
 
-FP32 = dict(out_tol=1e-3, loss_tol=1e-3, grad_tol={"grad_D": 2e-2, "grad_G": 2e-2}, cos_min=0.9999, mask_tol=1e-4)
-BF16_EMU = dict(out_tol=5e-3, loss_tol=2e-3, grad_tol={"grad_D": 2.5e-2, "grad_G": 8e-2}, cos_min=0.997, mask_tol=2e-3)
+# Gradient bounds = what these tests measure on MI355X (round 5, `pytest -s` prints every run's worst values as "PARITY ...")
+# times 1.25 - 3.5, not a round number that a 1 % defect would pass under (the round-4 review's point):
+#   fp32 parity mode, whole step at full width against the fp32 oracle: D 2.7e-4 ... 1.0e-3, G 1.4e-3 ... 1.5e-3 rel-L2 per tensor,
+#     cosine >= 0.999998 (config 1 at B = 8, config 3 at B = 32; the B = 2 full-width case of tests/test_gpu_step.py: 2e-6 / 2e-5).
+#     The spread is leaky-relu slope flips of units within rounding of zero (tests/test_gpu_step.py docstring): 5e-3 / 0.99999.
+#   bf16 timed mode against the bf16-EMULATING oracle: D 1.0e-2 ... 1.7e-2, G 4.8e-2 ... 5.3e-2, cosine 0.9986 ... 0.9999:
+#     D 2.1e-2, G 6.6e-2, cosine 0.9978 (1.25 x the worst seen).
+FP32 = dict(out_tol=1e-3, loss_tol=1e-3, grad_tol={"grad_D": 5e-3, "grad_G": 5e-3}, cos_min=0.99999, mask_tol=1e-4)
+BF16_EMU = dict(out_tol=5e-3, loss_tol=2e-3, grad_tol={"grad_D": 2.1e-2, "grad_G": 6.6e-2}, cos_min=0.9978, mask_tol=2e-3)
 
 
 def _check(res, tr, state, out_tol, loss_tol, grad_tol, cos_min, mask_tol, lr=0.002):
@@ -74,7 +81,7 @@ def _check(res, tr, state, out_tol, loss_tol, grad_tol, cos_min, mask_tol, lr=0.
                 if r > grad_tol[name] or c < cos_min:
                     fails.append((name, k, f"rel-L2 {r:.3e} (bound {grad_tol[name]:.1e})", f"cosine {c:.6f} (bound {cos_min})"))
     # (measured values in the record: `pytest -s` shows how far inside its bounds a run sits)
-    print("PARITY", {k: float(f"{v:.4g}") for k, v in worst.items()}, "bounds", grad_tol, cos_min)
+    print("PARITY", {k: float(f"{v:.7g}") for k, v in worst.items()}, "bounds", grad_tol, cos_min)
     assert not fails, (fails, worst)
     # post-Adam parameters: the first step at beta1 = 0 moves every element by ~lr * sign(g), so every element is within
     # 2 lr of the oracle's; D before the sync (the engine's own update), G and G_ema after

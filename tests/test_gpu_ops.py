@@ -310,6 +310,64 @@ def test_up_forward_64_channels_on_the_pingpong_kernel(L, Ci, H, W, B, force):
     assert rel_l2(out, y) < TOLBF
 
 
+@pytest.mark.parametrize("wmode", [0, 1])
+@pytest.mark.parametrize("force", [2, 7, 8])
+def test_wgrad_group_is_the_single_launches_in_one_grid(L, wmode, force):
+    """dg_wgrad_group (round 5): up to four layers' weight-gradient GEMMs as ONE launch - every tile shape of the LDS-DMA kernel
+    (128 / 64 input and output channels), tap pairs forced / forbidden / chosen, per-sample weights and the 3n-sample map on
+    one item, a fifth layer that overflows the group.  Same plan function, same partial tiles, same reduce: the gradients must
+    equal those of the single launches BIT FOR BIT."""
+    from dusty_gan_amd import engine as E
+    g = torch.Generator().manual_seed(31 + wmode + force)
+    n = 2
+    fa, fg = (4, 1) if wmode == 0 else (1, 4)
+    layers = [(128, 128, 4, 128), (64, 128, 8, 64), (128, 64, 4, 64), (64, 64, 2, 128), (128, 128, 2, 64)]
+    data = []
+    for Ci, Co, H, W in layers:
+        a = torch.randn(3 * n * fa * H * W * Ci, generator=g).to(DEV, torch.bfloat16)
+        e = torch.randn(2 * n * fg * H * W * Co, generator=g).to(DEV, torch.bfloat16)
+        data.append((a, e, (fa * H * W * Ci, Ci, 1), (fg * H * W * Co, Co, 1)))
+    rs = (torch.rand(3 * n, generator=g) + 0.5).to(DEV)
+
+    def run(grouped):
+        o = E.Ops(torch.bfloat16)
+        o.force = force
+        out = [torch.zeros(16, Ci, Co, device=DEV) for Ci, Co, _, _ in layers]
+        E.TRACE = []
+        try:
+            prev, E.Ops.group_enabled = E.Ops.group_enabled, grouped
+            with o.grouped():
+                for k, ((Ci, Co, H, W), (a, e, sa, sg)) in enumerate(zip(layers, data)):
+                    if k == 0:   # the discriminator's merged form: 3n input samples against 2n gradient samples, weighted
+                        o.wgrad(wmode, True, 3 * n, H, W, Ci, Co, a, sa, e, sg, out[k].data_ptr(), 0.05, rowscale=rs, g_mod=2 * n,
+                                defer=True)
+                    else:
+                        o.wgrad(wmode, True, 2 * n, H, W, Ci, Co, a, sa, e, sg, out[k].data_ptr(), 0.03 * k, defer=True)
+            tr = E.TRACE
+        finally:
+            E.TRACE, E.Ops.group_enabled = None, prev
+        E.WGRAD_WS.flush()
+        torch.cuda.synchronize()
+        return out, tr
+    want, tr0 = run(False)                                      # (also grows the split-K workspace to what the block needs)
+    got, tr = run(True)
+    groups = [t for t in tr if t[0] == "wgrad_group"]
+    assert len(groups) == 1 and groups[0][1] == 4, tr          # four layers in the one launch, the fifth on its own
+    assert not [t for t in tr0 if t[0] == "wgrad_group"]
+    assert [t[1] for t in tr if t[0] == "wgrad"] == [5] * 5
+    for k, (x, y) in enumerate(zip(got, want)):
+        assert float(y.abs().max()) > 0
+        assert torch.equal(x, y), (k, rel_l2(x.cpu(), y.cpu()))
+    # a workspace that has to GROW inside the block sums the pending partials before it moves: launches still queued in the
+    # open group must be issued first (a first version reduced partials nobody had written yet)
+    E.WGRAD_WS._by_stream.clear()
+    got2, tr2 = run(True)
+    assert E.WGRAD_WS.grows >= 2, E.WGRAD_WS.grows
+    for k, (x, y) in enumerate(zip(got2, want)):
+        assert torch.equal(x, y), ("grown inside the block", k, rel_l2(x.cpu(), y.cpu()))
+
+
+
 @pytest.mark.parametrize("force", [2, 7, 8], ids=["auto", "tap-pairs", "single-taps"])
 @pytest.mark.parametrize("wmode,Ci,Co,H,W", [(0, 128, 128, 4, 128), (1, 128, 64, 4, 64), (0, 64, 128, 8, 64)])
 def test_wgrad_workspace_and_sample_map(L, wmode, Ci, Co, H, W, force):

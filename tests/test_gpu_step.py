@@ -171,8 +171,11 @@ def run_both(arch, shape, in_ch, ch_base, ch_max, B, amp, steps=1, seed=0, pl=0.
     return tr, (G, D, G_ema), res
 
 
-# fp32 parity mode, gradients at full width (see the docstring below): set from measurements on MI355X, 1.25 x the worst seen
-FP32_GRAD_TOL, FP32_GRAD_COS = 2e-2, 0.9999
+# fp32 parity mode, gradients at full width (see the docstring of test_step_fp32_vs_oracle_full_width_64x1024): measured on
+# MI355X 2.2e-6 (D) / 1.7e-5 (G) with no flipped unit at B = 2, up to 1.5e-3 at B = 8 ... 32 where a few units flip
+# (tests/test_gpu_configs.py prints them): held to 5e-3 rel-L2 AND cosine 0.99999 (round 4: 2e-2 / 0.9999, 20 x looser than
+# anything measured - a 1 % defect of one layer would have passed)
+FP32_GRAD_TOL, FP32_GRAD_COS = 5e-3, 0.99999
 
 
 def _cos(a, b):
@@ -187,8 +190,8 @@ def test_step_fp32_vs_oracle_full_width_64x1024():
     per-op tests pin that to 1e-4; end to end a handful of the ~4M units whose pre-activation is within fp32
     rounding of zero (measured 3 of 3.9M, |pre| < 2e-8: scripts/diag_flips.py) take the other slope in the two
     implementations.  One flipped unit is an O(1) change of that unit's contribution, i.e. ~sqrt(#flips/#units)
-    ~ 1e-3 rel-L2 on every gradient downstream.  So gradients are held to 1e-3 when no unit flips (all of D in
-    this case: measured 2e-6) and to 2e-2 rel-L2 / cosine >= 0.9999 otherwise."""
+    ~ 1e-3 rel-L2 on every gradient downstream.  So gradients are held to 5e-3 rel-L2 AND cosine >= 0.99999 (measured in
+    this case: D 2e-6, G 2e-5 - no unit flipped; with flips up to 1.5e-3, tests/test_gpu_configs.py)."""
     tr, (G, D, G_ema), res = run_both("dusty2", (64, 1024), 512, 64, 512, 2, amp=False)
     sc_ref, ex, synth, gD, gG, scal = res[0]
     tol = 1e-4
@@ -205,7 +208,7 @@ def test_step_fp32_vs_oracle_full_width_64x1024():
             r, c = rel_l2(got[k], v), _cos(got[k], v)
             worst[name] = max(worst.get(name, 0.0), r)
             worst[name + "_cos"] = min(worst.get(name + "_cos", 1.0), c)
-    print("PARITY full-width fp32 B=2", {k: float(f"{v:.4g}") for k, v in worst.items()})
+    print("PARITY full-width fp32 B=2", {k: float(f"{v:.7g}") for k, v in worst.items()})
     for name in ("grad_D", "grad_G"):
         assert worst[name] < FP32_GRAD_TOL and worst[name + "_cos"] > FP32_GRAD_COS, (name, worst)
     tol = 1e-3
