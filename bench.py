@@ -609,9 +609,10 @@ def main():
         out.setdefault("roofline", {})["step"] = step
         # the gradient tolerances of the timed mode are its own (tests/test_gpu_configs.py), not north_star's 1e-3
         out["parity_of_this_mode"] = (
-            "bf16 storage, fp32 accumulate: outputs <= 5e-3, losses <= 2e-3, D gradients <= 2.5e-2 and G gradients <= 8e-2 "
-            "rel-L2 against the bf16-emulating oracle (measured 1.1e-3 / 8e-5 / 1.3e-2 / 5.3e-2); the <= 1e-3 north-star "
-            "tolerance is met by --precision fp32 (tests/test_gpu_configs.py)"
+            "bf16 storage, fp32 accumulate: outputs <= 5e-3, losses <= 2e-3, D gradients <= 2.1e-2 and G gradients <= 6.6e-2 "
+            "rel-L2 against the bf16-emulating oracle (measured 1.1e-3 / 8e-5 / 1.0-1.7e-2 / 4.8-5.3e-2); the <= 1e-3 north-star "
+            "tolerance is met by --precision fp32 (gradients <= 5e-3, cosine >= 0.99999: tests/test_gpu_configs.py); two runs "
+            "from one seed are bit-identical (tests/test_gpu_timed_path.py)"
             if args.precision == "bf16" else
             ("fp32x3: fp32 storage, operands split into bf16 hi + lo on the bf16 matrix instructions, fp32 accumulation: held to "
              "the fp32 mode's bounds against the reference digests at full width (tests/test_gpu_configs.py)"

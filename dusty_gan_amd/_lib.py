@@ -44,6 +44,7 @@ class DgConv(C.Structure):
         ("nscale", C.c_void_p),
         ("up_frag", C.c_void_p),
         ("dbias_ws", C.c_void_p),
+        ("dbias_part", C.c_void_p),
         ("mask_out", C.c_void_p),
         ("mask_in", C.c_void_p),
     ]
@@ -94,7 +95,7 @@ class DgWgradReduce(C.Structure):
 
 class DgConvPlan(C.Structure):
     _fields_ = [("family", C.c_int), ("bm", C.c_int), ("bn", C.c_int), ("tiles", C.c_int), ("workgroups", C.c_int),
-                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int), ("mask_bits", C.c_int)]
+                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int), ("mask_bits", C.c_int), ("dbias_rows", C.c_int)]
 
 
 _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64
@@ -108,7 +109,8 @@ PROTOTYPES = {
     "dg_conv_kernel_choice": [C.POINTER(DgConv)],
     "dg_wgrad": [C.POINTER(DgWgrad), _I, _I, _P],
     "dg_wgrad_plan": [C.POINTER(DgWgrad), _I, _I, C.POINTER(DgWgradPlan)],
-    "dg_wgrad_group": [C.POINTER(DgWgrad), _I, _I, _P],
+    "dg_wgrad_group": [C.POINTER(DgWgrad), _I, _I, _I, _P],
+    "dg_wgrad_group_plan": [C.POINTER(DgWgrad), _I, _I, _I, C.POINTER(DgWgradPlan)],
     "dg_wgrad_reduce": [C.POINTER(DgWgradReduce), _I, _P],
     "dg_wgrad_mfma_supported": [C.POINTER(DgWgrad)],
     "dg_wgrad_kernel_choice": [C.POINTER(DgWgrad)],
@@ -143,7 +145,8 @@ PROTOTYPES = {
     "dg_nsgan_g_step": [_P, _I, _F, _P, _P, _P],
     "dg_gan_d_step": [_I, _F, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
     "dg_gan_g_step": [_I, _P, _P, _I, _F, _P, _P, _P],
-    "dg_final_gan_bwd": [_I, _I, _F, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _I, _P, _F, _L, _I, _P, _P, _P, _P],
+    "dg_final_gan_bwd": [_I, _I, _F, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _P, _I, _P, _F, _L, _I, _P, _P, _P, _P, _P],
+    "dg_det_arena": [_P, _L, _P],
     "dg_mean_acc": [_P, _I, _P, _P],
     "dg_fetch_reals": [_P, _P, _F, _F, _F, _L, _P, _P],
     "dg_fetch_reals_sum": [_P, _P, _F, _F, _F, _I, _L, _P, _P, _P],
@@ -286,6 +289,7 @@ class AccArena:
     out once; None when the arena is not in use or exhausted (the caller then uses the self-zeroing entry point)."""
     SIZE = 8192
     buf, pos, epoch = None, 0, 0               # epoch: counts begin() calls (a slice is only meaningful within its epoch)
+    shadow = None                              # fixed-point shadow words of the slots (deterministic cross-block sums)
 
     @staticmethod
     def _same(dev, want):
@@ -300,6 +304,13 @@ class AccArena:
         import torch
         if cls.buf is None or not cls._same(cls.buf.device, device):
             cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
+            # bit-reproducible sums into the arena's slots (csrc/common.h dg_acc_add): a shadow of 16 bytes per float, zero at
+            # rest, registered with the library for this device; DUSTY_GAN_DETERMINISTIC=0 keeps the float atomics
+            if os.environ.get("DUSTY_GAN_DETERMINISTIC", "1") != "0":
+                cls.shadow = torch.zeros(cls.SIZE * 4, dtype=torch.int32, device=device)
+                torch.cuda.synchronize(cls.buf.device)
+                with torch.cuda.device(cls.buf.device):
+                    check(lib().dg_det_arena(ptr(cls.buf), cls.SIZE, ptr(cls.shadow)), "dg_det_arena")
         if draws:
             step_prologue([cls.buf] + list(also), list(draws))
         else:

@@ -8,12 +8,13 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan);
 int dg_wgrad_mfma_dma_supported(const WgradP* p);
 int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan);
-int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, hipStream_t stream);
+int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, int rounds, hipStream_t stream, DgWgradPlan* plans);
 int dg_conv_thin_launch(const ConvP* p, hipStream_t stream);
 int dg_conv_thin_supported(const ConvP* p);
 int dg_proj_stream_supported(const ConvP* p);
 int dg_proj_stream_launch(const ConvP* p, hipStream_t stream, DgConvPlan* plan);
 int dg_conv_thin_mfma_variant(const ConvP* p);
+int dg_conv_s2_mfma_blocks(const ConvP* p);
 int dg_wgrad_thin_mfma_variant(const WgradP* p);
 int dg_wgrad_thin_ws_splits(const WgradP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
@@ -44,7 +45,7 @@ static int conv_dispatch0(const DgConv* p, int force_flags, int wg_cap, hipStrea
   if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
-  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; plan->mask_bits = 0; }
+  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; plan->mask_bits = 0; plan->dbias_rows = 0; }
   // Proj forward (bf16, K = 512, B <= 32): the weight-streaming kernel (proj_stream.hip); force 10 asks for it, 2 for the
   // general MFMA kernel it replaces
   if ((force == 0 || force == 10) && dg_proj_stream_supported(p)) return dg_proj_stream_launch(p, s, plan);
@@ -54,7 +55,11 @@ static int conv_dispatch0(const DgConv* p, int force_flags, int wg_cap, hipStrea
   if (force == 0 && mfma_ok) return dg_conv_mfma_launch(p, s, wg_cap, plan, x3);
   if (force == 3 && !thin_ok) return DG_EUNSUPPORTED;
   if ((force == 3 || force == 0) && thin_ok) {
-    if (plan) { plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); plan->mask_bits = plan->thin_mfma == 1 ? 3 : 0; return DG_OK; }
+    if (plan) {
+      plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); plan->mask_bits = plan->thin_mfma == 1 ? 3 : 0;
+      plan->dbias_rows = plan->thin_mfma == 1 ? dg_conv_s2_mfma_blocks(p) : 0;
+      return DG_OK;
+    }
     return dg_conv_thin_launch(p, s);
   }
   if (plan) { plan->family = 1; return DG_OK; }
@@ -136,7 +141,7 @@ int dg_wgrad(const DgWgrad* p, int accumulate, int force, void* stream) {
   return wgrad_dispatch(p, accumulate, force, (hipStream_t)stream, nullptr);
 }
 
-int dg_wgrad_group(const DgWgrad* items, int n, int force_flags, void* stream) {
+static int wgrad_group_dispatch(const DgWgrad* items, int n, int force_flags, int rounds, hipStream_t stream, DgWgradPlan* plans) {
   const int force = force_flags & ~DG_FORCE_FP32X3;
   if (!items || n < 1) return DG_EINVAL;
   if (force != 0 && force != 2 && force != 7 && force != 8) return DG_EUNSUPPORTED;
@@ -145,7 +150,16 @@ int dg_wgrad_group(const DgWgrad* items, int n, int force_flags, void* stream) {
     if (!p->a || !p->g || !p->dw || p->B <= 0 || p->Ci <= 0 || p->Co <= 0 || p->Hc <= 0 || p->Wc <= 0) return DG_EINVAL;
     if (!dg_wgrad_mfma_supported(p)) return DG_EUNSUPPORTED;
   }
-  return dg_wgrad_mfma_dma_group_launch(items, n, force == 7 ? 1 : (force == 8 ? 2 : 0), (hipStream_t)stream);
+  return dg_wgrad_mfma_dma_group_launch(items, n, force == 7 ? 1 : (force == 8 ? 2 : 0), rounds, stream, plans);
+}
+
+int dg_wgrad_group(const DgWgrad* items, int n, int force, int rounds, void* stream) {
+  return wgrad_group_dispatch(items, n, force, rounds, (hipStream_t)stream, nullptr);
+}
+
+int dg_wgrad_group_plan(const DgWgrad* items, int n, int force, int rounds, DgWgradPlan* plans) {
+  if (!plans) return DG_EINVAL;
+  return wgrad_group_dispatch(items, n, force, rounds, nullptr, plans);
 }
 
 int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan) {

@@ -97,7 +97,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr bool STRIP = BN == 128;            // output stores through a per-wave LDS transpose strip (below)
   constexpr int SCR = STRIP ? 16 * WC * 2 : 0; // 16 pixels x the wave's channels
   constexpr int NHT = 256;                     // rows of the H-tap table (the launcher checks rows <= NHT)
-  constexpr int LDS_HT = NPS * PSTAGE + 3 * NDB * 4 + NWV * SCR;
+  // Bias-gradient sums (EPI_MASK): one ROW of accumulators per wave that can touch a channel (waves that differ only in
+  // their pixel block wm - in the both-parities tile all eight), NDBR * NDB floats laid over [s_bias (unused under EPI_MASK) |
+  // s_db | NDBX more]: a wave adds to its own row in its own program order and the rows are summed in a fixed order at the
+  // end, so a workgroup's partial sums do not depend on which wave's ds_add arrived first (round 5; one shared row before)
+  constexpr int NDBR = 4;                      // rows of NDB floats available (row stride = p.N, rows = DBW: DBW * N <= NDBR * NDB)
+  constexpr int NDBX = MASK ? (NDBR - 2) * NDB : 0;
+  constexpr int DBW = DUAL ? NWV : NWV / WN;   // waves that share a channel
+  constexpr int LDS_HT = NPS * PSTAGE + 3 * NDB * 4 + NDBX * 4 + NWV * SCR;
   static_assert(IB >= 1 && LDS_HT + NHT * 8 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_HT + NHT * 8];
 #ifdef DG_PP_DIAG
@@ -120,10 +127,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const int xe = (gi0 + nwx) * tq + (gi0 + nwx < tr ? gi0 + nwx : tr);
   const int t0 = xs + (int)(blockIdx.x >> 3);
   const int tcount = t0 < xe ? (xe - t0 + nwx - 1) / nwx : 0;
-  if (tcount == 0) return;
+  if (tcount == 0) {                           // (never with the launcher's grid; a zero row if it ever happens)
+    if (MASK && p.dbias && p.dbias_part)
+      for (int n = threadIdx.x; n < p.N; n += 64 * NWV) p.dbias_part[(long)blockIdx.x * p.N + n] = 0.f;
+    return;
+  }
 
   const unsigned long long tk0 = (dbg & 8) ? pp_stamp() : 0ull;   // (diagnostic build: phases of the workgroup's lifetime)
   const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int KC = p.K / 64;
   const int Ws = MODE == MODE_S2 ? 2 * p.Wc : p.Wc, cmul = MODE == MODE_S2 ? 2 : 1;
   const int Wo = MODE == MODE_S2 ? p.Wc : 2 * p.Wc;
@@ -172,7 +184,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 
   const bf16* in = (const bf16*)p.in;
   const bf16* w = (const bf16*)p.w;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lrow = lane >> 3, pos = lane & 7;
   // 16-byte chunk c of image row r lives at chunk c ^ swzA(r).  The fragment reads of the two taps start at rows r and
   // r + 1 of segments pitched SW + 1 rows, i.e. at ANY row offset: ((r >> 1) & 3) << 1 keeps the four 16-lane groups of
@@ -229,17 +240,21 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   const unsigned wrow = (unsigned)(wn * WC + (a16 >> 2) * CPL + (a16 & 3));
   const unsigned wbase = (unsigned)(AIMG + wrow * SB + ((g4 ^ (((a16 >> 1) & 1) | ((a16 >> 2) << 1))) << 4));
 
-  float* s_bias = (float*)(lds + NPS * PSTAGE);
+  float* s_rs = (float*)(lds + NPS * PSTAGE);  // per-sample weights of the bias-gradient sums (B <= NDB)
+  float* s_bias = s_rs + NDB;
   float* s_db = s_bias + NDB;
-  const unsigned sbias0 = lds0 + NPS * PSTAGE, sdb0 = sbias0 + NDB * 4;
-  float* s_rs = s_db + NDB;                    // per-sample weights of the bias-gradient sums (B <= NDB)
-  const unsigned srs0 = sdb0 + NDB * 4;
+  const unsigned srs0 = lds0 + NPS * PSTAGE, sbias0 = srs0 + NDB * 4, sdb0 = sbias0 + NDB * 4;
   const bool want_db = MASK && p.dbias != nullptr;
+  // per-wave rows when they fit (every layer of the step: N <= 512 with four sharing waves, N = 64 with eight)
+  const bool db_rows = MASK && DBW * p.N <= NDBR * NDB;
+  const unsigned sdbw0 = db_rows ? sbias0 + (unsigned)((DUAL ? wave : wave / WN) * p.N) * 4u : sdb0;
   for (int i = tid; i < NDB; i += 64 * NWV) {
     s_bias[i] = (!MASK && p.bias && i < p.N) ? p.bias[i % p.bias_mod] * (p.epi == EPI_LRELU ? SQRT2 : 1.f) : 0.f;
     s_db[i] = 0.f;
     s_rs[i] = (p.rowscale && i < p.B) ? p.rowscale[i] : 1.f;
   }
+  if (MASK)
+    for (int i = tid; i < NDBX; i += 64 * NWV) s_db[NDB + i] = 0.f;
   // (round 5: the same tables by LDS-DMA instead of ordinary loads - no dependent global round trip in front of the first
   //  tile's DMA - measured 400 cycles SLOWER per launch: the loads' latency already sat under the H-tap table's arithmetic,
   //  and a DMA piece costs ~100 cycles to issue; profiles/r05a_conv_lifetime_phases_b32.txt)
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int NRD = 16 / RPB;                // store instructions per block row (== NST / TM)
   static_assert(NRD == NST / TM, "strip geometry");
   auto swzS = [](int px) { return CH == 8 ? (px & 7) : ((px >> 1) & 3); };
-  const unsigned scr0 = lds0 + NPS * PSTAGE + 3 * NDB * 4 + (unsigned)wave * SCR;
+  const unsigned scr0 = lds0 + NPS * PSTAGE + 3 * NDB * 4 + NDBX * 4 + (unsigned)wave * SCR;   // (behind the bias-gradient rows)
   // (block row i / second store h: wave-uniform steps from one per-lane offset - the wave's 64 tile rows lie in one segment)
   const unsigned scr_w = scr0 + (unsigned)(a16 * (CH * 16) + (((g4 * NRD) ^ swzS(a16)) << 4));   // chunk h: ^ (h << 4)
   unsigned scr_r, st_off;
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0x128>(dbacc[c]);   // row_ror 8
     if (a16 == 0) {
-      const unsigned ad = sdb0 + (unsigned)(nt * NCH * 4) + lane_coff * 2;
+      const unsigned ad = sdbw0 + (unsigned)(nt * NCH * 4) + lane_coff * 2;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(ad), "v"(dbacc[c]), "n"(c * 4) : "memory");
     }
@@ -699,7 +714,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   if (want_db) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int n = tid; n < p.N; n += 64 * NWV) atomicAdd(&p.dbias[n % p.bias_mod], s_db[n]);
+    for (int n = tid; n < p.N; n += 64 * NWV) {
+      float v;
+      if (db_rows) {
+        v = s_bias[n];                           // (row 0; rows in a fixed order)
+#pragma unroll
+        for (int r = 1; r < DBW; ++r) v += s_bias[r * p.N + n];
+      } else v = s_db[n];
+      // dbias_part: this workgroup's row of the caller's workspace (summed by dg_wgrad_reduce in a fixed order) - else atomics
+      if (p.dbias_part) p.dbias_part[(long)blockIdx.x * p.N + n] = v;
+      else atomicAdd(&p.dbias[n % p.bias_mod], v);
+    }
   }
 }
 
@@ -724,6 +749,8 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
     plan->family = 5; plan->bm = DUAL ? 512 : 256; plan->bn = DUAL ? BN / 2 : BN; plan->tiles = g.ntiles; plan->workgroups = G;
     plan->tiles_per_wg = (g.ntiles + G - 1) / G;
     plan->mask_bits = MASK ? (bits ? 2 : 0) : 1;
+    // (per-wave bias-gradient rows need DBW * N floats of the kernel's LDS rows: 2048)
+    plan->dbias_rows = (MASK && (DUAL ? 8 : 4) * p->N <= 2048) ? G : 0;
     return DG_OK;
   }
   if constexpr (MASK) {

@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP == 2 ? 3
   constexpr int NS = CP == 2 ? 2 : 4;            // MFMA k-steps per kernel (without adjoint extras)
   __shared__ __attribute__((aligned(16))) unsigned char s_t[4][32 * 144];
   __shared__ float s_db[64];
+  __shared__ float s_dbw[4][64];                 // bias-gradient partial rows, one per wave (summed in a fixed order)
   __shared__ __attribute__((aligned(16))) float s_binit[64];   // bias / scale: what the accumulators start from
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1379,11 +1380,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP == 2 ? 3
     for (int e = 0; e < 8; ++e) {
       float v = csum[e];
       for (int d = 8; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-      if (lane < 8) atomicAdd(&s_db[lane * 8 + e], v);
+      if (lane < 8) s_dbw[tid >> 6][lane * 8 + e] = v;          // (round 5: per-wave rows instead of LDS atomics)
     }
     __syncthreads();
+    if (tid < 64) s_db[tid] = (s_dbw[0][tid] + s_dbw[1][tid]) + (s_dbw[2][tid] + s_dbw[3][tid]);
     if (tid < 64) {
-      if (p.dbias_ws && gridDim.x > DG_DBIAS_SLOTS) {
+      if (p.dbias_part) {
+        // one partial row per block in the caller's workspace, summed by dg_wgrad_reduce in a fixed order: bit-reproducible
+        p.dbias_part[(long)blockIdx.x * 64 + tid] = s_db[tid];
+      } else if (p.dbias_ws && gridDim.x > DG_DBIAS_SLOTS) {
         // 768 blocks adding one 256-byte row each into the SAME two lines retire one after the other (memory-side, ~10-20 ns
         // each: 16 us behind the Head backward-data).  Staged: block j adds into slot j % 32 of the caller's scratch (4 KB
         // apart, zero on entry), the last block to arrive at a slot (ticket behind the row, lane 0) folds it into dbias
@@ -1418,14 +1423,22 @@ int dg_conv_s2_mfma_supported(const ConvP* p) {
   return 1;
 }
 
+#ifndef S2_CAP
+#define S2_CAP 768
+#endif
+// grid of the thin matrix-core MODE_S2 kernel = the partial rows it writes to DgConv.dbias_part (DgConvPlan.dbias_rows)
+int dg_conv_s2_mfma_blocks(const ConvP* p) {
+  if (!dg_conv_s2_mfma_supported(p)) return 0;
+  const long ntiles = (long)p->B * p->Hc * (p->Wc / 32);
+  const long blocks = (ntiles + 3) / 4;
+  return (int)(blocks > S2_CAP ? S2_CAP : blocks);
+}
+
 int dg_conv_s2_mfma_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_s2_mfma_supported(p)) return DG_EUNSUPPORTED;
   const int tiles_x = p->Wc / 32;
   const long ntiles = (long)p->B * p->Hc * tiles_x;
   long blocks = (ntiles + 3) / 4;
-#ifndef S2_CAP
-#define S2_CAP 768
-#endif
   const long cap = S2_CAP;  // 3 blocks per CU.  Round 3 (164 VGPRs, 3 resident): 256 -> 50 us, 512 -> 34 us, 768 -> 31 us, 1024 -> 38 us
                          // for Down1 forward at batch 32; round 4 (116-120 VGPRs, 4 resident): 512 / 768 / 1024 -> 26.6 / 25.5 / 26.3 us
                          // (43.0 / 38.3 / 41.9 at batch 64) - the per-wave weight preload amortises over the tiles

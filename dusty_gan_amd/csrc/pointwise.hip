@@ -2,6 +2,10 @@
 // DiffAugment, NSGAN losses, fetch_reals and small reductions.  Images are fp32 [B,1,H,W]; feature maps are T.
 #include "common.h"
 
+// the registered accumulator arena of this device (dg_det_arena; common.h dg_acc_add): read by the kernels of this file that
+// sum across blocks into arena slots - per-sample image sums, logits, the augment adjoint's window sums
+__device__ DgDet g_det = {nullptr, nullptr, 0};
+
 // 16-byte loads / stores of feature-map elements as floats: V = 8 bf16 or 4 fp32 per access
 template <typename T> struct Vec16;
 template <> struct Vec16<bf16> {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
   }
   if (ssq) {
     const float sblk = dg_block_sum(ssacc, red);
-    if (threadIdx.x == 0) atomicAdd(&ssq[b], sblk);
+    if (threadIdx.x == 0) dg_acc_add(&ssq[b], sblk, gridDim.x, g_det);
   }
 }
 
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const T* __restrict__ d4
     }
   }
   const float s = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&y[b], s * scale + ((bias && blockIdx.x == 0) ? bias[0] : 0.f));
+  if (threadIdx.x == 0) dg_acc_add(&y[b], s * scale + ((bias && blockIdx.x == 0) ? bias[0] : 0.f), gridDim.x, g_det);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void final_fwd_scalar_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void final_fwd_scalar_kernel(const T* __restri
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     acc += (float)row[i] * wf[i];
   const float s = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&y[b], s * scale + ((bias && blockIdx.x == 0) ? bias[0] : 0.f));
+  if (threadIdx.x == 0) dg_acc_add(&y[b], s * scale + ((bias && blockIdx.x == 0) ? bias[0] : 0.f), gridDim.x, g_det);
 }
 
 // dd4[b][i] = up[b] * scale * wf[i] * lrelu'(d4[b][i]) * sqrt2 ; dbias4[i % C] += rowscale[b] * dd4[b][i]
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void head_post_fwd4_kernel(float* __restrict__
     acc += (dv[0] + dv[1]) + (dv[2] + dv[3]);
   }
   const float sblk = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&dsum[b], sblk);
+  if (threadIdx.x == 0) dg_acc_add(&dsum[b], sblk, (unsigned)(HW / chunk), g_det);
 }
 
 template <int arch>   // compile-time: the pixel function is then straight-line code and the unrolled trips batch their loads
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256) void head_post_fwd_kernel(float* __restrict__ 
     acc += dv;
   }
   const float sblk = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&dsum[b], sblk);
+  if (threadIdx.x == 0) dg_acc_add(&dsum[b], sblk, (unsigned)(HW / chunk), g_det);
 }
 
 // Backward of the above: ddepth [B,H,W] -> draw [B,1+k,H,W] planar (gradient w.r.t. the head conv outputs).
@@ -723,18 +727,35 @@ __global__ __launch_bounds__(256) void head_post_bwd4_kernel(const float* __rest
     const float s2 = arch >= 2 ? dg_block_sum(a2, red) : 0.f;
     if (threadIdx.x == 0) {
       if (bias_ws && gridDim.x > 1) {
-        float* w = bias_ws + (long)b * 1024;                // (4 KB apart: slots in one interleave unit serialise just the same)
-        atomicAdd(&w[0], s0);
-        if (arch >= 1) atomicAdd(&w[1], s1);
-        if (arch >= 2) atomicAdd(&w[2], s2);
+        // Round 5: the staged sums are 32.32 FIXED POINT (integer adds commute: the total no longer depends on the order in
+        // which blocks and samples arrive - common.h dg_acc_add has the argument).  Two levels, as before: the blocks of a
+        // sample add into that sample's slot; the last block of a sample (ticket) moves the slot's totals, still integers,
+        // into the launch's accumulators (upper half of slot 0) and takes a second ticket; the last SAMPLE converts and adds
+        // each head's total to dbias once.  Everything is left zero.
+        unsigned long long* w = (unsigned long long*)(bias_ws + (long)b * 1024);   // 4 KB apart
+        unsigned long long* gacc = (unsigned long long*)(bias_ws + 512);            // (slot 0, bytes 2048 ..)
+        const float sv[3] = {s0, s1, s2};
+        bool odd = false;
+#pragma unroll
+        for (int h = 0; h <= arch; ++h) {
+          if (!(fabsf(sv[h]) < 2147483000.f)) { atomicAdd(&dbias[h], sv[h]); odd = true; }
+          else atomicAdd(&w[h], (unsigned long long)__double2ll_rn((double)sv[h] * 4294967296.0));
+        }
+        (void)odd;
         // the adds above before the ticket: they are acknowledged from memory-side when vmcnt drains (a __threadfence()
         // here is buffer_wbl2 - a write-back of the megabytes of gradient this kernel has just stored, per block)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd((unsigned*)&w[3], 1u) == gridDim.x - 1) {
-          atomicAdd(&dbias[0], atomicExch(&w[0], 0.f));
-          if (arch >= 1) atomicAdd(&dbias[1], atomicExch(&w[1], 0.f));
-          if (arch >= 2) atomicAdd(&dbias[2], atomicExch(&w[2], 0.f));
+#pragma unroll
+          for (int h = 0; h <= arch; ++h) atomicAdd(&gacc[h], atomicExch(&w[h], 0ull));
           atomicExch((unsigned*)&w[3], 0u);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (atomicAdd((unsigned*)&gacc[3], 1u) == gridDim.y - 1) {
+#pragma unroll
+            for (int h = 0; h <= arch; ++h)
+              atomicAdd(&dbias[h], (float)((double)(long long)atomicExch(&gacc[h], 0ull) * (1.0 / 4294967296.0)));
+            atomicExch((unsigned*)&gacc[3], 0u);
+          }
         }
       } else {
         atomicAdd(&dbias[0], s0);
@@ -877,7 +898,7 @@ __global__ __launch_bounds__(256) void sample_sum_kernel(const float* __restrict
     }
   }
   const float s = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&out[b], s);
+  if (threadIdx.x == 0) dg_acc_add(&out[b], s, gridDim.x, g_det);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -1028,7 +1049,7 @@ __global__ __launch_bounds__(256) void diffaug_bwd_sum_kernel(AugP a, const floa
       if (!(xx >= c0 && xx < c1)) acc += row[xx];
   }
   const float s = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&gsum[b], s);
+  if (threadIdx.x == 0) dg_acc_add(&gsum[b], s, gridDim.x, g_det);
 }
 
 // Backward pass 2 (gather form of the scatter): gx[b,r,c] from gy.  One block per image row, as the forward kernel.
@@ -1295,7 +1316,7 @@ __global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode
                                                             float* __restrict__ dfinal_b, const T* __restrict__ d4,
                                                             const float* __restrict__ wf, float scale, long n, int C,
                                                             T* __restrict__ dd4, float* __restrict__ dbias,
-                                                            float* __restrict__ dwf) {
+                                                            float* __restrict__ dwf, float* __restrict__ dbias_part) {
   constexpr int V = Vec16<T>::V;
   __shared__ float part[4][64 * V];
   __shared__ float s_dy[256], s_u[256], s_r[256], red[17];
@@ -1344,7 +1365,12 @@ __global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * V; e += 256) {
       const long ie = (long)blockIdx.x * 64 * V + e;
-      if (ie < n) atomicAdd(&dbias[ie % C], part[0][e] + part[1][e] + part[2][e] + part[3][e]);
+      // dbias_part: one partial per element of the map (= per pixel and channel, summed over the samples in a fixed order);
+      // the caller sums the n / C pixel rows per channel with dg_wgrad_reduce - no atomics, bit-reproducible
+      if (ie < n) {
+        const float v = part[0][e] + part[1][e] + part[2][e] + part[3][e];
+        if (dbias_part) dbias_part[ie] = v; else atomicAdd(&dbias[ie % C], v);
+      }
     }
   }
   if (dwf) {
@@ -1405,7 +1431,7 @@ __global__ __launch_bounds__(256) void fetch_reals_kernel(const float* __restric
     acc += v;
   }
   const float sblk = dg_block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(&xsum[i0 / HW], sblk);
+  if (threadIdx.x == 0) dg_acc_add(&xsum[i0 / HW], sblk, (unsigned)(HW / chunk), g_det);
 }
 
 // y = a * x
@@ -1969,8 +1995,10 @@ int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, f
 // the caller then issues the separate calls.
 int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_real, const float* y_fake, int B, float w_gan,
                      int r1, float* dy, float* up, float* rs, float* acc, float* dfinal_b, const void* d4, int dtype,
-                     const float* wf, float scale, long n, int C, void* dd4, float* dbias, float* dwf, void* s_) {
+                     const float* wf, float scale, long n, int C, void* dd4, float* dbias, float* dwf, float* dbias_part,
+                     void* s_) {
   if (!y_fake || !dy || !acc || !d4 || !wf || !dd4 || B <= 0 || n <= 0) return DG_EINVAL;
+  if (dbias_part && (!dbias || n % C != 0)) return DG_EINVAL;
   if (!mode_g && !y_real) return DG_EINVAL;
   GanForm fm;
   const int rc = gan_form(metric, mode_g ? 1 : 0, mode_g ? 1.f : smoothing, &fm);
@@ -1986,10 +2014,10 @@ int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_rea
   hipStream_t s = (hipStream_t)s_;
   if (dtype == DG_BF16)
     final_gan_bwd_kernel<bf16><<<grid, 256, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
-                                                    (const bf16*)d4, wf, scale, n, C, (bf16*)dd4, dbias, dwf);
+                                                    (const bf16*)d4, wf, scale, n, C, (bf16*)dd4, dbias, dwf, dbias_part);
   else
     final_gan_bwd_kernel<float><<<grid, 256, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
-                                                     (const float*)d4, wf, scale, n, C, (float*)dd4, dbias, dwf);
+                                                     (const float*)d4, wf, scale, n, C, (float*)dd4, dbias, dwf, dbias_part);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -2024,3 +2052,13 @@ int dg_mean_acc(const float* x, int n, float* acc, void* s_) {
 }
 
 }  // extern "C"
+
+
+// ---- deterministic sums: the accumulator arena and its shadow (common.h dg_acc_add) ----------------------------------------
+extern "C" int dg_det_arena(float* arena, long n, void* shadow) {
+  if ((arena == nullptr) != (shadow == nullptr) || n < 0) return DG_EINVAL;
+  if (shadow && ((size_t)shadow & 15) != 0) return DG_EINVAL;
+  const DgDet d{arena, (unsigned long long*)shadow, arena ? n : 0};
+  HIP_CHECK_RET(hipMemcpyToSymbol(HIP_SYMBOL(g_det), &d, sizeof(d), 0, hipMemcpyHostToDevice));
+  return DG_OK;
+}

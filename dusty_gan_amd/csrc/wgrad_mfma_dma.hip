@@ -361,15 +361,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(GroupP g) {
 // the launch geometry of one layer: K split, tap pairs or single taps (pairs: 0 = by the K range per workgroup, 1 = always,
 // 2 = never; ws: partial tiles go to a workspace)
 struct DmaGeo { int tiles_m, tiles_n; long split; bool use_pairs; };
+// target: workgroups the launch should have (512 = two per CU for a launch of its own; a layer inside a group launch gets its
+// share of the group's workgroups: fewer, longer K ranges and proportionally fewer partial tiles)
 template <int BM, int BN>
-DmaGeo dma_geo(const WgradP* p, int accumulate, int pairs, bool ws) {
+DmaGeo dma_geo(const WgradP* p, int accumulate, int pairs, bool ws, long target = 512) {
   const int tiles_m = p->Ci / BM, tiles_n = p->Co / BN;
   const long units = (long)p->B * p->Hc;
   const bool can_split = accumulate || ws;
   auto split_for = [&](long tiles) {
     long split = 1;
     if (can_split) {
-      split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
+      split = (target + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
       if (split > units) split = units;
       if (split < 1) split = 1;
     }
@@ -502,19 +504,39 @@ int dg_wgrad_mfma_dma_launch(const WgradP* p, int accumulate, int pairs, hipStre
   return launch_dma<1, 64, 64>(p, accumulate, pairs, stream, plan);
 }
 
-// up to GROUP_MAX layers as one launch (see wgrad_group_kernel); every item must take the LDS-DMA kernel and bring its
-// workspace (DgWgrad.ws sized by dg_wgrad_plan: the geometry here is the same function's)
-int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, hipStream_t stream) {
+// up to GROUP_MAX layers as one launch (see wgrad_group_kernel); every item must take the LDS-DMA kernel.  rounds > 0: the
+// group as a whole aims at rounds * 512 workgroups, shared among the items by their FLOPs (each item's K split shrinks
+// accordingly: fewer partial tiles to store and to reduce); rounds <= 0: every item keeps the geometry of a launch of its own.
+// plans != NULL: fill them (splits, ws_floats, tap_pairs) and launch nothing; else every item brings its workspace
+// (DgWgrad.ws sized by the same call with plans).
+int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, int rounds, hipStream_t stream, DgWgradPlan* plans) {
   if (n < 1 || n > GROUP_MAX) return DG_EINVAL;
   GroupP g{};
   int blocks = 0;
+  double fl[GROUP_MAX], fsum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    fl[i] = (double)items[i].B * items[i].Hc * items[i].Wc * items[i].Ci * items[i].Co;
+    fsum += fl[i];
+  }
   for (int i = 0; i < n; ++i) {
     const WgradP* p = &items[i];
-    if (!dg_wgrad_mfma_dma_supported(p) || !p->ws) return DG_EUNSUPPORTED;
-    if (p->g_mod < 0 || ((size_t)p->ws & 15) != 0) return DG_EINVAL;
+    if (!dg_wgrad_mfma_dma_supported(p) || (!plans && !p->ws)) return DG_EUNSUPPORTED;
+    if (p->g_mod < 0 || (!plans && ((size_t)p->ws & 15) != 0)) return DG_EINVAL;
+    long target = 512;
+    if (rounds > 0) {
+      target = (long)(rounds * 512.0 * fl[i] / fsum + 0.5);
+      if (target < 64) target = 64;
+    }
     const int bm = p->Ci % 128 == 0 ? 128 : 64, bn = p->Co % 128 == 0 ? 128 : 64;
-    const DmaGeo ge = bm == 128 ? (bn == 128 ? dma_geo<128, 128>(p, 1, pairs, true) : dma_geo<128, 64>(p, 1, pairs, true))
-                                : (bn == 128 ? dma_geo<64, 128>(p, 1, pairs, true) : dma_geo<64, 64>(p, 1, pairs, true));
+    const DmaGeo ge = bm == 128 ? (bn == 128 ? dma_geo<128, 128>(p, 1, pairs, true, target) : dma_geo<128, 64>(p, 1, pairs, true, target))
+                                : (bn == 128 ? dma_geo<64, 128>(p, 1, pairs, true, target) : dma_geo<64, 64>(p, 1, pairs, true, target));
+    if (plans) {
+      plans[i].variant = 5;
+      plans[i].splits = (int)ge.split;
+      plans[i].ws_floats = ge.split * 16L * p->Ci * p->Co;
+      plans[i].tap_pairs = ge.use_pairs ? 1 : 0;
+      continue;
+    }
     GroupItem& it = g.it[i];
     it.p = *p;
     it.tiles_n = ge.tiles_n;
@@ -524,6 +546,7 @@ int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, hipStr
     it.accumulate = 1;
     blocks += (it.gx * it.gy * it.gz + 7) / 8 * 8;
   }
+  if (plans) return DG_OK;
   g.n = n;
   wgrad_group_kernel<<<(unsigned)blocks, 256, 0, stream>>>(g);
   HIP_CHECK_RET(hipGetLastError());

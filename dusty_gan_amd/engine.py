@@ -409,6 +409,14 @@ class MaskBits:
         return L.ptr(bits) + off // 8
 
 
+# Bit-reproducible gradients (round 5; DUSTY_GAN_DETERMINISTIC=0 restores the float atomics): bias-gradient sums leave the
+# matrix-core conv kernels and the fused final-conv backward as per-workgroup partial ROWS in the split-K workspace and are
+# summed by the reduce launch that already runs (fixed order), and the cross-block sums into the step's accumulator arena are
+# fixed-point integer adds (_lib.AccArena registers the arena's shadow: dg_det_arena).  Covers the kernels of the bf16 timed
+# path; the direct / VALU fall-back kernels of tiny or odd shapes keep their float atomics.
+DETERMINISTIC = os.environ.get("DUSTY_GAN_DETERMINISTIC", "1") != "0"
+
+
 class _WgradGroup:
     def __init__(self, ops):
         self.ops = ops
@@ -439,6 +447,8 @@ class _WgradGroup:
 class Ops:
     """Thin typed wrappers over the C ABI (struct filling); all launches go to torch's current stream."""
     group_enabled = os.environ.get("DUSTY_GAN_WGRAD_GROUP", "1") != "0"
+    # workgroups a group launch aims at, in residency rounds of 512 (0: every layer keeps the 512 of a launch of its own)
+    group_rounds = int(os.environ.get("DUSTY_GAN_WGRAD_ROUNDS", "0"))
     default_wg_cap = 0  # parity tests lower it so that small problems walk several tiles per persistent workgroup
     _dbias_ws = {}      # device -> DgConv.dbias_ws scratch (launches of one stream share it: each leaves it zero)
 
@@ -463,7 +473,9 @@ class Ops:
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
-             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None, up_frag=None):
+             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None, up_frag=None, defer_db=False):
+        """defer_db: the bias-gradient rows of a deterministic launch (DETERMINISTIC, kernels with DgConvPlan.dbias_rows) wait in
+        WGRAD_WS for the caller's flush like a deferred weight gradient's partials; otherwise they are summed at once."""
         p = L.DgConv()
         p.mode, p.adj, p.ring = mode, adj, int(ring)
         p.B, p.Hc, p.Wc, p.K, p.N = B, Hc, Wc, K, N
@@ -496,6 +508,14 @@ class Ops:
             if ws is None:
                 ws = Ops._dbias_ws[str(x.device)] = torch.zeros(L.DBIAS_WS_FLOATS, dtype=torch.float32, device=x.device)
             p.dbias_ws = L.ptr(ws)
+        db_rows = 0
+        if dbias is not None and DETERMINISTIC:
+            pl = L.DgConvPlan()
+            L.check(self.lib.dg_conv_plan(C.byref(p), self._f, self.wg_cap, C.byref(pl)), "dg_conv_plan")
+            if pl.dbias_rows > 0:
+                part = WGRAD_WS.take(pl.dbias_rows * N, x.device)
+                if part is not None:
+                    db_rows, p.dbias_part = pl.dbias_rows, part
         if TRACE is not None:
             pl = L.DgConvPlan()
             L.check(self.lib.dg_conv_plan(C.byref(p), self._f, self.wg_cap, C.byref(pl)), "dg_conv_plan")
@@ -504,6 +524,7 @@ class Ops:
                           (1 if p.mask_out else 0) | (pl.mask_bits & 2 if p.mask_in else 0)))
         if PROFILE is None:
             L.check(self.lib.dg_conv_ex(C.byref(p), self._f, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
+            self._db_rows_done(p, db_rows, dbias, N, defer_db)
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
@@ -516,10 +537,18 @@ class Ops:
         flops, nbytes = conv_algorithmic(mode, B, Hc, Wc, K, N, ies, oes, wes, epi == L.EPI_MASK, mb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(self.lib.dg_conv(C.byref(p), self._f, L.stream_ptr()), "dg_conv")
+        L.check(self.lib.dg_conv_ex(C.byref(p), self._f, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
         e1.record()
         PROFILE.append(({2: "conv_mfma_kernel", 3: "conv_thin_kernel"}.get(choice, "conv_direct_kernel"), flops, nbytes, e0, e1,
                         f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
+        self._db_rows_done(p, db_rows, dbias, N, defer_db)
+
+    def _db_rows_done(self, p, rows, dbias, N, defer_db):
+        """the launch left `rows` partial bias-gradient rows in the workspace: queue their sum onto dbias"""
+        if rows:
+            WGRAD_WS.add(p.dbias_part, dbias, N, rows, 1)
+            if not defer_db:
+                WGRAD_WS.flush()
 
     def wgrad_plan(self, p, accumulate=1):
         pl = L.DgWgradPlan()
@@ -534,16 +563,14 @@ class Ops:
         p = self._wgrad_params(wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale, a_dt,
                                g_dt, a_off, g_off, g_mod)
         pl = self.wgrad_plan(p, accumulate) if self.use_ws else None
+        if (self._group is not None and defer and pl is not None and pl.ws_floats > 0 and pl.variant == 5
+                and len(self._group) < self.GROUP_MAX and pl.ws_floats <= WgradWorkspace.FLOATS):
+            # inside `with ops.grouped():` - the launch joins the group's ONE launch (dg_wgrad_group) at the end of the block:
+            # its geometry (K split, workspace) is decided there, for the group as a whole
+            self._group.append((p, (wmode, B, Hc, Wc, Ci, Co), (a, g, rowscale), dw_ptr, int(accumulate)))
+            return
         if pl is not None and pl.ws_floats > 0:
             p.ws = WGRAD_WS.take(pl.ws_floats, a.device)
-        if self._group is not None and defer and p.ws and pl.variant == 5 and len(self._group) < self.GROUP_MAX:
-            # inside `with ops.grouped():` - the launch joins the group's ONE launch (dg_wgrad_group) at the end of the block;
-            # its partials wait in the workspace like any deferred launch's
-            if TRACE is not None:
-                TRACE.append(("wgrad", 5, f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}", pl.splits, pl.tap_pairs, True, g_mod))
-            self._group.append((p, (wmode, B, Hc, Wc, Ci, Co), (a, g, rowscale)))   # (the tensors: kept alive until the launch)
-            WGRAD_WS.add(p.ws, dw_ptr, 16 * Ci * Co, pl.splits, int(accumulate))
-            return
         if TRACE is not None:
             TRACE.append(("wgrad", self.lib.dg_wgrad_kernel_variant(C.byref(p), self._f),
                           f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}", 0 if pl is None else pl.splits,
@@ -576,37 +603,85 @@ class Ops:
         return _WgradGroup(self)
 
     def _launch_group(self, items):
+        """issue the queued launches of a `grouped()` block: ONE dg_wgrad_group launch when there are several (geometry from
+        dg_wgrad_group_plan - with Ops.group_rounds > 0 every layer gets its FLOP share of rounds x 512 workgroups instead of
+        512 of its own: fewer partial tiles), single launches otherwise.  The workspace of the whole group is taken in ONE
+        piece, so a reduce that the allocation triggers only ever sums partials of launches already issued."""
         if not items:
             return
-        if len(items) == 1 or not Ops.group_enabled:
-            for p, (wmode, B, Hc, Wc, Ci, Co), _ in items:
-                if PROFILE is None:
-                    L.check(self.lib.dg_wgrad(C.byref(p), 1, self._f, L.stream_ptr()), "dg_wgrad")
-                    continue
-                f, b = wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4, 2 if p.g_dtype == L.DG_BF16 else 4)
+        if len(items) > 1:
+            # a group whose partial tiles do not fit the workspace cap together goes out in pieces that do (each piece takes
+            # its workspace in one allocation, which may reduce the pieces before it early: they have been issued by then)
+            need = []
+            for it in items:
+                pl = self.wgrad_plan(it[0], 1)
+                need.append((pl.ws_floats + 63) // 64 * 64)
+            if sum(need) > WgradWorkspace.FLOATS:
+                piece, tot = [], 0
+                for it, nf in zip(items, need):
+                    if piece and tot + nf > WgradWorkspace.FLOATS:
+                        self._launch_group(piece)
+                        piece, tot = [], 0
+                    piece.append(it)
+                    tot += nf
+                if len(piece) < len(items):
+                    self._launch_group(piece)
+                    return
+        n = len(items)
+        arr = (L.DgWgrad * n)()
+        for i, it in enumerate(items):
+            C.memmove(C.byref(arr, i * C.sizeof(L.DgWgrad)), C.byref(it[0]), C.sizeof(L.DgWgrad))
+        plans = (L.DgWgradPlan * n)()
+        grouped = n > 1 and Ops.group_enabled
+        if grouped:
+            L.check(self.lib.dg_wgrad_group_plan(arr, n, self._f, Ops.group_rounds, plans), "dg_wgrad_group_plan")
+        else:
+            for i in range(n):
+                L.check(self.lib.dg_wgrad_plan(C.byref(arr[i]), 1, self._f, C.byref(plans[i])), "dg_wgrad_plan")
+        sizes = [(plans[i].ws_floats + 63) // 64 * 64 for i in range(n)]
+        base = WGRAD_WS.take(sum(sizes), items[0][2][0].device)
+        if base is None:     # (larger than the workspace cap: atomics onto dW, one launch each)
+            for it in items:
+                L.check(self.lib.dg_wgrad(C.byref(it[0]), it[4], self._f, L.stream_ptr()), "dg_wgrad")
+            return
+        off = 0
+        for i in range(n):
+            arr[i].ws = base + 4 * off
+            off += sizes[i]
+        descs = [f"wmode{d[0]} B{d[1]} {d[2]}x{d[3]} Ci{d[4]} Co{d[5]}" for _, d, _, _, _ in items]
+        if TRACE is not None:
+            for i, it in enumerate(items):
+                TRACE.append(("wgrad", 5, descs[i], plans[i].splits, plans[i].tap_pairs, True, it[0].g_mod))
+            if grouped:
+                TRACE.append(("wgrad_group", n, descs))
+
+        def algo(i):
+            p, (wmode, B, Hc, Wc, Ci, Co) = items[i][0], items[i][1]
+            return wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4, 2 if p.g_dtype == L.DG_BF16 else 4)
+        if grouped:
+            if PROFILE is None:
+                L.check(self.lib.dg_wgrad_group(arr, n, self._f, Ops.group_rounds, L.stream_ptr()), "dg_wgrad_group")
+            else:
+                fb = [algo(i) for i in range(n)]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                L.check(self.lib.dg_wgrad(C.byref(p), 1, self._f, L.stream_ptr()), "dg_wgrad")
+                L.check(self.lib.dg_wgrad_group(arr, n, self._f, Ops.group_rounds, L.stream_ptr()), "dg_wgrad_group")
                 e1.record()
-                PROFILE.append(("wgrad_mfma_kernel", f, b, e0, e1, f"wmode{wmode} B{B} {Hc}x{Wc} Ci{Ci} Co{Co}"))
-            return
-        arr = (L.DgWgrad * len(items))()
-        for i, (p, _, _) in enumerate(items):
-            C.memmove(C.byref(arr, i * C.sizeof(L.DgWgrad)), C.byref(p), C.sizeof(L.DgWgrad))
-        if TRACE is not None:
-            TRACE.append(("wgrad_group", len(items), [f"wmode{d[0]} B{d[1]} {d[2]}x{d[3]} Ci{d[4]} Co{d[5]}" for _, d, _ in items]))
-        if PROFILE is None:
-            L.check(self.lib.dg_wgrad_group(arr, len(items), self._f, L.stream_ptr()), "dg_wgrad_group")
-            return
-        flops = nbytes = 0.0
-        for p, (wmode, B, Hc, Wc, Ci, Co), _ in items:
-            f, b = wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, 2 if p.a_dtype == L.DG_BF16 else 4, 2 if p.g_dtype == L.DG_BF16 else 4)
-            flops, nbytes = flops + f, nbytes + b
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        L.check(self.lib.dg_wgrad_group(arr, len(items), self._f, L.stream_ptr()), "dg_wgrad_group")
-        e1.record()
-        PROFILE.append(("wgrad_mfma_kernel", flops, nbytes, e0, e1, f"group of {len(items)} layers"))
+                PROFILE.append(("wgrad_mfma_kernel", sum(f for f, _ in fb), sum(b for _, b in fb), e0, e1, f"group of {n} layers"))
+        else:
+            for i in range(n):
+                if PROFILE is None:
+                    L.check(self.lib.dg_wgrad(C.byref(arr[i]), 1, self._f, L.stream_ptr()), "dg_wgrad")
+                    continue
+                f, b = algo(i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.check(self.lib.dg_wgrad(C.byref(arr[i]), 1, self._f, L.stream_ptr()), "dg_wgrad")
+                e1.record()
+                PROFILE.append(("wgrad_mfma_kernel", f, b, e0, e1, descs[i]))
+        for i, it in enumerate(items):
+            (wmode, B, Hc, Wc, Ci, Co) = it[1]
+            WGRAD_WS.add(arr[i].ws, it[3], 16 * Ci * Co, plans[i].splits, it[4])
 
     def wgrad_takes_map(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr):
         """whether the kernel that would run this launch has the g-sample index map (DgWgrad.g_mod): the LDS-DMA kernel
@@ -789,7 +864,7 @@ class GEngine:
             hc, wc = self.grid[3]
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], hsrc, hstr, self.dp[3],
                    (hc * wc * chs[3], chs[3], 1), st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3],
-                   dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], **hkw_c)
+                   dbias=st.fptr("up3_b", st.grad), bias_mod=chs[3], defer_db=True, **hkw_c)
 
         def up_wgrad(i):
             hc, wc = self.grid[i - 1]
@@ -803,7 +878,7 @@ class GEngine:
             prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, self.dp[i], (4 * hc * wc * co, co, 1), self.dp[i - 1],
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), 1.0 / math.sqrt(co * 16), L.EPI_MASK, aux=self.a[i - 1],
-                   dbias=st.fptr(prev_b, st.grad), bias_mod=ci)
+                   dbias=st.fptr(prev_b, st.grad), bias_mod=ci, defer_db=True)
 
         # The weight gradients of Up1-3 only read finished buffers (a[i-1], dp[i]: nothing below overwrites them), so they are
         # collected while the backward-data chain is issued and leave as ONE launch behind it (dg_wgrad_group, round 5: the ring
@@ -874,7 +949,7 @@ class GEngine:
         kw = {} if gdt is None else {"in_dt": gdt}
         o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, c.nheads, chs[3], gsrc, gstr, dp[3], (hc * wc * chs[3], chs[3], 1),
                st.sptr("head_w"), 1.0, L.EPI_MASK, aux=self.a[3], dbias=st.fptr("up3_b", g) if full else None,
-               bias_mod=chs[3], **kw)
+               bias_mod=chs[3], defer_db=True, **kw)
         for i in (3, 2, 1):
             hc, wc = self.grid[i - 1]
             ci, co = chs[i - 1], chs[i]
@@ -886,7 +961,7 @@ class GEngine:
             prev_b = f"up{i - 1}_b" if i > 1 else "proj_b"
             o.conv(L.MODE_S2, 1, c.ring, B, hc, wc, co, ci, dp[i], (4 * hc * wc * co, co, 1), dp[i - 1],
                    (hc * wc * ci, ci, 1), st.sptr(f"up{i}_w"), s, L.EPI_MASK, aux=self.a[i - 1],
-                   dbias=st.fptr(prev_b, g) if full else None, bias_mod=ci)
+                   dbias=st.fptr(prev_b, g) if full else None, bias_mod=ci, defer_db=True)
         if full and second_of:
             self.proj_wgrad(st, dp[0], self.zT, B, True)        # z (x) tangent chain
             self.proj_wgrad(st, chain[2][0], self.vT, B, True)  # v (x) first-order chain
@@ -1068,7 +1143,7 @@ class DEngine:
                aux=None if first else self.h[i - 1],
                dbias=(st.fptr(f"d{i - 1}_b", st.grad) if (want_dbias and not first) else None), bias_mod=ci,
                rowscale=rowscale, x_off=slot * self.per[i], out_off=slot * self.per[i - 1],
-               aux_off=slot * self.per[i - 1], up_frag=frag)
+               aux_off=slot * self.per[i - 1], up_frag=frag, defer_db=True)
 
     def backward_data(self, st, slot, n, up, rowscale, want_dbias, skip_final=False):
         """Backward-data chain over batch slots [slot, slot+n): e4 = up*s_f*wf*mask4, then e3, e2, e1 (each the
@@ -1096,16 +1171,22 @@ class DEngine:
             return False
         o, lib = self.ops, L.lib()
         nf = self.per[4]
+        C4 = self.chs[4]
+        # Down4's bias gradient: one partial per element of the final map in the split-K workspace, summed per channel by the
+        # reduce launch that runs anyway (DETERMINISTIC) - instead of 131 072 float atomics onto 512 addresses
+        part = WGRAD_WS.take(nf, self.h[4].device) if (want_dbias and DETERMINISTIC and nf % C4 == 0 and C4 % 4 == 0) else None
         rc = lib.dg_final_gan_bwd(metric, int(mode_g), float(smoothing), y_real, y_fake, B, w_gan, int(r1), L.ptr(dy),
                                   L.ptr(up), L.ptr(rs), acc_ptr,
                                   st.fptr("final_b", st.grad) if not mode_g else None,
                                   L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), 1.0 / math.sqrt(nf), nf,
-                                  self.chs[4], L.ptr(self.e[4]) + o.es * slot * nf,
+                                  C4, L.ptr(self.e[4]) + o.es * slot * nf,
                                   st.fptr("d4_b", st.grad) if want_dbias else None,
-                                  st.fptr("final_w", st.grad) if want_wgrad else None, L.stream_ptr())
+                                  st.fptr("final_w", st.grad) if want_wgrad else None, part, L.stream_ptr())
         if rc == L.DG_EUNSUPPORTED:
-            return False
+            return False   # (nothing was launched; the bump allocation is simply re-used by the next take after the flush)
         L.check(rc, "dg_final_gan_bwd")
+        if part is not None:
+            WGRAD_WS.add(part, st.fptr("d4_b", st.grad), C4, nf // C4, 1)
         return True
 
     def r1_fused_ok(self):

@@ -70,6 +70,12 @@ typedef struct DgConv {
    * pre-activation; the backward / R1 tangent passes only ever need that sign).  Bit e of a mask buffer belongs to the
    * element at offset e of the tensor it describes (bit e % 8 of byte e / 8): the mask of `out` is indexed like `out`, the
    * mask of `aux` like `aux`.  Needs out_sn == 1 and N, out_sp, out_sb multiples of 8 (16 for the matrix-core kernels). */
+  float* dbias_part;         /* optional, with dbias (round 5, bit-reproducible bias gradients): kernels that take it
+                              * (DgConvPlan.dbias_rows > 0: the ping-pong conv, the thin matrix-core MODE_S2 kernel) store ONE
+                              * partial row of N floats per workgroup at dbias_part + row * N - summed inside the workgroup in a
+                              * fixed order - and add nothing to dbias; the caller sums the rows with
+                              * dg_wgrad_reduce(ws = dbias_part, dw = dbias, numel = N, splits = dbias_rows).  Kernels that do
+                              * not take it ignore it and add onto dbias with atomics as before. */
   void* mask_out;            /* optional, DG_EPI_LRELU: also store bit = (out element > 0) for every element written.  The
                               * ping-pong conv and the thin matrix-core MODE_S2 kernel write it from their epilogues, behind any
                               * other kernel the library adds one packing launch: the bits are there when dg_conv returns OK */
@@ -140,6 +146,7 @@ typedef struct DgConvPlan {
   int tiles_per_wg;  /* most tiles any workgroup walks */
   int thin_mfma;     /* family 3: 1 = thin_s2_mfma, 2 = thin_up_mfma (matrix cores), 0 = the VALU kernels */
   int mask_bits;     /* 1: the kernel writes DgConv.mask_out itself (else a packing launch follows it), 2: it reads mask_in */
+  int dbias_rows;    /* > 0: the kernel takes DgConv.dbias_part and writes this many partial rows of N floats; 0: it does not */
 } DgConvPlan;
 int dg_conv_ex(const DgConv* p, int force, int wg_cap, void* stream);
 int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan);
@@ -161,11 +168,15 @@ typedef struct DgWgradPlan {
 int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan);
 /* Up to 4 weight-gradient GEMMs as ONE launch (the layers of one network: independent of each other, all reading finished
  * activations and gradient chains - loss.backward() at trainers/dcgan_amp.py:235,309 produces them in one sweep too): every
- * item must run on the MFMA LDS-DMA kernel (dg_wgrad_plan: variant 5) and bring its split-K workspace (`ws`, ws_floats of its
- * plan under the same `force`); the partial tiles, the splits and the dg_wgrad_reduce that follows are exactly those of n
- * single dg_wgrad calls.  One grid instead of n residency rounds: the ring fill and the partial-tile stores of one layer's
- * workgroups run under the matrix work of its neighbours'.  DG_EUNSUPPORTED (nothing launched) if an item does not qualify. */
-int dg_wgrad_group(const DgWgrad* items, int n, int force, void* stream);
+ * item must run on the MFMA LDS-DMA kernel (dg_wgrad_plan: variant 5) and bring its split-K workspace `ws`, sized by
+ * dg_wgrad_group_plan for the same (items, force, rounds).  One grid instead of n residency rounds: the ring fill and the
+ * partial-tile stores of one layer's workgroups run under the matrix work of its neighbours'.  rounds > 0: the group as a
+ * whole aims at rounds x 512 workgroups, shared among the items by their FLOPs - fewer, longer K ranges per item than a launch
+ * of its own would use and proportionally fewer partial tiles; rounds <= 0: every item keeps the geometry (splits, ws_floats)
+ * of its own dg_wgrad_plan.  The caller sums the partials with dg_wgrad_reduce as for single launches.  DG_EUNSUPPORTED
+ * (nothing launched) if an item does not qualify. */
+int dg_wgrad_group(const DgWgrad* items, int n, int force, int rounds, void* stream);
+int dg_wgrad_group_plan(const DgWgrad* items, int n, int force, int rounds, DgWgradPlan* plans);
 /* dw[i] (+)= sum_s ws[s * numel + i] for up to 8 layers in one launch (fixed summation order: deterministic gradients) */
 typedef struct DgWgradReduce {
   const float* ws;
@@ -305,11 +316,22 @@ int dg_gan_g_step(int metric, const float* y_real, const float* y_fake, int B, f
  * the 2B (B) samples with those vectors, and - when dwf is given - the final conv's weight gradient
  * dwf[i] += scale * sum_b dy[b] d4[b][i] (dg_batch_wsum) from the same read of d4: `loss.backward()`'s first links,
  * trainers/dcgan_amp.py:203-235 and :259-309.  DG_EUNSUPPORTED (nothing launched) when the vector forms do not apply or
- * more than 256 samples are in the pass. */
+ * more than 256 samples are in the pass.  dbias_part (optional, n floats, with dbias): instead of atomics onto dbias the launch
+ * stores one partial per element of the map (summed over the samples in a fixed order) and the caller sums the n / C rows
+ * per channel: dg_wgrad_reduce(ws = dbias_part, dw = dbias, numel = C, splits = n / C) - bit-reproducible bias gradients. */
 int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_real, const float* y_fake, int B, float w_gan,
                      int r1, float* dy, float* up, float* rs, float* acc, float* dfinal_b, const void* d4, int dtype,
-                     const float* wf, float scale, long n, int C, void* dd4, float* dbias, float* dwf, void* stream);
+                     const float* wf, float scale, long n, int C, void* dd4, float* dbias, float* dwf, float* dbias_part,
+                     void* stream);
 int dg_mean_acc(const float* x, int n, float* acc, void* stream);
+/* Bit-reproducible cross-block sums (round 5).  Registers, for the current device, the arena of small fp32 accumulators the
+ * step zero-fills once (per-sample image sums, logits, the augment adjoint's window sums: dg_*_acc / dg_*_sum entry points
+ * accumulate into slices of it) together with a shadow of 16 bytes per arena float, zero at rest: kernels whose blocks add
+ * partial sums into an arena slot then add them as 32.32 fixed point to the slot's shadow word (integer addition commutes)
+ * and the last block to arrive converts the total - instead of float atomics, whose result depends on the arrival order.
+ * arena = shadow = NULL unregisters (float atomics again).  Nothing in the reference to replace: torch's reductions are
+ * deterministic on the CPU and the reference never asks for determinism on the GPU. */
+int dg_det_arena(float* arena, long n, void* shadow);
 
 /* ---- path-length regularisation  trainers/dcgan_amp.py:268-306 (the parts that are not convolutions) ------------
  * The penalty needs d/dtheta of |d(sum x y)/dz|: a forward-over-reverse pass built from dg_conv / dg_wgrad (the

@@ -243,9 +243,13 @@ def test_forced_segments_single_process_match_one_graph(monkeypatch):
     a, sa, na = run(True)
     b, sb, nb = run(False)
     assert na >= 4 and nb == 1
+    from dusty_gan_amd import engine as E
     for net in ("G", "D", "G_ema"):
         fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
-        assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb))
+        if E.DETERMINISTIC:   # round 5: the multi-rank schedule issues the same sums in the same order - equal to the bit
+            assert torch.equal(fa, fb), (net, rel_l2(fa, fb))
+        else:
+            assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb))
     for x, y in zip(sa, sb):
         for k in x:
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
@@ -293,7 +297,10 @@ def test_aborted_capture_leaves_no_pending_partials(monkeypatch):
     for net in ("G", "D", "G_ema"):
         fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
         assert torch.isfinite(fa).all()
-        assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb), seen)
+        if E.DETERMINISTIC:
+            assert torch.equal(fa, fb), (net, rel_l2(fa, fb), seen)
+        else:
+            assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb), seen)
     for x, y in zip(sa, sb):
         for k in x:
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
@@ -380,7 +387,11 @@ def test_single_rank_rccl_runs_the_multi_rank_schedule(monkeypatch, in_graph):
             assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
     for net, key in (("G", "G"), ("D", "D"), ("G_ema", "E")):
         fb = getattr(b, net).store.flat.cpu()
-        assert rel_l2(a[key], fb) < 2e-3, (net, rel_l2(a[key], fb))
+        from dusty_gan_amd import engine as E
+        if E.DETERMINISTIC:   # (measured round 5: bit-identical in both forms)
+            assert torch.equal(a[key], fb), (net, rel_l2(a[key], fb))
+        else:
+            assert rel_l2(a[key], fb) < 2e-3, (net, rel_l2(a[key], fb))
 
 
 def fused_worker(rank, world, init_file, out_dir, fuse, pl=0.0):

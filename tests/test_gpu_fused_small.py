@@ -458,22 +458,41 @@ def test_final_gan_bwd_equals_the_separate_launches(L, dtype, metric, mode_g, r1
                                  b["up"].data_ptr() if r1 else None, b["rs"].data_ptr() if r1 else None, b["acc"].data_ptr(),
                                  None if mode_g else b["fb"].data_ptr(), d4.data_ptr(), dt, wf.data_ptr(), scale, n, C,
                                  b["dd4"].data_ptr(), None if mode_g else b["db"].data_ptr(),
-                                 None if mode_g else b["dwf"].data_ptr(), None))
+                                 None if mode_g else b["dwf"].data_ptr(), None, None))
     torch.cuda.synchronize()
     for k in ("dy", "up", "rs", "acc", "fb", "dd4", "dwf"):
         assert torch.equal(a[k], b[k]), k
     assert float(a["dd4"].float().abs().mean()) > 0 and (mode_g or float(a["dwf"].abs().mean()) > 0)
     assert rel_l2(b["db"].cpu(), a["db"].cpu()) < 1e-5 or mode_g
+    if not mode_g:
+        # round 5, dbias_part: one partial per element of the map instead of atomics onto dbias, summed per channel by
+        # dg_wgrad_reduce - the same bias gradient, and two launches of it agree bit for bit
+        res = []
+        for _ in range(2):
+            c = bufs()
+            part = torch.full((n,), float("nan"), device=DEV)
+            L.check(lib.dg_final_gan_bwd(metric, mode_g, smoothing, y_real, y_fake, B, w_gan, r1, c["dy"].data_ptr(),
+                                         c["up"].data_ptr() if r1 else None, c["rs"].data_ptr() if r1 else None,
+                                         c["acc"].data_ptr(), c["fb"].data_ptr(), d4.data_ptr(), dt, wf.data_ptr(), scale, n, C,
+                                         c["dd4"].data_ptr(), c["db"].data_ptr(), c["dwf"].data_ptr(), part.data_ptr(), None))
+            item = (L.DgWgradReduce * 1)()
+            item[0].ws, item[0].dw, item[0].numel, item[0].splits, item[0].accumulate = part.data_ptr(), c["db"].data_ptr(), C, n // C, 1
+            L.check(lib.dg_wgrad_reduce(item, 1, None))
+            torch.cuda.synchronize()
+            assert torch.equal(c["dd4"], b["dd4"]) and torch.equal(c["dwf"], b["dwf"])
+            res.append(c["db"].clone())
+        assert rel_l2(res[0].cpu(), a["db"].cpu()) < 1e-5
+        assert torch.equal(res[0], res[1])
     # shapes the kernel refuses: nothing launched
     big = 200
     yb = torch.randn(2 * big, device=DEV)
     rc = lib.dg_final_gan_bwd(0, 0, 1.0, yb.data_ptr(), yb.data_ptr() + 4 * big, big, 1.0, 0, b["dy"].data_ptr(), None, None,
                               b["acc"].data_ptr(), None, d4.data_ptr(), dt, wf.data_ptr(), scale, n, C, b["dd4"].data_ptr(),
-                              None, None, None)
+                              None, None, None, None)
     assert rc == L.DG_EUNSUPPORTED
     assert lib.dg_final_gan_bwd(0, 1, 1.0, None, y_fake, B, 1.0, 1, b["dy"].data_ptr(), None, None, b["acc"].data_ptr(), None,
                                 d4.data_ptr(), dt, wf.data_ptr(), scale, n, C, b["dd4"].data_ptr(), None, None,
-                                None) == L.DG_EINVAL
+                                None, None) == L.DG_EINVAL
 
 
 def test_transpose_shadow_multi_tail_carries_the_counters(L):

@@ -351,6 +351,9 @@ def test_accumulated_step_replays_from_a_graph(monkeypatch):
     b, sb = run(False)
     for net in ("G", "D", "G_ema"):
         fa, fb = getattr(a, net).store.flat.cpu(), getattr(b, net).store.flat.cpu()
+        # (this 64x256 net has layers too narrow for the ping-pong conv - coarse rows of 32 columns - whose kernels still add
+        #  their bias gradients with float atomics: the deterministic sums of round 5 cover the benchmark's shapes,
+        #  tests/test_gpu_timed_path.py::test_two_runs_from_one_seed_are_bit_identical; measured here 8e-4 / 4e-4 / 2e-6)
         assert rel_l2(fa, fb) < 2.5e-3, (net, rel_l2(fa, fb))
     # (scripts/probes/acc_graph_flake.py, 16 repetitions: graph-vs-eager and eager-vs-eager have the SAME spread - the run-to-run
     #  noise of a bf16 step with atomics; losses <= 0.015, the mean raw logits `output/*` of 8 samples <= 0.024 in absolute terms)
