@@ -418,12 +418,13 @@ int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, D
 // KB): a block owns 16 elements and its 16 thread groups split the partials, met in LDS in a fixed order - 32-48 loads per
 // thread instead of 768 dependent batches for one.
 constexpr int RED_WIDE = 64;
-struct ReduceItems { DgWgradReduce it[8]; int first_block[9]; int n; };
+constexpr int RED_MAX = 16;   // layers per reduce launch (round 5: bias-gradient rows are items too - eight per network at the benchmark)
+struct ReduceItems { DgWgradReduce it[RED_MAX]; int first_block[RED_MAX + 1]; int n; };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceItems r) {
   __shared__ f32x4 s_part[16][17];
   int k = 0;
 #pragma unroll
-  for (int i = 1; i < 8; ++i)
+  for (int i = 1; i < RED_MAX; ++i)
     if (i < r.n && (int)blockIdx.x >= r.first_block[i]) k = i;
   const DgWgradReduce it = r.it[k];
   if (it.splits > RED_WIDE) {
@@ -554,13 +555,13 @@ int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, int ro
 }
 
 extern "C" int dg_wgrad_reduce(const DgWgradReduce* items, int n, void* stream) {
-  if (!items || n < 1 || n > 8) return DG_EINVAL;
+  if (!items || n < 1 || n > RED_MAX) return DG_EINVAL;
   ReduceItems r{};
   int blocks = 0;
   // longest sums first: a thread of a 32-split layer makes four dependent round trips, one of a 4-split layer one - with
   // the deep layers' blocks at the END of the grid the launch finished on a handful of CUs (25.5 us for the D phase's three
   // layers against 15 us for the sum of its parts, scripts/bench_reduce.py)
-  int order[8];
+  int order[RED_MAX];
   for (int i = 0; i < n; ++i) order[i] = i;
   for (int i = 1; i < n; ++i)
     for (int j = i; j > 0 && items[order[j]].splits > items[order[j - 1]].splits; --j) {

@@ -239,7 +239,7 @@ def wgrad_algorithmic(wmode, B, Hc, Wc, Ci, Co, aes, ges):
 class WgradWorkspace:
     """Split-K partial tiles of the step's weight-gradient launches (DgWgrad.ws): the MFMA LDS-DMA kernel stores every
     split's [16][Ci][Co] partial here with plain stores, and `flush` sums them into the gradients with ONE
-    dg_wgrad_reduce launch per <= 8 layers - instead of fp32 atomics onto dW, which the memory side executes at ~1.3 TB/s
+    dg_wgrad_reduce launch per <= 16 layers - instead of fp32 atomics onto dW, which the memory side executes at ~1.3 TB/s
     (8x dW's bytes per launch: VERDICT r02).  A bump allocator over one caller-owned buffer; the reduce is deferred to
     the point where the gradient is first needed (before an exchange / the optimizer), so one launch serves a whole
     network.  Fixed summation order: the gradients are bit-reproducible."""
@@ -305,11 +305,11 @@ class WgradWorkspace:
             # queued, not issued): issue them first - the reduce follows them in stream order
             self.pre_reduce()
         items, self.items, self.pos = self.items, [], 0
-        # one launch per <= 8 layers, and never two items with the same destination in one launch (micro-batches, the
+        # one launch per <= 16 layers, and never two items with the same destination in one launch (micro-batches, the
         # path-length terms: their blocks would read-modify-write the same dW concurrently) - those follow in stream order
         chunks, cur, seen = [], [], set()
         for it in items:
-            if len(cur) == 8 or it[1] in seen:
+            if len(cur) == 16 or it[1] in seen:
                 chunks.append(cur)
                 cur, seen = [], set()
             cur.append(it)

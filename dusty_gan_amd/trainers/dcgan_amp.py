@@ -1083,8 +1083,10 @@ class Trainer:
                     # the split-K partials queued by the aborted capture were never written: forget them while the CAPTURE
                     # stream is still current (E.WGRAD_WS is per stream - after __exit__ the default stream's workspace would be
                     # the one reset, and the retry on this capture stream would reduce never-written memory into the gradients
-                    # on every replay)
+                    # on every replay).  The workspace itself goes too: its buffer was allocated inside the aborted capture's
+                    # memory pool, which dies with that capture - the retry allocates a fresh one in ITS pool.
                     E.WGRAD_WS.discard()
+                    E.WGRAD_WS.drop_stream()
                     try:
                         self._cap_cur[1].__exit__(None, None, None)
                     except BaseException:

@@ -177,7 +177,7 @@ int dg_wgrad_plan(const DgWgrad* p, int accumulate, int force, DgWgradPlan* plan
  * (nothing launched) if an item does not qualify. */
 int dg_wgrad_group(const DgWgrad* items, int n, int force, int rounds, void* stream);
 int dg_wgrad_group_plan(const DgWgrad* items, int n, int force, int rounds, DgWgradPlan* plans);
-/* dw[i] (+)= sum_s ws[s * numel + i] for up to 8 layers in one launch (fixed summation order: deterministic gradients) */
+/* dw[i] (+)= sum_s ws[s * numel + i] for up to 16 layers in one launch (fixed summation order: deterministic gradients) */
 typedef struct DgWgradReduce {
   const float* ws;
   float* dw;

@@ -268,7 +268,9 @@ def test_aborted_capture_leaves_no_pending_partials(monkeypatch):
     def run(fail):
         monkeypatch.setenv("DUSTY_GAN_FORCE_SEG", "1")
         torch.manual_seed(91)
-        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8, amp=True)
+        # (B = 32: every fat layer on the ping-pong conv, whose sums are order-independent - the two runs can be compared
+        #  bit for bit; at B = 8 the small layers fall to kernels that still add bias gradients with float atomics)
+        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
         sc = [dict(tr.step(i).items()) for i in range(2)]       # the two eager warm-up steps
         seen = {"n": 0, "pending": 0}
         if fail:

@@ -321,7 +321,7 @@ def test_algorithmic_work_model_matches_the_survey():
 
 
 def test_wgrad_workspace_never_reduces_two_items_into_one_destination_per_launch(monkeypatch):
-    """engine.WgradWorkspace.flush: at most 8 layers per dg_wgrad_reduce launch and never two items with the same dW in one
+    """engine.WgradWorkspace.flush: at most 16 layers per dg_wgrad_reduce launch and never two items with the same dW in one
     launch (micro-batches and the path-length terms queue several partial sets for one gradient: their blocks would
     read-modify-write it concurrently) - the repeats follow in later launches, in queue order."""
     from dusty_gan_amd import _lib as L
@@ -335,15 +335,16 @@ def test_wgrad_workspace_never_reduces_two_items_into_one_destination_per_launch
     monkeypatch.setattr(L, "lib", lambda: FakeLib())
     monkeypatch.setattr(L, "stream_ptr", lambda: None)
     ws = E.WgradWorkspace()
-    items = [(1000 + i, dw, 64, 4, 1) for i, dw in enumerate([10, 20, 30, 10, 40, 20, 10, 50, 60, 70, 80, 90, 100, 110])]
+    dsts = [10, 20, 30, 10, 40, 20, 10] + list(range(50, 250, 10))          # the last run of 20 distinct ones: 16 + 4
+    items = [(1000 + i, dw, 64, 4, 1) for i, dw in enumerate(dsts)]
     for it in items:
         ws.add(*it)
     ws.flush()
     assert ws.items == [] and ws.pos == 0
     assert [it for chunk in launches for it in chunk] == items                 # everything, in order
     for chunk in launches:
-        assert len(chunk) <= 8 and len({it[1] for it in chunk}) == len(chunk)   # no destination twice in a launch
-    assert len(launches) == 3                                                   # [10 20 30] [10 40 20] [10 50 ... 110]
+        assert len(chunk) <= 16 and len({it[1] for it in chunk}) == len(chunk)  # no destination twice in a launch
+    assert [len(c) for c in launches] == [3, 3, 16, 5]                          # [10 20 30] [10 40 20] [10 50 ... 190] [200 ... 240]
 
 
 def test_counters_ride_and_mid_step_flush_without_gpu(monkeypatch):
