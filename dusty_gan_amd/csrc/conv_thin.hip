@@ -1419,6 +1419,7 @@ int dg_conv_s2_mfma_supported(const ConvP* p) {
   const int cp = p->in_sp;  // padded channel count of the input tensor
   if ((cp != 2 && cp != 4) || p->K > cp || p->in_sk != 1 || p->w_sk != 1 || p->out_sn != 1 || p->out_sp != 64) return 0;
   if (p->dbias && p->bias_mod != 64) return 0;
+  if (p->bias && p->scale == 0.f) return 0;      // (the bias is the accumulators' start value bias / scale: round-4 advice)
   if (p->out_sb % 64 != 0) return 0;             // (a tile's output and its mask bits are addressed as whole 64-channel pixels)
   return 1;
 }

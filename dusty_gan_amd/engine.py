@@ -380,7 +380,14 @@ WGRAD_WS = _PerStreamWorkspace()
 def grads_ready():
     """The engines' backward passes leave the split-K partial tiles of the fat layers' weight gradients in `WGRAD_WS`
     (`defer=True`): `st.grad` is complete only after this call (what `FlatAdam.step` and the trainer's all-reduce helpers
-    do first).  Anything else that reads a ParamStore's gradient after GEngine.backward / DEngine.wgrad calls it."""
+    do first).  Anything else that reads a ParamStore's gradient after GEngine.backward / DEngine.wgrad calls it.
+    Only the CURRENT stream's workspace is summed (a reduce must follow its launches in stream order): partials still pending
+    on another stream of this device mean that stream's gradients are incomplete - said out loud (round-4 advice)."""
+    other = WGRAD_WS.pending_elsewhere()
+    if other:
+        import warnings
+        warnings.warn(f"engine.grads_ready(): {other} layer(s) have split-K partials pending on ANOTHER stream of this device; "
+                      "call grads_ready() on the stream that ran their backward pass before reading those gradients")
     WGRAD_WS.flush()
 
 

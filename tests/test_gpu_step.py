@@ -346,6 +346,12 @@ def test_accumulated_step_replays_from_a_graph(monkeypatch):
         if graph:
             assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph) == 1
             assert tr.batches_drawn == 10     # the host loader moved on by num_accumulation batches per step
+            # ... and so did the DEVICE-side pool index the captured fetches read (n_acc per replay: round-4 advice - an
+            # off-by-one micro-batch in the captured fetches would pass every tolerance below)
+            from dusty_gan_amd import _lib as L
+            with L.Counters.bind(tr.counters):
+                L.Counters.flush_if(tr._pool_ctr)
+            assert int(tr._pool_ctr) == tr.batches_drawn == tr._pool_host, (int(tr._pool_ctr), tr.batches_drawn, tr._pool_host)
         return tr, sc
     a, sa = run(True)
     b, sb = run(False)
