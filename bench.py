@@ -38,7 +38,7 @@ def parse(argv=None):
     ap.add_argument("--precision", choices=["bf16", "fp32", "fp32x3"], default="bf16",
                     help="bf16: the timed mode; fp32: exact parity mode; fp32x3: fp32 storage, split-bf16 matrix instructions")
     ap.add_argument("--arch", choices=["none", "dusty1", "dusty2"], default=None,
-                    help="default: BASELINE configs[1] (dcgan_eqlr baseline) at N=1, configs[3] (dusty2) at N>1")
+                    help="default: BASELINE configs[1] (dcgan_eqlr baseline) at every N - one weak-scaling series; dusty2 = configs[3]'s model")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--shape", type=int, nargs=2, default=[64, 1024])
     ap.add_argument("--gp", type=float, default=1.0, help="R1 weight (solver.loss.gp); 0 disables R1")
