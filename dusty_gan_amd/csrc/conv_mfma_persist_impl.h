@@ -64,7 +64,7 @@ __device__ __forceinline__ bool next_tile(Tile& t, int tiles_n, int tiles_x, int
 
 // H taps of output row Y: up to 6 entries (src row << 2 | ky), 10 bits each, first tap in the low bits
 template <int MODE>
-__device__ __forceinline__ int pack_htaps(int adj, int Y, int Hc, unsigned long long& list) {
+__host__ __device__ __forceinline__ int pack_htaps(int adj, int Y, int Hc, unsigned long long& list) {
   list = 0;
   int n = 0;
 #pragma unroll

@@ -42,6 +42,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define PP_WAIT(vm) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(vm) : "memory")
 
+// H-tap lists of every output row (up to 6 taps of 10 bits, the count in bits 60-62), built by the LAUNCHER and passed as a
+// kernel argument: a tile reads its row's entry with one scalar load.  (Rounds 4-5 built this table in LDS in the kernel's
+// prologue - six rounds of boundary cases per row on one wave while the other seven waited at the barrier behind it: a good part
+// of the 2 500 cycles every launch spent before its first LDS-DMA piece, profiles/r05a_conv_lifetime_phases_b32.txt.)
+constexpr int NHT = 256;                       // rows of the table (the launcher checks rows <= NHT)
+struct HTab { unsigned long long e[NHT]; };
+
 // Diagnostics are compiled in only with -DDG_PP_DIAG=<bits> (make diag DIAGBITS=<bits>, default 8): every runtime check in the K-step loop costs issue
 // slots the loop does not have (the LOAD half is instruction-issue bound: ~6-7 cycles per instruction beside the partner
 // wave's MFMAs).  Bits as in the lock-step kernel's DG_CONV_DBG (1 no DMA, 2 no MFMA, 4 no epilogue, 16 no
@@ -72,7 +79,7 @@ __device__ __forceinline__ float row_add(float v) {  // v + (v of the lane CTRL 
 // BITS (MASK only): the slope comes from the saved 1-bit masks (DgConv.mask_in, 2 bytes per lane and block row) instead of the
 // saved activation itself (aux, 32 bytes per lane and block row, and 32 VGPRs to hold a tile's worth of it).
 template <int BN, int MODE, bool MASK, bool DUAL = false, bool BITS = false>
-__global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht) {
   static_assert(MASK || !BITS, "BITS: a flavour of the EPI_MASK epilogue");
   static_assert(!DUAL || (MODE == MODE_UP && BN == 128), "DUAL: both column parities of a 64-channel MODE_UP layer");
   constexpr int NCH = DUAL ? BN / 2 : BN;      // real output channels per tile
@@ -96,7 +103,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int NPAIR = MODE == MODE_S2 ? 2 : 1;   // pairs per (H tap, 64-channel chunk)
   constexpr bool STRIP = BN == 128;            // output stores through a per-wave LDS transpose strip (below)
   constexpr int SCR = STRIP ? 16 * WC * 2 : 0; // 16 pixels x the wave's channels
-  constexpr int NHT = 256;                     // rows of the H-tap table (the launcher checks rows <= NHT)
   // Bias-gradient sums (EPI_MASK): one ROW of accumulators per wave that can touch a channel (waves that differ only in
   // their pixel block wm - in the both-parities tile all eight), NDBR * NDB floats laid over [s_bias (unused under EPI_MASK) |
   // s_db | NDBX more]: a wave adds to its own row in its own program order and the rows are summed in a fixed order at the
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   constexpr int NDBX = MASK ? (NDBR - 2) * NDB : 0;
   constexpr int DBW = DUAL ? NWV : NWV / WN;   // waves that share a channel
   constexpr int LDS_HT = NPS * PSTAGE + 3 * NDB * 4 + NDBX * 4 + NWV * SCR;
-  static_assert(IB >= 1 && LDS_HT + NHT * 8 <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_HT + NHT * 8];
+  static_assert(IB >= 1 && LDS_HT <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_HT];
 #ifdef DG_PP_DIAG
   constexpr int dbg = DG_PP_DIAG;              // compile-time bit mask (make diag DIAGBITS=..): no runtime checks
 #else
@@ -258,14 +264,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
   // (round 5: the same tables by LDS-DMA instead of ordinary loads - no dependent global round trip in front of the first
   //  tile's DMA - measured 400 cycles SLOWER per launch: the loads' latency already sat under the H-tap table's arithmetic,
   //  and a DMA piece costs ~100 cycles to issue; profiles/r05a_conv_lifetime_phases_b32.txt)
-  // H-tap lists of every output row, built once (up to 6 taps of 10 bits, the count in bits 60-62): a tile reads its
-  // row's entry instead of running the tap enumeration (six rounds of boundary cases) again
-  const unsigned sht0 = lds0 + LDS_HT;
-  for (int y = tid; y < rows; y += 64 * NWV) {
-    unsigned long long hl;
-    const int nh = persist::pack_htaps<MODE>(p.adj, y, p.Hc, hl);
-    ((unsigned long long*)(lds + LDS_HT))[y] = hl | ((unsigned long long)nh << 60);
-  }
   __syncthreads();
   const unsigned long long tk1 = (dbg & 8) ? pp_stamp() : 0ull;
 
@@ -649,14 +647,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g) {
     unsigned long long hl;
     int nh;
     {
-      // (inline asm, like every LDS read of the loop: the compiler must not see an LDS access it would order against the
-      //  LDS-DMA pieces in flight with a vmcnt(0))
-      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-      u32x2_t e;
-      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(sht0 + (unsigned)ti.Y * 8u) : "memory");
-      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)e.x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)e.y);
-      nh = (int)(hi >> 28) & 7;
-      hl = ((unsigned long long)(hi & 0x0fffffffu) << 32) | lo;
+      // (a scalar load from the kernel-argument segment: lgkmcnt only, nothing the LDS-DMA pieces in flight are ordered against)
+      const unsigned long long e = ht.e[ti.Y];
+      nh = (int)(e >> 60) & 7;
+      hl = e & 0x0fffffffffffffffull;
     }
     const char* in_t = (const char*)(in + (long)(ti.bt * g.NSB) * p.in_sb);
     const char* w_t = (const char*)(w + (long)(ti.nt * NCH) * p.w_sn);
@@ -753,10 +747,19 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
     plan->dbias_rows = (MASK && (DUAL ? 8 : 4) * p->N <= 2048) ? G : 0;
     return DG_OK;
   }
+  HTab ht;
+  {
+    const int rows = MODE == MODE_S2 ? p->Hc : 2 * p->Hc;      // (<= NHT: checked by dg_conv_mfma_pp_launch)
+    for (int y = 0; y < NHT; ++y) {
+      unsigned long long hl = 0;
+      const int nh = y < rows ? persist::pack_htaps<MODE>(p->adj, y, p->Hc, hl) : 0;
+      ht.e[y] = hl | ((unsigned long long)nh << 60);
+    }
+  }
   if constexpr (MASK) {
-    if (bits) conv_pp_kernel<BN, MODE, true, DUAL, true><<<(unsigned)G, 512, 0, stream>>>(*p, g);
-    else conv_pp_kernel<BN, MODE, true, DUAL, false><<<(unsigned)G, 512, 0, stream>>>(*p, g);
-  } else conv_pp_kernel<BN, MODE, false, DUAL><<<(unsigned)G, 512, 0, stream>>>(*p, g);
+    if (bits) conv_pp_kernel<BN, MODE, true, DUAL, true><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
+    else conv_pp_kernel<BN, MODE, true, DUAL, false><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
+  } else conv_pp_kernel<BN, MODE, false, DUAL><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
