@@ -16,6 +16,7 @@ if os.environ.get("DUSTY_GAN_LIB_DIAG"):  # kernel-development aid: `make -C csr
 
 DG_OK, DG_EINVAL, DG_EUNSUPPORTED, DG_EHIP = 0, 1, 2, 3
 DG_F32, DG_BF16 = 0, 1
+DG_BF16X2 = 2   # split-bf16 pairs (hi | lo per 64 channels), 4 bytes per element: include/dusty_gan_hip.h
 MODE_S2, MODE_UP, MODE_GEMM = 0, 1, 2
 EPI_LINEAR, EPI_LRELU, EPI_MASK = 0, 1, 2
 DG_FORCE_FP32X3 = 0x100   # flag bit of the `force` arguments (include/dusty_gan_hip.h)
@@ -171,6 +172,8 @@ PROTOTYPES = {
     "dg_zero_multi": [_P, _P, _I, _P],
     "dg_adam_ema_step": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dg_cast": [_P, _P, _I, _L, _P],
+    "dg_uncast": [_P, _I, _P, _L, _P],
+    "dg_cast_x2_multi": [_P, _P, _P, _I, _P],
     "dg_transpose_shadow": [_P, _P, _I, _I, _I, _P],
     "dg_transpose_shadow_multi": [_P, _P, _I, _I, _I, _P],
     "dg_transpose_shadow_multi_frags": [_P, _P, _I, _I, _I, C.POINTER(DgUpFrag), _I, _P],

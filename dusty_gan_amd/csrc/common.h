@@ -145,11 +145,22 @@ struct AdamEpi {
 
 int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream);
 
+// DG_BF16X2 (include/dusty_gan_hip.h): element i = the bf16 pair (hi, lo) at bf16 index 2 i - i % 64 and 64 further
+__host__ __device__ __forceinline__ long dg_x2_index(long i) { return 2 * i - (i & 63); }
 __device__ __forceinline__ float dg_ld(const void* p, long i, int dtype) {
+  if (dtype == DG_BF16X2) {
+    const bf16* q = (const bf16*)p + dg_x2_index(i);
+    return (float)q[0] + (float)q[64];
+  }
   return dtype == DG_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
 }
 __device__ __forceinline__ void dg_st(void* p, long i, int dtype, float v) {
-  if (dtype == DG_BF16) ((bf16*)p)[i] = (bf16)v;
+  if (dtype == DG_BF16X2) {
+    bf16* q = (bf16*)p + dg_x2_index(i);
+    const bf16 hi = (bf16)v;
+    q[0] = hi;
+    q[64] = (bf16)(v - (float)hi);
+  } else if (dtype == DG_BF16) ((bf16*)p)[i] = (bf16)v;
   else ((float*)p)[i] = v;
 }
 

@@ -362,7 +362,14 @@ static int launch_cfg(const ConvP* p, hipStream_t stream, DgConvPlan* plan) {
 }
 
 // Shapes this kernel takes; everything else goes to the thin / direct kernels (dg_conv in api.hip decides).
+int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan, int dual);
+
 extern "C" int dg_conv_mfma_supported(const ConvP* p) {
+  if (p->in_dtype == DG_BF16X2 || p->out_dtype == DG_BF16X2 || p->w_dtype == DG_BF16X2) {
+    // split-bf16 pairs: the ping-pong kernel or nothing (its launcher describes the launch without making it)
+    DgConvPlan pl;
+    return dg_conv_mfma_pp_launch(p, nullptr, 1, 0, &pl, 1) == DG_OK;
+  }
   const int es = p->in_dtype == DG_BF16 ? 2 : 4;
   const int BK = 128 / es;  // K must be a multiple of the largest stage (128 B of channels)
   if (p->in_dtype != p->out_dtype || p->in_dtype != p->w_dtype) return 0;
@@ -386,6 +393,7 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
 // 128 x 128 tiles); everything else -> one tile per workgroup (below, family 2).
 int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPlan* plan, int fp32x3) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
+  if (p->in_dtype == DG_BF16X2) return dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan, 1);
   if (p->in_dtype == DG_BF16) {
     const int rc = dg_conv_mfma_pp_launch(p, stream, 256, wg_cap, plan, 1);
     if (rc != DG_EUNSUPPORTED) return rc;
@@ -421,7 +429,9 @@ int dg_conv_mfma_launch(const ConvP* p, hipStream_t stream, int wg_cap, DgConvPl
 int dg_conv_mfma_big_launch(const ConvP* p, hipStream_t stream, int family, int wg_cap, DgConvPlan* plan) {
   if (!dg_conv_mfma_supported(p)) return DG_EUNSUPPORTED;
   if (family == 5 || family == 9)   // 9: the ping-pong kernel without its both-parities tile (A/B, parity tests)
-    return p->in_dtype == DG_BF16 ? dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan, family == 5) : DG_EUNSUPPORTED;
+    return (p->in_dtype == DG_BF16 || p->in_dtype == DG_BF16X2) ? dg_conv_mfma_pp_launch(p, stream, 1, wg_cap, plan, family == 5)
+                                                               : DG_EUNSUPPORTED;
+  if (p->in_dtype == DG_BF16X2) return DG_EUNSUPPORTED;
   return p->in_dtype == DG_BF16 ? dg_conv_mfma_persist_launch_bf16(p, stream, 0, wg_cap, plan)
                                 : dg_conv_mfma_persist_launch_f32(p, stream, 0, wg_cap, plan);
 }

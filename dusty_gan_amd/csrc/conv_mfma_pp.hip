@@ -78,9 +78,15 @@ __device__ __forceinline__ float row_add(float v) {  // v + (v of the lane CTRL 
 // LDS-DMA issue of their LOAD halves - 6 pieces per wave and pair for 32 MFMAs against 8 for 64 in the 128-channel tile.
 // BITS (MASK only): the slope comes from the saved 1-bit masks (DgConv.mask_in, 2 bytes per lane and block row) instead of the
 // saved activation itself (aux, 32 bytes per lane and block row, and 32 VGPRs to hold a tile's worth of it).
-template <int BN, int MODE, bool MASK, bool DUAL = false, bool BITS = false>
+// X2 (round 5, the fp32x3 precision mode on THIS kernel): input, weights, output and mask source are DG_BF16X2 - per 64
+// channels 128 bytes of hi = bf16(x) followed by 128 bytes of lo = bf16(x - hi) (include/dusty_gan_hip.h).  A 64-channel K
+// chunk then is three K steps on the same stages and fragments, x_hi w_hi + x_lo w_hi + x_hi w_lo - the chunk's source
+// addresses move by 128 bytes, nothing else in the loop changes - and the epilogue stores both halves of its fp32 values
+// (straight from the accumulator layout: 64-byte runs).  The launcher hands over strides in bf16 units (twice the elements).
+template <int BN, int MODE, bool MASK, bool DUAL = false, bool BITS = false, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht) {
   static_assert(MASK || !BITS, "BITS: a flavour of the EPI_MASK epilogue");
+  static_assert(!X2 || !BITS, "X2: mask source = the saved activation's hi half");
   static_assert(!DUAL || (MODE == MODE_UP && BN == 128), "DUAL: both column parities of a 64-channel MODE_UP layer");
   constexpr int NCH = DUAL ? BN / 2 : BN;      // real output channels per tile
   constexpr int BM = 256, NWV = 8, WN = 2;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
   constexpr int NST = TM * CPL * 2 / 16;       // 16-byte stores per lane per tile
   constexpr int NDB = 512;
   constexpr int NPAIR = MODE == MODE_S2 ? 2 : 1;   // pairs per (H tap, 64-channel chunk)
-  constexpr bool STRIP = BN == 128;            // output stores through a per-wave LDS transpose strip (below)
+  constexpr bool STRIP = BN == 128 && !X2;     // output stores through a per-wave LDS transpose strip (below)
   constexpr int SCR = STRIP ? 16 * WC * 2 : 0; // 16 pixels x the wave's channels
   // Bias-gradient sums (EPI_MASK): one ROW of accumulators per wave that can touch a channel (waves that differ only in
   // their pixel block wm - in the both-parities tile all eight), NDBR * NDB floats laid over [s_bias (unused under EPI_MASK) |
@@ -279,7 +285,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
 
   // ---- epilogue pieces
   bf16* out = (bf16*)p.out;
-  const unsigned lane_coff = (unsigned)(((DUAL ? 0 : wn * WC) + g4 * CPL) * 2);  // this lane's first channel inside the N tile, bytes
+  const unsigned lane_c0 = (unsigned)((DUAL ? 0 : wn * WC) + g4 * CPL);           // this lane's first channel inside the N tile
+  const unsigned lane_coff = X2 ? lane_c0 * 2 + ((lane_c0 >> 6) << 7) : lane_c0 * 2;   // ... in bytes of the output row
   const unsigned par_off = DUAL ? (unsigned)(wn * (int)p.out_sp * 2) : 0u;          // DUAL: the wave's column parity, bytes
   const long px_b = (long)(MODE == MODE_S2 ? 1 : 2) * p.out_sp * 2;   // bytes between consecutive tile rows of a segment
   unsigned pix_off;                            // byte offset of this lane's pixel of block row 0 from the tile base
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
   auto tile_off = [&](const Tile& t) __attribute__((always_inline)) -> long {  // element offset of (sample group, row Y, first column, first channel)
     const int n0 = t.xt * BM;
     return (long)(t.bt * g.NSB) * p.out_sb + ((long)t.Y * Wo + (MODE == MODE_S2 ? n0 : 2 * n0 + t.px)) * p.out_sp +
-           t.nt * NCH;
+           t.nt * NCH * (X2 ? 2 : 1);
   };
   // The leaky-relu mask source of a tile being finished (EPI_MASK) is fetched during the tile's last MFMA half into
   // registers of its own (one lane's 4 pixels x 16 TN bytes); the epilogue runs at the END of the next LOAD half, behind that
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dbacc[c] = row_add<0x128>(dbacc[c]);   // row_ror 8
     if (a16 == 0) {
-      const unsigned ad = sdbw0 + (unsigned)(nt * NCH * 4) + lane_coff * 2;
+      const unsigned ad = sdbw0 + (unsigned)(nt * NCH * 4) + lane_c0 * 4;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(ad), "v"(dbacc[c]), "n"(c * 4) : "memory");
     }
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
       asm volatile("ds_read_b32 %0, %1" : "=v"(rs) : "v"(ra) : "memory");
     }
     if (!MASK) {
-      const unsigned ba = sbias0 + (unsigned)(t.nt * NCH * 4) + lane_coff * 2;
+      const unsigned ba = sbias0 + (unsigned)(t.nt * NCH * 4) + lane_c0 * 4;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[j]) : "v"(ba), "n"(j * 16) : "memory");
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
 #pragma unroll
       for (int h = 0; h < NST / TM; ++h) {
         const i32x4 ax = axr[(MASK && !BITS) ? (NST / TM) * i + h : 0];   // mask source of channels 8h .. 8h+7 (MASK, aux form)
-        i32x4 pk;
+        i32x4 pk, pkl;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {                 // two channels per 32-bit word
           float v2[2];
@@ -459,6 +466,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
           unsigned pw;                                   // both halves in one conversion (RNE, as (bf16)v)
           asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw) : "v"(v2[0]), "v"(v2[1]));
           pk[e2] = (int)pw;
+          if constexpr (X2) {                            // lo = bf16(v - hi)
+            const float l0 = v2[0] - __builtin_bit_cast(float, pw << 16);
+            const float l1 = v2[1] - __builtin_bit_cast(float, pw & 0xffff0000u);
+            unsigned pl;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pl) : "v"(l0), "v"(l1));
+            pkl[e2] = (int)pl;
+          }
         }
         if (!MASK && mob) {
           // the saved mask of these 8 channels from the ROUNDED values (what an EPI_MASK pass would test on the stored
@@ -479,8 +493,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
           }
         }
         if (!STRIP) {                                    // N tile 64: the four lanes of a pixel already write one 64 B run
-          char* dstp = ob + (long)(i * 16) * px_b + pix_off;
+          char* dstp = ob + (long)(i * 16) * px_b + pix_off + h * 16;
           if (!(dbg & 128)) *(i32x4*)dstp = pk; else asm volatile("" ::"v"(pk));
+          if constexpr (X2) {
+            if (!(dbg & 128)) *(i32x4*)(dstp + 128) = pkl; else asm volatile("" ::"v"(pkl));
+          }
           continue;
         }
         if (h == 0 && i > 0) store_row(i - 1);           // (its reads were issued a block row of arithmetic ago)
@@ -671,9 +688,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
       hl >>= 10;
       const char* sA_row = in_t + (long)it_r * Ws * spb;
       const char* sB_row = w_t + (long)(it_ky * 4) * tap_b;
-      for (int kc = 0; kc < KC; ++kc) {
-        const char* sA_k = sA_row + kc * SB;
-        const char* sB_k = sB_row + kc * SB;
+      for (int kc = 0; kc < (X2 ? 3 : 1) * KC; ++kc) {
+        // X2: chunk kc / 3 as (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo): the lo halves sit 128 bytes behind their hi halves
+        const int kq = X2 ? kc / 3 : kc, sub = X2 ? kc - 3 * kq : 0;
+        const char* sA_k = sA_row + kq * (X2 ? 2 * SB : SB) + (sub == 1 ? SB : 0);
+        const char* sB_k = sB_row + kq * (X2 ? 2 * SB : SB) + (sub == 2 ? SB : 0);
 #pragma unroll
         for (int pi = 0; pi < NPAIR; ++pi) {
           pair_iter(std::true_type{}, firstg, pi, sA_k, sB_k + (long)(kxa + pi) * tap_b, sB_k + (long)(kxb + pi) * tap_b,
@@ -722,10 +741,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
   }
 }
 
-template <int BN, int MODE, bool MASK, bool DUAL = false>
+template <int BN, int MODE, bool MASK, bool DUAL = false, bool X2 = false>
 int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConvPlan* plan) {
   constexpr int CPL_ = (BN / 2 / 16) * 4;      // bits per lane and block row: whole bytes / 16-bit words of the mask buffers
-  const bool bits_ok = p->out_sn == 1 && p->out_sb % 8 == 0 && p->out_sp % CPL_ == 0 && p->N % CPL_ == 0;
+  const bool bits_ok = !X2 && p->out_sn == 1 && p->out_sb % 8 == 0 && p->out_sp % CPL_ == 0 && p->N % CPL_ == 0;
   if (!MASK && p->mask_out && !bits_ok) return DG_EUNSUPPORTED;
   const bool bits = MASK && p->mask_in && bits_ok;
   Geo g = g0;
@@ -756,7 +775,9 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
       ht.e[y] = hl | ((unsigned long long)nh << 60);
     }
   }
-  if constexpr (MASK) {
+  if constexpr (X2) {
+    conv_pp_kernel<BN, MODE, MASK, DUAL, false, true><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
+  } else if constexpr (MASK) {
     if (bits) conv_pp_kernel<BN, MODE, true, DUAL, true><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
     else conv_pp_kernel<BN, MODE, true, DUAL, false><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
   } else conv_pp_kernel<BN, MODE, false, DUAL><<<(unsigned)G, 512, 0, stream>>>(*p, g, ht);
@@ -769,9 +790,20 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
 // bf16 layers that tile into 256-pixel x 128- (or 64-) channel tiles; DG_EUNSUPPORTED otherwise (the caller falls back
 // to the lock-step kernels).  min_tiles: the auto rule wants every CU busy.
 // dual: 1 = a 64-channel MODE_UP layer may take the both-parities tile (512 pixels x 64 channels), 0 = never (A/B, tests)
-int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan, int dual) {
-  if (p->mode != MODE_S2 && p->mode != MODE_UP) return DG_EUNSUPPORTED;
-  if (p->in_dtype != DG_BF16 || p->out_dtype != DG_BF16 || p->w_dtype != DG_BF16) return DG_EUNSUPPORTED;
+int dg_conv_mfma_pp_launch(const ConvP* p0, hipStream_t stream, int min_tiles, int wg_cap, DgConvPlan* plan, int dual) {
+  if (p0->mode != MODE_S2 && p0->mode != MODE_UP) return DG_EUNSUPPORTED;
+  const bool x2 = p0->in_dtype == DG_BF16X2;
+  if (p0->in_dtype != p0->out_dtype || p0->in_dtype != p0->w_dtype || (p0->in_dtype != DG_BF16 && !x2)) return DG_EUNSUPPORTED;
+  ConvP q = *p0;
+  if (x2) {
+    // DG_BF16X2: whole 64-channel groups everywhere, 256-byte aligned tensors; from here on strides in bf16 units
+    if (p0->K % 64 || p0->N % 64 || p0->in_sp % 64 || p0->in_sb % 64 || p0->out_sp % 64 || p0->out_sb % 64 || p0->w_sn % 64 ||
+        p0->w_st % 64 || (((size_t)p0->in | (size_t)p0->out | (size_t)p0->w | (size_t)p0->aux) & 255))
+      return DG_EUNSUPPORTED;
+    if (p0->mask_out || p0->mask_in) return DG_EUNSUPPORTED;   // (saved 1-bit masks: bf16 tensors only)
+    q.in_sb *= 2; q.in_sp *= 2; q.out_sb *= 2; q.out_sp *= 2; q.w_st *= 2; q.w_sn *= 2;
+  }
+  const ConvP* p = &q;
   if (p->K % 64 != 0 || !p->ring || p->nscale) return DG_EUNSUPPORTED;
   // a tile must span at least two pair iterations (the compute side finishes the previous tile during the first one and
   // its epilogue runs at the start of the second): the adjoint MODE_UP pass with K == 64 could have one (a single H tap at
@@ -792,6 +824,8 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
   if (dual && p->mode == MODE_UP && p->N % 128 != 0 && p->N % 64 == 0 && persist::make_geo<256, 64>(p, g) && g.SW >= 64 &&
       g.NSB * (g.SW + 2) <= 264 && g.ntiles / 2 >= min_tiles) {
     g.ntiles /= 2;                             // one tile = both column parities of 256 coarse columns
+    if (x2) return mask ? pp::launch<128, MODE_UP, true, true, true>(p, g, stream, wg_cap, plan)
+                        : pp::launch<128, MODE_UP, false, true, true>(p, g, stream, wg_cap, plan);
     return mask ? pp::launch<128, MODE_UP, true, true>(p, g, stream, wg_cap, plan)
                 : pp::launch<128, MODE_UP, false, true>(p, g, stream, wg_cap, plan);
   }
@@ -799,6 +833,16 @@ int dg_conv_mfma_pp_launch(const ConvP* p, hipStream_t stream, int min_tiles, in
   else if (p->N % 64 == 0 && persist::make_geo<256, 64>(p, g) && g.SW >= 64 && g.ntiles >= min_tiles) bn = 64;
   if (!bn) return DG_EUNSUPPORTED;
   const int sel = (bn == 128 ? 0 : 4) + (p->mode == MODE_UP ? 2 : 0) + (mask ? 1 : 0);
+  if (x2) switch (sel) {
+    case 0: return pp::launch<128, MODE_S2, false, false, true>(p, g, stream, wg_cap, plan);
+    case 1: return pp::launch<128, MODE_S2, true, false, true>(p, g, stream, wg_cap, plan);
+    case 2: return pp::launch<128, MODE_UP, false, false, true>(p, g, stream, wg_cap, plan);
+    case 3: return pp::launch<128, MODE_UP, true, false, true>(p, g, stream, wg_cap, plan);
+    case 4: return pp::launch<64, MODE_S2, false, false, true>(p, g, stream, wg_cap, plan);
+    case 5: return pp::launch<64, MODE_S2, true, false, true>(p, g, stream, wg_cap, plan);
+    case 6: return pp::launch<64, MODE_UP, false, false, true>(p, g, stream, wg_cap, plan);
+    default: return pp::launch<64, MODE_UP, true, false, true>(p, g, stream, wg_cap, plan);
+  }
   switch (sel) {
     case 0: return pp::launch<128, MODE_S2, false>(p, g, stream, wg_cap, plan);
     case 1: return pp::launch<128, MODE_S2, true>(p, g, stream, wg_cap, plan);

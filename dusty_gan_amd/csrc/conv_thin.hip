@@ -116,8 +116,10 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
 #define SN_PX 64
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
-template <typename T, int N>
+// X2 (T = float): the input is DG_BF16X2 - the staged pixel rows are the same 4 K bytes, read as hi + lo pairs
+template <typename T, int N, bool X2 = false>
 __global__ __launch_bounds__(256) void thin_smalln_kernel(ConvP p) {
+  static_assert(!X2 || sizeof(T) == 4, "DG_BF16X2 input: the fp32 build");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = sizeof(T);
   const int K = p.K;
@@ -169,6 +171,25 @@ __global__ __launch_bounds__(256) void thin_smalln_kernel(ConvP p) {
       for (int jx = 0; jx < 2; ++jx) {
         const unsigned char* src = smem + ((trow[ti] * (SN_PX + 2) + lane + 1 + dcol[jx]) * rowb);
         const T* wt = (const T*)p.w + (long)(tky[ti] * 4 + kxs[jx]) * p.w_st;  // [n][k] of this tap, uniform
+        if constexpr (X2) {
+          for (int k0 = 0; k0 < K; k0 += 8) {
+            const unsigned char* q = src + (k0 >> 6) * 256 + (k0 & 63) * 2;
+            const uint4 h = *(const uint4*)q, l = *(const uint4*)(q + 128);
+            const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+            float a8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a8[2 * e] = __builtin_bit_cast(float, hw[e] << 16) + __builtin_bit_cast(float, lw[e] << 16);
+              a8[2 * e + 1] = __builtin_bit_cast(float, hw[e] & 0xffff0000u) + __builtin_bit_cast(float, lw[e] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              const float* wq = (const float*)(wt + (long)j * p.w_sn + k0);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j] += a8[e] * wq[e];
+            }
+          }
+        } else
         for (int k0 = 0; k0 < K; k0 += 16 / ES) {
           const uint4 raw = *(const uint4*)(src + k0 * ES);
           if constexpr (ES == 2) {
@@ -869,7 +890,9 @@ int dg_conv_thin_supported(const ConvP* p) {
   // MODE_UP: wide K -> small N; weights = the T shadow [tap][n][k]; no mask / bias-grad epilogue
   if (p->N > 3 || p->Wc % SN_PX != 0 || p->in_sk != 1 || p->w_sk != 1) return 0;
   const int es = p->in_dtype == DG_BF16 ? 2 : 4;
-  if ((p->K * es) % 16 != 0 || p->w_dtype != p->in_dtype) return 0;
+  const bool x2 = p->in_dtype == DG_BF16X2;       // (split-bf16 input rows, fp32 weights and output)
+  if (x2 && (p->K % 64 != 0 || p->in_sp % 64 != 0 || p->in_sb % 64 != 0 || ((size_t)p->in & 255) || p->out_dtype == DG_BF16X2)) return 0;
+  if ((p->K * es) % 16 != 0 || p->w_dtype != (x2 ? DG_F32 : p->in_dtype)) return 0;
   if (p->epi != EPI_LINEAR || p->dbias) return 0;
   return 1;
 }
@@ -900,6 +923,10 @@ int dg_conv_thin_launch(const ConvP* p, hipStream_t s) {
       if (p->N == 1) thin_smalln_kernel<bf16, 1><<<grid, 256, lds, s>>>(*p);
       else if (p->N == 2) thin_smalln_kernel<bf16, 2><<<grid, 256, lds, s>>>(*p);
       else thin_smalln_kernel<bf16, 3><<<grid, 256, lds, s>>>(*p);
+    } else if (p->in_dtype == DG_BF16X2) {
+      if (p->N == 1) thin_smalln_kernel<float, 1, true><<<grid, 256, lds, s>>>(*p);
+      else if (p->N == 2) thin_smalln_kernel<float, 2, true><<<grid, 256, lds, s>>>(*p);
+      else thin_smalln_kernel<float, 3, true><<<grid, 256, lds, s>>>(*p);
     } else {
       if (p->N == 1) thin_smalln_kernel<float, 1><<<grid, 256, lds, s>>>(*p);
       else if (p->N == 2) thin_smalln_kernel<float, 2><<<grid, 256, lds, s>>>(*p);

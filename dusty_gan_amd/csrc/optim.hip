@@ -202,6 +202,54 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
   if (i < n) dst[i] = (T)src[i];
 }
 
+// fp32 <-> DG_BF16X2 (include/dusty_gan_hip.h: per 64 elements 128 bytes of hi = bf16(x), then 128 bytes of lo = bf16(x - hi)):
+// a thread owns 8 consecutive elements = one 16-byte piece of each half
+struct CastItems { const float* src[16]; void* dst[16]; long first8[17]; int n; };
+__device__ __forceinline__ void x2_pack8(const float* __restrict__ src, unsigned short* __restrict__ dst, long i8) {
+  const float4 a = ((const float4*)src)[2 * i8], b = ((const float4*)src)[2 * i8 + 1];
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16 h0 = (bf16)v[2 * e], h1 = (bf16)v[2 * e + 1];
+    const bf16 l0 = (bf16)(v[2 * e] - (float)h0), l1 = (bf16)(v[2 * e + 1] - (float)h1);
+    hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  }
+  unsigned short* q = dst + dg_x2_index(8 * i8);
+  *(uint4*)q = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  *(uint4*)(q + 64) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+__global__ __launch_bounds__(256) void cast_x2_kernel(CastItems it) {
+  const long i8 = (long)blockIdx.x * 256 + threadIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i)
+    if (i < it.n && i8 >= it.first8[i]) k = i;
+  if (i8 >= it.first8[it.n]) return;
+  x2_pack8(it.src[k], (unsigned short*)it.dst[k], i8 - it.first8[k]);
+}
+__global__ __launch_bounds__(256) void uncast_x2_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long n8) {
+  const long i8 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i8 >= n8) return;
+  const unsigned short* q = src + dg_x2_index(8 * i8);
+  const uint4 h = *(const uint4*)q, l = *(const uint4*)(q + 64);
+  const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = __builtin_bit_cast(float, hw[e] << 16) + __builtin_bit_cast(float, lw[e] << 16);
+    v[2 * e + 1] = __builtin_bit_cast(float, hw[e] & 0xffff0000u) + __builtin_bit_cast(float, lw[e] & 0xffff0000u);
+  }
+  ((float4*)dst)[2 * i8] = make_float4(v[0], v[1], v[2], v[3]);
+  ((float4*)dst)[2 * i8 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <typename T>
+__global__ void uncast_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
 // master [16][ci][co] fp32 -> shadow [16][co][ci] T, through a 32x32 LDS tile per (tap, ci-tile, co-tile)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* __restrict__ src, T* __restrict__ dst,
@@ -462,8 +510,39 @@ int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema
   return DG_OK;
 }
 
+// up to 16 fp32 buffers -> DG_BF16X2 twins in one launch (the split-bf16 copies of the fat layers' weight shadows)
+int dg_cast_x2_multi(const float* const* src, void* const* dst, const long* n, int count, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!src || !dst || !n || count < 1 || count > 16) return DG_EINVAL;
+  CastItems it{};
+  long tot = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!src[i] || !dst[i] || n[i] <= 0 || n[i] % 64 != 0 || ((size_t)src[i] & 15) || ((size_t)dst[i] & 255)) return DG_EINVAL;
+    it.src[i] = src[i]; it.dst[i] = dst[i]; it.first8[i] = tot;
+    tot += n[i] / 8;
+  }
+  it.first8[count] = tot;
+  it.n = count;
+  cast_x2_kernel<<<nblk(tot), 256, 0, s>>>(it);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+int dg_uncast(const void* src, int dtype, float* dst, long n, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!src || !dst || n <= 0) return DG_EINVAL;
+  if (dtype == DG_BF16X2) {
+    if (n % 64 != 0 || ((size_t)src & 255) || ((size_t)dst & 15)) return DG_EINVAL;
+    uncast_x2_kernel<<<nblk(n / 8), 256, 0, s>>>((const unsigned short*)src, dst, n / 8);
+  } else if (dtype == DG_BF16) uncast_kernel<bf16><<<nblk(n), 256, 0, s>>>((const bf16*)src, dst, n);
+  else uncast_kernel<float><<<nblk(n), 256, 0, s>>>((const float*)src, dst, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 int dg_cast(const float* src, void* dst, int dtype, long n, void* s_) {
   hipStream_t s = (hipStream_t)s_;
+  if (dtype == DG_BF16X2) return dg_cast_x2_multi(&src, &dst, &n, 1, s_);
   if (dtype == DG_BF16) cast_kernel<bf16><<<nblk(n), 256, 0, s>>>(src, (bf16*)dst, n);
   else cast_kernel<float><<<nblk(n), 256, 0, s>>>(src, (float*)dst, n);
   HIP_CHECK_RET(hipGetLastError());

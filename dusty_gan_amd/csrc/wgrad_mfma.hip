@@ -344,7 +344,10 @@ int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t st
   return DG_OK;
 }
 
+int dg_wgrad_mfma_dma_supported(const WgradP* p);
+
 extern "C" int dg_wgrad_mfma_supported(const WgradP* p) {
+  if (p->a_dtype == DG_BF16X2 || p->g_dtype == DG_BF16X2) return dg_wgrad_mfma_dma_supported(p);   // (that kernel or nothing)
   if (p->a_dtype != p->g_dtype) return 0;
   if (p->a_sc != 1 || p->g_sc != 1) return 0;
   if (p->Ci % 64 != 0 || p->Co % 64 != 0) return 0;
@@ -357,7 +360,7 @@ extern "C" int dg_wgrad_mfma_supported(const WgradP* p) {
 
 // accumulate = 1: dw += (atomics, K split over workgroups); accumulate = 0: dw = (single pass, plain stores)
 int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream, int fp32x3) {
-  if (!dg_wgrad_mfma_supported(p)) return DG_EUNSUPPORTED;
+  if (!dg_wgrad_mfma_supported(p) || p->a_dtype == DG_BF16X2) return DG_EUNSUPPORTED;
   const bool m128 = p->Ci % 128 == 0, n128 = p->Co % 128 == 0;
   if (p->a_dtype == DG_BF16) {
     if (m128 && n128) return launch_cfg<bf16, 128, 128>(p, accumulate, stream);

@@ -57,7 +57,12 @@ constexpr int stage_bytes() { return BKP * BM * 2 + (NT == 2 ? 1024 : 0) + BKP *
 
 // One workgroup of the (tile, tap or tap pair, K split) grid gx x gy x gz, linear index `id`; `lds`: NS stages.  The body of
 // wgrad_dma_kernel (one layer per launch) and of wgrad_group_kernel (several layers' workgroups in ONE launch, below).
-template <int WMODE, int BM, int BN, int NT>
+// X2 (round 5, the fp32x3 precision mode on THIS kernel): a and g are DG_BF16X2 - per 64 channels 128 bytes of hi = bf16(x),
+// then 128 bytes of lo = bf16(x - hi) (include/dusty_gan_hip.h).  Every 64-pixel chunk is staged and multiplied three times,
+// (a_hi, g_hi), (a_lo, g_hi), (a_hi, g_lo): only the pieces' source addresses change (the lo half of a channel group sits 128
+// bytes behind its hi half), stages, fragment reads and matrix instructions are the bf16 kernel's.  Strides arrive in bf16
+// units (twice the elements: the launcher).
+template <int WMODE, int BM, int BN, int NT, bool X2 = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_n, const int accumulate, const int id,
                                                const int gx, const int gy, const int gz, unsigned char* lds) {
   constexpr int RA = BM * 2, RG = BN * 2;                 // LDS row bytes (one pixel)
@@ -98,20 +103,22 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_
   auto swz = [](int row, int rowbytes) { return rowbytes == 256 ? (row & 3) : ((row >> 1) & 1); };
   int rowA[PA], rowG[PG];
   unsigned chA[PA], chG[PG];                              // byte offset of the lane's (swizzled) chunk inside its pixel
+  // (X2: chunk c of the tile's hi - or lo - half lives in channel group c / 8, 256 bytes per group)
+  auto chunk_off = [](int c) { return (unsigned)(X2 ? (c >> 3) * 256 + (c & 7) * 16 : c * 16); };
 #pragma unroll
   for (int v = 0; v < PA; ++v) {
     const int r = (wave + 4 * v) * RPA + lane / CA, c = lane % CA;
     rowA[v] = r;
-    chA[v] = (unsigned)(((((c >> 2) ^ swz(r, RA)) << 2) | (c & 3)) * 16);
+    chA[v] = chunk_off((((c >> 2) ^ swz(r, RA)) << 2) | (c & 3));
   }
 #pragma unroll
   for (int v = 0; v < PG; ++v) {
     const int r = (wave + 4 * v) * RPG + lane / CG, c = lane % CG;
     rowG[v] = r;
-    chG[v] = (unsigned)(((((c >> 2) ^ swz(r, RG)) << 2) | (c & 3)) * 16);
+    chG[v] = chunk_off((((c >> 2) ^ swz(r, RG)) << 2) | (c & 3));
   }
   const int rowX = BKP + lane / CA;                       // the image's last piece (rows 64 ..): wave 0
-  const unsigned chX = (unsigned)((((((lane % CA) >> 2) ^ swz(rowX, RA)) << 2) | (lane % CA & 3)) * 16);
+  const unsigned chX = chunk_off(((((lane % CA) >> 2) ^ swz(rowX, RA)) << 2) | (lane % CA & 3));
   const unsigned aspb = (unsigned)asp * 2u, gspb = (unsigned)gsp * 2u;   // bytes per pixel (< 2^24)
   // A image row m of a chunk starting at coarse column x0 holds A-grid column amul (x0 + m) + da; the pair's taps read
   // image rows r + 0 and r + 1 for chunk pixel r:
@@ -142,27 +149,32 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_
       return (const char*)(((unsigned long long)hi << 32) | lo);
     };
     const int bg = p.g_mod > 0 ? b % p.g_mod : b;          // (one launch over real | fake | tangent input samples)
-    abase = uni(A + (long)b * p.a_sb + (long)rowa * Wa * asp + ci0);
-    gbase = uni(G + (long)bg * p.g_sb + (long)rowg * Wg * gsp + co0);
+    abase = uni(A + (long)b * p.a_sb + (long)rowa * Wa * asp + ci0 * (X2 ? 2 : 1));
+    gbase = uni(G + (long)bg * p.g_sb + (long)rowg * Wg * gsp + co0 * (X2 ? 2 : 1));
   };
   set_unit(ib, im);
+  int iseg = 0;                                             // X2: the chunk's pass (a_hi g_hi | a_lo g_hi | a_hi g_lo)
   auto issue = [&](unsigned st_off) __attribute__((always_inline)) {
     const unsigned base = lds0 + st_off + (unsigned)wave * 1024u;
     const int x0 = ixc * BKP;
+    const char* ab = abase + ((X2 && iseg == 1) ? 128 : 0);
+    const char* gb = gbase + ((X2 && iseg == 2) ? 128 : 0);
 #pragma unroll
     for (int v = 0; v < PA; ++v) {                          // circular columns: Wa is a power of two (launcher check)
       const unsigned ca = (unsigned)(((WMODE == 0 ? 2 : 1) * (x0 + rowA[v]) + da) & (Wa - 1));
-      dma_s(__umul24(ca, aspb) + chA[v], abase, base + 4 * v * 1024);
+      dma_s(__umul24(ca, aspb) + chA[v], ab, base + 4 * v * 1024);
     }
     if (NT == 2 && wave == 0) {
       const unsigned ca = (unsigned)(((WMODE == 0 ? 2 : 1) * (x0 + rowX) + da) & (Wa - 1));
-      dma_s(__umul24(ca, aspb) + chX, abase, lds0 + st_off + 4 * PA * 1024);
+      dma_s(__umul24(ca, aspb) + chX, ab, lds0 + st_off + 4 * PA * 1024);
     }
 #pragma unroll
     for (int v = 0; v < PG; ++v) {
       const unsigned cg = (unsigned)((WMODE == 1 ? 2 : 1) * (x0 + rowG[v]) + dg);
-      dma_s(__umul24(cg, gspb) + chG[v], gbase, base + STA + 4 * v * 1024);
+      dma_s(__umul24(cg, gspb) + chG[v], gb, base + STA + 4 * v * 1024);
     }
+    if (X2 && ++iseg < 3) return;
+    iseg = 0;
     if (++ixc == cpr) {
       ixc = 0;
       if (++im == p.Hc) { im = 0; ++ib; }
@@ -211,10 +223,12 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_
   //      compute chunk s
   if (nchunks > 0) issue(0);
   unsigned so = 0;                                          // LDS offset of the stage being computed
-  for (int s = 0; s < nchunks; ++s) {
+  const int npass = nchunks * (X2 ? 3 : 1);
+  int cseg = 0;
+  for (int s = 0; s < npass; ++s) {
     DG_WAITV(0);
     __builtin_amdgcn_s_barrier();
-    if (s + 1 < nchunks) issue(so ^ (unsigned)STAGE);
+    if (s + 1 < npass) issue(so ^ (unsigned)STAGE);
     // the reads of k-step kq+1 are issued before the MFMAs of kq (two fragment sets, counted lgkmcnt)
     i32x2 alo[2][NT][TM], ahi[2][NT][TM], glo[2][TN], ghi[2][TN];   // [set][tap][..]
     unsigned ra[NT][TM], rg[TN];
@@ -271,12 +285,14 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_
     mfmas(1);
     so ^= (unsigned)STAGE;
     // per-sample weights: running sum kept divided by the current sample's weight (wgrad_mfma.hip)
+    if (X2 && ++cseg < 3) continue;
+    cseg = 0;
     if (++cxc == cpr) {
       cxc = 0;
       if (++cm == p.Hc) {
         cm = 0;
         ++cb_s;
-        if (p.rowscale && s + 1 < nchunks) {
+        if (p.rowscale && s + 1 < npass) {
           float rn = p.rowscale[cb_s];
           if (fabsf(rn) < 1e-30f) rn = rn < 0.f ? -1e-30f : 1e-30f;
           const float ratio = cur_rs / rn;
@@ -316,11 +332,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradP& p, const int tiles_
   }
 }
 
-template <int WMODE, int BM, int BN, int NT>
+template <int WMODE, int BM, int BN, int NT, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n, int accumulate) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * stage_bytes<BM, BN, NT>()];
-  wgrad_dma_body<WMODE, BM, BN, NT>(p, tiles_n, accumulate, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)),
-                                    (int)gridDim.x, (int)gridDim.y, (int)gridDim.z, lds);
+  wgrad_dma_body<WMODE, BM, BN, NT, X2>(p, tiles_n, accumulate, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)),
+                                        (int)gridDim.x, (int)gridDim.y, (int)gridDim.z, lds);
 }
 
 // ---- several layers in ONE launch.  A weight-gradient launch is one residency round of ~512 workgroups that start
@@ -334,7 +350,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradP p, int tiles_n
 constexpr int GROUP_MAX = 4;
 struct GroupItem { WgradP p; int tiles_n, gx, gy, gz, first, variant, accumulate; };
 struct GroupP { GroupItem it[GROUP_MAX]; int n; };
-constexpr int variant_code(int wmode, int bm, int bn, int nt) { return wmode * 8 + (bm == 128 ? 4 : 0) + (bn == 128 ? 2 : 0) + (nt == 2 ? 1 : 0); }
+constexpr int variant_code(int wmode, int bm, int bn, int nt, bool x2 = false) {
+  return (x2 ? 16 : 0) + wmode * 8 + (bm == 128 ? 4 : 0) + (bn == 128 ? 2 : 0) + (nt == 2 ? 1 : 0);
+}
 
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(GroupP g) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * stage_bytes<128, 128, 2>()];
@@ -347,7 +365,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(GroupP g) {
   const int id = (int)blockIdx.x - it.first;
   if (id >= it.gx * it.gy * it.gz) return;       // (items are padded to multiples of 8 blocks: id & 7 stays the XCD label)
 #define DG_GROUP_CASE(W, M, N, T) \
-  case variant_code(W, M, N, T): wgrad_dma_body<W, M, N, T>(it.p, it.tiles_n, it.accumulate, id, it.gx, it.gy, it.gz, lds); break;
+  case variant_code(W, M, N, T): wgrad_dma_body<W, M, N, T>(it.p, it.tiles_n, it.accumulate, id, it.gx, it.gy, it.gz, lds); break; \
+  case variant_code(W, M, N, T, true): wgrad_dma_body<W, M, N, T, true>(it.p, it.tiles_n, it.accumulate, id, it.gx, it.gy, it.gz, lds); break;
   switch (it.variant) {
     DG_GROUP_CASE(0, 64, 64, 1) DG_GROUP_CASE(0, 64, 64, 2) DG_GROUP_CASE(0, 64, 128, 1) DG_GROUP_CASE(0, 64, 128, 2)
     DG_GROUP_CASE(0, 128, 64, 1) DG_GROUP_CASE(0, 128, 64, 2) DG_GROUP_CASE(0, 128, 128, 1) DG_GROUP_CASE(0, 128, 128, 2)
@@ -389,6 +408,13 @@ DmaGeo dma_geo(const WgradP* p, int accumulate, int pairs, bool ws, long target 
   return DmaGeo{tiles_m, tiles_n, split, use_pairs};
 }
 
+// DG_BF16X2 operands: the kernel takes their strides in bf16 units
+static WgradP x2_strides(const WgradP& p) {
+  WgradP q = p;
+  if (p.a_dtype == DG_BF16X2) { q.a_sb *= 2; q.a_sp *= 2; q.g_sb *= 2; q.g_sp *= 2; }
+  return q;
+}
+
 // plan != NULL: describe the launch, launch nothing.
 template <int WMODE, int BM, int BN>
 int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, DgWgradPlan* plan) {
@@ -402,12 +428,16 @@ int launch_dma(const WgradP* p, int accumulate, int pairs, hipStream_t stream, D
     plan->tap_pairs = ge.use_pairs ? 1 : 0;
     return DG_OK;
   }
+  const WgradP q = x2_strides(*p);
+  const bool x2 = p->a_dtype == DG_BF16X2;
   if (ge.use_pairs) {
     dim3 grid((unsigned)(tiles_m * tiles_n), 8u, (unsigned)split);
-    wgrad_dma_kernel<WMODE, BM, BN, 2><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+    if (x2) wgrad_dma_kernel<WMODE, BM, BN, 2, true><<<grid, 256, 0, stream>>>(q, tiles_n, accumulate);
+    else wgrad_dma_kernel<WMODE, BM, BN, 2><<<grid, 256, 0, stream>>>(q, tiles_n, accumulate);
   } else {
     dim3 grid((unsigned)(tiles_m * tiles_n), 16u, (unsigned)split);
-    wgrad_dma_kernel<WMODE, BM, BN, 1><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
+    if (x2) wgrad_dma_kernel<WMODE, BM, BN, 1, true><<<grid, 256, 0, stream>>>(q, tiles_n, accumulate);
+    else wgrad_dma_kernel<WMODE, BM, BN, 1><<<grid, 256, 0, stream>>>(q, tiles_n, accumulate);
   }
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
@@ -478,13 +508,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceItems r) {
 }  // namespace
 
 int dg_wgrad_mfma_dma_supported(const WgradP* p) {
-  if (p->a_dtype != DG_BF16 || p->g_dtype != DG_BF16) return 0;
+  const bool x2 = p->a_dtype == DG_BF16X2;
+  if (p->a_dtype != p->g_dtype || (p->a_dtype != DG_BF16 && !x2)) return 0;
+  if (x2 && (p->a_sp % 64 || p->g_sp % 64 || p->a_sb % 64 || p->g_sb % 64 || (((size_t)p->a | (size_t)p->g) & 255))) return 0;
   if (p->wmode != 0 && p->wmode != 1) return 0;
   if (!p->ring || p->a_sc != 1 || p->g_sc != 1) return 0;
   if (p->Ci % 64 != 0 || p->Co % 64 != 0 || p->Wc % BKP != 0 || p->Hc < 2) return 0;
   if (p->a_sp % 8 != 0 || p->g_sp % 8 != 0) return 0;      // 16-byte DMA granules
   if ((p->Wc & (p->Wc - 1)) != 0) return 0;                // circular column wrap by mask
-  if (p->a_sp * 2 >= (1 << 24) || p->g_sp * 2 >= (1 << 24)) return 0;  // 24-bit offset multiply
+  if (p->a_sp * (x2 ? 4 : 2) >= (1 << 24) || p->g_sp * (x2 ? 4 : 2) >= (1 << 24)) return 0;  // 24-bit offset multiply
   if ((long)p->B * p->Hc * (p->Wc / BKP) > 0x7fffffffL) return 0;
   return 1;
 }
@@ -539,11 +571,11 @@ int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, int ro
       continue;
     }
     GroupItem& it = g.it[i];
-    it.p = *p;
+    it.p = x2_strides(*p);
     it.tiles_n = ge.tiles_n;
     it.gx = ge.tiles_m * ge.tiles_n; it.gy = ge.use_pairs ? 8 : 16; it.gz = (int)ge.split;
     it.first = blocks;
-    it.variant = variant_code(p->wmode, bm, bn, ge.use_pairs ? 2 : 1);
+    it.variant = variant_code(p->wmode, bm, bn, ge.use_pairs ? 2 : 1, p->a_dtype == DG_BF16X2);
     it.accumulate = 1;
     blocks += (it.gx * it.gy * it.gz + 7) / 8 * 8;
   }

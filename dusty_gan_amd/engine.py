@@ -424,6 +424,42 @@ class MaskBits:
 DETERMINISTIC = os.environ.get("DUSTY_GAN_DETERMINISTIC", "1") != "0"
 
 
+# ---- split-bf16 pairs (DG_BF16X2, round 5): the storage form of the fp32x3 mode's fat feature maps and weight shadows.  A
+# tensor keeps torch dtype float32 (4 bytes per element, same element strides) and carries the attribute `_dg_x2 = True`: its
+# bytes are (hi | lo) bf16 halves per 64 channels (include/dusty_gan_hip.h).  Ops.conv / Ops.wgrad pass the dtype code by the
+# tag; kernels that do not take the form get an fp32 copy (Proj's GEMMs, the final conv's pointwise kernels: small tensors).
+X2_TWIN = {}   # device pointer of an fp32 weight shadow -> device pointer of its DG_BF16X2 copy (ParamStore.refresh_x2)
+
+
+def is_x2(t):
+    return t is not None and getattr(t, "_dg_x2", False)
+
+
+def tag_x2(t):
+    """mark a float32 tensor as holding DG_BF16X2 data (256-byte aligned, whole 64-channel groups: the allocator's job)"""
+    assert t.dtype == torch.float32 and t.data_ptr() % 256 == 0 and t.numel() % 64 == 0
+    t._dg_x2 = True
+    return t
+
+
+def x2_pack(src, dst=None, off=0, n=None):
+    """fp32 `src` (n elements from `off`) -> DG_BF16X2 at the same offsets of `dst` (a tagged tensor; default: a new one)"""
+    n = src.numel() - off if n is None else n
+    if dst is None:
+        dst = tag_x2(torch.empty(src.numel(), dtype=torch.float32, device=src.device))
+    L.check(L.lib().dg_cast(L.ptr(src) + 4 * off, L.ptr(dst) + 4 * off, L.DG_BF16X2, n, L.stream_ptr()), "dg_cast")
+    return dst
+
+
+def x2_unpack(src, dst=None, off=0, n=None):
+    """DG_BF16X2 `src` -> fp32 `dst` (same offsets)"""
+    n = src.numel() - off if n is None else n
+    if dst is None:
+        dst = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+    L.check(L.lib().dg_uncast(L.ptr(src) + 4 * off, L.DG_BF16X2, L.ptr(dst) + 4 * off, n, L.stream_ptr()), "dg_uncast")
+    return dst
+
+
 class _WgradGroup:
     def __init__(self, ops):
         self.ops = ops
@@ -473,6 +509,15 @@ class Ops:
         self.wg_cap = Ops.default_wg_cap  # dg_conv_ex: cap on the persistent conv's workgroup count (0 = one residency wave)
         self.use_ws = True  # split-K partials through WGRAD_WS + dg_wgrad_reduce (False: fp32 atomics onto dW)
         self._group = None  # the open `grouped()` block's launches
+        self._x2_scratch = {}  # (role, numel) -> fp32 copy of a DG_BF16X2 operand for kernels that do not take the form
+
+    def _f32_copy(self, role, t):
+        """fp32 scratch of the same size as the tagged tensor `t` (one per role and size, reused launch after launch)"""
+        key = (role, t.numel(), str(t.device))
+        b = self._x2_scratch.get(key)
+        if b is None:
+            b = self._x2_scratch[key] = torch.empty(t.numel(), dtype=torch.float32, device=t.device)
+        return b
 
     @property
     def _f(self):
@@ -484,6 +529,26 @@ class Ops:
              x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None, up_frag=None, defer_db=False):
         """defer_db: the bias-gradient rows of a deterministic launch (DETERMINISTIC, kernels with DgConvPlan.dbias_rows) wait in
         WGRAD_WS for the caller's flush like a deferred weight gradient's partials; otherwise they are summed at once."""
+        x2_out = None
+        if mode == L.MODE_GEMM and (is_x2(x) or is_x2(out) or is_x2(aux)):
+            # Proj's GEMMs run on the fp32 kernels: split-bf16 operands through fp32 copies (4 M elements at the benchmark)
+            if is_x2(x):
+                x = x2_unpack(x, self._f32_copy("x", x), x_off, B * K)
+            if is_x2(aux):
+                aux = x2_unpack(aux, self._f32_copy("aux", aux), aux_off, B * N)
+            if is_x2(out):
+                x2_out, out = out, self._f32_copy("out", out)
+        if is_x2(x):
+            in_dt = L.DG_BF16X2
+        if is_x2(out):
+            out_dt = L.DG_BF16X2
+            assert aux is None or is_x2(aux), "DG_EPI_MASK: aux has out's layout and dtype"
+        if in_dt == L.DG_BF16X2 and out_dt == L.DG_BF16X2 and w_strides is None:
+            # both sides split-bf16: the ping-pong conv with the weight shadow's split twin
+            tw = X2_TWIN.get(int(w_ptr))
+            if tw is None:
+                raise L.DgError("no DG_BF16X2 twin registered for this weight shadow (ParamStore.enable_x2)")
+            w_ptr, w_dt = tw, L.DG_BF16X2
         p = L.DgConv()
         p.mode, p.adj, p.ring = mode, adj, int(ring)
         p.B, p.Hc, p.Wc, p.K, p.N = B, Hc, Wc, K, N
@@ -533,6 +598,8 @@ class Ops:
         if PROFILE is None:
             L.check(self.lib.dg_conv_ex(C.byref(p), self._f, self.wg_cap, L.stream_ptr()), "dg_conv_ex")
             self._db_rows_done(p, db_rows, dbias, N, defer_db)
+            if x2_out is not None:
+                x2_pack(out, x2_out, out_off, B * N)
             return
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
@@ -550,6 +617,8 @@ class Ops:
         PROFILE.append(({2: "conv_mfma_kernel", 3: "conv_thin_kernel"}.get(choice, "conv_direct_kernel"), flops, nbytes, e0, e1,
                         f"mode{mode}adj{adj} B{B} {Hc}x{Wc} K{K} N{N}"))
         self._db_rows_done(p, db_rows, dbias, N, defer_db)
+        if x2_out is not None:
+            x2_pack(out, x2_out, out_off, B * N)
 
     def _db_rows_done(self, p, rows, dbias, N, defer_db):
         """the launch left `rows` partial bias-gradient rows in the workspace: queue their sum onto dbias"""
@@ -700,6 +769,15 @@ class Ops:
 
     def _wgrad_params(self, wmode, ring, B, Hc, Wc, Ci, Co, a, a_strides, g, g_strides, dw_ptr, scale, rowscale, a_dt, g_dt,
                       a_off, g_off, g_mod):
+        if wmode == 2:   # Proj's GEMM shape runs on the fp32 kernels: split-bf16 operands through fp32 copies
+            if is_x2(a):
+                a = x2_unpack(a, self._f32_copy("wa", a))
+            if is_x2(g):
+                g = x2_unpack(g, self._f32_copy("wg", g))
+        if is_x2(a):
+            a_dt = L.DG_BF16X2
+        if is_x2(g):
+            g_dt = L.DG_BF16X2
         p = L.DgWgrad()
         p.wmode, p.ring = wmode, int(ring)
         p.B, p.Hc, p.Wc, p.Ci, p.Co = B, Hc, Wc, Ci, Co

@@ -30,6 +30,15 @@ extern "C" {
 
 #define DG_F32 0
 #define DG_BF16 1
+/* DG_BF16X2 (round 5, the storage form of the "fp32x3" precision mode on the bf16 kernels): every element x is the PAIR
+ * hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits kept), 4 bytes per element like DG_F32 and addressed with the same element
+ * strides, laid out per 64 channels as 128 bytes of hi followed by 128 bytes of lo: element i (flat element offset from a
+ * 256-byte aligned base, channel-minor, channel count a multiple of 64) has hi at bf16 index 2 i - i % 64 and lo 64 further.
+ * A matrix-core kernel then contracts x . w as x_hi w_hi + x_lo w_hi + x_hi w_lo with the bf16 kernels' own 128-byte channel
+ * chunks (three K steps per real one) - no splitting in registers, no fp32 staging.  Taken by: the ping-pong conv (in, w, out,
+ * aux all DG_BF16X2), the LDS-DMA weight-gradient kernel (a and g), the direct and the thin VALU kernels (any operand),
+ * dg_cast / dg_uncast.  Everything else answers DG_EUNSUPPORTED. */
+#define DG_BF16X2 2
 
 /* conv-like op geometry: a COARSE grid Hc x Wc and a FINE grid 2Hc x 2Wc */
 #define DG_MODE_S2 0   /* out on coarse, in on fine : Down forward, Up backward-data          */
@@ -429,6 +438,11 @@ int dg_adam_ema_step(float* p, const float* grad, float* m, float* v, float* ema
                      long n, float gscale, float lr, float beta1, float beta2, float eps, int step, float ema_decay,
                      void* stream);
 int dg_cast(const float* src, void* dst, int dtype, long n, void* stream);
+/* the way back: dst[i] = (float)src[i] for DG_BF16 / DG_BF16X2 sources (hi + lo), a copy for DG_F32 */
+int dg_uncast(const void* src, int dtype, float* dst, long n, void* stream);
+/* up to 16 fp32 buffers (n[i] elements, multiples of 64) -> DG_BF16X2 copies in ONE launch: the split-bf16 twins of the fat
+ * layers' weight shadows, rebuilt behind every optimizer step in the fp32x3 mode */
+int dg_cast_x2_multi(const float* const* src, void* const* dst, const long* n, int count, void* stream);
 int dg_transpose_shadow(const float* master, void* dst, int dtype, int Ci, int Co, void* stream);
 /* every conv segment of a network in one launch: desc_dev[5 i + (0..4)] = (source element offset in master, destination
  * pointer, Ci, Co, first tile index), tiles = 16 taps x ceil(Ci/32) x ceil(Co/32) per segment (device memory) */
