@@ -63,6 +63,10 @@ class ParamStore:
         self.shadow_dtype = None
         self._seen_version = -1
         self.up_frags = {}  # (name, Hc, adj) -> [buffer, DgUpFrag]: weight fragments of the thin matrix-core MODE_UP kernel
+        # DG_BF16X2 twins of the fat conv layers' fp32 shadows (fp32x3 mode with split storage: `enable_x2`), both forms:
+        # name -> tensor for [tap][ci][co] (x2_cico) and [tap][co][ci] (x2_coci); rebuilt behind every shadow refresh
+        self.x2 = False
+        self.x2_cico, self.x2_coci = {}, {}
 
     # -- views
     def view(self, name, buf=None):
@@ -77,6 +81,7 @@ class ParamStore:
             if t is not None:
                 setattr(self, k, fn(t))
         self.coci = {k: fn(v) for k, v in self.coci.items()}
+        self._drop_x2()
         self._tdesc = None  # the descriptor table holds the old pointers
         self._seen_version = -1
         self.up_frags = {}  # (re-registered by the engines, on the new device)
@@ -128,10 +133,58 @@ class ParamStore:
         self.refresh_transposed()
         self._seen_version = ver
 
+    # -- split-bf16 twins (fp32x3 mode with split storage)
+    def enable_x2(self):
+        """keep DG_BF16X2 copies of the fat conv layers' fp32 shadows (both layouts) and register them in X2_TWIN, so that
+        Ops.conv finds the split weights behind the fp32 shadow pointer the engines pass"""
+        if not self.x2:
+            self.x2 = True
+            self._seen_version = -1   # (the next refresh_shadows builds them)
+
+    def _drop_x2(self):
+        for t in list(self.x2_cico.values()) + list(self.x2_coci.values()):
+            for k in [k for k, v in X2_TWIN.items() if v == t.data_ptr()]:
+                del X2_TWIN[k]
+        self.x2_cico, self.x2_coci = {}, {}
+        self._x2_key = None
+
+    def _refresh_x2(self):
+        if not self.x2 or self.shadow is None or self.shadow_dtype != torch.float32:
+            return
+        fat = [(name, s) for name, s in self.seg.items()
+               if s.kind == "conv" and s.shape[2] % 64 == 0 and s.shape[3] % 64 == 0 and name in self.coci]
+        if not fat:
+            return
+        key = (self.shadow.data_ptr(),) + tuple(self.coci[name].data_ptr() for name, _ in fat)
+        if getattr(self, "_x2_key", None) != key:   # (first use, or the fp32 shadows moved: new twins, new registrations)
+            self._x2_key = key
+            self._drop_x2()
+            for name, s in fat:
+                self.x2_cico[name] = tag_x2(torch.empty(s.numel, dtype=torch.float32, device=self.flat.device))
+                self.x2_coci[name] = tag_x2(torch.empty(s.numel, dtype=torch.float32, device=self.flat.device))
+                X2_TWIN[self.sptr(name)] = self.x2_cico[name].data_ptr()
+                X2_TWIN[self.coci[name].data_ptr()] = self.x2_coci[name].data_ptr()
+            srcs, dsts, ns = [], [], []
+            for name, s in fat:
+                srcs += [self.sptr(name), self.coci[name].data_ptr()]
+                dsts += [self.x2_cico[name].data_ptr(), self.x2_coci[name].data_ptr()]
+                ns += [s.numel, s.numel]
+            k = len(srcs)
+            self._x2_args = ((C.c_void_p * k)(*srcs), (C.c_void_p * k)(*dsts), (C.c_long * k)(*ns), k)
+        a = self._x2_args
+        for i in range(0, a[3], 16):   # (16 buffers per launch; the benchmark's networks have 6 each)
+            n = min(16, a[3] - i)
+            L.check(L.lib().dg_cast_x2_multi(C.byref(a[0], i * C.sizeof(C.c_void_p)), C.byref(a[1], i * C.sizeof(C.c_void_p)),
+                                             C.byref(a[2], i * C.sizeof(C.c_long)), n, L.stream_ptr()), "dg_cast_x2_multi")
+
     def refresh_transposed(self, tail=False):
         """[tap][ci][co] fp32 master -> [tap][co][ci] T shadow of every conv segment, one launch per network.  tail: the call
         behind an optimizer step - when the trainer has flagged it (`_lib.Counters.ride`) this is the step's last launch
-        and carries the pending counter advances and the scalar snapshot."""
+        and carries the pending counter advances and the scalar snapshot.  (+ the split-bf16 twins, when enabled)"""
+        self._refresh_transposed(tail)
+        self._refresh_x2()
+
+    def _refresh_transposed(self, tail=False):
         lib, st = L.lib(), L.stream_ptr()
         convs = [(name, s) for name, s in self.seg.items() if s.kind == "conv"]
         if not convs:
@@ -793,12 +846,21 @@ class Ops:
         return p
 
 
+def x2_eligible(cfg):
+    """networks whose fat layers the split-bf16 kernels tile (the ping-pong conv: 64-channel groups, circular power-of-two rows
+    of at least 64 columns at every level); anything else keeps fp32 storage and the register-split kernels"""
+    return bool(cfg.ring and all(c % 64 == 0 for c in cfg.ch) and (cfg.W & (cfg.W - 1)) == 0 and cfg.w0 >= 64)
+
+
 class GEngine:
     """Generator forward / backward on one ParamStore (models/gans/dcgan_eqlr.py:49-72 + models/dusty.py)."""
 
-    def __init__(self, cfg: NetCfg, dtype, x3=False):
+    def __init__(self, cfg: NetCfg, dtype, x3=False, x2=False):
         self.cfg, self.dtype = cfg, dtype
         self.ops = Ops(dtype, x3=x3)
+        # fp32x3 with split storage: the feature maps a0..a3 and their gradient chains are DG_BF16X2 (tagged float32 tensors)
+        self.x2_asked = bool(x2)
+        self.x2 = self.x2_asked and self.ops.x3 and x2_eligible(cfg)
         self.ws_B = 0
 
     def alloc(self, B, device):
@@ -811,6 +873,9 @@ class GEngine:
         self.grid = hw
         self.a = [torch.empty(B * hw[i][0] * hw[i][1] * chs[i], dtype=T, device=device) for i in range(4)]
         self.dp = [torch.empty_like(t) for t in self.a]  # gradients w.r.t. the pre-activations of a0..a3
+        if self.x2:
+            for t in self.a + self.dp:
+                tag_x2(t)
         # 1-bit leaky-relu mask of a3 only: its consumer (the Head's backward-data) is HBM-bound and a3 is 57 % of the
         # generator's activation bytes.  Measured per layer (scripts/bench_conv.py, batch 32): writing the bits costs the Up
         # forward passes 3.6-5.5 us each (the MODE_UP tiles write every other pixel: 2-byte pieces 64 bytes apart) and
@@ -843,6 +908,8 @@ class GEngine:
         c, o, lib = self.cfg, self.ops, L.lib()
         B = z.shape[0]
         self.alloc(B, z.device)
+        if self.x2:
+            st.enable_x2()
         st.refresh_shadows(self.dtype)
         sp = L.stream_ptr()
         chs = [c.ch[3], c.ch[2], c.ch[1], c.ch[0]]
@@ -1064,7 +1131,8 @@ class GEngine:
         if getattr(self, "_dzT", None) is None or self._dzT.shape != (Np, Bp):
             self._dzT = torch.zeros(Np, Bp, dtype=self.dtype, device=self.dp[0].device)
             self._dzw = torch.empty(c.nz, Bp, dtype=torch.float32, device=self.dp[0].device)
-        self._dzT[:, :B].copy_(self.dp[0].view(B, Np).t())
+        dp0 = x2_unpack(self.dp[0]) if is_x2(self.dp[0]) else self.dp[0]
+        self._dzT[:, :B].copy_(dp0.view(B, Np).t())
         L.zero_(self._dzw)
         shadow = st.shadow[st.seg["proj_w"].off:st.seg["proj_w"].off + Np * c.nz]
         # the kernel splits its reduction over (sample, row) units: present the Np rows as R "samples" of Np / R rows
@@ -1082,6 +1150,9 @@ class GEngine:
         if getattr(self, "ta", None) is None or self.ta[0].numel() != self.a[0].numel():
             self.ta = [torch.empty_like(t) for t in self.a]
             self.dp2 = [torch.empty_like(t) for t in self.a]
+            if self.x2:
+                for t in self.ta + self.dp2:
+                    tag_x2(t)
             self.vT = torch.empty_like(self.zT)
             self.tout = torch.empty_like(self.gout)
             self.draw2 = torch.empty_like(self.gout)
@@ -1126,9 +1197,13 @@ class DEngine:
     """Discriminator passes (models/gans/dcgan_eqlr.py:85-96): forward, the shared backward-data chain, the R1
     tangent pass and the weight gradients."""
 
-    def __init__(self, cfg: NetCfg, dtype, x3=False):
+    def __init__(self, cfg: NetCfg, dtype, x3=False, x2=False):
         self.cfg, self.dtype = cfg, dtype
         self.ops = Ops(dtype, x3=x3)
+        # fp32x3 with split storage: h1..h4 and e1..e4 are DG_BF16X2; the final conv's pointwise kernels (logits, loss step,
+        # its weight gradient) see fp32 copies of h4 / write an fp32 e4 that is packed behind them (131 072 elements a sample)
+        self.x2_asked = bool(x2)
+        self.x2 = self.x2_asked and self.ops.x3 and x2_eligible(cfg)
         self.ws_B = 0
 
     def alloc(self, nb, device):
@@ -1144,6 +1219,11 @@ class DEngine:
         # 1-bit leaky-relu masks of h1..h3 (h4's only reader of bits is the R1 tangent's last layer: measured in the step,
         # writing them cost the two Down4 forward launches +6 us and saved that pass 0.8 us)
         self.hbits = [MaskBits.register(t) for t in self.h[1:4]]
+        self.h4f = self.e4f = None
+        if self.x2:
+            for t in self.h[1:] + self.e[1:]:
+                tag_x2(t)
+            self.h4f, self.e4f = torch.empty_like(self.h[4]), torch.empty_like(self.e[4])
         self.y = torch.empty(nb, dtype=torch.float32, device=device)
         self.ws_B = nb
 
@@ -1192,6 +1272,8 @@ class DEngine:
         """Down x4 + the final conv on h[0][slot : slot + n]"""
         c, o, lib = self.cfg, self.ops, L.lib()
         sp = L.stream_ptr()
+        if self.x2:
+            st.enable_x2()
         st.refresh_shadows(self.dtype)
         es = o.es
         for i in range(1, 5):
@@ -1205,14 +1287,30 @@ class DEngine:
                    aux_off=(tangent_of or 0) * self.per[i])
         if tangent_of is None:
             nf = self.per[4]
+            h4 = self._h4(slot, n)
             y = L.AccArena.take(n, self.y.device)  # logits: a pre-zeroed slice of the step's arena while a step runs
             if y is not None:
-                L.check(lib.dg_final_fwd_acc(L.ptr(self.h[4]) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
+                L.check(lib.dg_final_fwd_acc(L.ptr(h4) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
                                              1.0 / math.sqrt(nf), n, nf, L.ptr(y), sp), "dg_final_fwd_acc")
                 return y
-            L.check(lib.dg_final_fwd(L.ptr(self.h[4]) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
+            L.check(lib.dg_final_fwd(L.ptr(h4) + es * slot * nf, o.dt, st.fptr("final_w"), st.fptr("final_b"),
                                      1.0 / math.sqrt(nf), n, nf, L.ptr(self.y) + 4 * slot, sp), "dg_final_fwd")
         return self.y[slot:slot + n]
+
+    def _h4(self, slot, n):
+        """h4 as the pointwise kernels of the final conv read it: the tensor itself, or (split storage) the fp32 copy with the
+        slots [slot, slot + n) brought up to date"""
+        if not self.x2:
+            return self.h[4]
+        return x2_unpack(self.h[4], self.h4f, slot * self.per[4], n * self.per[4])
+
+    def _e4(self):
+        """where the final conv's backward-data writes e4 (split storage: fp32, packed into e[4] by `_e4_done`)"""
+        return self.e4f if self.x2 else self.e[4]
+
+    def _e4_done(self, slot, n):
+        if self.x2:
+            x2_pack(self.e4f, self.e[4], slot * self.per[4], n * self.per[4])
 
     def _bwd_layer(self, st, i, slot, n, rowscale, want_dbias):
         """e[i-1] = lrelu'(h[i-1]) * sqrt2 * s_i * conv_i^T(e[i])  (no mask for i == 1: BlurVH has no activation)"""
@@ -1239,11 +1337,12 @@ class DEngine:
         o, lib = self.ops, L.lib()
         nf = self.per[4]
         if not skip_final:
-            L.check(lib.dg_final_bwd_data(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), L.ptr(up),
+            L.check(lib.dg_final_bwd_data(L.ptr(self._h4(slot, n)) + o.es * slot * nf, o.dt, st.fptr("final_w"), L.ptr(up),
                                           L.ptr(rowscale), 1.0 / math.sqrt(nf), n, nf, self.chs[4],
-                                          L.ptr(self.e[4]) + o.es * slot * nf,
+                                          L.ptr(self._e4()) + o.es * slot * nf,
                                           st.fptr("d4_b", st.grad) if want_dbias else None, L.stream_ptr()),
                     "dg_final_bwd_data")
+            self._e4_done(slot, n)
         for i in (4, 3, 2):
             self._bwd_layer(st, i, slot, n, rowscale, want_dbias)
 
@@ -1261,16 +1360,19 @@ class DEngine:
         # Down4's bias gradient: one partial per element of the final map in the split-K workspace, summed per channel by the
         # reduce launch that runs anyway (DETERMINISTIC) - instead of 131 072 float atomics onto 512 addresses
         part = WGRAD_WS.take(nf, self.h[4].device) if (want_dbias and DETERMINISTIC and nf % C4 == 0 and C4 % 4 == 0) else None
+        nsl = B if mode_g else 2 * B             # samples the launch covers from `slot`
+        h4 = self._h4(slot, nsl)
         rc = lib.dg_final_gan_bwd(metric, int(mode_g), float(smoothing), y_real, y_fake, B, w_gan, int(r1), L.ptr(dy),
                                   L.ptr(up), L.ptr(rs), acc_ptr,
                                   st.fptr("final_b", st.grad) if not mode_g else None,
-                                  L.ptr(self.h[4]) + o.es * slot * nf, o.dt, st.fptr("final_w"), 1.0 / math.sqrt(nf), nf,
-                                  C4, L.ptr(self.e[4]) + o.es * slot * nf,
+                                  L.ptr(h4) + o.es * slot * nf, o.dt, st.fptr("final_w"), 1.0 / math.sqrt(nf), nf,
+                                  C4, L.ptr(self._e4()) + o.es * slot * nf,
                                   st.fptr("d4_b", st.grad) if want_dbias else None,
                                   st.fptr("final_w", st.grad) if want_wgrad else None, part, L.stream_ptr())
         if rc == L.DG_EUNSUPPORTED:
             return False   # (nothing was launched; the bump allocation is simply re-used by the next take after the flush)
         L.check(rc, "dg_final_gan_bwd")
+        self._e4_done(slot, nsl)
         if part is not None:
             WGRAD_WS.add(part, st.fptr("d4_b", st.grad), C4, nf // C4, 1)
         return True
@@ -1353,5 +1455,5 @@ class DEngine:
         """dwf += s_f * sum_b coef[b] * h4[slot+b]"""
         o, lib = self.ops, L.lib()
         nf = self.per[4]
-        L.check(lib.dg_batch_wsum(L.ptr(self.h[4]) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n,
+        L.check(lib.dg_batch_wsum(L.ptr(self._h4(slot, n)) + o.es * slot * nf, o.dt, L.ptr(coef), 1.0 / math.sqrt(nf), n,
                                   nf, st.fptr("final_w", st.grad), L.stream_ptr()), "dg_batch_wsum")

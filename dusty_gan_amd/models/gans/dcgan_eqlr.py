@@ -152,9 +152,11 @@ class Generator(_EngineNet):
 
     def engine(self):
         x3 = bool(getattr(self, "fp32_split", False))   # (set by the Trainer on ITS networks: fp32x3 parity mode)
-        if self._eng is None or self._eng.dtype != self.compute_dtype or self._eng.ops.x3 != (x3 and self.compute_dtype == torch.float32):
+        x2 = bool(getattr(self, "fp32_pairs", False))   # (... with split-bf16 storage of the fat feature maps: DG_BF16X2)
+        if (self._eng is None or self._eng.dtype != self.compute_dtype
+                or self._eng.ops.x3 != (x3 and self.compute_dtype == torch.float32) or self._eng.x2_asked != x2):
             cfg = E.NetCfg(self.shape, self.in_ch, self.chs, self.masker, self.ring, self.tau, self.drop_const)
-            self._eng = E.GEngine(cfg, self.compute_dtype, x3=x3)
+            self._eng = E.GEngine(cfg, self.compute_dtype, x3=x3, x2=x2)
         self._eng.cfg.tau, self._eng.cfg.drop_const = float(self.tau), float(self.drop_const)
         return self._eng
 
@@ -205,9 +207,11 @@ class Discriminator(_EngineNet):
 
     def engine(self):
         x3 = bool(getattr(self, "fp32_split", False))
-        if self._eng is None or self._eng.dtype != self.compute_dtype or self._eng.ops.x3 != (x3 and self.compute_dtype == torch.float32):
+        x2 = bool(getattr(self, "fp32_pairs", False))
+        if (self._eng is None or self._eng.dtype != self.compute_dtype
+                or self._eng.ops.x3 != (x3 and self.compute_dtype == torch.float32) or self._eng.x2_asked != x2):
             cfg = E.NetCfg(self.shape, 1, self.chs, "none", self.ring, dis_in_ch=self.in_ch)
-            self._eng = E.DEngine(cfg, self.compute_dtype, x3=x3)
+            self._eng = E.DEngine(cfg, self.compute_dtype, x3=x3, x2=x2)
         return self._eng
 
     def forward(self, x):

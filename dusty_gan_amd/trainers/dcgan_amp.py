@@ -245,6 +245,10 @@ def _own_counters(fn):
 
 
 class Trainer:
+    # fp32x3 mode: split-bf16 storage of the fat feature maps (set False for the register-splitting kernels of round 4: A/B
+    # measurements, tests of that path)
+    fp32_pairs_default = True
+
     def __init__(self, cfg, local_cfg, loader=None):
         self.counters = L.CounterQueue()   # this trainer's queued Philox / Adam / pool counter advances (never another trainer's)
         with L.Counters.bind(self.counters):
@@ -339,8 +343,15 @@ class Trainer:
         # engines pass DG_FORCE_FP32X3 with every launch (nothing process-wide; a second trainer of another precision in the
         # same process keeps its own kernels)
         self.fp32_split = (not self.enable_amp) and os.environ.get("DUSTY_GAN_FP32_SPLIT", "0") == "1"
+        # ... and keep the fat layers' feature maps as split-bf16 PAIRS (DG_BF16X2: hi | lo halves per 64 channels, 4 bytes per
+        # element like fp32), so that those layers run on the bf16 kernels of the timed path - the ping-pong conv and the LDS-DMA
+        # weight gradient, three K steps per real one - instead of the register-splitting one-tile kernels.  One rank only: the
+        # data-parallel schedule ships Proj's operands as raw buffers.
+        self.fp32_pairs = (self.fp32_split and Trainer.fp32_pairs_default and _world() == 1
+                           and os.environ.get("DUSTY_GAN_FORCE_SEG", "0") != "1")
         for net in (_backbone(self.G), self.D, _backbone(self.G_ema)):
             net.fp32_split = self.fp32_split
+            net.fp32_pairs = self.fp32_pairs
 
         # resume (reference :134-144)
         self.start_iteration = 0
@@ -495,7 +506,7 @@ class Trainer:
             from ..engine import GEngine
             bb = _backbone(self.G)
             first = bb.engine()
-            self._geng = [first] + [GEngine(first.cfg, self.dtype, x3=self.fp32_split) for _ in range(self.n_acc - 1)]
+            self._geng = [first] + [GEngine(first.cfg, self.dtype, x3=self.fp32_split, x2=self.fp32_pairs) for _ in range(self.n_acc - 1)]
         return self._geng
 
     def _sample_noise(self, B):
@@ -934,7 +945,7 @@ class Trainer:
         from ..engine import GEngine
         lib, sp = L.lib(), L.stream_ptr()
         if self._geng_pl is None:
-            self._geng_pl = GEngine(self._g_engines()[0].cfg, self.dtype, x3=self.fp32_split)
+            self._geng_pl = GEngine(self._g_engines()[0].cfg, self.dtype, x3=self.fp32_split, x2=self.fp32_pairs)
         geng = self._geng_pl
         nz = int(self.cfg.model.gen.in_ch)
         if inj is not None:

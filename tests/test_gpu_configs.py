@@ -135,15 +135,20 @@ def test_timed_mode_gradients_tight_against_emulating_oracle(trace, arch):
     _check(res[0], tr, state, **BF16_EMU)
 
 
-@pytest.mark.parametrize("x3", [False, True], ids=["fp32", "fp32x3"])
-def test_hip_path_matches_reference_at_full_width(monkeypatch, x3):
+@pytest.mark.parametrize("x3,pairs", [(False, False), (True, True), (True, False)], ids=["fp32", "fp32x3", "fp32x3-register-split"])
+def test_hip_path_matches_reference_at_full_width(monkeypatch, x3, pairs):
     """The HIP fp32 path against what the REFERENCE's own modules computed at 64x1024 / 512 channels (dusty2, B = 2, one
     step): digests from tests/golden/full_dusty2.npz, inputs regenerated from its seed.  Outputs, logits, losses 1e-4;
     gradients 2e-2 on the digests (a unit within fp32 rounding of zero takes the other slope in the two
     implementations - tests/test_gpu_step.py::test_step_fp32_vs_oracle_full_width_64x1024); updated parameters 1e-3.
     fp32x3: the same bounds with the fat layers' contractions on the bf16 matrix instructions (operands split into bf16
-    hi + lo, DG_FORCE_FP32X3 on every launch of this trainer's engines) - the fast parity mode of `bench.py --precision fp32x3`."""
+    hi + lo, DG_FORCE_FP32X3 on every launch of this trainer's engines) - the fast parity mode of `bench.py --precision fp32x3`:
+    with the fat feature maps STORED as split-bf16 pairs (DG_BF16X2, round 5: the bf16 ping-pong conv and LDS-DMA weight
+    gradient contract the halves in three K steps; what the mode runs) and with fp32 storage and the split made in registers
+    by the one-tile kernels (round 4's form, `Trainer.fp32_pairs_default = False`)."""
     monkeypatch.setenv("DUSTY_GAN_FP32_SPLIT", "1" if x3 else "0")
+    from dusty_gan_amd.trainers.dcgan_amp import Trainer
+    monkeypatch.setattr(Trainer, "fp32_pairs_default", pairs)
     g = load("full_dusty2")
     if str(g["meta/torch"]) != torch.__version__:
         pytest.skip(f"fixture made with torch {g['meta/torch']}: the regenerated inputs need the same CPU generator")
@@ -154,6 +159,7 @@ def test_hip_path_matches_reference_at_full_width(monkeypatch, x3):
     assert abs(tr.ema_decay - float(g["meta/ema_decay"])) < 1e-12
     assert tr.fp32_split == x3
     assert tr.D.engine().ops.x3 == x3 and tr._g_engines()[0].ops.x3 == x3   # per engine: nothing process-wide to reset
+    assert tr.fp32_pairs == pairs and tr.D.engine().x2 == pairs and tr._g_engines()[0].x2 == pairs
     tr.G.load_state_dict(G)
     tr.G_ema.load_state_dict(G)
     sync_D(tr, D)
