@@ -23,10 +23,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  fp32x3: fp32 operands split into bf16 hi + lo, two
-# v_mfma_f32_32x32x16_bf16 per 4 k of an fp32 fragment (8 of their 32 k-slots carry distinct products... 4 useful k per 2 x 16):
-# 1/8 of the bf16 rate in fp32-equivalent FLOPs
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 312.5}
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  fp32x3: every product is three bf16 products
+# (x_hi w_hi + x_lo w_hi + x_hi w_lo on operands stored as split-bf16 pairs, DG_BF16X2): a third of the bf16 rate in
+# fp32-equivalent FLOPs.  (Round 4 split fp32 operands in registers, two half-used matrix instructions per 4 k: 1/8.)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 833.3}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -36,7 +36,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", choices=["bf16", "fp32", "fp32x3"], default="bf16",
-                    help="bf16: the timed mode; fp32: exact parity mode; fp32x3: fp32 storage, split-bf16 matrix instructions")
+                    help="bf16: the timed mode; fp32: exact parity mode; fp32x3: fp32 parameters, split-bf16 pairs on the bf16 kernels")
     ap.add_argument("--arch", choices=["none", "dusty1", "dusty2"], default=None,
                     help="default: BASELINE configs[1] (dcgan_eqlr baseline) at every N - one weak-scaling series; dusty2 = configs[3]'s model")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
@@ -614,8 +614,9 @@ def main():
             "tolerance is met by --precision fp32 (gradients <= 5e-3, cosine >= 0.99999: tests/test_gpu_configs.py); two runs "
             "from one seed are bit-identical (tests/test_gpu_timed_path.py)"
             if args.precision == "bf16" else
-            ("fp32x3: fp32 storage, operands split into bf16 hi + lo on the bf16 matrix instructions, fp32 accumulation: held to "
-             "the fp32 mode's bounds against the reference digests at full width (tests/test_gpu_configs.py)"
+            ("fp32x3: fp32 parameters and accumulation, the fat layers' feature maps and weight shadows stored as split-bf16 pairs "
+             "(hi + lo, 16 mantissa bits; DG_BF16X2) and contracted as three bf16 products on the timed path's own kernels: held to "
+             "the fp32 mode's bounds against the reference digests at full width (tests/test_gpu_configs.py, tests/test_gpu_x2.py)"
              if args.precision == "fp32x3" else "fp32 parity mode: <= 1e-3 against the oracle / reference fixtures"))
     if (rank == 0 and world == 1 and not args.no_other_configs and args.arch is None and args.shape == [64, 1024]
             and args.batch == 32 and args.precision == "bf16" and args.pl == 0.0 and args.gp == 1.0 and not args.no_augment):

@@ -87,10 +87,29 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
   if (p.bias)
     for (int j = 0; j < 4; ++j) bias[j] = p.bias[(n + j) % p.bias_mod];
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool x2fast = p.out_dtype == DG_BF16X2 && p.out_sn == 1;   // four consecutive channels: 8 bytes of hi, 8 bytes of lo
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int X = n0 + pg * 4 + i;
     const long o = (long)b * p.out_sb + ((long)Y * p.Wc + X) * p.out_sp + (long)n * p.out_sn;
+    if (x2fast) {
+      const long q = dg_x2_index(o);
+      uint2 ah = make_uint2(0, 0);
+      if (p.epi == EPI_MASK) ah = *(const uint2*)((const unsigned short*)p.aux + q);   // (the sign lives in the hi half)
+      const unsigned aw[4] = {ah.x << 16, ah.x & 0xffff0000u, ah.y << 16, ah.y & 0xffff0000u};
+      unsigned hw[4], lw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = dg_epilogue(acc[i][j], p.scale, p.epi, bias[j], __builtin_bit_cast(float, aw[j]));
+        const bf16 h = (bf16)v;
+        hw[j] = __builtin_bit_cast(unsigned short, h);
+        lw[j] = __builtin_bit_cast(unsigned short, (bf16)(v - (float)h));
+        colsum[j] += v;
+      }
+      *(uint2*)((unsigned short*)p.out + q) = make_uint2(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16));
+      *(uint2*)((unsigned short*)p.out + q + 64) = make_uint2(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16));
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float auxv = p.epi == EPI_MASK ? dg_ld(p.aux, o + j * p.out_sn, p.out_dtype) : 0.f;
@@ -265,14 +284,28 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_kernel(WgradP p, int co_b
       for (int c = 0; c < CMAX; ++c) acc[i][c] = 0.f;
     const long gb = (long)b * p.g_sb + (long)m * p.Wc * p.g_sp + (long)(co_base + co) * p.g_sc;
     const float* row = s_a + (long)ky * ncol * CMAX;
+    auto walk = [&](auto loadg) __attribute__((always_inline)) {
 #pragma unroll 4
-    for (int x = 0; x < p.Wc; ++x) {
-      const float g = dg_ld(p.g, gb + (long)x * p.g_sp, p.g_dtype);
-      // input columns 2x-1 .. 2x+2 live at LDS columns 2x .. 2x+3
+      for (int x = 0; x < p.Wc; ++x) {
+        const float g = loadg(x);
+        // input columns 2x-1 .. 2x+2 live at LDS columns 2x .. 2x+3
 #pragma unroll
-      for (int kx = 0; kx < 4; ++kx)
+        for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) acc[kx][c] += g * row[(2 * x + kx) * CMAX + c];
+          for (int c = 0; c < CMAX; ++c) acc[kx][c] += g * row[(2 * x + kx) * CMAX + c];
+      }
+    };
+    if (p.g_dtype == DG_BF16X2 && p.g_sc == 1 && p.g_sp % 64 == 0) {
+      // split-bf16 gradient rows: the pixel stride is whole channel groups, so the (hi, lo) pair of this thread's channel
+      // moves by a constant 2 g_sp halves per pixel (the generic dg_ld redoes the 64-bit index split per element)
+      const unsigned short* gq = (const unsigned short*)p.g + dg_x2_index(gb);
+      const long gs2 = 2 * p.g_sp;
+      walk([&](int x) {
+        const unsigned short* q = gq + (long)x * gs2;
+        return __builtin_bit_cast(float, (unsigned)q[0] << 16) + __builtin_bit_cast(float, (unsigned)q[64] << 16);
+      });
+    } else {
+      walk([&](int x) { return dg_ld(p.g, gb + (long)x * p.g_sp, p.g_dtype); });
     }
     const float rs = p.rowscale ? p.rowscale[b] : 1.f;
 #pragma unroll
@@ -324,23 +357,35 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_kernel(WgradP p, int ci_bas
 #pragma unroll
       for (int c = 0; c < NMAX; ++c) acc[i][c] = 0.f;
     // sliding window over the input row: a[x-1], a[x], a[x+1] (circular)
-    float am = dg_ld(p.a, ab + (long)(p.Wc - 1) * p.a_sp, p.a_dtype);
-    float a0 = dg_ld(p.a, ab, p.a_dtype);
+    auto walk = [&](auto loada) __attribute__((always_inline)) {
+      float am = loada(p.Wc - 1);
+      float a0 = loada(0);
 #pragma unroll 4
-    for (int x = 0; x < p.Wc; ++x) {
-      const int xn = x + 1 == p.Wc ? 0 : x + 1;
-      const float ap = dg_ld(p.a, ab + (long)xn * p.a_sp, p.a_dtype);
-      // kx=1: (px 0, a[x]); kx=3: (px 0, a[x-1]); kx=0: (px 1, a[x+1]); kx=2: (px 1, a[x])
+      for (int x = 0; x < p.Wc; ++x) {
+        const int xn = x + 1 == p.Wc ? 0 : x + 1;
+        const float ap = loada(xn);
+        // kx=1: (px 0, a[x]); kx=3: (px 0, a[x-1]); kx=0: (px 1, a[x+1]); kx=2: (px 1, a[x])
 #pragma unroll
-      for (int c = 0; c < NMAX; ++c) {
-        const float g0 = grow[(2 * x) * NMAX + c], g1 = grow[(2 * x + 1) * NMAX + c];
-        acc[1][c] += a0 * g0;
-        acc[3][c] += am * g0;
-        acc[0][c] += ap * g1;
-        acc[2][c] += a0 * g1;
+        for (int c = 0; c < NMAX; ++c) {
+          const float g0 = grow[(2 * x) * NMAX + c], g1 = grow[(2 * x + 1) * NMAX + c];
+          acc[1][c] += a0 * g0;
+          acc[3][c] += am * g0;
+          acc[0][c] += ap * g1;
+          acc[2][c] += a0 * g1;
+        }
+        am = a0;
+        a0 = ap;
       }
-      am = a0;
-      a0 = ap;
+    };
+    if (p.a_dtype == DG_BF16X2 && p.a_sc == 1 && p.a_sp % 64 == 0) {   // (as in thin_wgrad_down: constant stride between pairs)
+      const unsigned short* aq = (const unsigned short*)p.a + dg_x2_index(ab);
+      const long as2 = 2 * p.a_sp;
+      walk([&](int x) {
+        const unsigned short* q = aq + (long)x * as2;
+        return __builtin_bit_cast(float, (unsigned)q[0] << 16) + __builtin_bit_cast(float, (unsigned)q[64] << 16);
+      });
+    } else {
+      walk([&](int x) { return dg_ld(p.a, ab + (long)x * p.a_sp, p.a_dtype); });
     }
     const float rs = p.rowscale ? p.rowscale[b] : 1.f;
 #pragma unroll

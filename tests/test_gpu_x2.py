@@ -345,3 +345,37 @@ def test_proj_gemms_go_through_fp32_copies(L):
     o.wgrad(2, 1, 1, 1, B, N, K, out_x, (0, N, 1), z.view(-1), (0, K, 1), dw_x.data_ptr(), s, accumulate=0)
     torch.cuda.synchronize()
     assert torch.equal(dw_f, dw_x)
+
+
+def test_whole_step_split_storage_equals_register_split(monkeypatch):
+    """One whole training step (dusty2, 64x1024, 512 / 64..512 channels, R1 + DiffAugment + path-length regulariser: every pass
+    of both engines incl. the tangent and forward-over-reverse walks, trainers/dcgan_amp.py:162-325) in the fp32x3 mode with
+    the fat feature maps stored as split-bf16 pairs against the same mode with fp32 storage and the split made in registers
+    (round 4's kernels), same parameters, batches and randomness - and both against the fp32 oracle at the fp32 mode's bounds.
+    B = 4: the 64-column maps tile into the ping-pong conv's 256-row tiles (four samples' segments); the path-length walk
+    runs at B / 2 = 2, where those layers fall back to the direct kernels on the same split buffers."""
+    from dusty_gan_amd.trainers.dcgan_amp import Trainer
+    from tests.test_gpu_step import FP32_GRAD_COS, FP32_GRAD_TOL, _cos, run_both
+    monkeypatch.setenv("DUSTY_GAN_FP32_SPLIT", "1")
+    out = {}
+    for pairs in (True, False):
+        monkeypatch.setattr(Trainer, "fp32_pairs_default", pairs)
+        tr, state, res = run_both("dusty2", (64, 1024), 512, 64, 512, 4, amp=False, pl=2.0, sync=True)
+        assert tr.fp32_split and tr.fp32_pairs == pairs and tr.D.engine().x2 == pairs and tr._g_engines()[0].x2 == pairs
+        out[pairs] = res[0]
+        del tr
+    (ref_a, ex_a, synth_a, gD_a, gG_a, scal_a), (_, _, synth_b, gD_b, gG_b, scal_b) = out[True], out[False]
+    for va, vb in zip(scal_a, scal_b):
+        assert abs(va - vb) <= 1e-4 * max(1.0, abs(vb)), (scal_a, scal_b)
+    for k in synth_a:
+        if k != "mask":
+            assert rel_l2(synth_a[k], synth_b[k]) < 1e-4, k
+    for ga, gb, tag in ((gD_a, gD_b, "D"), (gG_a, gG_b, "G")):
+        for k in ga:
+            if ga[k].numel() <= 4:     # (one-element head bias gradients: sums that cancel to 1e-3 of their absolute sum)
+                assert rel_l2(ga[k], gb[k]) < 6e-2, (tag, k)
+                continue
+            assert rel_l2(ga[k], gb[k]) < FP32_GRAD_TOL and _cos(ga[k], gb[k]) > FP32_GRAD_COS, (tag, k, rel_l2(ga[k], gb[k]))
+    # ... and the split-storage step against the oracle's gradients
+    for k, v in gD_a.items():
+        assert rel_l2(v, ex_a["grad_D"][k]) < FP32_GRAD_TOL, ("oracle D", k, rel_l2(v, ex_a["grad_D"][k]))
