@@ -780,12 +780,20 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_mfma_kernel(WgradP p, int g
 // The table is one per device: launches that use it must be ordered on one stream (they are: the step is one stream).
 typedef __attribute__((ext_vector_type(4))) float tw_f32x4;
 __device__ __attribute__((aligned(16))) unsigned char g_up_frag[UP_FRAG_BYTES];  // [class][frag][64 lanes][16 B]
+__device__ __attribute__((aligned(16))) unsigned char g_up_frag_lo[UP_FRAG_BYTES];   // (X2: the lo halves of the folded fp32 weights)
 
 // class 0 interior (built at m = 1), 1 first row, 2 last row (thin_up_frag.h)
 __global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
   const bf16* w = (const bf16*)p.w;
   up_frag_element(blockIdx.y, blockIdx.x * 256 + threadIdx.x, p.N, p.Hc, p.adj,
                   [&](int tap, int n, int ci) { return (float)w[(long)tap * p.w_st + (long)n * p.w_sn + ci]; }, g_up_frag);
+}
+// X2 (fp32 weights, split-bf16 input): both tables, blockIdx.z = 0 hi / 1 lo
+__global__ __launch_bounds__(256) void thin_up_prep_x2_kernel(ConvP p) {
+  const float* w = (const float*)p.w;
+  auto ld = [&](int tap, int n, int ci) { return w[(long)tap * p.w_st + (long)n * p.w_sn + ci]; };
+  if (blockIdx.z == 0) up_frag_element<false>(blockIdx.y, blockIdx.x * 256 + threadIdx.x, p.N, p.Hc, p.adj, ld, g_up_frag);
+  else up_frag_element<true>(blockIdx.y, blockIdx.x * 256 + threadIdx.x, p.N, p.Hc, p.adj, ld, g_up_frag_lo);
 }
 
 #define TU_PX 64
@@ -798,10 +806,15 @@ __global__ __launch_bounds__(256) void thin_up_prep_kernel(ConvP p) {
 // per tile - made one round trip to memory PER PIECE (a loop the compiler did not unroll: load, s_waitcnt vmcnt(0),
 // ds_write) plus two per epilogue, ~5 us per tile; pipelining that design took it from 40 to 30 us, and it stayed bound
 // by the 3x re-read.
+// X2 (round 5, the fp32x3 mode's Head forward / Down1 backward-data): the input is DG_BF16X2 (a pixel = 128 bytes of hi + 128 bytes
+// of lo), the weights fp32: rows are staged with both halves, the weight fragments exist twice (hi / lo of the folded fp32
+// weights, thin_up_prep_x2_kernel) and every k-step is three matrix instructions, w_hi x_hi + w_hi x_lo + w_lo x_hi.
+template <bool X2>
 __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x, int nseg) {
-  constexpr int RB = 144;                                            // LDS pixel stride: 128 B of channels + 16 B
+  constexpr int PPP = X2 ? 16 : 8;                                   // 16-byte pieces per pixel
+  constexpr int RB = PPP * 16 + 16;                                  // LDS pixel stride: the pixel's bytes + 16 B
   constexpr int RPX = TU_PX + 2, ROWB = RPX * RB;                    // a staged row: the tile's pixels + halo
-  constexpr int NLD = (RPX * 8 + 255) / 256;                         // 16-byte pieces per thread and row (the last partial)
+  constexpr int NLD = (RPX * PPP + 255) / 256;                       // 16-byte pieces per thread and row (the last partial)
   __shared__ __attribute__((aligned(16))) unsigned char s_in[4 * ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -813,19 +826,19 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   const int xt = logical % tiles_x, sg = (logical / tiles_x) % nseg, b = logical / (tiles_x * nseg);
   const int m0 = sg * TU_RS, m1 = m0 + TU_RS < Hc ? m0 + TU_RS : Hc;
-  const char* in = (const char*)((const bf16*)p.in + (long)b * p.in_sb);
+  const char* in = (const char*)p.in + (long)b * p.in_sb * (X2 ? 4 : 2);
   const int col = lane & 15, kg = lane >> 4;
-  const unsigned spb = (unsigned)p.in_sp * 2u;                       // bytes per pixel
-  unsigned goff[NLD], loff[NLD];                                     // piece u of a row: pixel (tid >> 3) + 32 u, channel piece tid & 7
+  const unsigned spb = (unsigned)p.in_sp * (X2 ? 4u : 2u);           // bytes per pixel
+  unsigned goff[NLD], loff[NLD];                                     // piece u of a row: pixel tid / PPP + (256 / PPP) u, piece tid % PPP
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
-    const int px = (tid >> 3) + 32 * u;
+    const int px = tid / PPP + (256 / PPP) * u;
     int cc = xt * TU_PX - 1 + px;
     if (cc < 0) cc += Wc; else if (cc >= Wc) cc -= Wc;
-    goff[u] = (unsigned)cc * spb + (tid & 7) * 16;
-    loff[u] = px * RB + (tid & 7) * 16;
+    goff[u] = (unsigned)cc * spb + (tid % PPP) * 16;
+    loff[u] = px * RB + (tid % PPP) * 16;
   }
-  const bool last_ok = (tid >> 3) + 32 * (NLD - 1) < RPX;
+  const bool last_ok = tid / PPP + (256 / PPP) * (NLD - 1) < RPX;
   auto fetch_row = [&](int r, tw_u32x4 (&st)[NLD]) __attribute__((always_inline)) {
     r = r < 0 ? 0 : (r >= Hc ? Hc - 1 : r);                          // rows outside the grid carry zero weights
     const char* row = in + (unsigned)(r * Wc) * spb;
@@ -854,9 +867,9 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
     e_bias[h] = p.bias ? p.bias[n % p.bias_mod] : 0.f;
   }
   int cls = -1;
-  tw_bf16x8 fa[18];
+  tw_bf16x8 fa[18], fal[X2 ? 18 : 1];
   // the caller's fragments (kept current with its shadows) or the ones thin_up_prep_kernel has just built
-  const unsigned char* frags = p.up_frag ? (const unsigned char*)p.up_frag : g_up_frag;
+  const unsigned char* frags = (p.up_frag && !X2) ? (const unsigned char*)p.up_frag : g_up_frag;
   __syncthreads();
   const int xl = wave * 16 + col;                                    // this lane's pixel inside the tile
   const int x = xt * TU_PX + xl;
@@ -868,6 +881,10 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
       cls = mcls;
 #pragma unroll
       for (int f = 0; f < 18; ++f) fa[f] = *(const tw_bf16x8*)(frags + ((cls * 18 + f) * 64 + lane) * 16);
+      if constexpr (X2) {
+#pragma unroll
+        for (int f = 0; f < 18; ++f) fal[f] = *(const tw_bf16x8*)(g_up_frag_lo + ((cls * 18 + f) * 64 + lane) * 16);
+      }
     }
     tw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -879,6 +896,14 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
         const tw_bf16x8 b1 = *(const tw_bf16x8*)(rowp + d * RB + 64);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 0], b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 1], b1, acc, 0, 0, 0);
+        if constexpr (X2) {
+          const tw_bf16x8 l0 = *(const tw_bf16x8*)(rowp + d * RB + 128);
+          const tw_bf16x8 l1 = *(const tw_bf16x8*)(rowp + d * RB + 192);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 0], l0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(rr * 3 + d) * 2 + 1], l1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[(rr * 3 + d) * 2 + 0], b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[(rr * 3 + d) * 2 + 1], b1, acc, 0, 0, 0);
+        }
       }
     }
     // D: column = pixel (lane & 15), rows 4 kg + j  ->  m' = 4 kg + j = (py * N + n) * 2 + px
@@ -903,7 +928,9 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
 
 int dg_conv_up_mfma_supported(const ConvP* p) {
   if (p->mode != MODE_UP || !p->ring) return 0;
-  if (p->in_dtype != DG_BF16 || p->w_dtype != DG_BF16) return 0;
+  const bool x2 = p->in_dtype == DG_BF16X2;        // split-bf16 input, fp32 weights, fp32 / bf16 output (the fp32x3 mode)
+  if (x2 ? (p->w_dtype != DG_F32 || p->out_dtype == DG_BF16X2 || p->in_sp % 64 != 0 || p->in_sb % 64 != 0 || ((size_t)p->in & 255))
+         : (p->in_dtype != DG_BF16 || p->w_dtype != DG_BF16)) return 0;
   if (p->K != 64 || p->N < 1 || p->N > 4 || p->Wc % TU_PX != 0 || p->Hc < 2) return 0;
   if (p->in_sk != 1 || p->w_sk != 1 || p->in_sp % 8 != 0 || p->in_sb % 8 != 0) return 0;
   if (p->epi != EPI_LINEAR || p->dbias) return 0;
@@ -913,13 +940,16 @@ int dg_conv_up_mfma_supported(const ConvP* p) {
 int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_up_mfma_supported(p)) return DG_EUNSUPPORTED;
   if (p->up_frag && ((size_t)p->up_frag & 15)) return DG_EINVAL;
-  if (!p->up_frag) thin_up_prep_kernel<<<dim3(UP_FRAG_BLOCKS, 3), 256, 0, s>>>(*p);
+  const bool x2 = p->in_dtype == DG_BF16X2;
+  if (x2) thin_up_prep_x2_kernel<<<dim3(UP_FRAG_BLOCKS, 3, 2), 256, 0, s>>>(*p);
+  else if (!p->up_frag) thin_up_prep_kernel<<<dim3(UP_FRAG_BLOCKS, 3), 256, 0, s>>>(*p);
   // (a column-walker variant with an LDS-DMA row ring that fetched every input row once instead of three times measured
   //  within noise of this kernel on the step - 0.277 vs 0.282 ms for the family - and was removed in round 2)
   const int tiles_x = p->Wc / TU_PX, nseg = (p->Hc + TU_RS - 1) / TU_RS;
   const long blocks = (long)p->B * nseg * tiles_x;
   if (blocks >= (1L << 31)) return DG_EUNSUPPORTED;
-  thin_up_mfma_kernel<<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, nseg);
+  if (x2) thin_up_mfma_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, nseg);
+  else thin_up_mfma_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(*p, tiles_x, nseg);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

@@ -11,7 +11,9 @@ constexpr int UP_FRAG_BYTES = 3 * 18 * 1024;
 constexpr int UP_FRAG_BLOCKS = 36;               // blocks of 256 elements per class
 
 // element e (0 .. 9215) of class cls; w(tap, n, ci) -> the bf16-rounded weight as float
-template <typename LoadW>
+// LO (the split-bf16 form of the fp32x3 mode: w returns the fp32 weight): the table of lo = bf16(v - bf16(v)) beside the table of
+// hi = bf16(v), v the folded fp32 weight
+template <bool LO = false, typename LoadW>
 __device__ __forceinline__ void up_frag_element(int cls, int e, int N, int Hc, int adj, LoadW w, unsigned char* frag) {
   const int m = cls == 0 ? 1 : (cls == 1 ? 0 : Hc - 1);
   if (cls == 0 && Hc < 3) return;
@@ -32,5 +34,5 @@ __device__ __forceinline__ void up_frag_element(int cls, int e, int N, int Hc, i
       }
     }
   }
-  *(bf16*)(frag + (((cls * 18 + f) * 64 + l) * 8 + j) * 2) = (bf16)v;
+  *(bf16*)(frag + (((cls * 18 + f) * 64 + l) * 8 + j) * 2) = LO ? (bf16)(v - (float)(bf16)v) : (bf16)v;
 }

@@ -266,7 +266,7 @@ def test_network_ends_on_the_thin_kernels(L, nheads):
     o.conv(L.MODE_UP, 0, True, B, H, W, C, nheads, xf, (H * W * C, C, 1), ref, (nheads * HW, 1, HW), wd.data_ptr(), 0.25,
            L.EPI_LINEAR, bias=b.to(DEV).data_ptr(), bias_mod=nheads, out_dt=L.DG_F32)
     torch.cuda.synchronize()
-    assert rel_l2(out.cpu(), ref.cpu()) < 1e-6
+    assert rel_l2(out.cpu(), ref.cpu()) < TOL      # (the split input on thin_up_mfma<X2>: three bf16 products per product)
     # Head backward-data: K = nheads (fp32, planar) -> N = 64 split-bf16, EPI_MASK with a split mask source + bias-gradient sums
     gy = torch.randn(B, nheads, 2 * H, 2 * W, generator=g).to(DEV)
     auxf = torch.randn(B * H * W * C, generator=g)
@@ -316,7 +316,7 @@ def test_network_ends_on_the_thin_kernels(L, nheads):
                 dw.data_ptr(), 0.2)
         torch.cuda.synchronize()
         outs[form] = (dst.cpu(), dw.cpu())
-    assert rel_l2(outs["x2"][0], outs["f32"][0]) < 1e-6 and rel_l2(outs["x2"][1], outs["f32"][1]) < 1e-6
+    assert rel_l2(outs["x2"][0], outs["f32"][0]) < TOL and rel_l2(outs["x2"][1], outs["f32"][1]) < 1e-6
 
 
 def test_proj_gemms_go_through_fp32_copies(L):
