@@ -157,8 +157,8 @@ class ParamStore:
             return
         key = (self.shadow.data_ptr(),) + tuple(self.coci[name].data_ptr() for name, _ in fat)
         if getattr(self, "_x2_key", None) != key:   # (first use, or the fp32 shadows moved: new twins, new registrations)
-            self._x2_key = key
             self._drop_x2()
+            self._x2_key = key
             for name, s in fat:
                 self.x2_cico[name] = tag_x2(torch.empty(s.numel, dtype=torch.float32, device=self.flat.device))
                 self.x2_coci[name] = tag_x2(torch.empty(s.numel, dtype=torch.float32, device=self.flat.device))
