@@ -119,10 +119,40 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
     }
   }
   if (p.dbias) {
+    // the block's 64 channel sums in a fixed order (16 pixel groups per channel through LDS), then - with the caller's staging
+    // scratch (DgConv.dbias_ws, zero on entry and left zero) - order-independent across blocks: 32.32 fixed-point integer
+    // adds onto 64 staging words, a ticket, and the LAST block adds the totals onto dbias once (round 5: the fp32 modes'
+    // bias gradients of Down1 / Up3 were float atomics in arrival order)
+    __syncthreads();                              // (s_in is dead: its first 16 x 64 floats hold the partial rows)
+    float* part = &s_in[0][0][0];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(&s_db[cg * 4 + j], colsum[j]);
+    for (int j = 0; j < 4; ++j) part[pg * 64 + cg * 4 + j] = colsum[j];
     __syncthreads();
-    if (tid < 64) atomicAdd(&p.dbias[(n_base + tid) % p.bias_mod], s_db[tid] * (p.rowscale ? p.rowscale[b] : 1.f));
+    if (tid < 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += part[r * 64 + tid];
+      v *= p.rowscale ? p.rowscale[b] : 1.f;
+      if (p.dbias_ws && fabsf(v) < 2147483000.f) {
+        unsigned long long* w = (unsigned long long*)p.dbias_ws;
+        atomicAdd(&w[tid], (unsigned long long)__double2ll_rn((double)v * 4294967296.0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (memory-side atomics acknowledged before the ticket is drawn)
+      } else {
+        atomicAdd(&p.dbias[(n_base + tid) % p.bias_mod], v);
+      }
+    }
+    if (p.dbias_ws) {
+      __shared__ unsigned s_ticket;
+      __syncthreads();
+      if (tid == 0) s_ticket = atomicAdd((unsigned*)((unsigned long long*)p.dbias_ws + 64), 1u);
+      __syncthreads();
+      if (s_ticket == gridDim.x - 1 && tid < 64) {
+        unsigned long long* w = (unsigned long long*)p.dbias_ws;
+        const long long tot = (long long)atomicExch(&w[tid], 0ull);
+        atomicAdd(&p.dbias[(n_base + tid) % p.bias_mod], (float)((double)tot * (1.0 / 4294967296.0)));
+        if (tid == 0) atomicExch((unsigned*)(w + 64), 0u);
+      }
+    }
   }
 }
 
@@ -313,11 +343,16 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_kernel(WgradP p, int co_b
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) tot[i][c] += rs * acc[i][c];
   }
+  // p.ws: the block's partial tile with plain stores (summed by dg_wgrad_reduce in a fixed order) instead of atomics on dw
+  float* wsb = p.ws ? p.ws + (long)blockIdx.x * 16 * p.Ci * p.Co : nullptr;
 #pragma unroll
   for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-      if (c < p.Ci) atomicAdd(&p.dw[((long)(ky * 4 + kx) * p.Ci + c) * p.Co + co_base + co], tot[kx][c] * p.scale);
+      if (c < p.Ci) {
+        const long o = ((long)(ky * 4 + kx) * p.Ci + c) * p.Co + co_base + co;
+        if (wsb) wsb[o] = tot[kx][c] * p.scale; else atomicAdd(&p.dw[o], tot[kx][c] * p.scale);
+      }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -393,11 +428,15 @@ __global__ __launch_bounds__(256) void thin_wgrad_up_kernel(WgradP p, int ci_bas
 #pragma unroll
       for (int c = 0; c < NMAX; ++c) tot[i][c] += rs * acc[i][c];
   }
+  float* wsb = p.ws ? p.ws + (long)blockIdx.x * 16 * p.Ci * p.Co : nullptr;   // (as thin_wgrad_down)
 #pragma unroll
   for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
     for (int c = 0; c < NMAX; ++c)
-      if (c < p.Co) atomicAdd(&p.dw[((long)(ky * 4 + kx) * p.Ci + ci_base + ci) * p.Co + c], tot[kx][c] * p.scale);
+      if (c < p.Co) {
+        const long o = ((long)(ky * 4 + kx) * p.Ci + ci_base + ci) * p.Co + c;
+        if (wsb) wsb[o] = tot[kx][c] * p.scale; else atomicAdd(&p.dw[o], tot[kx][c] * p.scale);
+      }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1063,7 +1102,12 @@ static int wgrad_down_rows_pb(const WgradP* p) {
   return ((long)p->B * p->Hc >= 2048 && p->Hc % 4 == 0) ? 4 : WG_ROWS_PB;
 }
 // Partial tiles (= blocks) of the launch when the kernel that runs has the workspace form (DgWgrad.ws: plain-store partials
-// of 16 Ci Co floats each, summed by dg_wgrad_reduce): the two matrix-core kernels, single-pass launches.  0: no such form.
+// of 16 Ci Co floats each, summed by dg_wgrad_reduce): the two matrix-core kernels (single-pass launches) and, round 5, the
+// VALU kernels of the fp32 modes (one partial tile per block of their <= 1024-block grid).  0: no such form.
+static unsigned wgrad_valu_grid(const WgradP* p) {
+  const long units = (long)p->B * p->Hc;
+  return units < 1024 ? (unsigned)units : 1024u;
+}
 int dg_wgrad_thin_ws_splits(const WgradP* p) {
   if (!dg_wgrad_thin_supported(p)) return 0;
   const long units = (long)p->B * p->Hc;
@@ -1072,7 +1116,7 @@ int dg_wgrad_thin_ws_splits(const WgradP* p) {
   else if (wgrad_up_mfma_ok(p)) {
     const bool one_pass = p->Co <= 2 || (wgrad_up_pairs(p) == 2 && wgrad_up_mfma_lds(p) == wgrad_up_mfma_lds_np(p, 2));
     if (one_pass) nb = units / WGU_ROWS_PB;
-  }
+  } else if (!p->g_mod) nb = wgrad_valu_grid(p);
   return nb > 0 && nb <= 65536 ? (int)nb : 0;
 }
 
@@ -1081,7 +1125,7 @@ int dg_wgrad_thin_launch(const WgradP* p, hipStream_t s) {
   if (p->ws && !dg_wgrad_thin_ws_splits(p)) return DG_EUNSUPPORTED;
   if (p->g_mod && !wgrad_down_mfma_ok(p)) return DG_EUNSUPPORTED;   // only thin_wgrad_down_mfma has the sample map
   const long units = (long)p->B * p->Hc;
-  unsigned grid = units < 1024 ? (unsigned)units : 1024u;
+  const unsigned grid = wgrad_valu_grid(p);
   if (wgrad_down_mfma_ok(p)) {
     const size_t lds = wgrad_down_mfma_lds(p);
     const int Wf = 2 * p->Wc;

@@ -167,22 +167,27 @@ def test_graph_replay_matches_eager_at_bench_size(monkeypatch):
             assert abs(x[k] - y[k]) < tol * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
-@pytest.mark.parametrize("arch", ["none", "dusty2"])
-def test_two_runs_from_one_seed_are_bit_identical(monkeypatch, arch):
+@pytest.mark.parametrize("arch,amp", [("none", True), ("dusty2", True), ("dusty2", False)], ids=["none", "dusty2", "dusty2-fp32x3"])
+def test_two_runs_from_one_seed_are_bit_identical(monkeypatch, arch, amp):
     """SURVEY section 5 "determinism check by double-run", at the timed configuration (64x1024, bf16, B = 32; `none` =
     BASELINE config 2, `dusty2` = config 4's per-GPU share): two trainers built from one seed end five steps with IDENTICAL
     bits in G, D and G_ema - replayed from the hipGraph and launched eagerly, and the two forms agree with each other too.
     Rounds 1-4 ended such runs 1e-3 apart: bias-gradient sums and per-sample image sums / logits went through float atomics
     in arrival order, and Adam at beta1 = 0 turns a sign flip of a rounding-noise gradient into a +-lr step.  Round 5:
     per-workgroup partial rows summed in a fixed order (DgConv.dbias_part, dg_final_gan_bwd's dbias_part) and fixed-point
-    integer accumulation for the accumulator arena (dg_det_arena)."""
+    integer accumulation for the accumulator arena (dg_det_arena).  fp32x3: the parity-class mode with split-bf16 storage (B = 8)
+    - its fat layers run the same kernels in their DG_BF16X2 forms, the two-channel ends the fp32 VALU kernels, whose bias-gradient
+    sums (thin_smallk: fixed-point staging) and weight gradients (partial tiles through the split-K workspace) are
+    order-independent too."""
     from dusty_gan_amd import engine as E
     assert E.DETERMINISTIC
+    monkeypatch.setenv("DUSTY_GAN_FP32_SPLIT", "0" if amp else "1")
 
     def run(graph):
         monkeypatch.setenv("DUSTY_GAN_GRAPH", "1" if graph else "0")
         torch.manual_seed(4242)
-        tr = make_trainer(arch, True, (64, 1024), 512, 64, 512, 32, amp=True)
+        tr = make_trainer(arch, True, (64, 1024), 512, 64, 512, 32 if amp else 8, amp=amp)
+        assert amp or (tr.fp32_pairs and tr.D.engine().x2)
         sc = [dict(tr.step(i).items()) for i in range(5)]
         assert (tr._graph is not None) == graph
         torch.cuda.synchronize()
