@@ -345,10 +345,10 @@ class Trainer:
         self.fp32_split = (not self.enable_amp) and os.environ.get("DUSTY_GAN_FP32_SPLIT", "0") == "1"
         # ... and keep the fat layers' feature maps as split-bf16 PAIRS (DG_BF16X2: hi | lo halves per 64 channels, 4 bytes per
         # element like fp32), so that those layers run on the bf16 kernels of the timed path - the ping-pong conv and the LDS-DMA
-        # weight gradient, three K steps per real one - instead of the register-splitting one-tile kernels.  One rank only: the
-        # data-parallel schedule ships Proj's operands as raw buffers.
-        self.fp32_pairs = (self.fp32_split and Trainer.fp32_pairs_default and _world() == 1
-                           and os.environ.get("DUSTY_GAN_FORCE_SEG", "0") != "1")
+        # weight gradient, three K steps per real one - instead of the register-splitting one-tile kernels.  (The data-parallel
+        # schedule gathers Proj's gradient operand as raw bytes: whole 64-element groups per rank, so the gathered buffer is
+        # the same form - `_like`.)
+        self.fp32_pairs = self.fp32_split and Trainer.fp32_pairs_default
         for net in (_backbone(self.G), self.D, _backbone(self.G_ema)):
             net.fp32_split = self.fp32_split
             net.fp32_pairs = self.fp32_pairs
@@ -828,7 +828,7 @@ class Trainer:
             else:
                 dp0, zT, nloc = self._proj_operands(geng, B)
                 if self._gather is None or self._gather[0].numel() != self.world * zT.numel():
-                    self._gather = (zT.new_empty(self.world * zT.numel()), dp0.new_empty(self.world * dp0.numel()))
+                    self._gather = (zT.new_empty(self.world * zT.numel()), self._like(dp0, self.world * dp0.numel()))
                 zg, dg = self._gather
                 self._coll(lambda: (D_.all_gather_into(zg, zT), D_.all_gather_into(dg, dp0)), name="all-gather Proj operands")
             nbg = self.world * nloc
@@ -873,11 +873,17 @@ class Trainer:
         self._mb = []
         return scal
 
+    @staticmethod
+    def _like(src, n):
+        """an uninitialised buffer of n elements for rows of `src`, in src's storage form (split-bf16 pairs keep their tag)"""
+        t = src.new_empty(n)
+        return E.tag_x2(t) if E.is_x2(src) else t
+
     def _gather_bufs(self, geng, B):
         """static all-gather destinations for Proj's gradient operands (z rows, dL/da0 rows) of the global batch"""
         n = self.world * geng.zT.numel()
         if self._gather is None or self._gather[0].numel() != n:
-            self._gather = (geng.zT.new_empty(n), geng.dp[0].new_empty(self.world * geng.dp[0].numel()))
+            self._gather = (geng.zT.new_empty(n), self._like(geng.dp[0], self.world * geng.dp[0].numel()))
         return self._gather
 
     def launch_mode(self):
@@ -927,7 +933,7 @@ class Trainer:
         Bp = gp.ws_B
         n = B + 2 * Bp
         if getattr(self, "_cat", None) is None or self._cat[0].numel() != n * geng.dp[0].numel() // B:
-            self._cat = (geng.dp[0].new_empty(n * geng.dp[0].numel() // B), geng.zT.new_empty(n * geng.zT.numel() // B))
+            self._cat = (self._like(geng.dp[0], n * geng.dp[0].numel() // B), geng.zT.new_empty(n * geng.zT.numel() // B))
         d, z = self._cat
         nd, nzv = geng.dp[0].numel(), geng.zT.numel()
         d[:nd].copy_(geng.dp[0]); z[:nzv].copy_(geng.zT)

@@ -227,16 +227,19 @@ def test_two_ranks_segmented_graph_matches_eager(full):
     assert torch.equal(res[True][0]["G"], res[True][1]["G"])
 
 
-def test_forced_segments_single_process_match_one_graph(monkeypatch):
+@pytest.mark.parametrize("x3", [False, True], ids=["bf16", "fp32x3"])
+def test_forced_segments_single_process_match_one_graph(monkeypatch, x3):
     """DUSTY_GAN_FORCE_SEG=1: one process runs the multi-rank schedule (bucket order, chain-first G backward, operand
     gather, graph segments) with degenerate collectives - it must train like the single-graph replay at the benchmark's
-    size, bf16."""
+    size, bf16; and in the fp32x3 mode with split-bf16 storage (B = 8), where the gathered Proj operand is a DG_BF16X2 buffer."""
     from tests.test_gpu_step import make_trainer
+    monkeypatch.setenv("DUSTY_GAN_FP32_SPLIT", "1" if x3 else "0")
 
     def run(seg):
         monkeypatch.setenv("DUSTY_GAN_FORCE_SEG", "1" if seg else "0")
         torch.manual_seed(77)
-        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 32, amp=True)
+        tr = make_trainer("none", True, (64, 1024), 512, 64, 512, 8 if x3 else 32, amp=not x3)
+        assert tr.fp32_pairs == x3
         sc = [dict(tr.step(i).items()) for i in range(5)]
         segs = sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graph)
         return tr, sc, segs
