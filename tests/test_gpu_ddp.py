@@ -465,3 +465,49 @@ def test_bench_launches_its_own_ranks():
     assert out["distributed"]["exchanges_per_step"] == 4 and out["distributed"]["bytes_per_step"]["total"] > 0
     assert out["step_ms_device"]["p50"] > 0
     assert out["roofline"]["model_self_check"] == "ok" and 0 < out["roofline"]["step"]["frac"] < 1
+
+
+def x3_worker(rank, world, init_file, out_dir, pairs):
+    """the fp32x3 mode on two gloo ranks sharing the GPU (same seed on both: identical nets), device RNG, 3 steps"""
+    from dusty_gan_amd.trainers.dcgan_amp import Trainer
+    from tests.test_gpu_step import make_trainer
+    os.environ["DUSTY_GAN_FP32_SPLIT"] = "1"
+    Trainer.fp32_pairs_default = pairs
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world, timeout=PG_TIMEOUT)
+    torch.manual_seed(300)
+    tr = make_trainer("dusty2", True, (64, 1024), 128, 64, 256, 8, amp=False)
+    assert tr.fp32_pairs == pairs and tr.D.engine().x2 == pairs and tr._g_engines()[0].x2 == pairs
+    scal = [dict(tr.step(i).items()) for i in range(3)]
+    torch.cuda.synchronize()
+    torch.save({"G": tr.G.store.flat.cpu(), "D": tr.D.store.flat.cpu(), "E": tr.G_ema.store.flat.cpu(), "scal": scal,
+                "mode": tr.launch_mode()}, os.path.join(out_dir, f"x3_p{int(pairs)}_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_fp32x3_split_storage_keep_identical_replicas():
+    """The fp32x3 mode with split-bf16 storage under the data-parallel schedule on two real ranks (gloo, sharing the GPU): Proj's
+    gradient operand is all-gathered as raw bytes of DG_BF16X2 - two ranks' whole 64-element groups side by side are again that
+    form (checked on its own below) - and the gradient GEMM runs on the unpacked global batch.  The replicas must stay identical
+    to the bit, and the run must train like the same two ranks with fp32 storage (the register-split kernels): the first step's
+    scalars to 1e-4, three steps' parameters within 3e-3 (Adam at beta1 = 0 moves every element by ~lr per step whichever way its
+    gradient's sign falls: a wrong gradient operand would move half of Proj.weight the other way in the first step already)."""
+    from dusty_gan_amd import engine as E
+    g = torch.Generator().manual_seed(9)
+    parts = [torch.randn(3 * 64 * k, generator=g).cuda() for k in (5, 2)]
+    raw = torch.cat([E.x2_pack(t) for t in parts])
+    assert torch.equal(E.x2_unpack(E.tag_x2(raw)), torch.cat([E.x2_unpack(E.x2_pack(t)) for t in parts]))
+    with tempfile.TemporaryDirectory() as td:
+        for pairs in (True, False):
+            mp.spawn(x3_worker, args=(2, os.path.join(td, f"init{int(pairs)}"), td, pairs), nprocs=2, join=True)
+        a, b = (torch.load(os.path.join(td, f"x3_p1_r{r}.pt")) for r in range(2))
+        ref = torch.load(os.path.join(td, "x3_p0_r0.pt"))
+    for k in ("G", "D", "E"):
+        assert torch.equal(a[k], b[k]), k
+        assert bool(torch.isfinite(a[k]).all())
+        assert rel_l2(a[k], ref[k]) < 3e-3, (k, rel_l2(a[k], ref[k]))
+    for k in a["scal"][0]:
+        assert abs(a["scal"][0][k] - ref["scal"][0][k]) < 1e-4 * max(1.0, abs(ref["scal"][0][k])), k
+    for x, y in zip(a["scal"], ref["scal"]):
+        for k in x:
+            assert abs(x[k] - y[k]) < 2e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
