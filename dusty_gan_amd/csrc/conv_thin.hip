@@ -23,7 +23,10 @@
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------
-// thin_smallk: block = (b, coarse row Y, 64 output columns); thread = 4 pixels x 4 channels (N == 64 per pass).
+// thin_smallk: block = (b, coarse row Y), walking the row's 64-column tiles; thread = 4 pixels x 4 channels (N == 64 per pass).
+// (Round 5: one block per TILE re-loaded the pass's 16 x K x 64 weights and rebuilt the tap list for every 64 pixels and made
+// three dependent round trips to memory per 16 KB of output - 141 us for Down1 forward at 64 samples in the fp32x3 mode.  A block
+// now keeps weights and taps for the whole row and has the next tile's input window in flight, in registers, while it computes.)
 #define SK_PX 64
 template <int KMAX>
 __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, int n_base) {
@@ -32,10 +35,7 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
   __shared__ int s_tap[1 + 2 * 6];
   __shared__ float s_db[64];
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  const int xt = bid % tiles_x; bid /= tiles_x;
-  const int Y = bid % p.Hc, b = bid / p.Hc;
-  const int n0 = xt * SK_PX;
+  const int Y = blockIdx.x % p.Hc, b = blockIdx.x / p.Hc;
   const int Wf = 2 * p.Wc;
   if (tid == 0) {
     int nt = 0;
@@ -54,15 +54,45 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
   __syncthreads();
   const int ntap = s_tap[0];
   const int ncol = 2 * SK_PX + 2;
-  for (int i = tid; i < ntap * ncol * p.K; i += 256) {
-    const int k = i % p.K, c = (i / p.K) % ncol, t = i / (p.K * ncol);
-    int col = 2 * n0 - 1 + c;
-    if (col < 0) col += Wf; else if (col >= Wf) col -= Wf;
-    s_in[t][c][k] = dg_ld(p.in, (long)b * p.in_sb + ((long)s_tap[1 + 2 * t] * Wf + col) * p.in_sp + (long)k * p.in_sk,
-                          p.in_dtype);
+  // the window of a tile: element i = (tap row t, column c, channel k), NPRE per thread; decoded once (the tile only moves c)
+  constexpr int NPRE = (6 * (2 * SK_PX + 2) * KMAX + 255) / 256;
+  const int nst = ntap * ncol * p.K;
+  int pc[NPRE], pl[NPRE];                         // window column, LDS index
+  long pg_[NPRE];                                  // source offset without the column
+  float pre[NPRE];
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int i = tid + 256 * u;
+    const int k = i % p.K, c = (i / p.K) % ncol, t = min(i / (p.K * ncol), 5);
+    pc[u] = c;
+    pl[u] = (t * ncol + c) * KMAX + k;
+    pg_[u] = (long)b * p.in_sb + (long)s_tap[1 + 2 * (i < nst ? t : 0)] * Wf * p.in_sp + (long)k * p.in_sk;
   }
-  __syncthreads();
+  auto fetch = [&](int xt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      if (tid + 256 * u >= nst) continue;
+      int col = 2 * xt * SK_PX - 1 + pc[u];
+      if (col < 0) col += Wf; else if (col >= Wf) col -= Wf;
+      pre[u] = dg_ld(p.in, pg_[u] + (long)col * p.in_sp, p.in_dtype);
+    }
+  };
+  fetch(0);
   const int cg = tid & 15, pg = tid >> 4;  // 4 channels, 4 pixels
+  const int n = n_base + cg * 4;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias)
+    for (int j = 0; j < 4; ++j) bias[j] = p.bias[(n + j) % p.bias_mod];
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool x2fast = p.out_dtype == DG_BF16X2 && p.out_sn == 1;   // four consecutive channels: 8 bytes of hi, 8 bytes of lo
+  for (int xt = 0; xt < tiles_x; ++xt) {
+  const int n0 = xt * SK_PX;
+  __syncthreads();                                // (the previous tile's reads of s_in are done)
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u)
+    if (tid + 256 * u < nst) (&s_in[0][0][0])[pl[u]] = pre[u];
+  __syncthreads();
+  if (xt + 1 < tiles_x) fetch(xt + 1);            // in flight during this tile's arithmetic and stores
   float acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -82,12 +112,6 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
       }
     }
   }
-  const int n = n_base + cg * 4;
-  float bias[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias)
-    for (int j = 0; j < 4; ++j) bias[j] = p.bias[(n + j) % p.bias_mod];
-  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool x2fast = p.out_dtype == DG_BF16X2 && p.out_sn == 1;   // four consecutive channels: 8 bytes of hi, 8 bytes of lo
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int X = n0 + pg * 4 + i;
@@ -118,6 +142,7 @@ __global__ __launch_bounds__(256) void thin_smallk_kernel(ConvP p, int tiles_x, 
       colsum[j] += v;
     }
   }
+  }   // tiles of the row
   if (p.dbias) {
     // the block's 64 channel sums in a fixed order (16 pixel groups per channel through LDS), then - with the caller's staging
     // scratch (DgConv.dbias_ws, zero on entry and left zero) - order-independent across blocks: 32.32 fixed-point integer
@@ -1023,7 +1048,7 @@ int dg_conv_thin_launch(const ConvP* p, hipStream_t s) {
   if (dg_conv_up_mfma_supported(p)) return dg_conv_up_mfma_launch(p, s);
   if (p->mode == MODE_S2) {
     const int tiles_x = p->Wc / SK_PX;
-    const unsigned grid = (unsigned)((long)p->B * p->Hc * tiles_x);
+    const unsigned grid = (unsigned)((long)p->B * p->Hc);   // a block walks the tiles of one output row
     for (int nb = 0; nb < p->N; nb += 64) {
       if (p->K <= 2) thin_smallk_kernel<2><<<grid, 256, 0, s>>>(*p, tiles_x, nb);
       else thin_smallk_kernel<4><<<grid, 256, 0, s>>>(*p, tiles_x, nb);
