@@ -322,6 +322,27 @@ __global__ __launch_bounds__(256) void thin_wgrad_down_kernel(WgradP p, int co_b
   for (long u = u0; u < u1; ++u) {
     const int b = (int)(u / p.Hc), m = (int)(u % p.Hc);
     __syncthreads();
+    if (CMAX == 2 && p.Ci == 2 && p.a_dtype == DG_F32 && p.a_sc == 1 && p.a_sp == 2 && p.a_sb % 4 == 0 && ((size_t)p.a & 15) == 0) {
+      // the two-channel fp32 image (Down1 in the fp32 modes): a row is 2 Wf contiguous floats - 16-byte loads of two pixels
+      // instead of a scalar load with two integer divisions per element (32 per thread and row set at Wf = 1024)
+      const float* A = (const float*)p.a + (long)b * p.a_sb;
+      for (int i = tid; i < 4 * (Wf / 2); i += 256) {
+        const int j = i % (Wf / 2), kk = i / (Wf / 2);
+        int ra, rg;
+        dg_wgrad1d(0, 0, m, p.Hc, kk, ra, rg);
+        const float4 v = *(const float4*)(A + ((long)ra * Wf + 2 * j) * 2);
+        float* d = s_a + ((long)kk * ncol + 2 * j + 1) * 2;          // (column cc lives at LDS column cc + 1: 8-byte aligned)
+        *(float2*)d = make_float2(v.x, v.y);
+        *(float2*)(d + 2) = make_float2(v.z, v.w);
+      }
+      if (tid < 8) {                                                  // the circular halo: column -1 = Wf - 1, column Wf = 0
+        const int kk = tid >> 1, hi = tid & 1;
+        int ra, rg;
+        dg_wgrad1d(0, 0, m, p.Hc, kk, ra, rg);
+        const float2 v = *(const float2*)(A + ((long)ra * Wf + (hi ? 0 : Wf - 1)) * 2);
+        *(float2*)(s_a + ((long)kk * ncol + (hi ? Wf + 1 : 0)) * 2) = v;
+      }
+    } else
     for (int i = tid; i < 4 * ncol * p.Ci; i += 256) {
       const int c = i % p.Ci, col = (i / p.Ci) % ncol, kk = i / (p.Ci * ncol);
       int ra, rg;
