@@ -141,6 +141,12 @@ class ParamStore:
             self.x2 = True
             self._seen_version = -1   # (the next refresh_shadows builds them)
 
+    def __del__(self):   # (the twin registry is keyed by device pointers: a dead store must not leave its entries behind)
+        try:
+            self._drop_x2()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def _drop_x2(self):
         for t in list(self.x2_cico.values()) + list(self.x2_coci.values()):
             for k in [k for k, v in X2_TWIN.items() if v == t.data_ptr()]:
