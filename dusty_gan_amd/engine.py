@@ -75,11 +75,12 @@ class ParamStore:
         return buf[s.off:s.off + s.numel].view(s.shape)
 
     def apply(self, fn):
+        aliased = self.shadow is self.flat          # (fp32: the shadow is the master itself)
         self.flat = fn(self.flat)
         for k in ("grad", "m", "v", "shadow"):
             t = getattr(self, k)
             if t is not None:
-                setattr(self, k, fn(t))
+                setattr(self, k, self.flat if (k == "shadow" and aliased) else fn(t))
         self.coci = {k: fn(v) for k, v in self.coci.items()}
         self._drop_x2()
         self._tdesc = None  # the descriptor table holds the old pointers
@@ -124,12 +125,15 @@ class ParamStore:
             return
         lib, st = L.lib(), L.stream_ptr()
         if self.shadow is None or self.shadow_dtype != dtype or self.shadow.device != self.flat.device:
-            self.shadow = torch.empty(self.n, dtype=dtype, device=self.flat.device)
+            # fp32: the "[tap][ci][co] shadow in T" IS the master - no second 280 MB buffer, no copy here, and the optimizer's
+            # shadow store lands on the line it has just written (round 5; rounds 1-4 kept and rewrote a copy every step)
+            self.shadow = self.flat if dtype == torch.float32 else torch.empty(self.n, dtype=dtype, device=self.flat.device)
             self.coci = {}
             self._tdesc = None
             self.up_frags = {}
             self.shadow_dtype = dtype
-        L.check(lib.dg_cast(L.ptr(self.flat), L.ptr(self.shadow), L.dtype_code(dtype), self.n, st), "dg_cast")
+        if self.shadow is not self.flat:
+            L.check(lib.dg_cast(L.ptr(self.flat), L.ptr(self.shadow), L.dtype_code(dtype), self.n, st), "dg_cast")
         self.refresh_transposed()
         self._seen_version = ver
 

@@ -214,7 +214,8 @@ class FlatAdam:
         # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
         L.check(lib.dg_adam_ema_step_dev(L.ptr(st.flat) + 4 * off, L.ptr(st.grad) + 4 * off,
                                          None if m_ptr is None else m_ptr + 4 * off, L.ptr(st.v) + 4 * off,
-                                         None if ema_ptr is None else ema_ptr + 4 * off, L.ptr(st.shadow) + ses * off,
+                                         None if ema_ptr is None else ema_ptr + 4 * off,
+                                         None if st.shadow is st.flat else L.ptr(st.shadow) + ses * off,   # (fp32: the master IS the shadow)
                                          sdt, st.n - off, gscale, self.lr, self.betas[0],
                                          self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
                 "dg_adam_ema_step_dev")
@@ -585,7 +586,15 @@ class Trainer:
         self._coll(wait, name="wait " + "+".join(keys))
 
     def _cap_open(self):
-        import os
+        import gc
+        # No cyclic garbage collection while a capture is open: a collection that starts in the middle of it may finalize objects
+        # of EARLIER trainers - their hipGraphs, tensors of their private pools - and destroying a graph or freeing pool memory
+        # from inside a capturing thread aborts the process (round 5: torch 2.10's graph context no longer collects on entry,
+        # and the suite died in whichever test the allocation counters happened to trigger it).  Collect now, outside.
+        if self._cap_cur is None and not getattr(self, "_gc_was_on", None):
+            gc.collect()
+            self._gc_was_on = gc.isenabled()
+            gc.disable()
         g = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while this thread captures
         ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self._multi else "global")
@@ -602,6 +611,13 @@ class Trainer:
         if not any("is empty" in str(w.message) for w in caught):
             self._cap.append(g)
         self._cap_cur = None
+        self._gc_restore()
+
+    def _gc_restore(self):
+        import gc
+        if getattr(self, "_gc_was_on", None):
+            gc.enable()
+        self._gc_was_on = None
 
     def _bucketed(self):
         """multi-rank schedule (also with DUSTY_GAN_FORCE_SEG=1 in one process): bucketed, overlapped exchanges"""
@@ -1111,6 +1127,7 @@ class Trainer:
                 else:
                     E.WGRAD_WS.discard()
                 self._cap_cur = None
+                self._gc_restore()
                 L.Counters.pending.clear()  # (advances queued by the aborted capture were never going to run)
                 L.Counters.snap, L.Counters.ride = None, False
                 self._works.clear()
