@@ -675,3 +675,37 @@ def test_pool_index_follows_the_loader_when_something_else_draws_a_batch(monkeyp
     assert device_index() == tr.batches_drawn == 6
     tr.step(5)
     assert device_index() == tr.batches_drawn == 7
+
+
+def test_capture_survives_an_eager_garbage_collector():
+    """A cyclic-garbage collection that starts while the step is being captured can finalize an EARLIER trainer - its hipGraph,
+    the tensors of its private pool - and releasing those from inside a capturing thread aborts the process (seen once in this
+    suite, at whichever test the allocation counters chose).  `Trainer._cap_open` collects before the capture opens and keeps
+    the collector off until it closes.  Here: an old trainer with a captured graph is left in a reference cycle that survives
+    until the new trainer's capturing step (the collector is off until then), and that step runs with the collector set to fire
+    every few allocations.  (The abort itself is intermittent - one suite run in four without the guard, never in this small
+    case alone, scripts/probes/gc_in_capture.py - so this test pins the guard's bookkeeping: the garbage is gone before the
+    capture, the collector is back on after it, the step trains.)"""
+    import gc
+    thr, was_on = gc.get_threshold(), gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        old = make_trainer("none", True, (32, 256), 64, 16, 64, 4, amp=True)
+        for i in range(4):
+            old.step(i)
+        assert old._graph is not None
+        cycle = [old]
+        cycle.append(cycle)
+        del old, cycle                   # unreachable now, but only the cyclic collector can free it
+        tr = make_trainer("none", True, (32, 256), 64, 16, 64, 4, amp=True)
+        out = [dict(tr.step(i).items()) for i in range(2)]     # the two eager warm-up steps
+        gc.enable()
+        gc.set_threshold(5, 1, 1)
+        out += [dict(tr.step(i).items()) for i in range(2, 5)]  # capture + replays
+        assert tr._graph is not None and gc.isenabled()
+    finally:
+        gc.set_threshold(*thr)
+        if was_on:
+            gc.enable()
+    assert all(v == v for s in out for v in s.values())
