@@ -683,7 +683,7 @@ def test_capture_survives_an_eager_garbage_collector():
     suite, at whichever test the allocation counters chose).  `Trainer._cap_open` collects before the capture opens and keeps
     the collector off until it closes.  Here: an old trainer with a captured graph is left in a reference cycle that survives
     until the new trainer's capturing step (the collector is off until then), and that step runs with the collector set to fire
-    every few allocations.  (The abort itself is intermittent - one suite run in four without the guard, never in this small
+    every few allocations.  (The abort itself is intermittent - one suite run in about eight without the guard, never in this small
     case alone, scripts/probes/gc_in_capture.py - so this test pins the guard's bookkeeping: the garbage is gone before the
     capture, the collector is back on after it, the step trains.)"""
     import gc
