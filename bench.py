@@ -28,6 +28,7 @@ import torch.distributed as dist  # noqa: E402
 # fp32-equivalent FLOPs.  (Round 4 split fp32 operands in registers, two half-used matrix instructions per 4 k: 1/8.)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x3": 833.3}
 PEAK_HBM_GBS = 8000.0
+PEAK_CLOCK_GHZ = 2.4   # the clock the dense peaks are quoted at
 
 
 def parse(argv=None):
@@ -49,6 +50,9 @@ def parse(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short lines for BASELINE configs 3 / 4-share / 5-share appended after the timed region")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each appended configuration")
+    ap.add_argument("--soak-steps", type=int, default=2000,
+                    help="replayed steps of the long window appended behind the timed region (N = 1 headline run; 0 = none)")
+    ap.add_argument("--no-clock", action="store_true", help="skip the held-clock probe (scripts/conv_clock.py on the diagnostic library)")
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the bounded CPU-oracle sample (default: the workload's own)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps of the CPU sample (~13 s of CPU work at batch 32)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU-oracle sample")
@@ -108,19 +112,30 @@ def step_model(shape, arch, gp, batch, es, P_G, P_D):
     return fl * batch, nbytes
 
 
-def roofline_pass(tr, steps=2):
+def roofline_pass(tr, steps=6):
     """Instrumented steps (HIP events on the launch stream around every conv / wgrad launch), run right after the
-    timed region on the same workload.  Returns the roofline object of the dominant kernel family."""
+    timed region on the same workload.  Every step issues the same launches in the same order, so each launch position has
+    `steps` samples: its time is their MEDIAN (round 5 summed two eager steps and read 9 % off the replayed step's kernel
+    trace on a box with a long tail).  Returns per family: ms / flops / bytes / launches PER STEP."""
     from dusty_gan_amd import engine as E
+    import statistics
     E.PROFILE = []
+    marks = [0]
     for i in range(steps):
         tr.step(i)
+        marks.append(len(E.PROFILE))
     torch.cuda.synchronize()
     rec, E.PROFILE = E.PROFILE, None
+    per = [rec[marks[i]:marks[i + 1]] for i in range(steps)]
+    n0 = len(per[0])
+    same = all(len(p) == n0 and all(a[0] == b[0] and a[5] == b[5] for a, b in zip(p, per[0])) for p in per)
+    if not same:   # (never seen; fall back to plain sums over the steps that look like the first)
+        per = [p for p in per if len(p) == n0] or per[:1]
     fam = {}
     detail = {}
-    for name, flops, nbytes, e0, e1, tag in rec:
-        ms = e0.elapsed_time(e1)
+    for k in range(n0):
+        name, flops, nbytes, _, _, tag = per[0][k]
+        ms = statistics.median(p[k][3].elapsed_time(p[k][4]) for p in per)
         d = detail.setdefault((name, tag), [0.0, 0.0, 0])
         d[0] += ms
         d[1] += flops
@@ -134,7 +149,61 @@ def roofline_pass(tr, steps=2):
         for (name, tag), (ms, fl, n) in sorted(detail.items(), key=lambda kv: -kv[1][0]):
             print(f"  {name:20s} {tag:40s} n={n:3d} avg {1e3 * ms / n:8.1f} us  {fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s",
                   file=sys.stderr)
+    for f in fam.values():
+        f["steps"] = len(per)
     return fam
+
+
+def soak(tr, steps):
+    """`steps` more replayed steps of the timed workload with a HIP event after each (same protocol as the timed region: the
+    previous step's scalars are read back while the next runs): the long window behind the K-step headline - percentiles of
+    the per-step device time and the wall-clock mean."""
+    import gc
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    gc.collect()
+    gc.disable()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    prev = None
+    for i in range(steps):
+        cur = tr.step(i)
+        marks[i + 1].record()
+        if prev is not None:
+            _ = list(prev.values())
+        prev = cur
+        if i % 100 == 99:
+            progress(f"soak step {i + 1}")      # (N > 1: the supervisor watches for progress lines)
+    _ = list(prev.values())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    q = lambda f: round(per[min(len(per) - 1, int(f * len(per)))], 4)
+    return {"steps": steps, "ms_per_step_wall": round(1e3 * dt / steps, 4), "seconds": round(dt, 2),
+            "step_ms_device": {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90), "p99": q(0.99), "min": round(per[0], 4),
+                               "max": round(per[-1], 4)}}
+
+
+def held_clock():
+    """the clock the chip holds inside the dominant conv kernel: scripts/conv_clock.py on the diagnostic build of the
+    library (built by __graft_entry__.build()), as a CHILD process after the timed region; None when that library is absent"""
+    import subprocess
+    diag = os.path.join(ROOT, "dusty_gan_amd", "csrc", "libdustygan_hip_diag.so")
+    if not os.path.exists(diag):
+        return None, "no diagnostic library (make -C dusty_gan_amd/csrc diag DIAGBITS=8)"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DUSTY_GAN_LIB_DIAG"] = "1"
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_clock.py"), "2"], capture_output=True,
+                             text=True, timeout=120, env=env)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not line:
+            return None, f"conv_clock.py exited {res.returncode}: {res.stderr[-200:]}"
+        r = json.loads(line[-1])
+        return r.get("clock_ghz"), r
+    except Exception as e:  # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
 
 
 def cpu_baseline(args, arch):
@@ -236,14 +305,18 @@ def other_config_lines(args):
     an out-of-memory kill or a hang in an appended configuration costs its own entry, never the headline record."""
     import subprocess
     out = {}
-    for tag, arch, shape, batch, prec in (("config3_dusty1_64x1024_b32", "dusty1", [64, 1024], 32, args.precision),
-                                          ("config4_share_dusty2_64x1024_b32", "dusty2", [64, 1024], 32, args.precision),
-                                          ("config5_share_dusty2_128x2048_b64", "dusty2", [128, 2048], 64, args.precision),
-                                          # the headline workload in the fast parity mode (<= 1e-3 tolerance class)
-                                          ("config2_none_64x1024_b32_fp32x3", "none", [64, 1024], 32, "fp32x3")):
+    for tag, arch, shape, batch, prec, gp, extra in (
+            ("config3_dusty1_64x1024_b32", "dusty1", [64, 1024], 32, args.precision, args.gp, []),
+            ("config4_share_dusty2_64x1024_b32", "dusty2", [64, 1024], 32, args.precision, args.gp, []),
+            ("config5_share_dusty2_128x2048_b64", "dusty2", [128, 2048], 64, args.precision, args.gp, []),
+            # SURVEY 8d, config 2 as BASELINE.json words it (no R1, no DiffAugment named): solver.loss.gp=0 solver.augment=[]
+            ("config2_nogp_noaug", "none", [64, 1024], 32, args.precision, 0.0, ["--no-augment"]),
+            # the headline workload in the fast parity mode (<= 1e-3 tolerance class)
+            ("config2_none_64x1024_b32_fp32x3", "none", [64, 1024], 32, "fp32x3", args.gp, [])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--arch", arch, "--shape", str(shape[0]), str(shape[1]),
                "--batch", str(batch), "--steps", str(args.other_steps), "--warmup", "5", "--precision", prec,
-               "--gp", str(args.gp), "--pl", str(args.pl), "--no-roofline", "--no-cpu-baseline", "--no-other-configs"]
+               "--gp", str(gp), "--pl", str(args.pl), "--no-roofline", "--no-cpu-baseline", "--no-other-configs",
+               "--soak-steps", "0", "--no-clock"] + extra
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
@@ -325,6 +398,30 @@ def supervise(args):
     pfx = f"dusty_bench/{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
     history = []
     tmp = tempfile.mkdtemp(prefix=f"dusty_bench_r{rank}_")
+    live = {"proc": None}
+
+    def _reap(signum=None, frame=None):
+        """the supervisor is going away (an exception in the poll loop, SIGTERM / SIGINT from the launcher's teardown): its
+        measuring child runs in a session of its own and would otherwise survive holding the GPU"""
+        if live["proc"] is not None and live["proc"].poll() is None:
+            _kill_group(live["proc"])
+        if signum is not None:
+            sys.exit(128 + signum)
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, _reap)
+        except (ValueError, OSError):   # (not the main thread: tests)
+            pass
+    try:
+        return _supervise_attempts(args, rank, world, stall, cap, first, child_cmd, store, pfx, history, tmp, live)
+    finally:
+        _reap()
+
+
+def _supervise_attempts(args, rank, world, stall, cap, first, child_cmd, store, pfx, history, tmp, live):
+    import socket
+    import subprocess
     for a in range(first, len(ATTEMPTS)):
         name, extra = ATTEMPTS[a]
         key = f"{pfx}/a{a}"
@@ -347,6 +444,7 @@ def supervise(args):
         t0 = time.time()
         with open(out_path, "w") as fout:
             proc = subprocess.Popen(cmd, env=env, stdout=fout, start_new_session=True)
+        live["proc"] = proc
         outcome, last_size, last_change = None, -1, t0
         while outcome is None:
             time.sleep(0.25)
@@ -426,6 +524,12 @@ def self_launch(args):
         return proc.wait(timeout=budget)
     except subprocess.TimeoutExpired:
         print(f"bench.py: the launcher did not finish within {budget:.0f} s; killing its process group", file=sys.stderr)
+        import signal
+        try:   # SIGTERM first: every supervisor's handler kills its measuring child's own session before it goes
+            os.killpg(proc.pid, signal.SIGTERM)
+            proc.wait(timeout=20)
+        except Exception:  # noqa: BLE001
+            pass
         _kill_group(proc)
         return 1
 
@@ -490,16 +594,18 @@ def main():
             progress(f"warm-up step {i}: {tr.launch_mode()}")
     if last is not None:
         _ = list(last.values())
-    sync()
-    progress("timed region")
     # per-step device times: one HIP event after every step on the launch stream (the replayed graph / the eager
     # launches of a step run on torch's current stream, so consecutive events bracket exactly one step)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     # no Python garbage-collection pass inside the timed region (one run of this script showed a single 12.6 ms step
-    # among 2.9 ms ones: a host-side stall, not device time)
+    # among 2.9 ms ones: a host-side stall, not device time).  All of this BEFORE the bracket's barrier + synchronize: the
+    # collection takes tens of milliseconds, and a GPU left idle that long starts the timed steps at a lower clock (round 6:
+    # the first steps of a 20-step window ran 5-15 % above the soak's median).
     import gc
     gc.collect()
     gc.disable()
+    progress("timed region")
+    sync()
     t0 = time.perf_counter()
     marks[0].record()
     prev = None
@@ -534,7 +640,8 @@ def main():
                                   "Adam+EMA, random-init weights",
                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
            "step_ms_device": {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90), "min": round(per[0], 4),
-                              "max": round(per[-1], 4), "note": "HIP events between consecutive steps, rank 0"},
+                              "max": round(per[-1], 4), "first_steps": [round(marks[i].elapsed_time(marks[i + 1]), 4) for i in range(min(5, args.steps))],
+                              "note": "HIP events between consecutive steps, rank 0"},
            "launch_mode": tr.launch_mode(),
            "scalars_last_step": {k: round(v, 5) for k, v in scal.items()}}
     if dist.is_initialized():
@@ -542,6 +649,16 @@ def main():
                               "devices_visible": torch.cuda.device_count()}
         out["distributed"]["attempt"] = (ATTEMPTS[int(os.environ["DUSTY_BENCH_ATTEMPT"])][0]
                                          if "DUSTY_BENCH_ATTEMPT" in os.environ else "unsupervised")
+        try:   # every rank's device identity, gathered: the record itself shows N distinct GPUs (or says that they are shared)
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            ident = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x} " \
+                    f"uuid={getattr(pr, 'uuid', '?')} {pr.name}"
+            idents = [None] * dist.get_world_size()
+            dist.all_gather_object(idents, ident)
+            out["distributed"]["devices"] = idents
+            out["distributed"]["distinct_devices"] = len(set(idents))
+        except Exception as e:  # noqa: BLE001
+            out["distributed"]["devices"] = f"not gathered ({type(e).__name__}: {e})"
         out["distributed"]["exchanges_per_step"] = 4  # D.hi, D.lo, G.gather (one coalesced pair), G.tail (+ the async scalars)
         try:
             out["distributed"]["bytes_per_step"] = tr.comm_bytes()
@@ -556,6 +673,15 @@ def main():
                                                              "(no host-side call to time); DUSTY_GAN_GRAPH_COMM=0 measures the segmented form")
         except Exception as e:  # noqa: BLE001
             out["distributed"]["exposed_ms_per_step"] = f"not measured ({type(e).__name__}: {e})"
+    if args.soak_steps > 0:
+        try:
+            progress("soak")
+            # (ranks sharing a device over gloo - a functional check, every exchange through the host - take ~0.1 s per step)
+            out["soak"] = soak(tr, args.soak_steps if (world == 1 or backend == "nccl") else min(args.soak_steps, 40))
+            out["soak"]["vs_timed_region"] = round(out["soak"]["ms_per_step_wall"] / ms, 4)
+            progress("soak done")
+        except Exception as e:  # noqa: BLE001  (instrumentation behind the timed region: never at the price of the line)
+            out["soak"] = {"error": f"{type(e).__name__}: {e}"}
     fl, f_g, f_d = flops_per_sample(args.shape, arch, args.gp)
     out["step_flops_fraction_of_mfma_peak"] = round(fl * args.batch * steps_s / 1e12 / PEAK_TFLOPS[args.precision], 4)
 
@@ -576,11 +702,21 @@ def main():
                                "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
                                "traffic_source": src, "kernel_source_sha": kernel_source_sha(),
                                "algorithmic_bytes_per_launch": round(f["bytes"] / f["n"]),
-                               "launches": f["n"], "avg_launch_us": round(1e3 * f["ms"] / f["n"], 2)}
+                               "launches": f["n"], "avg_launch_us": round(1e3 * f["ms"] / f["n"], 2),
+                               "timing": f"HIP events around every launch of {f['steps']} eager steps behind the timed region, "
+                                         "per-launch median, summed per step"}
             if traffic:
                 out["roofline"]["traffic_over_algorithmic"] = round(traffic / (f["bytes"] / f["n"]), 3)
+            if not args.no_clock and args.precision == "bf16" and name == "conv_mfma_kernel":
+                # what the peak is at the clock this chip holds inside this kernel (the 2.5 PFLOP/s of `peak` is 2.4 GHz)
+                ghz, info = held_clock()
+                out["roofline"]["clock_ghz"] = ghz
+                out["roofline"]["clock_source"] = info
+                if ghz:
+                    out["roofline"]["peak_at_held_clock"] = round(PEAK_TFLOPS[args.precision] * ghz / PEAK_CLOCK_GHZ, 1)
+                    out["roofline"]["frac_at_held_clock"] = round(tf / (PEAK_TFLOPS[args.precision] * ghz / PEAK_CLOCK_GHZ), 4)
             out["kernel_families"] = {
-                k: {"ms_per_step": round(v["ms"] / 2, 3), "launches_per_step": v["n"] // 2,
+                k: {"ms_per_step": round(v["ms"], 3), "launches_per_step": v["n"],
                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                     "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
             # the model checks itself: no family can run above either roof on its ALGORITHMIC work - if one does, the

@@ -81,9 +81,28 @@ class DgWgrad(C.Structure):
     ]
 
 
+XSUM_PARTS = 8   # DG_XSUM_PARTS of include/dusty_gan_hip.h
+
+
+class DgFetch(C.Structure):
+    _fields_ = [("pol", C.c_void_p), ("mask", C.c_void_p), ("pool_ctr", C.c_void_p), ("npool", C.c_int),
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("drop_const", C.c_float), ("B", C.c_int), ("HW", C.c_long),
+                ("out", C.c_void_p), ("parts", C.c_void_p)]
+
+
 class DgAugSet(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("xsum", C.c_void_p), ("u_b", C.c_void_p), ("u_c", C.c_void_p), ("t_h", C.c_void_p),
+    _fields_ = [("x", C.c_void_p), ("xsum", C.c_void_p), ("xsum_parts", C.c_int), ("u_b", C.c_void_p), ("u_c", C.c_void_p), ("t_h", C.c_void_p),
                 ("t_w", C.c_void_p), ("o_x", C.c_void_p), ("o_y", C.c_void_p)]
+
+
+class DgOptSeg(C.Structure):
+    _fields_ = [("off", C.c_longlong), ("numel", C.c_longlong), ("part", C.c_void_p), ("splits", C.c_int), ("accumulate", C.c_int),
+                ("kind", C.c_int), ("ci", C.c_int), ("co", C.c_int), ("shadow_t", C.c_void_p), ("ws_src", C.c_void_p),
+                ("ws_coef", C.c_void_p), ("ws_stride", C.c_longlong), ("ws_n", C.c_int), ("ws_bf16", C.c_int),
+                ("ws_scale", C.c_float), ("first_block", C.c_int)]
+
+
+OPT_MAX_SEG = 20   # DG_OPT_MAX_SEG
 
 
 class DgWgradPlan(C.Structure):
@@ -121,6 +140,7 @@ PROTOTYPES = {
     "dg_blur_fwd_mean": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "dg_blur_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "dg_blur_bwd_r1": [_P, _I, _P, _F, _P, _I, _I, _I, _I, _P],
+    "dg_blur_r1_tangent": [_P, _I, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "dg_final_fwd": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
     "dg_final_fwd_acc": [_P, _I, _P, _P, _F, _I, _L, _P, _P],
     "dg_final_bwd_data": [_P, _I, _P, _P, _P, _F, _I, _L, _I, _P, _P, _P],
@@ -183,12 +203,14 @@ PROTOTYPES = {
     "dg_aug_draw": [_U64, _U64, _U64, _I, _I, _I, _P, _P, _P],
     "dg_counter_add": [_P, _U64, _P],
     "dg_step_prologue": [_P, _P, _I, C.POINTER(DgDraw), _I, _P],
+    "dg_step_prologue_fetch": [_P, _P, _I, C.POINTER(DgDraw), _I, C.POINTER(DgFetch), _P],
     "dg_counter_add_multi": [_P, _P, _I, _P],
     "dg_counter_add_multi_snap": [_P, _P, _I, _I, _P, _I, _P, _I, _P],
     "dg_philox_fill_dev": [_U64, _U64, _P, _I, _F, _F, _I, _I, _L, _P, _P],
     "dg_aug_draw_dev": [_U64, _U64, _P, _I, _I, _I, _P, _P, _P],
     "dg_philox_logistic_dev": [_U64, _U64, _P, _F, _L, _P, _P],
     "dg_adam_ema_step_dev": [_P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _P, _F, _P],
+    "dg_adam_fused": [_P, _P, _P, _P, _P, _I, C.POINTER(DgOptSeg), _I, _F, _F, _F, _F, _P, _F, _P],
     "dg_adam_proj_fused": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _L, _I, _F, _F, _F, _F, _F, _P, _F, _P],
 }
 
@@ -204,6 +226,16 @@ def build(verbose=False):
     if verbose:
         print(res.stdout)
     return LIB_PATH
+
+
+def build_diag(bits=8):
+    """The diagnostic twin of the library (libdustygan_hip_diag.so: the ping-pong conv with cycle stamps; `make diag`).  Never
+    loaded by the product path, the tests or the timed region: scripts/conv_clock.py reads the clock the chip holds inside
+    the conv kernel from it (bench.py `roofline.clock_ghz`).  Returns its path, or None when the build fails (a missing
+    diagnostic library costs one key of the bench line, never the line)."""
+    res = subprocess.run(["make", "-C", CSRC, "diag", f"DIAGBITS={int(bits)}"], capture_output=True, text=True)
+    path = os.path.join(CSRC, "libdustygan_hip_diag.so")
+    return path if res.returncode == 0 and os.path.exists(path) else None
 
 
 def lib():
@@ -272,8 +304,9 @@ def zero_multi(tensors):
         check(lib().dg_zero_multi(ptrs, cnts, len(chunk), stream_ptr()), "dg_zero_multi")
 
 
-def step_prologue(tensors, draws):
-    """zero-fill up to 4 contiguous fp32 tensors and run up to 6 DgDraw jobs in ONE launch (dg_step_prologue)"""
+def step_prologue(tensors, draws, fetch=None):
+    """zero-fill up to 4 contiguous fp32 tensors and run up to 6 DgDraw jobs in ONE launch (dg_step_prologue); fetch: a DgFetch -
+    fetch_reals of the step's batch as more workgroups of the same launch (dg_step_prologue_fetch)"""
     import ctypes as C
     import torch
     ts = [t for t in tensors if t is not None and t.numel() > 0]
@@ -282,6 +315,10 @@ def step_prologue(tensors, draws):
     ptrs = (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
     cnts = (C.c_long * max(len(ts), 1))(*[t.numel() for t in ts])
     arr = (DgDraw * max(len(draws), 1))(*draws)
+    if fetch is not None:
+        check(lib().dg_step_prologue_fetch(ptrs, cnts, len(ts), arr, len(draws), C.byref(fetch), stream_ptr()),
+              "dg_step_prologue_fetch")
+        return
     check(lib().dg_step_prologue(ptrs, cnts, len(ts), arr, len(draws), stream_ptr()), "dg_step_prologue")
 
 
@@ -301,21 +338,22 @@ class AccArena:
         return dev.type == want.type and (want.index is None or dev.index == want.index)
 
     @classmethod
-    def begin(cls, device, also=(), draws=()):
+    def begin(cls, device, also=(), draws=(), fetch=None):
         """open a new epoch: the arena - and the fp32 buffers in `also` (the step's gradient buffers) - zero-filled by
-        one launch, which also runs the DgDraw jobs in `draws` (the step's parameter draws)"""
+        one launch, which also runs the DgDraw jobs in `draws` (the step's parameter draws) and, with `fetch` (a DgFetch),
+        fetch_reals of the step's batch"""
         import torch
         if cls.buf is None or not cls._same(cls.buf.device, device):
             cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
-            # bit-reproducible sums into the arena's slots (csrc/common.h dg_acc_add): a shadow of 16 bytes per float, zero at
+            # bit-reproducible sums into the arena's slots (csrc/common.h dg_acc_add): a shadow of 128 bytes per float, zero at
             # rest, registered with the library for this device; DUSTY_GAN_DETERMINISTIC=0 keeps the float atomics
             if os.environ.get("DUSTY_GAN_DETERMINISTIC", "1") != "0":
-                cls.shadow = torch.zeros(cls.SIZE * 4, dtype=torch.int32, device=device)
+                cls.shadow = torch.zeros(cls.SIZE * 32, dtype=torch.int32, device=device)   # DG_DET_STRIDE = 128 bytes per slot
                 torch.cuda.synchronize(cls.buf.device)
                 with torch.cuda.device(cls.buf.device):
                     check(lib().dg_det_arena(ptr(cls.buf), cls.SIZE, ptr(cls.shadow)), "dg_det_arena")
-        if draws:
-            step_prologue([cls.buf] + list(also), list(draws))
+        if draws or fetch is not None:
+            step_prologue([cls.buf] + list(also), list(draws), fetch)
         else:
             zero_multi([cls.buf] + list(also))
         cls.pos = 0
@@ -465,18 +503,23 @@ class Counters(metaclass=_CountersMeta):
                 check(lib().dg_counter_add_multi(ptrs, dels, len(chunk), stream_ptr()), "dg_counter_add_multi")
 
 
-def tag_sums(t, sums):
+def tag_sums(t, sums, parts=1):
     """remember on an image tensor the per-sample sums its producer kernel accumulated (DiffAugment's contrast reads them
-    instead of making its own pass) - valid while the arena epoch lasts and the tensor is not rewritten"""
-    t._dg_sums = (sums, AccArena.epoch, t._version)
+    instead of making its own pass) - valid while the arena epoch lasts and the tensor is not rewritten.  parts > 1: `sums` is
+    [B][parts] partial sums, to be added in index order (dg_step_prologue_fetch)"""
+    t._dg_sums = (sums, AccArena.epoch, t._version, int(parts))
     return t
 
 
-def tagged_sums(t):
+def tagged_sums(t, with_parts=False):
+    """the per-sample sums tagged on `t`, or None; with_parts: (sums, parts) - readers that only take one float per sample
+    (with_parts=False) see None for a tensor that carries partial sums"""
     tag = getattr(t, "_dg_sums", None)
     if tag is None or tag[1] != AccArena.epoch or tag[2] != t._version:
         return None
-    return tag[0]
+    if with_parts:
+        return tag[0], tag[3]
+    return tag[0] if tag[3] == 1 else None
 
 
 def policy_mask(policy):

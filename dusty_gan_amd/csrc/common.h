@@ -179,18 +179,22 @@ __device__ __forceinline__ float dg_wave_sum(float v) {
 
 // ---- deterministic cross-block sums (round 5).  A float atomicAdd from many blocks sums in arrival order: the last bits of
 // the total - a per-sample image sum, a logit - differ from run to run, and everything downstream with them.  For
-// accumulators inside the registered arena (dg_det_arena: the step's AccArena, plus a shadow of 16 bytes per float, zero at
-// rest) a block instead adds its partial as 32.32 FIXED POINT to the slot's 64-bit shadow word - integer addition is
+// accumulators inside the registered arena (dg_det_arena: the step's AccArena, plus a shadow of DG_DET_STRIDE bytes per float,
+// zero at rest) a block instead adds its partial as 32.32 FIXED POINT to the slot's 64-bit shadow word - integer addition is
 // associative, the order no longer matters - and takes a ticket; the block that draws the last ticket converts the total and
 // adds it to the float ONCE, leaving the shadow zero.  The integer add is acknowledged (s_waitcnt vmcnt(0): atomics execute
 // memory-side) before the ticket is taken, so the last ticket holder reads every contribution.  Range +-2^31, resolution
 // 2.3e-10 per contribution; a non-finite or larger partial reaches the float as it is (a NaN stays a NaN).  Anything outside
 // the arena, or with no arena registered, falls back to the float atomic.
+// One 128-byte line per slot (round 6): device-scope atomics execute memory-side and adds to ONE line serialise - with 16 bytes
+// per slot the 32 per-sample sums of a batch shared four lines, and every image-sized kernel that sums per sample paid 4-5 us
+// for its 512-1536 adds (scripts/bench_pointwise.py: head_post_fwd 10.6 us with sums, 6.9 without).
+#define DG_DET_STRIDE 128
 struct DgDet { float* base; unsigned long long* shadow; long n; };
 __device__ __forceinline__ void dg_acc_add(float* dst, float v, unsigned contributors, const DgDet d) {
   const long k = dst - d.base;
   if (d.shadow == nullptr || k < 0 || k >= d.n || contributors <= 1) { atomicAdd(dst, v); return; }
-  unsigned long long* acc = d.shadow + 2 * k;
+  unsigned long long* acc = d.shadow + (DG_DET_STRIDE / 8) * k;
   unsigned* ticket = (unsigned*)(acc + 1);
   if (!(fabsf(v) < 2147483000.f)) { atomicAdd(dst, v); v = 0.f; }
   const long long q = __double2ll_rn((double)v * 4294967296.0);
@@ -201,6 +205,29 @@ __device__ __forceinline__ void dg_acc_add(float* dst, float v, unsigned contrib
     atomicExch(ticket, 0u);
     atomicAdd(dst, (float)((double)tot * (1.0 / 4294967296.0)));
   }
+}
+
+// dg_acc_add that also tells its caller whether it drew the LAST ticket: 1 = last (total = the sum of all `contributors`
+// partials of this round, already added to *dst), 0 = not last, -1 = dst is outside the registered arena (a float atomic was
+// issued; nobody knows who is last).  For a second-level sum by the last contributors only (blur_r1_tangent_kernel's batch mean:
+// 32 adds to one word instead of 512).
+__device__ __forceinline__ int dg_acc_add_last(float* dst, float v, unsigned contributors, const DgDet d, float& total) {
+  const long k = dst - d.base;
+  if (d.shadow == nullptr || k < 0 || k >= d.n) { atomicAdd(dst, v); return -1; }
+  unsigned long long* acc = d.shadow + (DG_DET_STRIDE / 8) * k;
+  unsigned* ticket = (unsigned*)(acc + 1);
+  if (!(fabsf(v) < 2147483000.f)) { atomicAdd(dst, v); v = 0.f; }
+  const long long q = __double2ll_rn((double)v * 4294967296.0);
+  atomicAdd(acc, (unsigned long long)q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (atomicAdd(ticket, 1u) == contributors - 1) {
+    const long long tot = (long long)atomicExch(acc, 0ull);
+    atomicExch(ticket, 0u);
+    total = (float)((double)tot * (1.0 / 4294967296.0));
+    atomicAdd(dst, total);
+    return 1;
+  }
+  return 0;
 }
 
 // Block-wide sum (blockDim.x a multiple of 64, <= 1024); result valid in thread 0.

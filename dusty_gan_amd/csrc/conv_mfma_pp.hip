@@ -146,6 +146,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
   }
 
   const unsigned long long tk0 = (dbg & 8) ? pp_stamp() : 0ull;   // (diagnostic build: phases of the workgroup's lifetime)
+  // ... and the constant 100 MHz counter beside the shader-clock stamp: (tk2 - tk0) / (tr2 - tr0) x 100 MHz is the clock the
+  // chip HELD while this workgroup ran (MI355X_MICROARCH.md, DVFS give-back, check 6; scripts/conv_clock.py)
+  const unsigned long long tr0 = (dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int KC = p.K / 64;
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
   }
   pair_iter(std::false_type{}, true, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
   const unsigned long long tk2 = (dbg & 8) ? pp_stamp() : 0ull;
+  const unsigned long long tr2 = (dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (pending && !(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epilogue(tprev);
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvP p, Geo g, HTab ht
     float* ph = (float*)p.out + 64 + wave * 8;
     ph[0] = (float)(tk1 - tk0); ph[1] = (float)(tkf - tk0); ph[2] = (float)(tk2 - tk0); ph[3] = (float)(tk3 - tk0);
     ph[4] = (float)tcount;
+    ph[5] = (float)(tr2 - tr0);                // 100 MHz ticks over the same span as ph[2] (shader cycles): the held clock
   }
   // Both groups' FINAL epilogues run side by side: group A's last barrier (the one that pairs with group B's late start) is
   // the drain pair's last one, taken BEFORE its epilogue.  (Round 4 had it after group A's epilogue: group B, one barrier

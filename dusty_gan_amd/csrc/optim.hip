@@ -3,6 +3,7 @@
 #include "common.h"
 #include "thin_up_frag.h"
 #include <cstdlib>
+typedef __attribute__((ext_vector_type(4))) float f32x4_opt;
 
 // torch.optim.Adam (no weight decay / amsgrad) as configured at trainers/dcgan_amp.py:116-125, fused with
 // ema_inplace (:30-35) and with the T-typed shadow copy the conv kernels read.  All buffers are flat.
@@ -54,6 +55,178 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
         ((uint2*)shadow)[i] = pk;
       } else {
         ((float4*)shadow)[i] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: the optimizer of a network as ONE launch that also FORMS the gradients it consumes (reference:
+// trainers/dcgan_amp.py:238 / :312-316 - scaler.step(optim) + ema_inplace - behind loss.backward()'s last reductions).
+// Before: dg_batch_wsum (final conv's R1 term) -> dg_wgrad_reduce (sums the split-K partial tiles and the bias-gradient rows
+// into the gradient buffer) -> dg_adam_ema_step_dev (reads it back) -> dg_transpose_shadow_multi (re-reads the updated
+// master for the [tap][co][ci] shadows): four dependent launches, the gradient written and read once for nothing.
+// Here a workgroup owns a piece of the parameter buffer, sums that piece's partial tiles in a fixed order (bit-reproducible),
+// applies Adam (beta1 = 0: exp_avg is the gradient itself) + the EMA, and writes master, exp_avg_sq, EMA, the gradient (kept:
+// checkpoints rebuild exp_avg from it, tests read it), the compute-type shadow and - for the fat conv layers, whose piece is a
+// (tap, 32 ci x 32 co) tile - the transposed shadow through an LDS tile.
+//   kind 0  flat piece of 1024 elements, <= 64 partial rows summed per thread (8 loads in flight); optional extra term
+//           g += ws_scale * sum_b ws_coef[b] * ws_src[b][i] (the final conv's weight gradient from the R1 tangent, dg_batch_wsum)
+//   kind 2  flat piece of 64 elements whose > 64 partial rows are split over 16 thread groups and meet in LDS
+//   kind 1  conv tile: 1024 consecutive elements of a [16][Ci][Co] segment as (R ci rows) x (CW co columns), Co = 64 (R 16) or a
+//           multiple of 128 (R 8), Ci % R == 0; also writes the [16][Co][Ci] shadow
+typedef DgOptSeg OptSeg;               // (include/dusty_gan_hip.h)
+#define OPT_MAX_SEG DG_OPT_MAX_SEG
+struct OptSegs { OptSeg s[OPT_MAX_SEG]; int n; int total_blocks; };
+
+template <typename ST>
+__global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ grad, float* __restrict__ v,
+                                                         float* __restrict__ ema, ST* __restrict__ shadow, OptSegs segs,
+                                                         float gscale, float lr, float b2, float eps, float ema_decay,
+                                                         const unsigned long long* __restrict__ stepp) {
+  __shared__ f32x4_opt s_part[16][17];
+  __shared__ float tile[16 * 65 > 8 * 129 ? 16 * 65 : 8 * 129];   // kind 1: [R][CW + 1], (R, CW) = (16, 64) or (8, 128)
+  int k = 0;
+  for (int i = 1; i < segs.n; ++i)
+    if ((int)blockIdx.x >= segs.s[i].first_block) k = i;
+  const OptSeg& sg = segs.s[k];
+  const int blk = (int)blockIdx.x - sg.first_block;
+  const float t = (float)(*stepp + 1ull);
+  const float inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, t));
+  // Adam (beta1 = 0) + EMA + every store of four consecutive parameters at flat float4 index i4, given their gradient sum
+  auto update4 = [&](long i4, f32x4_opt g, float (&pn)[4]) {
+    const float4 v4 = ((const float4*)v)[i4];
+    const float4 p4 = ((const float4*)p)[i4];
+    const float4 e4 = ema ? ((const float4*)ema)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ((f32x4_opt*)grad)[i4] = g;
+    const float gg[4] = {g[0] * gscale, g[1] * gscale, g[2] * gscale, g[3] * gscale};
+    float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+    pn[0] = p4.x; pn[1] = p4.y; pn[2] = p4.z; pn[3] = p4.w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float vi = b2 * vv[q] + (1.f - b2) * gg[q] * gg[q];
+      vv[q] = vi;
+      pn[q] = pn[q] - lr * (gg[q] / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+      ev[q] = ema_decay * ev[q] + (1.f - ema_decay) * pn[q];
+    }
+    ((float4*)p)[i4] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    ((float4*)v)[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (ema) ((float4*)ema)[i4] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    if (shadow) {
+      if constexpr (sizeof(ST) == 2) {
+        const ST h[4] = {(ST)pn[0], (ST)pn[1], (ST)pn[2], (ST)pn[3]};
+        uint2 pk;
+        pk.x = (unsigned)__builtin_bit_cast(unsigned short, h[0]) | ((unsigned)__builtin_bit_cast(unsigned short, h[1]) << 16);
+        pk.y = (unsigned)__builtin_bit_cast(unsigned short, h[2]) | ((unsigned)__builtin_bit_cast(unsigned short, h[3]) << 16);
+        ((uint2*)shadow)[i4] = pk;
+      } else {
+        ((float4*)shadow)[i4] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+      }
+    }
+  };
+  // the sum of a piece's partial rows for the float4 at index e4 of the SEGMENT, rows sp0, sp0 + step, ... (8 loads in flight)
+  auto part_sum = [&](long e4, int sp0, int step) {
+    f32x4_opt acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_opt* src = (const f32x4_opt*)sg.part + e4;
+    const long stride = sg.numel / 4;
+    int sp = sp0;
+    for (; sp + 7 * step < sg.splits; sp += 8 * step) {
+      f32x4_opt r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = __builtin_nontemporal_load(src + (long)(sp + j * step) * stride);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += r[j];
+    }
+    for (; sp < sg.splits; sp += step) acc += __builtin_nontemporal_load(src + (long)sp * stride);
+    return acc;
+  };
+  if (sg.kind == 2) {
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long e4 = (long)blk * 16 + el;
+    const bool in = 4 * e4 < sg.numel;
+    s_part[grp][el] = in ? part_sum(e4, grp, 16) : f32x4_opt{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (grp == 0 && in) {
+      f32x4_opt g = s_part[0][el];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) g += s_part[j][el];
+      const long i4 = sg.off / 4 + e4;
+      if (sg.accumulate) g += ((const f32x4_opt*)grad)[i4];
+      float pn[4];
+      update4(i4, g, pn);
+    }
+    return;
+  }
+  if (sg.kind == 0) {
+    const long e4 = (long)blk * 256 + threadIdx.x;
+    if (4 * e4 >= sg.numel) return;
+    const long i4 = sg.off / 4 + e4;
+    f32x4_opt g = {0.f, 0.f, 0.f, 0.f};
+    if (sg.part) g = part_sum(e4, 0, 1);
+    if (sg.accumulate) g += ((const f32x4_opt*)grad)[i4];
+    if (sg.ws_src) {                               // + ws_scale * sum_b coef[b] * src[b][4 e4 .. 4 e4 + 3]
+      f32x4_opt w = {0.f, 0.f, 0.f, 0.f};
+      for (int b0 = 0; b0 < sg.ws_n; b0 += 8) {
+        f32x4_opt r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int b = b0 + j;
+          r[j] = f32x4_opt{0.f, 0.f, 0.f, 0.f};
+          if (b < sg.ws_n) {
+            if (sg.ws_bf16) {
+              const uint2 q = *(const uint2*)((const bf16*)sg.ws_src + (long)b * sg.ws_stride + 4 * e4);
+              r[j] = f32x4_opt{__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+                               __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u)};
+            } else {
+              r[j] = *(const f32x4_opt*)((const float*)sg.ws_src + (long)b * sg.ws_stride + 4 * e4);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (b0 + j < sg.ws_n) w += (sg.ws_coef ? sg.ws_coef[b0 + j] : 1.f) * r[j];
+      }
+      g += sg.ws_scale * w;
+    }
+    float pn[4];
+    update4(i4, g, pn);
+    return;
+  }
+  // kind 1: a tile of 1024 elements = R rows (ci) x CW columns (co) of one tap, CW = min(Co, 128), R = 1024 / CW: CONTIGUOUS
+  // runs of 4 CW bytes in the master and in every partial row (a first version walked 32 x 32 tiles - 128-byte runs - and
+  // summed the D network's 168 MB of partial tiles no faster than the reduce launch alone).  Thread = (row ty, columns 4 tx..).
+  const int Ci = sg.ci, Co = sg.co;
+  const int CW = Co < 128 ? Co : 128, R = 1024 / CW, tcw = Co / CW, tr = Ci / R;
+  int tt = blk;
+  const int tap = tt / (tr * tcw);
+  tt -= tap * tr * tcw;
+  const int ci0 = (tt / tcw) * R, co0 = (tt % tcw) * CW;
+  const int tx = threadIdx.x % (CW / 4), ty = threadIdx.x / (CW / 4);
+  const long e4 = (((long)tap * Ci + ci0 + ty) * Co + co0) / 4 + tx;
+  const long i4 = sg.off / 4 + e4;
+  f32x4_opt g = {0.f, 0.f, 0.f, 0.f};
+  if (sg.part) g = part_sum(e4, 0, 1);
+  if (sg.accumulate) g += ((const f32x4_opt*)grad)[i4];
+  float pn[4];
+  update4(i4, g, pn);
+  float* tl = (float*)tile;                        // [R][CW + 1]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tl[ty * (CW + 1) + 4 * tx + q] = pn[q];
+  __syncthreads();
+  // transposed shadow: row co0 + c of [co][ci] gets the R consecutive ci of this tile (R = 8: 16 bytes of bf16 per row)
+  for (int c = threadIdx.x; c < CW; c += 256) {
+    ST* dst = (ST*)sg.shadow_t + ((long)tap * Co + co0 + c) * Ci + ci0;
+    for (int r0 = 0; r0 < R; r0 += 4) {
+      const float o[4] = {tl[(r0 + 0) * (CW + 1) + c], tl[(r0 + 1) * (CW + 1) + c], tl[(r0 + 2) * (CW + 1) + c],
+                          tl[(r0 + 3) * (CW + 1) + c]};
+      if constexpr (sizeof(ST) == 2) {
+        const ST h[4] = {(ST)o[0], (ST)o[1], (ST)o[2], (ST)o[3]};
+        uint2 pk;
+        pk.x = (unsigned)__builtin_bit_cast(unsigned short, h[0]) | ((unsigned)__builtin_bit_cast(unsigned short, h[1]) << 16);
+        pk.y = (unsigned)__builtin_bit_cast(unsigned short, h[2]) | ((unsigned)__builtin_bit_cast(unsigned short, h[3]) << 16);
+        *(uint2*)(dst + r0) = pk;
+      } else {
+        *(float4*)(dst + r0) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
   }
@@ -454,7 +627,57 @@ __global__ void aug_draw_dev_kernel(uint64_t seed, uint64_t stream, const unsign
 // logistic noise, DiffAugment parameters - as extra blocks.  Four dependent launches of 4-8 us each otherwise.
 struct PrologueZero { float* p[4]; long first[5]; int k; int blocks; };
 struct PrologueDraws { DgDraw d[6]; int first_block[7]; int n; };
-__global__ __launch_bounds__(256) void step_prologue_kernel(PrologueZero z, PrologueDraws dr) {
+// fetch_reals as more blocks of the same launch (round 6; trainers/dcgan_amp.py:154-160, utils/lidar.py:31-36): block j of the
+// job owns pixels [j chunk, (j + 1) chunk) of the batch - chunk = HW / DG_XSUM_PARTS, so a sample is DG_XSUM_PARTS blocks - and
+// STORES its partial sum to parts[j]: the per-sample sums DiffAugment's contrast needs leave as DG_XSUM_PARTS partials per
+// sample, summed by the reader in a fixed order.  No accumulator that this very launch would have to zero first, no atomics.
+struct PrologueFetch { DgFetch f; int first_block; int blocks; long chunk; };
+__device__ __forceinline__ float prologue_fetch_px(float pol, float m, float min_d, float max_d, float drop_const) {
+  const float depth = pol * (max_d - min_d) + min_d;   // (pointwise.hip fetch_real_px: the same expressions)
+  const float disp = 1.f / depth;
+  float inv = (disp - 1.f / max_d) / (1.f / min_d - 1.f / max_d);
+  inv = inv * 2.f - 1.f;
+  return m * inv + (1.f - m) * drop_const;
+}
+__global__ __launch_bounds__(256) void step_prologue_kernel(PrologueZero z, PrologueDraws dr, PrologueFetch fe) {
+  if (fe.blocks > 0 && (int)blockIdx.x >= fe.first_block) {
+    __shared__ float red[16];
+    const DgFetch& f = fe.f;
+    const int j = (int)blockIdx.x - fe.first_block;
+    const float* pol = f.pol;
+    const float* mask = f.mask;
+    if (f.pool_ctr) {
+      const long off = (long)(*f.pool_ctr % (unsigned long long)f.npool) * ((long)f.B * f.HW);
+      pol += off;
+      mask += off;
+    }
+    const long i0 = (long)j * fe.chunk;
+    float acc = 0.f;
+    constexpr int U = 4;                                   // four trips' loads in flight per lane (8 x 16 bytes)
+    for (long k0 = (long)threadIdx.x * 4; k0 < fe.chunk; k0 += U * 1024) {
+      float4 p4[U], m4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long k = k0 + u * 1024;
+        if (k < fe.chunk) { p4[u] = *(const float4*)(pol + i0 + k); m4[u] = *(const float4*)(mask + i0 + k); }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long k = k0 + u * 1024;
+        if (k >= fe.chunk) break;
+        float4 o;
+        o.x = prologue_fetch_px(p4[u].x, m4[u].x, f.min_depth, f.max_depth, f.drop_const);
+        o.y = prologue_fetch_px(p4[u].y, m4[u].y, f.min_depth, f.max_depth, f.drop_const);
+        o.z = prologue_fetch_px(p4[u].z, m4[u].z, f.min_depth, f.max_depth, f.drop_const);
+        o.w = prologue_fetch_px(p4[u].w, m4[u].w, f.min_depth, f.max_depth, f.drop_const);
+        *(float4*)(f.out + i0 + k) = o;
+        acc += (o.x + o.y) + (o.z + o.w);
+      }
+    }
+    const float sblk = dg_block_sum(acc, red);
+    if (threadIdx.x == 0) f.parts[j] = sblk;
+    return;
+  }
   if ((int)blockIdx.x < z.blocks) {
     const long stride = (long)z.blocks * 256, total = z.first[z.k];
     for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; 4 * i4 < total; i4 += stride) {
@@ -647,8 +870,10 @@ int dg_philox_logistic_dev(uint64_t seed, uint64_t stream, const unsigned long l
   return DG_OK;
 }
 
-// zero-fill of k <= 4 fp32 buffers (as dg_zero_multi; k may be 0) + ndraw <= 6 draws (DgDraw) in one launch
-int dg_step_prologue(float* const* ptrs, const long* counts, int k, const DgDraw* draws, int ndraw, void* s_) {
+// zero-fill of k <= 4 fp32 buffers (as dg_zero_multi; k may be 0) + ndraw <= 6 draws (DgDraw) + optionally fetch_reals of one
+// batch (DgFetch) in one launch
+static int step_prologue_impl(float* const* ptrs, const long* counts, int k, const DgDraw* draws, int ndraw, const DgFetch* fetch,
+                              void* s_) {
   if (k < 0 || k > 4 || ndraw < 0 || ndraw > 6 || (k && (!ptrs || !counts)) || (ndraw && !draws)) return DG_EINVAL;
   PrologueZero z{};
   long tot = 0;
@@ -688,10 +913,29 @@ int dg_step_prologue(float* const* ptrs, const long* counts, int k, const DgDraw
   }
   dr.first_block[ndraw] = (int)blocks;
   dr.n = ndraw;
-  if (zb + blocks == 0) return DG_OK;
-  step_prologue_kernel<<<(unsigned)(zb + blocks), 256, 0, (hipStream_t)s_>>>(z, dr);
+  PrologueFetch fe{};
+  if (fetch) {
+    const DgFetch& f = *fetch;
+    if (!f.pol || !f.mask || !f.out || !f.parts || f.B <= 0 || f.HW <= 0 || (f.pool_ctr && f.npool <= 0)) return DG_EINVAL;
+    // 16-byte accesses, whole 1024-pixel sweeps per block, DG_XSUM_PARTS blocks per sample
+    if (f.HW % (1024L * DG_XSUM_PARTS) != 0 || (((size_t)f.pol | (size_t)f.mask | (size_t)f.out) & 15) != 0) return DG_EUNSUPPORTED;
+    fe.f = f;
+    fe.chunk = f.HW / DG_XSUM_PARTS;
+    fe.blocks = f.B * DG_XSUM_PARTS;
+    fe.first_block = (int)(zb + blocks);
+  }
+  if (zb + blocks + fe.blocks == 0) return DG_OK;
+  step_prologue_kernel<<<(unsigned)(zb + blocks + fe.blocks), 256, 0, (hipStream_t)s_>>>(z, dr, fe);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
+}
+int dg_step_prologue(float* const* ptrs, const long* counts, int k, const DgDraw* draws, int ndraw, void* s_) {
+  return step_prologue_impl(ptrs, counts, k, draws, ndraw, nullptr, s_);
+}
+int dg_step_prologue_fetch(float* const* ptrs, const long* counts, int k, const DgDraw* draws, int ndraw, const DgFetch* fetch,
+                           void* s_) {
+  if (!fetch) return DG_EINVAL;
+  return step_prologue_impl(ptrs, counts, k, draws, ndraw, fetch, s_);
 }
 
 int dg_aug_draw_dev(uint64_t seed, uint64_t stream, const unsigned long long* offset_dev, int B, int H, int W,
@@ -717,6 +961,53 @@ int dg_adam_ema_step_dev(float* p, const float* grad, float* m, float* v, float*
     adam_ema_kernel<bf16><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (bf16*)shadow, n4, gscale, 0.f, 0.f, beta1, beta2, eps, ema_decay, step_dev, lr);
   else
     adam_ema_kernel<float><<<grid, 256, 0, s>>>(p, grad, m, v, ema, (float*)shadow, n4, gscale, 0.f, 0.f, beta1, beta2, eps, ema_decay, step_dev, lr);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
+/* The optimizer of a network as one launch that sums the pieces' partial gradient rows itself (adam_fused_kernel above) */
+int dg_adam_fused(float* p, float* grad, float* v, float* ema, void* shadow, int shadow_dtype, const DgOptSeg* segs, int nseg,
+                  float gscale, float lr, float beta2, float eps, const unsigned long long* step_dev, float ema_decay, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!p || !grad || !v || !segs || !step_dev || nseg < 1 || nseg > DG_OPT_MAX_SEG) return DG_EINVAL;
+  if (shadow && shadow_dtype != DG_BF16 && shadow_dtype != DG_F32) return DG_EINVAL;
+  if ((((size_t)p | (size_t)grad | (size_t)v | (size_t)ema | (size_t)shadow) & 15) != 0) return DG_EINVAL;
+  OptSegs g{};
+  long blocks = 0;
+  for (int i = 0; i < nseg; ++i) {
+    DgOptSeg q = segs[i];
+    if (q.off < 0 || q.numel <= 0 || q.off % 4 != 0 || q.numel % 4 != 0 || q.splits < 0 || (q.splits > 0) != (q.part != nullptr))
+      return DG_EINVAL;
+    if (q.part && ((size_t)q.part & 15) != 0) return DG_EINVAL;
+    if (q.kind == 1) {
+      if (q.ci <= 0 || q.co <= 0 || !(q.co == 64 || q.co % 128 == 0) || q.ci % 16 != 0 || q.numel != 16LL * q.ci * q.co ||
+          !q.shadow_t || !shadow || ((size_t)q.shadow_t & 15) != 0 || q.ws_src)
+        return DG_EINVAL;
+      q.first_block = (int)blocks;
+      blocks += q.numel / 1024;
+    } else if (q.kind == 0) {
+      if (q.ws_src && (q.ws_n < 1 || q.ws_stride < q.numel || ((size_t)q.ws_src & 15) != 0 || q.ws_stride % 4 != 0)) return DG_EINVAL;
+      if (q.splits > 64) {
+        if (q.ws_src) return DG_EINVAL;
+        q.kind = 2;                               // wide: 16 float4 per workgroup, 16 groups of partial rows
+        q.first_block = (int)blocks;
+        blocks += (q.numel / 4 + 15) / 16;
+      } else {
+        q.first_block = (int)blocks;
+        blocks += (q.numel / 4 + 255) / 256;
+      }
+    } else {
+      return DG_EINVAL;
+    }
+    if (blocks > (1L << 30)) return DG_EUNSUPPORTED;
+    g.s[i] = q;
+  }
+  g.n = nseg;
+  g.total_blocks = (int)blocks;
+  if (shadow && shadow_dtype == DG_BF16)
+    adam_fused_kernel<bf16><<<(unsigned)blocks, 256, 0, s>>>(p, grad, v, ema, (bf16*)shadow, g, gscale, lr, beta2, eps, ema_decay, step_dev);
+  else
+    adam_fused_kernel<float><<<(unsigned)blocks, 256, 0, s>>>(p, grad, v, ema, (float*)shadow, g, gscale, lr, beta2, eps, ema_decay, step_dev);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }
@@ -770,7 +1061,12 @@ int dg_transpose_shadow_multi(const float* master, const long long* desc_dev, in
 static int transpose_multi(const float* master, const long long* desc_dev, int nseg, int total_tiles, int dtype,
                            const DgUpFrag* frags, int nfrag, const CounterAdds* ca, void* s_) {
   hipStream_t s = (hipStream_t)s_;
-  if (!master || !desc_dev || nseg <= 0 || total_tiles <= 0 || nfrag < 0 || nfrag > 4 || (nfrag && !frags)) return DG_EINVAL;
+  // (nseg == 0, total_tiles == 0: no transposes - the launch only builds the fragments and / or advances the counters, round 6:
+  //  dg_adam_fused writes the fat layers' transposed shadows itself)
+  if (!master || nseg < 0 || total_tiles < 0 || (nseg > 0) != (total_tiles > 0) || (nseg && !desc_dev) || nfrag < 0 || nfrag > 4 ||
+      (nfrag && !frags))
+    return DG_EINVAL;
+  if (total_tiles + nfrag == 0 && !ca) return DG_OK;
   if (nfrag && dtype != DG_BF16) return DG_EUNSUPPORTED;   // (the kernel that reads them is bf16 only)
   UpFrags uf{};
   uf.n = nfrag; uf.first_block = total_tiles;

@@ -225,6 +225,125 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// R1's turn-around at the image in ONE launch (round 6; trainers/dcgan_amp.py:218-235): g = BlurVH^T(e0) is the gradient of
+// sum(y_real) w.r.t. the augmented real image, the penalty reads |g_b|^2, and the double backward's tangent v = oscale g goes
+// straight back up through BlurVH (models/ops/common.py:74-88) - so g never needs to exist in memory: a block owns a band
+// of R1T_ROWS rows of one sample, forms oscale g for the band and one halo row on either side in LDS (the same expressions,
+// in the same order, as blur_bwd4_kernel), then BlurVH of those rows (blur_fwd4_kernel's expressions) into the tangent
+// slot of h0.  ssq[b] += |g_b|^2 over the band's own rows; mean_acc[0] += the same / mean_n (the logged penalty: its mean
+// over the batch is the sum of all blocks' shares - no second pass over ssq).  W % 4 == 0, H % R1T_ROWS == 0.
+#define R1T_ROWS 4
+template <typename T>
+__global__ __launch_bounds__(256) void blur_r1_tangent_kernel(const T* __restrict__ d, T* __restrict__ out, int H, int W,
+                                                              int ring, float oscale, float* __restrict__ ssq,
+                                                              float* __restrict__ mean_acc, int mean_n) {
+  extern __shared__ float s_g[];                  // [R1T_ROWS + 2][W]: oscale * g of rows y0 - 1 .. y0 + R1T_ROWS
+  __shared__ float red[16];
+  const int W4 = W >> 2, b = blockIdx.y;
+  const long base = (long)b * H * W;
+  const int y0 = blockIdx.x * R1T_ROWS;
+  float ssacc = 0.f;
+  for (int r = 0; r < R1T_ROWS + 2; ++r) {
+    const int y = y0 - 1 + r;
+    if (y < 0 || y >= H) continue;                // (block-uniform: the rows beyond the image are never read below)
+    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+      const int x0 = q4 * 4;
+      auto row8 = [&](int yy, float (&v)[8]) {    // (ch0, ch1) of pixels x0 .. x0+3 of row yy
+        const T* p = d + (base + (long)yy * W + x0) * 2;
+        if constexpr (sizeof(T) == 2) {
+          Vec16<bf16>::load((const bf16*)p, v);
+        } else {
+          const float4 a = *(const float4*)p, b2 = *(const float4*)(p + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b2.x; v[5] = b2.y; v[6] = b2.z; v[7] = b2.w;
+        }
+      };
+      auto D1 = [&](int yy, int xq) { return (float)d[(base + (long)yy * W + xq) * 2 + 1]; };
+      float m[8], tu[8], td[8];
+      row8(y, m);
+      row8(y > 0 ? y - 1 : y, tu);
+      row8(y < H - 1 ? y + 1 : y, td);
+      float el = 0.f, er = 0.f;
+      if (ring) { el = D1(y, x0 == 0 ? W - 1 : x0 - 1); er = D1(y, x0 + 3 == W - 1 ? 0 : x0 + 4); }
+      float v[4], h[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = 0.5f * m[2 * k];
+      if (y > 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += 0.25f * tu[2 * k]; }
+      if (y < H - 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += 0.25f * td[2 * k]; }
+      if (y == 1) { float t[8]; row8(0, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+      if (y == H - 2) { float t[8]; row8(H - 1, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int xx = x0 + k;
+        h[k] = 0.5f * m[2 * k + 1];
+        const bool hasl = k > 0, hasr = k < 3;
+        if (ring) {
+          h[k] += 0.25f * (hasl ? m[2 * k - 1] : el) + 0.25f * (hasr ? m[2 * k + 3] : er);
+        } else {
+          if (xx > 0) h[k] += 0.25f * (hasl ? m[2 * k - 1] : D1(y, xx - 1));
+          if (xx < W - 1) h[k] += 0.25f * (hasr ? m[2 * k + 3] : D1(y, xx + 1));
+          if (xx == 1) h[k] += 0.25f * D1(y, 0);
+          if (xx == W - 2) h[k] += 0.25f * D1(y, W - 1);
+        }
+      }
+      const float g0 = v[0] + h[0], g1 = v[1] + h[1], g2 = v[2] + h[2], g3 = v[3] + h[3];
+      *(float4*)(s_g + r * W + x0) = make_float4(oscale * g0, oscale * g1, oscale * g2, oscale * g3);
+      if (r >= 1 && r <= R1T_ROWS) ssacc += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
+    }
+  }
+  __syncthreads();
+  for (int yy = 0; yy < R1T_ROWS; ++yy) {
+    const int y = y0 + yy;
+    const int yu = y == 0 ? 1 : y - 1, yd = y == H - 1 ? H - 2 : y + 1;
+    const float* rc = s_g + (y - y0 + 1) * W;
+    const float* ru = s_g + (yu - y0 + 1) * W;
+    const float* rd = s_g + (yd - y0 + 1) * W;
+    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+      const int x0 = q4 * 4;
+      const float4 c4 = *(const float4*)(rc + x0);
+      const float4 u4 = *(const float4*)(ru + x0);
+      const float4 d4 = *(const float4*)(rd + x0);
+      int xl = x0 - 1, xr = x0 + 4;
+      if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
+      else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
+      const float c[6] = {rc[xl], c4.x, c4.y, c4.z, c4.w, rc[xr]};
+      const float u[4] = {u4.x, u4.y, u4.z, u4.w}, dn[4] = {d4.x, d4.y, d4.z, d4.w};
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[2 * k] = 0.25f * u[k] + 0.5f * c[k + 1] + 0.25f * dn[k];
+        o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
+      }
+      T* op = out + (base + (long)y * W + x0) * 2;
+      if constexpr (sizeof(T) == 2) {
+        Vec16<bf16>::store((bf16*)op, o);
+      } else {
+        *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+  const float sblk = dg_block_sum(ssacc, red);
+  if (threadIdx.x == 0) {
+    // the sample's last band adds the sample's total to the batch mean: gridDim.y adds to that word, not gridDim.x gridDim.y
+    // (512 adds to ONE word serialise memory-side: 9 us of this launch, scripts/bench_pointwise.py)
+    float tot = 0.f;
+    const int last = dg_acc_add_last(&ssq[b], sblk, gridDim.x, g_det, tot);
+    if (mean_acc) {
+      if (last == 1) dg_acc_add(mean_acc, tot / (float)mean_n, gridDim.y, g_det);
+      else if (last < 0) atomicAdd(mean_acc, sblk / (float)mean_n);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // Final EqualLR(Conv2d(C,1,(h0,w0))) (models/gans/dcgan_eqlr.py:95): y[b] = scale * <d4[b], wf> + bias.
 template <typename T>
 __global__ __launch_bounds__(256) void final_fwd_kernel(const T* __restrict__ d4, const float* __restrict__ wf,
@@ -381,6 +500,19 @@ __global__ void batch_wsum_scalar_kernel(const T* __restrict__ src, const float*
 // dsum != nullptr: dsum[b] += sum of depth[b] - the per-sample sum DiffAugment's contrast needs of its input, produced where
 // the image is produced.  A block then owns `chunk` consecutive pixels of ONE sample (HW % chunk == 0) and issues one atomic:
 // with one block per 256 pixels the 8192 atomics on 32 addresses cost 80 us (round 1 met the same in head_post_bwd).
+// tanh for the depth head (Generator.forward, models/gans/dcgan_eqlr.py:71) in ~17 VALU instructions: libm's tanhf made
+// head_post_fwd4_kernel VALU-bound (8.4 M pixels x ~45 instructions = the whole 11 us of the launch, round 6).
+//   |x| >= 0.25: (1 - e) / (1 + e) with e = exp(-2 |x|) in (0, 0.61]: no cancellation, ~2 ulp
+//   |x| <  0.25: the odd Taylor polynomial through x^9 (next term < 9e-9 relative at 0.25)
+__device__ __forceinline__ float dg_tanh(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-2.f * ax);
+  const float big = (1.f - e) * __frcp_rn(1.f + e);
+  const float x2 = x * x;
+  const float small = ax + ax * x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f)));
+  return copysignf(ax < 0.25f ? small : big, x);
+}
+
 template <int arch>
 __device__ __forceinline__ float head_post_px(float* __restrict__ gout, const float* __restrict__ noise_pixel,
                                               const float* __restrict__ noise_image, int training,
@@ -389,7 +521,7 @@ __device__ __forceinline__ float head_post_px(float* __restrict__ gout, const fl
   const long idx = (long)b * HW + p;
   const int nch = 1 + (arch == 0 ? 0 : arch);
   float* g = gout + (long)b * nch * HW + p;
-  const float t = tanhf(g[0]);
+  const float t = dg_tanh(g[0]);
   g[0] = t;
   if (arch == 0) return t;
   const float sp = 1.f / (1.f + __expf(-(g[HW] + noise_pixel[idx]) * inv_tau));
@@ -426,14 +558,30 @@ __global__ __launch_bounds__(256) void head_post_fwd4_kernel(float* __restrict__
   float* g = gout + (long)b * nch * HW + p0;
   const float ni = (arch == 2 && training) ? noise_image[b] : 0.f;
   float acc = 0.f;
-#pragma unroll 2
-  for (int k = threadIdx.x * 4; k < chunk; k += 1024) {
-    float4 g0 = *(const float4*)(g + k);
-    float t[4] = {tanhf(g0.x), tanhf(g0.y), tanhf(g0.z), tanhf(g0.w)};
+  // the loads of four trips issued before the first store (gout is rewritten in place: the compiler cannot hoist a later
+  // trip's loads over an earlier trip's stores, and one load in flight per wave left the launch at a third of the HBM rate)
+  constexpr int U = 4;
+  for (int k0 = threadIdx.x * 4; k0 < chunk; k0 += U * 1024) {
+    float4 g0u[U], g1u[U], npu[U], g2u[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * 1024;
+      if (k < chunk) {
+        g0u[u] = *(const float4*)(g + k);
+        if (arch >= 1) { g1u[u] = *(const float4*)(g + HW + k); npu[u] = *(const float4*)(noise_pixel + (long)b * HW + p0 + k); }
+        if (arch == 2) g2u[u] = *(const float4*)(g + 2 * HW + k);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int k = k0 + u * 1024;
+    if (k >= chunk) break;
+    const float4 g0 = g0u[u];
+    float t[4] = {dg_tanh(g0.x), dg_tanh(g0.y), dg_tanh(g0.z), dg_tanh(g0.w)};
     *(float4*)(g + k) = make_float4(t[0], t[1], t[2], t[3]);
     float dv[4] = {t[0], t[1], t[2], t[3]};
     if (arch >= 1) {
-      const float4 g1 = *(const float4*)(g + HW + k), np = *(const float4*)(noise_pixel + (long)b * HW + p0 + k);
+      const float4 g1 = g1u[u], np = npu[u];
       const float l1[4] = {g1.x + np.x, g1.y + np.y, g1.z + np.z, g1.w + np.w};
       float mp[4], m[4];
 #pragma unroll
@@ -445,7 +593,7 @@ __global__ __launch_bounds__(256) void head_post_fwd4_kernel(float* __restrict__
       if (arch == 1) {
         *(float4*)(mask + (long)b * HW + p0 + k) = make_float4(mp[0], mp[1], mp[2], mp[3]);
       } else {
-        const float4 g2 = *(const float4*)(g + 2 * HW + k);
+        const float4 g2 = g2u[u];
         const float l2[4] = {g2.x, g2.y, g2.z, g2.w};
         float mi[4];
 #pragma unroll
@@ -466,6 +614,7 @@ __global__ __launch_bounds__(256) void head_post_fwd4_kernel(float* __restrict__
     }
     *(float4*)(depth + i0 + k) = make_float4(dv[0], dv[1], dv[2], dv[3]);
     acc += (dv[0] + dv[1]) + (dv[2] + dv[3]);
+    }
   }
   const float sblk = dg_block_sum(acc, red);
   if (threadIdx.x == 0) dg_acc_add(&dsum[b], sblk, (unsigned)(HW / chunk), g_det);
@@ -957,19 +1106,23 @@ __global__ __launch_bounds__(256) void diffaug_fwd_kernel(AugP a, const float* _
 // only ever the discriminator's input, so it is never written - every output pixel evaluates the augmentation at its five
 // blur taps straight from the source image.  Up to two source sets in one launch (the D phase's real | fake halves,
 // trainers/dcgan_amp.py:199-204): sample b < a[0].B reads set 0, the rest set 1.  Grid (row, sample), 4 pixels per thread.
-struct AugSrc { AugP a; const float* x; const float* xsum; };
+struct AugSrc { AugP a; const float* x; const float* xsum; int parts; };
 // The three source rows of an output row go through LDS with 16-byte loads (the translation wraps columns modulo W - 1,
 // so the augmented row is a rotated copy: unaligned - read from LDS, not from global memory, where a first version with
 // 14 scalar gathers per 4 pixels ran no faster than the two kernels it replaced).
+// Round 6: a block owns a BAND of DAB_ROWS output rows of one sample and stages the DAB_ROWS + 2 source rows it needs once
+// (one row per output row before: three staged rows per output row, 4096 short blocks per 64 images, 17 us for 34 MB).
+#define DAB_ROWS 4
 template <typename T>
 __global__ __launch_bounds__(256) void diffaug_blur_fwd_kernel(AugSrc s0, AugSrc s1, T* __restrict__ out, int ring) {
-  extern __shared__ float s_rows[];               // [3][W] source rows (row k of the three: up, centre, down)
+  extern __shared__ float s_rows[];               // [DAB_ROWS + 2][W]: source rows of augmented rows y0 - 1 .. y0 + DAB_ROWS
   const int set = (int)blockIdx.y >= s0.a.B;
   const AugP& a = set ? s1.a : s0.a;
   const float* x = set ? s1.x : s0.x;
   const float* xsum = set ? s1.xsum : s0.xsum;
+  const int parts = set ? s1.parts : s0.parts;
   const int b = (int)blockIdx.y - (set ? s0.a.B : 0);
-  const int y = blockIdx.x, H = a.H, W = a.W, Wm1 = a.W - 1, W4 = a.W >> 2;
+  const int y0 = blockIdx.x * DAB_ROWS, H = a.H, W = a.W, Wm1 = a.W - 1, W4 = a.W >> 2;
   const long HW = (long)H * W;
   int th = 0, tw = 0;
   if (a.policy & 8) {
@@ -983,49 +1136,74 @@ __global__ __launch_bounds__(256) void diffaug_blur_fwd_kernel(AugSrc s0, AugSrc
   if (a.policy & 4) {
     const float u = a.u_c[b];
     cc = 1.f + 0.5f * u * u;
-    mean = xsum[b] / (float)HW + br;
+    float sx = 0.f;
+    if (parts > 1) {                              // the producer's partial sums, added in index order (dg_step_prologue_fetch)
+      for (int j = 0; j < parts; ++j) sx += xsum[(long)b * parts + j];
+    } else sx = xsum[b];
+    mean = sx / (float)HW + br;
   }
-  // the three augmented rows of this output row (reflected at the border): source row, validity, cut-out columns
-  const int yr[3] = {y == 0 ? 1 : y - 1, y, y == H - 1 ? H - 2 : y + 1};
-  bool ok[3];
-  int c0[3], c1[3];
+  // stage: LDS row r holds the source row of augmented row ya = y0 - 1 + r (rows outside the image are never read below; a
+  // row whose source row falls outside the image is all zeros after the translation: any valid row is staged, `ok` says so)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int sy = yr[k] + th;
-    ok[k] = sy >= 0 && sy < H;
-    const float* src = x + (long)b * HW + (long)(ok[k] ? sy : 0) * W;
-    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) *(float4*)(s_rows + k * W + q4 * 4) = *(const float4*)(src + q4 * 4);
-    const bool cutrow = (a.policy & 16) && yr[k] >= r0 && yr[k] < r0 + a.cut_h;
-    c0[k] = cutrow ? cl : 0;
-    c1[k] = cutrow ? cl + a.cut_w : 0;
+  for (int r = 0; r < DAB_ROWS + 2; ++r) {
+    const int ya = y0 - 1 + r;
+    if (ya < 0 || ya >= H) continue;
+    const int sy = ya + th;
+    const bool okr = sy >= 0 && sy < H;
+    const float* src = x + (long)b * HW + (long)(okr ? sy : 0) * W;
+    // brightness and contrast where the pixel is STAGED (once per source pixel, not once per tap that reads it): the same
+    // two expressions as diffaug_fwd_kernel; a row the translation moved out of the image is staged as zeros
+    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+      const float4 p = *(const float4*)(src + q4 * 4);
+      float v[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = v[q] + br;
+        t = mean + cc * (t - mean);
+        v[q] = okr ? t : 0.f;
+      }
+      *(float4*)(s_rows + r * W + q4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
   __syncthreads();
-  auto aug = [&](int k, int xx) {                 // augmented image at (row k of the three, column xx)
-    int sx = xx + tw;
-    if (sx >= Wm1) sx -= Wm1;
-    float v = s_rows[k * W + sx] + br;
-    v = mean + cc * (v - mean);
-    return (ok[k] && !(xx >= c0[k] && xx < c1[k])) ? v : 0.f;
-  };
-  T* orow = out + ((long)blockIdx.y * HW + (long)y * W) * 2;
-  for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
-    const int x0 = q4 * 4;
-    int xl = x0 - 1, xr = x0 + 4;
-    if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
-    else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
-    const float c[6] = {aug(1, xl), aug(1, x0), aug(1, x0 + 1), aug(1, x0 + 2), aug(1, x0 + 3), aug(1, xr)};
-    float o[8];
+  for (int yy = 0; yy < DAB_ROWS; ++yy) {
+    const int y = y0 + yy;
+    // the three augmented rows of this output row (reflected at the border): staged row, validity, cut-out columns
+    const int yr[3] = {y == 0 ? 1 : y - 1, y, y == H - 1 ? H - 2 : y + 1};
+    int c0[3], c1[3];
+    const float* rowp[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      o[2 * k] = 0.25f * aug(0, x0 + k) + 0.5f * c[k + 1] + 0.25f * aug(2, x0 + k);
-      o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
+    for (int k = 0; k < 3; ++k) {
+      rowp[k] = s_rows + (yr[k] - y0 + 1) * W;
+      const bool cutrow = (a.policy & 16) && yr[k] >= r0 && yr[k] < r0 + a.cut_h;
+      c0[k] = cutrow ? cl : 0;
+      c1[k] = cutrow ? cl + a.cut_w : 0;
     }
-    T* op = orow + x0 * 2;
-    if constexpr (sizeof(T) == 2) {
-      Vec16<bf16>::store((bf16*)op, o);
-    } else {
-      *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
-      *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    auto aug = [&](int k, int xx) {               // augmented image at (row k of the three, column xx)
+      int sx = xx + tw;
+      if (sx >= Wm1) sx -= Wm1;
+      return (xx >= c0[k] && xx < c1[k]) ? 0.f : rowp[k][sx];
+    };
+    T* orow = out + ((long)blockIdx.y * HW + (long)y * W) * 2;
+    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+      const int x0 = q4 * 4;
+      int xl = x0 - 1, xr = x0 + 4;
+      if (ring) { if (xl < 0) xl += W; if (xr >= W) xr -= W; }
+      else      { if (xl < 0) xl = 1;  if (xr >= W) xr = W - 2; }
+      const float c[6] = {aug(1, xl), aug(1, x0), aug(1, x0 + 1), aug(1, x0 + 2), aug(1, x0 + 3), aug(1, xr)};
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[2 * k] = 0.25f * aug(0, x0 + k) + 0.5f * c[k + 1] + 0.25f * aug(2, x0 + k);
+        o[2 * k + 1] = 0.25f * c[k] + 0.5f * c[k + 1] + 0.25f * c[k + 2];
+      }
+      T* op = orow + x0 * 2;
+      if constexpr (sizeof(T) == 2) {
+        Vec16<bf16>::store((bf16*)op, o);
+      } else {
+        *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
     }
   }
 }
@@ -1309,7 +1487,7 @@ __global__ __launch_bounds__(256) void gan_step_kernel(GanForm fm, int mode_g, c
 // D mode: ns = 2B samples [real | fake]; r1: chain upstream [1 | dy_fake], bias-gradient weights [dy_real | 1] (the R1
 // schedule), else upstream dy, weights 1.  G mode: ns = B samples (the fake batch), upstream dy.
 template <typename T>
-__global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode_g, const float* __restrict__ y_real,
+__global__ __launch_bounds__(512) void final_gan_bwd_kernel(GanForm fm, int mode_g, const float* __restrict__ y_real,
                                                             const float* __restrict__ y_fake, int B, float w_gan, int r1,
                                                             float* __restrict__ dy, float* __restrict__ up,
                                                             float* __restrict__ rs, float* __restrict__ acc,
@@ -1318,20 +1496,21 @@ __global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode
                                                             T* __restrict__ dd4, float* __restrict__ dbias,
                                                             float* __restrict__ dwf, float* __restrict__ dbias_part) {
   constexpr int V = Vec16<T>::V;
-  __shared__ float part[4][64 * V];
+  constexpr int NW = 8;                           // waves per workgroup (round 6: four left one workgroup per CU with 16-32 KB in flight)
+  __shared__ float part[NW][64 * V];
   __shared__ float s_dy[256], s_u[256], s_r[256], red[17];
   const int ns = mode_g ? B : 2 * B;
   gan_step_body(fm, mode_g, y_real, y_fake, B, w_gan, s_dy, r1 ? s_u : nullptr, r1 ? s_r : nullptr, blockIdx.x == 0, acc,
                 dfinal_b, red);
   __syncthreads();
   if (blockIdx.x == 0)
-    for (int b = threadIdx.x; b < ns; b += 256) {
+    for (int b = threadIdx.x; b < ns; b += 64 * NW) {
       dy[b] = s_dy[b];
       if (up && r1) up[b] = s_u[b];
       if (rs && r1) rs[b] = s_r[b];
     }
   if (!r1) {
-    for (int b = threadIdx.x; b < ns; b += 256) { s_u[b] = s_dy[b]; s_r[b] = 1.f; }
+    for (int b = threadIdx.x; b < ns; b += 64 * NW) { s_u[b] = s_dy[b]; s_r[b] = 1.f; }
     __syncthreads();
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1345,30 +1524,49 @@ __global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode
       const float4 r = *(const float4*)(wf + i + k4);
       w[k4] = r.x * scale; w[k4 + 1] = r.y * scale; w[k4 + 2] = r.z * scale; w[k4 + 3] = r.w * scale;
     }
-#pragma unroll 4
-    for (int b = wave; b < ns; b += 4) {
-      float a[V], g[V];
-      Vec16<T>::load(d4 + (long)b * n + i, a);
-      const float u = s_u[b], rsb = s_r[b], c = s_dy[b];
+    // (round 6) eight samples' loads in flight per lane: with four, one workgroup per CU kept 16 KB in flight and the launch
+    // ran at 1.8 TB/s of its 34 MB
+    constexpr int NB = 8;
+    for (int b0 = wave; b0 < ns; b0 += NW * NB) {
+      float a[NB][V];
 #pragma unroll
-      for (int k = 0; k < V; ++k) {
-        g[k] = u * w[k] * (a[k] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
-        db[k] += rsb * g[k];
-        dw[k] += c * a[k];
+      for (int j = 0; j < NB; ++j) {
+        const int b = b0 + NW * j;
+        if (b < ns) Vec16<T>::load(d4 + (long)b * n + i, a[j]);
+        else {
+#pragma unroll
+          for (int k = 0; k < V; ++k) a[j][k] = 0.f;
+        }
       }
-      Vec16<T>::store(dd4 + (long)b * n + i, g);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int b = b0 + NW * j;
+        if (b < ns) {
+          float g[V];
+          const float u = s_u[b], rsb = s_r[b], c = s_dy[b];
+#pragma unroll
+          for (int k = 0; k < V; ++k) {
+            g[k] = u * w[k] * (a[j][k] > 0.f ? SQRT2 : LRELU_SLOPE * SQRT2);
+            db[k] += rsb * g[k];
+            dw[k] += c * a[j][k];
+          }
+          Vec16<T>::store(dd4 + (long)b * n + i, g);
+        }
+      }
     }
   }
   if (dbias) {
 #pragma unroll
     for (int k = 0; k < V; ++k) part[wave][lane * V + k] = db[k];
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * V; e += 256) {
+    for (int e = threadIdx.x; e < 64 * V; e += 64 * NW) {
       const long ie = (long)blockIdx.x * 64 * V + e;
       // dbias_part: one partial per element of the map (= per pixel and channel, summed over the samples in a fixed order);
       // the caller sums the n / C pixel rows per channel with dg_wgrad_reduce - no atomics, bit-reproducible
       if (ie < n) {
-        const float v = part[0][e] + part[1][e] + part[2][e] + part[3][e];
+        float v = part[0][e];
+#pragma unroll
+        for (int w8 = 1; w8 < NW; ++w8) v += part[w8][e];
         if (dbias_part) dbias_part[ie] = v; else atomicAdd(&dbias[ie % C], v);
       }
     }
@@ -1378,9 +1576,14 @@ __global__ __launch_bounds__(256) void final_gan_bwd_kernel(GanForm fm, int mode
 #pragma unroll
     for (int k = 0; k < V; ++k) part[wave][lane * V + k] = dw[k];
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * V; e += 256) {
+    for (int e = threadIdx.x; e < 64 * V; e += 64 * NW) {
       const long ie = (long)blockIdx.x * 64 * V + e;
-      if (ie < n) dwf[ie] += (part[0][e] + part[1][e] + part[2][e] + part[3][e]) * scale;
+      if (ie < n) {
+        float v = part[0][e];
+#pragma unroll
+        for (int w8 = 1; w8 < NW; ++w8) v += part[w8][e];
+        dwf[ie] += v * scale;
+      }
     }
   }
 }
@@ -1606,6 +1809,25 @@ int dg_blur_bwd_r1(const void* d, int dtype, float* dx, float oscale, float* ssq
   return DG_OK;
 }
 
+// dg_blur_bwd_r1 + dg_blur_fwd_mean as ONE launch: out[b] = BlurVH(oscale * BlurVH^T(d[b])) in `dtype` (the R1 tangent's first
+// feature map from the real chain's last gradient map), ssq[b] += |BlurVH^T(d[b])|^2, mean_acc[0] += sum_b of that / mean_n
+// (mean_acc optional).  ssq / mean_acc zeroed by the caller.  DG_EUNSUPPORTED - nothing launched - unless W % 4 == 0,
+// H % 4 == 0 and the band's six image rows fit 64 KB of LDS.
+int dg_blur_r1_tangent(const void* d, int dtype, void* out, float oscale, float* ssq, float* mean_acc, int mean_n, int B, int H,
+                       int W, int ring, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (!d || !out || !ssq || B <= 0 || (mean_acc && mean_n < 1)) return DG_EINVAL;
+  if (dtype != DG_BF16 && dtype != DG_F32) return DG_EINVAL;
+  const size_t lds = (size_t)(R1T_ROWS + 2) * W * sizeof(float);
+  if (W % 4 != 0 || W < 8 || H < 4 || H % R1T_ROWS != 0 || lds > 60 * 1024 || ((size_t)d & 15) != 0 || ((size_t)out & 15) != 0)
+    return DG_EUNSUPPORTED;
+  const dim3 grid(H / R1T_ROWS, B);
+  if (dtype == DG_BF16) blur_r1_tangent_kernel<bf16><<<grid, 256, lds, s>>>((const bf16*)d, (bf16*)out, H, W, ring, oscale, ssq, mean_acc, mean_n);
+  else blur_r1_tangent_kernel<float><<<grid, 256, lds, s>>>((const float*)d, (float*)out, H, W, ring, oscale, ssq, mean_acc, mean_n);
+  HIP_CHECK_RET(hipGetLastError());
+  return DG_OK;
+}
+
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
                  void* s_) {
   return final_fwd_impl(d4, dtype, wf, bias, scale, B, n, y, true, s_);
@@ -1804,10 +2026,13 @@ int dg_diffaug_blur_fwd(const DgAugSet* sets, int nsets, int policy, int B, int 
     src[k].a = make_aug(q.u_b, q.u_c, q.t_h, q.t_w, q.o_x, q.o_y, policy, B, H, W);
     src[k].x = q.x;
     src[k].xsum = q.xsum;
+    src[k].parts = q.xsum_parts;
+    if (q.xsum_parts < 0 || q.xsum_parts > 64) return DG_EINVAL;
   }
-  const dim3 grid(H, nsets * B);
-  const size_t lds = (size_t)3 * W * sizeof(float);
-  if (lds > 64 * 1024) return DG_EUNSUPPORTED;
+  if (H % DAB_ROWS != 0) return DG_EUNSUPPORTED;                     // bands of DAB_ROWS output rows
+  const dim3 grid(H / DAB_ROWS, nsets * B);
+  const size_t lds = (size_t)(DAB_ROWS + 2) * W * sizeof(float);
+  if (lds > 60 * 1024) return DG_EUNSUPPORTED;
   if (dtype == DG_BF16) diffaug_blur_fwd_kernel<bf16><<<grid, 256, lds, s>>>(src[0], src[1], (bf16*)out, ring);
   else diffaug_blur_fwd_kernel<float><<<grid, 256, lds, s>>>(src[0], src[1], (float*)out, ring);
   HIP_CHECK_RET(hipGetLastError());
@@ -2013,10 +2238,10 @@ int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_rea
   const unsigned grid = nblk(n / V, 64);
   hipStream_t s = (hipStream_t)s_;
   if (dtype == DG_BF16)
-    final_gan_bwd_kernel<bf16><<<grid, 256, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
+    final_gan_bwd_kernel<bf16><<<grid, 512, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
                                                     (const bf16*)d4, wf, scale, n, C, (bf16*)dd4, dbias, dwf, dbias_part);
   else
-    final_gan_bwd_kernel<float><<<grid, 256, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
+    final_gan_bwd_kernel<float><<<grid, 512, 0, s>>>(fm, mode_g ? 1 : 0, y_real, y_fake, B, w_gan, r1, dy, up, rs, acc, dfinal_b,
                                                      (const float*)d4, wf, scale, n, C, (float*)dd4, dbias, dwf, dbias_part);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;

@@ -187,42 +187,60 @@ class ParamStore:
             L.check(L.lib().dg_cast_x2_multi(C.byref(a[0], i * C.sizeof(C.c_void_p)), C.byref(a[1], i * C.sizeof(C.c_void_p)),
                                              C.byref(a[2], i * C.sizeof(C.c_long)), n, L.stream_ptr()), "dg_cast_x2_multi")
 
-    def refresh_transposed(self, tail=False):
+    def is_fat_conv(self, name):
+        """conv segments whose [tap][co][ci] shadow the fused optimizer writes itself (dg_adam_fused kind 1: 1024-element tiles)"""
+        s = self.seg[name]
+        return s.kind == "conv" and s.shape[2] % 16 == 0 and (s.shape[3] == 64 or s.shape[3] % 128 == 0)
+
+    def refresh_transposed(self, tail=False, small_only=False):
         """[tap][ci][co] fp32 master -> [tap][co][ci] T shadow of every conv segment, one launch per network.  tail: the call
         behind an optimizer step - when the trainer has flagged it (`_lib.Counters.ride`) this is the step's last launch
-        and carries the pending counter advances and the scalar snapshot.  (+ the split-bf16 twins, when enabled)"""
-        self._refresh_transposed(tail)
+        and carries the pending counter advances and the scalar snapshot.  (+ the split-bf16 twins, when enabled)
+        small_only (behind dg_adam_fused, which has written the fat layers' transposed shadows itself): only the conv
+        segments that kernel does not tile (Down1 / Head: a few KB), the thin kernels' weight fragments and the ride."""
+        self._refresh_transposed(tail, small_only)
         self._refresh_x2()
 
-    def _refresh_transposed(self, tail=False):
+    def _refresh_transposed(self, tail=False, small_only=False):
         lib, st = L.lib(), L.stream_ptr()
         convs = [(name, s) for name, s in self.seg.items() if s.kind == "conv"]
         if not convs:
             return
         if self._tdesc is None or self._tdesc_dtype != self.shadow_dtype or self._tdesc.device != self.flat.device:
             desc, tiles = [], 0
+            small, stiles = [], 0
             for name, s in convs:
                 _, _, ci, co = s.shape
                 self.coci[name] = torch.empty(16 * ci * co, dtype=self.shadow_dtype, device=self.flat.device)
                 desc += [s.off, L.ptr(self.coci[name]), ci, co, tiles]
-                tiles += 16 * ((ci + 31) // 32) * ((co + 31) // 32)
+                nt = 16 * ((ci + 31) // 32) * ((co + 31) // 32)
+                tiles += nt
+                if not self.is_fat_conv(name):
+                    small += [s.off, L.ptr(self.coci[name]), ci, co, stiles]
+                    stiles += nt
             self._tdesc = torch.tensor(desc, dtype=torch.int64).to(self.flat.device)
             self._tdesc_tiles, self._tdesc_dtype = tiles, self.shadow_dtype
+            self._tdesc_small = torch.tensor(small, dtype=torch.int64).to(self.flat.device) if small else None
+            self._tdesc_small_tiles, self._tdesc_small_n = stiles, len(small) // 5
+        tdesc, ntiles, nconv = self._tdesc, self._tdesc_tiles, len(convs)
+        if small_only:
+            tdesc, ntiles, nconv = self._tdesc_small, self._tdesc_small_tiles, self._tdesc_small_n
         nf = len(self.up_frags) if self.shadow_dtype == torch.bfloat16 else 0
         arr = (L.DgUpFrag * max(nf, 1))(*[d for _, d in self.up_frags.values()][:nf])
         ride = L.Counters.take_for_ride() if tail else None
         if ride is not None:
-            L.check(lib.dg_transpose_shadow_multi_tail(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
+            L.check(lib.dg_transpose_shadow_multi_tail(L.ptr(self.flat), L.ptr(tdesc), nconv, ntiles,
                                                        L.dtype_code(self.shadow_dtype), arr, nf, *ride, st),
                     "dg_transpose_shadow_multi_tail")
             return
         if nf:
-            L.check(lib.dg_transpose_shadow_multi_frags(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
+            L.check(lib.dg_transpose_shadow_multi_frags(L.ptr(self.flat), L.ptr(tdesc), nconv, ntiles,
                                                         L.dtype_code(self.shadow_dtype), arr, nf, st),
                     "dg_transpose_shadow_multi_frags")
             return
-        L.check(lib.dg_transpose_shadow_multi(L.ptr(self.flat), L.ptr(self._tdesc), len(convs), self._tdesc_tiles,
-                                              L.dtype_code(self.shadow_dtype), st), "dg_transpose_shadow_multi")
+        if nconv:
+            L.check(lib.dg_transpose_shadow_multi(L.ptr(self.flat), L.ptr(tdesc), nconv, ntiles,
+                                                  L.dtype_code(self.shadow_dtype), st), "dg_transpose_shadow_multi")
 
     def sptr(self, name):
         """device pointer of the T shadow of a segment"""
@@ -1410,6 +1428,23 @@ class DEngine:
                                 int(c.ring), L.stream_ptr()), "dg_blur_bwd")
         return True
 
+    def r1_turnaround(self, st, slot, n, tslot, oscale, ssq, mean_ptr):
+        """R1 at the image, round 6 (trainers/dcgan_amp.py:218-235): Down1 backward-data on the chain of slots [slot, slot+n),
+        then ONE launch (dg_blur_r1_tangent) that forms g = BlurVH^T(e0), adds |g_b|^2 to ssq[b] (and their mean over the n
+        samples to *mean_ptr) and writes BlurVH(oscale g) - the tangent's first feature map - into h[0] at slots
+        [tslot, tslot+n); then the tangent's Down layers through the saved masks of `slot`.  g itself is never written.
+        False - NOTHING launched - where that kernel does not take the image shape: the caller runs backward_input +
+        forward(tangent_of=...)."""
+        c, o, lib = self.cfg, self.ops, L.lib()
+        if c.W % 4 or c.H % 4 or 6 * c.W * 4 > 60 * 1024:
+            return False
+        self._bwd_layer(st, 1, slot, n, None, False)
+        L.check(lib.dg_blur_r1_tangent(L.ptr(self.e[0]) + o.es * slot * self.per[0], o.dt,
+                                       L.ptr(self.h[0]) + o.es * tslot * self.per[0], float(oscale), L.ptr(ssq), mean_ptr, int(n),
+                                       n, c.H, c.W, int(c.ring), L.stream_ptr()), "dg_blur_r1_tangent")
+        self._layers(st, n, tslot, slot)
+        return True
+
     def backward_input_aug(self, st, slot, n, A, rp, lazy=False):
         """d loss / d x for D(A(x)): Down1 backward-data, then BlurVH's adjoint and DiffAugment's adjoint - two launches:
         the BlurVH adjoint also accumulates the masked per-sample sums DiffAugment's contrast term needs
@@ -1460,6 +1495,12 @@ class DEngine:
                 else:
                     self.wgrad(st, 0, 0, 2 * B, rs3, layers=(i,))
                     self.wgrad(st, 2 * B, 0, B, None, layers=(i,))
+
+    def final_wgrad_term(self, slot, n):
+        """the operands of final_wgrad(st, slot, n, None) for the optimizer's launch to sum (FlatAdam.step `extra`, dg_adam_fused
+        ws_*): (source pointer, is_bf16, coefficient pointer, samples, sample stride, scale)"""
+        nf = self.per[4]
+        return (L.ptr(self.h[4]) + self.ops.es * slot * nf, self.dtype == torch.bfloat16, None, int(n), nf, 1.0 / math.sqrt(nf))
 
     def final_wgrad(self, st, slot, n, coef):
         """dwf += s_f * sum_b coef[b] * h4[slot+b]"""

@@ -180,12 +180,82 @@ class FlatAdam:
         if pos < st.n:
             L.zero_(st.grad[pos:])
 
-    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None, between=None):
+    # round 6: one launch sums the pending split-K partials / bias-gradient rows, applies Adam + EMA and writes every shadow
+    # (dg_adam_fused) - DUSTY_GAN_FUSED_OPT=0 keeps the four-launch form (A/B, tests)
+    fused_enabled = os.environ.get("DUSTY_GAN_FUSED_OPT", "1") != "0"
+
+    def will_fuse(self, shadow_dtype):
+        """whether `step` will take the one-launch optimizer (the caller may then leave gradient terms to it: `extra`)"""
+        return (FlatAdam.fused_enabled and shadow_dtype == torch.bfloat16 and self.betas[0] == 0.0 and E.PROFILE is None
+                and self.store.shadow is not None and self.store.shadow is not self.store.flat)
+
+    def _fused_plan(self, st, off, extra):
+        """the DgOptSeg list of dg_adam_fused for flat[off:] from the store's segments and the split-K workspace's pending items
+        (each must be THE one gradient term of a whole segment), or None (the caller then reduces first and runs the plain
+        optimizer).  extra: {segment: (src_ptr, is_bf16, coef_ptr, n, stride, scale)} - a dg_batch_wsum term folded in."""
+        ws = E.WGRAD_WS._cur()
+        by_dw = {}
+        for it in ws.items:
+            if it[1] in by_dw:
+                return None            # two terms for one destination (micro-batches, path-length terms): the reduce orders them
+            by_dw[it[1]] = it
+        segs, run = [], None
+
+        def flat(a, b):
+            q = L.DgOptSeg()
+            q.off, q.numel, q.accumulate = a, b - a, 1
+            return q
+        for name, sg in st.seg.items():
+            if sg.off < off:
+                continue
+            it = by_dw.pop(st.fptr(name, st.grad), None)
+            fat = st.is_fat_conv(name) and name in st.coci
+            ex = extra.get(name) if extra else None
+            if it is None and not fat and ex is None:
+                run = sg.off if run is None else run
+                continue
+            if run is not None:
+                segs.append(flat(run, sg.off))
+                run = None
+            if sg.numel % 4 or (it is not None and it[2] != sg.numel):
+                return None
+            q = flat(sg.off, sg.off + sg.numel)
+            if it is not None:
+                q.part, q.splits, q.accumulate = it[0], it[3], it[4]
+            if fat:
+                q.kind, q.ci, q.co, q.shadow_t = 1, sg.shape[2], sg.shape[3], L.ptr(st.coci[name])
+            if ex is not None:
+                if fat:
+                    return None
+                q.ws_src, q.ws_bf16, q.ws_coef, q.ws_n, q.ws_stride, q.ws_scale = ex[0], int(ex[1]), ex[2], ex[3], ex[4], ex[5]
+            segs.append(q)
+        if run is not None:
+            segs.append(flat(run, st.n))
+        if by_dw or not segs or len(segs) > L.OPT_MAX_SEG:
+            return None
+        return (L.DgOptSeg * len(segs))(*segs), len(segs), ws
+
+    def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None, between=None,
+             extra=None):
         """fused_proj = (dp0, zT, op_dtype, nb, Np, K, wscale): the first segment of the store is Proj.weight [Np][K] and
         its gradient is NOT in st.grad - the kernel forms wscale * dp0^T zT itself (dg_adam_proj_fused).  Returns
-        False (and does nothing) if that kernel refuses the shape, so the caller can fall back."""
+        False (and does nothing) if that kernel refuses the shape, so the caller can fall back.
+        extra: gradient terms the caller left to the optimizer launch (`will_fuse`): {segment: dg_batch_wsum operands}."""
         st = self.store
-        E.WGRAD_WS.flush()  # (split-K partials still waiting to be summed into st.grad)
+        off = 0
+        assert not (fused_proj is not None and extra), "extra terms are applied before the call can still fall back"
+        if fused_proj is not None:
+            if self.betas[0] != 0.0:
+                return False
+            off = fused_proj[4] * fused_proj[5]
+        plan = self._fused_plan(st, off, extra) if self.will_fuse(shadow_dtype) else None
+        if plan is None:
+            if extra:   # (the terms left to the fused launch, as launches of their own)
+                for name, (src, is_bf16, coef, n, stride, scale) in extra.items():
+                    assert stride == st.seg[name].numel
+                    L.check(L.lib().dg_batch_wsum(src, L.DG_BF16 if is_bf16 else L.DG_F32, coef, scale, n, st.seg[name].numel,
+                                                  st.fptr(name, st.grad), L.stream_ptr()), "dg_batch_wsum")
+            E.WGRAD_WS.flush()  # (split-K partials still waiting to be summed into st.grad)
         if self._step_dev is None or self._step_dev.device != st.flat.device:
             self._step_dev = torch.full((1,), self.step_count, dtype=torch.int64, device=st.flat.device)
         # beta1 == 0 (the reference's solver): exp_avg == scaled gradient, so the kernel neither reads nor writes it
@@ -195,32 +265,35 @@ class FlatAdam:
         sdt = L.dtype_code(shadow_dtype)
         ses = 2 if shadow_dtype == torch.bfloat16 else 4
         ema_ptr = L.ptr(ema_store.flat) if ema_store is not None else None
-        off = 0
         if fused_proj is not None:
             dp0, zT, op_dt, nb, Np, K, wscale = fused_proj
-            if self.betas[0] != 0.0:
-                return False
             rc = lib.dg_adam_proj_fused(L.ptr(st.flat), L.ptr(st.v), ema_ptr, L.ptr(st.shadow), sdt, L.ptr(dp0), L.ptr(zT),
                                         op_dt, nb, Np, K, wscale, gscale, self.lr, self.betas[1], self.eps,
                                         L.ptr(self._step_dev), ema_decay, L.stream_ptr())
             if rc == L.DG_EUNSUPPORTED:
-                return False
+                return False   # (nothing consumed: the caller's fall-back call plans again)
             L.check(rc, "dg_adam_proj_fused")
-            off = Np * K
             if between is not None:
                 between()   # (multi-GPU: the tail bucket's exchange has been travelling beside the kernel above)
         self.step_count += 1
         self._last_gscale = gscale
-        # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
-        L.check(lib.dg_adam_ema_step_dev(L.ptr(st.flat) + 4 * off, L.ptr(st.grad) + 4 * off,
-                                         None if m_ptr is None else m_ptr + 4 * off, L.ptr(st.v) + 4 * off,
-                                         None if ema_ptr is None else ema_ptr + 4 * off,
-                                         None if st.shadow is st.flat else L.ptr(st.shadow) + ses * off,   # (fp32: the master IS the shadow)
-                                         sdt, st.n - off, gscale, self.lr, self.betas[0],
-                                         self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
-                "dg_adam_ema_step_dev")
+        if plan is not None:
+            arr, nseg, ws = plan
+            L.check(lib.dg_adam_fused(L.ptr(st.flat), L.ptr(st.grad), L.ptr(st.v), ema_ptr, L.ptr(st.shadow), sdt, arr, nseg,
+                                      gscale, self.lr, self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay,
+                                      L.stream_ptr()), "dg_adam_fused")
+            ws.items, ws.pos, ws.demand = [], 0, 0      # (the pending partials are summed: what `flush` would have left)
+        else:
+            # step count in device memory (bias corrections computed in the kernel) so the launch is graph-replayable
+            L.check(lib.dg_adam_ema_step_dev(L.ptr(st.flat) + 4 * off, L.ptr(st.grad) + 4 * off,
+                                             None if m_ptr is None else m_ptr + 4 * off, L.ptr(st.v) + 4 * off,
+                                             None if ema_ptr is None else ema_ptr + 4 * off,
+                                             None if st.shadow is st.flat else L.ptr(st.shadow) + ses * off,   # (fp32: the master IS the shadow)
+                                             sdt, st.n - off, gscale, self.lr, self.betas[0],
+                                             self.betas[1], self.eps, L.ptr(self._step_dev), ema_decay, L.stream_ptr()),
+                    "dg_adam_ema_step_dev")
         L.Counters.add(self._step_dev, 1)  # (queued: one launch advances all of the step's counters)
-        st.refresh_transposed(tail=True)
+        st.refresh_transposed(tail=True, small_only=plan is not None)
         if ema_store is not None:
             ema_store._seen_version = -1  # its shadows are rebuilt lazily when G_ema is used
         return True
@@ -379,6 +452,7 @@ class Trainer:
         self._pending = None
         self._dev_scal = None
         self._pool_ctr = None   # device-resident loader position of the synthetic pool (dg_fetch_reals_pool_sum)
+        self._fetch_in_prologue = os.environ.get("DUSTY_GAN_FETCH_IN_PROLOGUE", "1") != "0"   # (A/B switch, tests)
         self._pool_host = 0     # its host mirror: checked against batches_drawn before every graph step
         # the logged scalars leave the device with the step's last launch, into a ring of mapped pinned host memory
         # (RingSlot); DUSTY_GAN_SCALAR_RING=0: a device copy + a blocking read-back per step instead
@@ -414,7 +488,7 @@ class Trainer:
         mask = raw_batch["mask"].to(self.device, non_blocking=True).float()
         return self.lidar.fetch_reals(pol, mask, float(self.cfg.model.gen.drop_const))
 
-    def _begin_step(self, draw_B=None):
+    def _begin_step(self, draw_B=None, fetch=None):
         """Open the step's accumulator arena and zero both networks' gradient buffers (optim.zero_grad, reference :177 and
         :246) with ONE launch; `optimize_D` / `optimize_G` then skip their own fills (a single micro-batch overwrites
         Proj.weight's 268 MB gradient, or never forms it, so that segment is not filled).  draw_B: the same launch also
@@ -428,7 +502,7 @@ class Trainer:
         draws, adv = (), None
         if draw_B is not None:
             draws, adv = self._draw_jobs(int(draw_B))
-        L.AccArena.begin(self.device, also=(Dst.grad, g) if ok else (), draws=draws)
+        L.AccArena.begin(self.device, also=(Dst.grad, g) if ok else (), draws=draws, fetch=fetch)
         if adv is not None:
             adv()
         self._arena_ready = True
@@ -480,8 +554,6 @@ class Trainer:
         the kernel produces beside x_real survive until DiffAugment reads them.  pooled: `raw_batch` is the batch the
         synthetic loader just yielded (number batches_drawn - 1); the kernel picks that same batch ON THE DEVICE from the
         pool by a counter the step advances (dg_fetch_reals_pool_sum), so a hipGraph replay needs no copy of it."""
-        if begin:   # (begin=False: a further micro-batch of an accumulated step - the arena is open, the draws follow per micro-batch)
-            self._begin_step(draw_B=self.local_batch)   # (a step that fetches its own batch also draws its own parameters)
         if pooled:
             ds = self.dataset
             if self._pool_ctr is None:
@@ -491,14 +563,31 @@ class Trainer:
                 self._pool_ctr = torch.full((1,), first, dtype=torch.int64, device=self.device)
                 self._pool_host = first
             L.Counters.flush_if(self._pool_ctr)
-            x = self.lidar.fetch_reals_pool(ds.pool_depth, ds.pool_mask, self._pool_ctr,
-                                            float(self.cfg.model.gen.drop_const))
+            x = None
+            job = (self.lidar.fetch_job(ds.pool_depth, ds.pool_mask, self._pool_ctr, float(self.cfg.model.gen.drop_const))
+                   if self._fetch_in_prologue else None)
+            if job is not None:
+                # round 6: the fetch rides on the step's first launch (arena + gradient zero-fill + the draws); its per-sample
+                # sums leave as XSUM_PARTS partials per sample (nothing that launch would have to zero first).  A further
+                # micro-batch of an accumulated step (begin=False): the same kernel as a launch of its own.
+                if begin:
+                    self._begin_step(draw_B=self.local_batch, fetch=job[0])
+                else:
+                    L.step_prologue([], [], fetch=job[0])
+                x = L.tag_sums(job[1], job[2], parts=L.XSUM_PARTS)
+            else:
+                if begin:
+                    self._begin_step(draw_B=self.local_batch)
+                x = self.lidar.fetch_reals_pool(ds.pool_depth, ds.pool_mask, self._pool_ctr,
+                                                float(self.cfg.model.gen.drop_const))
             L.Counters.add(self._pool_ctr, 1)   # (queued: applied with the step's other counters, inside the graph)
             if not torch.cuda.is_current_stream_capturing():
                 self._pool_host += 1            # (host mirror of the device index; a capture executes nothing)
             # no mask on this path: the loader's host batch is NOT what a replay reads (the device picks the batch), and
             # nothing downstream uses the reals' mask (reference :154-160 returns it, :162-325 never reads it)
             return x, None
+        if begin:   # (begin=False: a further micro-batch of an accumulated step - the arena is open, the draws follow per micro-batch)
+            self._begin_step(draw_B=self.local_batch)   # (a step that fetches its own batch also draws its own parameters)
         return self.fetch_reals(raw_batch)
 
     def _g_engines(self):
@@ -633,11 +722,14 @@ class Trainer:
 
     def _allreduce(self, store):
         """SUM all-reduce of a network's flat gradient; returns the factor Adam applies (1/world = DDP's average)."""
-        E.WGRAD_WS.flush()  # the split-K partials of the weight gradients become the gradient here
         if self._multi:
+            E.WGRAD_WS.flush()  # the split-K partials of the weight gradients become the gradient here
             self._coll(lambda: D_.allreduce_grads(store.grad), name="all-reduce grads")
         elif self._force_seg:
+            E.WGRAD_WS.flush()
             self._coll(lambda: None)
+        # (one rank: the optimizer's launch sums the pending partials itself - FlatAdam.step / dg_adam_fused, round 6 - or
+        #  reduces them first where it cannot)
         return 1.0 / self.world
 
     def _allreduce_async(self, key, buf):
@@ -667,6 +759,7 @@ class Trainer:
         gp = float(self.loss_weight.get("gp", 0.0)) if "gp" in self.criterion else 0.0
         w_gan = float(self.loss_weight["gan"]) / self.n_acc
         self._mb = []
+        extra_D = None
         dev = self.device
         # real, fake, adv, gp, G adv, path-length baseline, path-length penalty (sums over micro-batches)
         # every small accumulator of the step (these scalars, per-sample sums, logits) comes zeroed out of ONE arena
@@ -716,24 +809,26 @@ class Trainer:
             cut = Dst.seg["d4_w"].off
             if gp > 0:
                 deng.backward_data(Dst, 0, 2 * B, up, rs, want_dbias=True, skip_final=fused)
-                g = torch.empty(B, 1, self.H, self.W, **f32)
                 # R1 (:218-235): g = d sum(y_real) / dx_real, penalty = gp / 2 * mean_b |g_b|^2, and its double backward's
                 # tangent v = d penalty / dg = (gp / B) g, pushed forward through D below
                 vscale = gp / self.n_acc / B
                 ssq = L.AccArena.take(B, dev)
-                vg = torch.empty_like(g)
-                if ssq is None or not deng.backward_input(Dst, 0, B, vg, r1=(vscale, ssq)):
-                    # (shapes the fused adjoint does not take - refused before anything is launched - or no arena:
-                    # three passes)
-                    deng.backward_input(Dst, 0, B, g)
-                    if ssq is None:
-                        ssq = torch.empty(B, **f32)
-                        L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
-                    else:
-                        L.check(lib.dg_sample_sum_acc(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum_acc")
-                    L.check(lib.dg_scale(L.ptr(g), vscale, g.numel(), L.ptr(vg), sp), "dg_scale")
-                # (:229: the penalty's logged mean rides on the tangent's BlurVH launch)
-                deng.forward(Dst, vg, 2 * B, tangent_of=0, mean=(ssq, B, L.ptr(scal) + 12))
+                # (:229: the penalty's logged mean rides on the same launch)
+                if ssq is None or not deng.r1_turnaround(Dst, 0, B, 2 * B, vscale, ssq, L.ptr(scal) + 12):
+                    g = torch.empty(B, 1, self.H, self.W, **f32)
+                    vg = torch.empty_like(g)
+                    if ssq is None or not deng.backward_input(Dst, 0, B, vg, r1=(vscale, ssq)):
+                        # (shapes the fused adjoint does not take - refused before anything is launched - or no arena:
+                        # three passes)
+                        deng.backward_input(Dst, 0, B, g)
+                        if ssq is None:
+                            ssq = torch.empty(B, **f32)
+                            L.check(lib.dg_sample_sum(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum")
+                        else:
+                            L.check(lib.dg_sample_sum_acc(L.ptr(g), B, self.H * self.W, 1, L.ptr(ssq), sp), "dg_sample_sum_acc")
+                        L.check(lib.dg_scale(L.ptr(g), vscale, g.numel(), L.ptr(vg), sp), "dg_scale")
+                    # (:229: the penalty's logged mean rides on the tangent's BlurVH launch)
+                    deng.forward(Dst, vg, 2 * B, tangent_of=0, mean=(ssq, B, L.ptr(scal) + 12))
                 # weight gradients: real (weighted by dLoss/dy_real) + fake halves and tangent (x) real chain, one launch
                 # per fat layer (engine.DEngine.wgrad_r1)
                 for layers in (((4,), (3, 2, 1)) if bucketed else ((4, 3, 2, 1),)):
@@ -741,7 +836,11 @@ class Trainer:
                     if 4 in layers:
                         if not fused:
                             deng.final_wgrad(Dst, 0, 2 * B, dy)
-                        deng.final_wgrad(Dst, 2 * B, B, None)
+                        if (not bucketed and self.n_acc == 1 and not deng.x2 and self.optim_D.will_fuse(self.dtype)):
+                            # (round 6: the R1 term of the final conv's weight gradient is summed by the optimizer's launch)
+                            extra_D = {"final_w": deng.final_wgrad_term(2 * B, B)}
+                        else:
+                            deng.final_wgrad(Dst, 2 * B, B, None)
                         if bucketed:
                             self._allreduce_async("D.hi", Dst.grad[cut:])
             else:
@@ -763,7 +862,7 @@ class Trainer:
             gscale = 1.0 / self.world
         else:
             gscale = self._allreduce(Dst)
-        self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype)  # :238
+        self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype, extra=extra_D)  # :238
         self._dev_scal = scal
         return scal
 

@@ -92,12 +92,13 @@ class DiffAugment(nn.Module):
     def aug_set(self, x, rp):
         """(DgAugSet, keep-alive) for the fused DiffAugment + BlurVH pass of the discriminator's input, or None when the
         per-sample sums of x were not made by its producer in this step (the caller then runs `apply` + BlurVH)"""
-        pre = L.tagged_sums(x)
-        if pre is None or not x.is_contiguous() or x.dtype != torch.float32 or x.shape[1] != 1:
+        tag = L.tagged_sums(x, with_parts=True)
+        if tag is None or not x.is_contiguous() or x.dtype != torch.float32 or x.shape[1] != 1:
             return None
+        pre, parts = tag
         args, keep = self._args(rp, x.shape[0], x.device)
         q = L.DgAugSet()
-        q.x, q.xsum = L.ptr(x), L.ptr(pre)
+        q.x, q.xsum, q.xsum_parts = L.ptr(x), L.ptr(pre), parts
         q.u_b, q.u_c, q.t_h, q.t_w, q.o_x, q.o_y = args
         return q, (keep, pre, x)
 

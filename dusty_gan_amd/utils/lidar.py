@@ -58,12 +58,40 @@ class LiDAR:
                                                 L.stream_ptr()), "dg_fetch_reals_pool_sum")
         return L.tag_sums(out, sums)
 
+    def fetch_job(self, pool_pol, pool_mask, pool_ctr, drop_const):
+        """fetch_reals as a job of the step's FIRST launch (dg_step_prologue_fetch): (DgFetch, out, parts) - `out` the batch's
+        inverse-depth images, `parts` [B, XSUM_PARTS] the partial sums the launch stores - or None where that form does not apply
+        (H W % (1024 XSUM_PARTS) != 0).  pool_ctr given: pool_pol / pool_mask are [P,B,1,H,W] pools and the batch is
+        (*pool_ctr % P), read on the device; None: they ARE the batch [B,1,H,W].  The caller passes the job to
+        `_lib.AccArena.begin` (or `_lib.step_prologue`) and tags out with the sums."""
+        pooled = pool_ctr is not None
+        P = pool_pol.shape[0] if pooled else 1
+        first = pool_pol[0] if pooled else pool_pol
+        B, HW = first.shape[0], first[0].numel()
+        if (HW % (1024 * L.XSUM_PARTS) != 0 or pool_pol.dtype != torch.float32 or pool_mask.dtype != torch.float32
+                or not pool_pol.is_contiguous() or not pool_mask.is_contiguous()):
+            return None
+        out = torch.empty_like(first)
+        parts = torch.empty(B, L.XSUM_PARTS, dtype=torch.float32, device=pool_pol.device)
+        f = L.DgFetch()
+        f.pol, f.mask, f.pool_ctr, f.npool = L.ptr(pool_pol), L.ptr(pool_mask), L.ptr(pool_ctr), P
+        f.min_depth, f.max_depth, f.drop_const = self.min_depth, self.max_depth, float(drop_const)
+        f.B, f.HW, f.out, f.parts = B, HW, L.ptr(out), L.ptr(parts)
+        return f, out, parts
+
     def fetch_reals(self, pol, mask, drop_const):
         """pol [B,1,H,W] in [0,1], mask [B,1,H,W] {0,1} float -> inverse depth in [-1,1], dropped pixels = drop_const"""
         pol = pol.contiguous().float()
         mask = mask.contiguous().float()
-        out = torch.empty_like(pol)
         B, HW = pol.shape[0], pol[0].numel()
+        if L.AccArena.buf is not None and pol.is_cuda:
+            # the kernel the graph-replayed step runs as part of its first launch, here as a launch of its own: the image AND
+            # the per-sample sums (XSUM_PARTS stored partials) are then the same bits on both paths (round 6)
+            job = self.fetch_job(pol, mask, None, drop_const)
+            if job is not None:
+                L.step_prologue([], [], fetch=job[0])
+                return L.tag_sums(job[1], job[2], parts=L.XSUM_PARTS), mask
+        out = torch.empty_like(pol)
         sums = L.AccArena.take(B, pol.device) if HW % 256 == 0 else None
         if sums is not None:  # per-sample sums of the result in the same pass (DiffAugment's contrast reads them)
             L.check(L.lib().dg_fetch_reals_sum(L.ptr(pol), L.ptr(mask), self.min_depth, self.max_depth, float(drop_const),

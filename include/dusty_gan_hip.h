@@ -214,6 +214,13 @@ int dg_blur_bwd(const void* d, int dtype, float* dx, int B, int H, int W, int ri
  * (ssq zeroed by the caller) in one pass instead of dg_blur_bwd + dg_sample_sum + dg_scale; DG_EUNSUPPORTED unless W % 4 == 0
  * and H W % 1024 == 0 */
 int dg_blur_bwd_r1(const void* d, int dtype, float* dx, float oscale, float* ssq, int B, int H, int W, int ring, void* stream);
+/* ... and with the R1 tangent's BlurVH in the SAME launch (round 6): out[b] = BlurVH(oscale * g_b) [B,H,W,2] in `dtype`,
+ * g_b = BlurVH^T(d[b]) never written; ssq[b] += |g_b|^2 and (mean_acc non-NULL) mean_acc[0] += sum_b |g_b|^2 / mean_n - the
+ * logged penalty, trainers/dcgan_amp.py:229 - both zeroed by the caller.  The two launches it replaces: dg_blur_bwd_r1 +
+ * dg_blur_fwd_mean; same arithmetic in the same order, so out is bit-identical to theirs.  DG_EUNSUPPORTED (nothing launched)
+ * unless W % 4 == 0, H % 4 == 0 and six image rows fit 60 KB of LDS. */
+int dg_blur_r1_tangent(const void* d, int dtype, void* out, float oscale, float* ssq, float* mean_acc, int mean_n, int B, int H,
+                       int W, int ring, void* stream);
 
 /* ---- final EqualLR(Conv2d(C,1,(h0,w0)))  models/gans/dcgan_eqlr.py:95 ------------------------------------ */
 int dg_final_fwd(const void* d4, int dtype, const float* wf, const float* bias, float scale, int B, long n, float* y,
@@ -267,10 +274,13 @@ int dg_diffaug_bwd_acc(const float* gy, const float* u_b, const float* u_c, cons
  * two modules every D(A(x)) call runs, trainers/dcgan_amp.py:199-204,255-260): the augmented image is only ever D's input,
  * so it is not written - out = BlurVH(A(x)) [nsets B, H, W, 2] in `dtype`.  One or two source sets per launch (the D
  * phase's real | fake halves); xsum = the per-sample sums of x (dg_fetch_reals_sum / dg_head_post_fwd_sum), read by the
- * contrast stage.  DG_EUNSUPPORTED unless W % 4 == 0. */
+ * contrast stage.  DG_EUNSUPPORTED unless W % 4 == 0, H % 4 == 0 (a workgroup owns a band of four output rows) and six image
+ * rows fit 60 KB of LDS. */
+#define DG_XSUM_PARTS 8       /* partial sums per sample where a producer leaves them un-summed (dg_step_prologue_fetch) */
 typedef struct DgAugSet {
   const float* x;            /* [B,1,H,W] fp32 */
-  const float* xsum;         /* [B] */
+  const float* xsum;         /* [B], or with xsum_parts = DG_XSUM_PARTS: [B][DG_XSUM_PARTS] partial sums, added in index order */
+  int xsum_parts;            /* 0 / 1: one float per sample */
   const float *u_b, *u_c;    /* [B] the uniform(-1,1) draws of brightness / contrast */
   const int *t_h, *t_w, *o_x, *o_y;
 } DgAugSet;
@@ -335,7 +345,8 @@ int dg_final_gan_bwd(int metric, int mode_g, float smoothing, const float* y_rea
 int dg_mean_acc(const float* x, int n, float* acc, void* stream);
 /* Bit-reproducible cross-block sums (round 5).  Registers, for the current device, the arena of small fp32 accumulators the
  * step zero-fills once (per-sample image sums, logits, the augment adjoint's window sums: dg_*_acc / dg_*_sum entry points
- * accumulate into slices of it) together with a shadow of 16 bytes per arena float, zero at rest: kernels whose blocks add
+ * accumulate into slices of it) together with a shadow of 128 bytes per arena float (a cache line each: adds to one line
+ * serialise memory-side), zero at rest: kernels whose blocks add
  * partial sums into an arena slot then add them as 32.32 fixed point to the slot's shadow word (integer addition commutes)
  * and the last block to arrive converts the total - instead of float atomics, whose result depends on the arrival order.
  * arena = shadow = NULL unregisters (float atomics again).  Nothing in the reference to replace: torch's reductions are
@@ -518,6 +529,25 @@ typedef struct DgDraw {
   int* qi;                   /* kind 2: [4][B] */
 } DgDraw;
 int dg_step_prologue(float* const* zero_ptrs, const long* zero_counts, int k, const DgDraw* draws, int ndraw, void* stream);
+/* ... and fetch_reals of the step's batch as more workgroups of the SAME launch (round 6; trainers/dcgan_amp.py:154-160 with
+ * Coordinate.invert_depth, utils/lidar.py:31-36, and sigmoid_to_tanh, utils/__init__.py:70-73; same arithmetic as
+ * dg_fetch_reals_pool_sum): out[B,1,H,W] = the inverse-depth image in [-1, 1] of batch (*pool_ctr % npool) of the device-resident
+ * pool (pool_ctr NULL: pol / mask ARE the batch), and parts[B][DG_XSUM_PARTS] = the partial sums of out per sample - block j owns
+ * pixels [j HW / DG_XSUM_PARTS, (j + 1) HW / DG_XSUM_PARTS) of the batch and STORES its sum (no accumulator this launch would
+ * have to zero first, no atomics: bit-reproducible); DgAugSet.xsum_parts tells the reader.  DG_EUNSUPPORTED (nothing launched)
+ * unless HW % (1024 DG_XSUM_PARTS) == 0 and the images are 16-byte aligned. */
+typedef struct DgFetch {
+  const float *pol, *mask;              /* [npool][B][HW] (or [B][HW]) polar depth in [0, 1] and validity {0, 1} */
+  const unsigned long long* pool_ctr;   /* device-resident loader position, or NULL */
+  int npool;
+  float min_depth, max_depth, drop_const;
+  int B;
+  long HW;
+  float* out;                           /* [B][HW] */
+  float* parts;                         /* [B][DG_XSUM_PARTS] */
+} DgFetch;
+int dg_step_prologue_fetch(float* const* zero_ptrs, const long* zero_counts, int k, const DgDraw* draws, int ndraw,
+                           const DgFetch* fetch, void* stream);
 int dg_aug_draw_dev(uint64_t seed, uint64_t stream_id, const unsigned long long* offset_dev, int B, int H, int W,
                     float* uf, int* qi, void* stream);
 /* Adam with the (0-based, already-completed) step count in device memory: this call is step *step_dev + 1 */
@@ -525,6 +555,29 @@ int dg_adam_ema_step_dev(float* p, const float* grad, float* m, float* v, float*
                          long n, float gscale, float lr, float beta1, float beta2, float eps,
                          const unsigned long long* step_dev, float ema_decay, void* stream);
 
+/* The optimizer of a network as ONE launch that forms the gradients it consumes (round 6; trainers/dcgan_amp.py:238, :312-316
+ * behind loss.backward()'s last reductions): per piece of the flat buffers, the sum of the piece's split-K partial rows
+ * (`part`, [splits][numel], fixed order - what dg_wgrad_reduce would add to the gradient; `accumulate`: + the gradient buffer's
+ * content), optionally + ws_scale * sum_b ws_coef[b] * ws_src[b][i] (dg_batch_wsum: the final conv's weight gradient from the
+ * R1 tangent; ws_coef NULL = 1), then Adam with beta1 = 0 + the EMA (`ema` NULL: none) exactly as dg_adam_ema_step_dev, and
+ * every store: master, exp_avg_sq, EMA, the summed gradient (kept), the compute-type shadow, and for kind 1 - a [16][ci][co]
+ * conv segment, co == 64 or co % 128 == 0, ci % 16 == 0 - the [16][co][ci] shadow `shadow_t` (dg_transpose_shadow_multi's output).  Replaces
+ * dg_batch_wsum + dg_wgrad_reduce + dg_adam_ema_step_dev + the fat layers' share of dg_transpose_shadow_multi; the results are
+ * bit-identical to theirs (same order of additions) except where ws_src folds dg_batch_wsum in.  Pieces must not overlap;
+ * anything of the buffers no piece covers is left untouched.  `first_block` is filled by the library. */
+#define DG_OPT_MAX_SEG 20
+typedef struct DgOptSeg {
+  long long off, numel;          /* piece [off, off + numel) of p / grad / v / ema / shadow, multiples of 4 */
+  const float* part;             /* partial rows or NULL */
+  int splits, accumulate;
+  int kind, ci, co;              /* kind 0: flat; 1: conv tile walk (needs shadow_t) */
+  void* shadow_t;
+  const void* ws_src; const float* ws_coef; long long ws_stride; int ws_n, ws_bf16; float ws_scale;
+  int first_block;
+} DgOptSeg;
+int dg_adam_fused(float* p, float* grad, float* v, float* ema, void* shadow, int shadow_dtype, const DgOptSeg* segs, int nseg,
+                  float gscale, float lr, float beta2, float eps, const unsigned long long* step_dev, float ema_decay,
+                  void* stream);
 /* Adam (beta1 = 0) + EMA of Proj.weight [Np][K] with its weight gradient wscale * dp0^T z (trainers/dcgan_amp.py:309,312:
  * loss_G.backward() + optim_G.step() for that one tensor) formed inside the kernel from the bf16 operands dp0 [nb][Np]
  * and zT [nb][K]: the 268 MB gradient is never written.  Two kernels behind it: an LDS-resident VALU kernel for the

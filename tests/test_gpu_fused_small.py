@@ -320,6 +320,46 @@ def test_blurvh_adjoint_with_augment_sum(L, H, W, dtype):
     assert rel_l2(got.cpu(), ref.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("H,W,ring", [(32, 64, 1), (64, 1024, 1), (16, 48, 0), (8, 2048, 1), (6, 64, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_r1_turnaround_in_one_launch(L, H, W, ring, dtype):
+    """dg_blur_r1_tangent (round 6: BlurVH^T, |g|^2, the scaling and the tangent's BlurVH in ONE launch, g never written;
+    trainers/dcgan_amp.py:218-235 through models/ops/common.py:74-88) == dg_blur_bwd_r1 + dg_blur_fwd: the tangent map bit for
+    bit, the per-sample sums and their mean to rounding; against the oracle's blur_vh; refused shapes launch nothing."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3 * H + W)
+    B = 3
+    dt = L.dtype_code(dtype)
+    d = torch.randn(B, H, W, 2, generator=g).to(DEV, dtype)
+    out = torch.full((B, H, W, 2), 7.0, device=DEV, dtype=dtype)
+    ssq, macc = torch.zeros(B, device=DEV), torch.zeros(1, device=DEV)
+    rc = lib.dg_blur_r1_tangent(d.data_ptr(), dt, out.data_ptr(), 0.375, ssq.data_ptr(), macc.data_ptr(), B, B, H, W, ring, None)
+    torch.cuda.synchronize()
+    if H % 4 or 6 * W * 4 > 60 * 1024:
+        assert rc == L.DG_EUNSUPPORTED and float((out.float() - 7.0).abs().max()) == 0.0
+        return
+    L.check(rc)
+    vg, ssq2 = torch.empty(B, 1, H, W, device=DEV), torch.zeros(B, device=DEV)
+    ok = lib.dg_blur_bwd_r1(d.data_ptr(), dt, vg.data_ptr(), 0.375, ssq2.data_ptr(), B, H, W, ring, None)
+    if ok == L.DG_EUNSUPPORTED:                         # (H W % 1024 != 0: the plain adjoint, scaled here)
+        L.check(lib.dg_blur_bwd(d.data_ptr(), dt, vg.data_ptr(), B, H, W, ring, None))
+        ssq2 = (vg.double() ** 2).sum(dim=[1, 2, 3]).float()
+        vg = vg * 0.375
+    ref = torch.empty(B, H, W, 2, device=DEV, dtype=dtype)
+    L.check(lib.dg_blur_fwd(vg.data_ptr(), ref.data_ptr(), dt, B, H, W, ring, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert rel_l2(ssq.cpu(), ssq2.cpu()) < 1e-6
+    assert abs(float(macc) - float(ssq2.sum()) / B) <= 1e-6 * float(ssq2.sum()) / B
+    if ring:   # the oracle: BlurVH of the scaled adjoint image (autograd of the reference composition)
+        x = torch.zeros(B, 1, H, W, requires_grad=True)
+        y = O.blur_vh(x, ring=True)
+        (gx,) = torch.autograd.grad(y, x, d.float().cpu().permute(0, 3, 1, 2))
+        want = O.blur_vh(0.375 * gx, ring=True).permute(0, 2, 3, 1)
+        assert rel_l2(out.float().cpu(), want) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert lib.dg_blur_r1_tangent(d.data_ptr(), dt, out.data_ptr(), 1.0, None, None, B, B, H, W, ring, None) == L.DG_EINVAL
+
+
 def test_fetch_reals_from_the_device_resident_pool(L):
     """dg_fetch_reals_pool_sum picks batch (*counter % pool) on the device: == dg_fetch_reals_sum of that batch"""
     lib = L.lib()
@@ -337,6 +377,64 @@ def test_fetch_reals_from_the_device_resident_pool(L):
                                             out.data_ptr(), s.data_ptr(), None))
         torch.cuda.synchronize()
         assert torch.equal(out, ref) and rel_l2(s.cpu(), rs.cpu()) < 1e-6
+
+
+def test_fetch_reals_rides_on_the_step_prologue(L):
+    """dg_step_prologue_fetch (round 6): fetch_reals of the pooled batch as more workgroups of the step's first launch -
+    the image bit for bit what dg_fetch_reals_pool_sum writes (and the oracle's fetch_reals, trainers/dcgan_amp.py:154-160), the
+    per-sample sums as DG_XSUM_PARTS stored partials whose in-order sum is the sample's sum; the zero-fill of the same launch
+    still happens; two launches agree bit for bit; and dg_diffaug_blur_fwd reads the partial form like the single sums."""
+    lib = L.lib()
+    P, B, H, W = 3, 4, 16, 512                       # HW = 8192 = 1024 x DG_XSUM_PARTS
+    g = torch.Generator().manual_seed(19)
+    pol = torch.rand(P, B, 1, H, W, generator=g).to(DEV)
+    m = (torch.rand(P, B, 1, H, W, generator=g) < 0.8).float().to(DEV)
+    for k in (0, 2, 7):
+        ctr = torch.full((1,), k, dtype=torch.int64, device=DEV)
+        ref, rs = torch.empty(B, 1, H, W, device=DEV), torch.zeros(B, device=DEV)
+        L.check(lib.dg_fetch_reals_pool_sum(pol.data_ptr(), m.data_ptr(), ctr.data_ptr(), P, 0.9, 120.0, -1.0, B, H * W,
+                                            ref.data_ptr(), rs.data_ptr(), None))
+        res = []
+        for _ in range(2):
+            out = torch.full((B, 1, H, W), float("nan"), device=DEV)
+            parts = torch.full((B, L.XSUM_PARTS), float("nan"), device=DEV)
+            dirty = torch.ones(1024, device=DEV)
+            f = L.DgFetch()
+            f.pol, f.mask, f.pool_ctr, f.npool = pol.data_ptr(), m.data_ptr(), ctr.data_ptr(), P
+            f.min_depth, f.max_depth, f.drop_const, f.B, f.HW = 0.9, 120.0, -1.0, B, H * W
+            f.out, f.parts = out.data_ptr(), parts.data_ptr()
+            L.step_prologue([dirty], [], fetch=f)
+            torch.cuda.synchronize()
+            assert float(dirty.abs().max()) == 0.0
+            res.append((out, parts))
+        out, parts = res[0]
+        assert torch.equal(out, ref) and torch.equal(res[1][0], out) and torch.equal(res[1][1], parts)
+        want = O.fetch_reals(pol[k % P].cpu(), m[k % P].cpu())[0]
+        assert float((out.cpu() - want).abs().max()) < 1e-5
+        assert rel_l2(parts.sum(1).cpu(), rs.cpu()) < 1e-6
+        assert rel_l2(parts.double().cpu(), out.double().view(B, L.XSUM_PARTS, -1).sum(2).cpu()) < 1e-6
+    # the reader: DiffAugment + BlurVH with the partial sums == with their in-order total as the single sum
+    from dusty_gan_amd.utils.diff_augment import DiffAugment
+    A = DiffAugment()
+    rp = A.draw(B, H, W, torch.device(DEV))
+    args, keep = A._args(rp, B, torch.device(DEV))
+    tot = torch.zeros(B, device=DEV)
+    for j in range(L.XSUM_PARTS):                    # (the kernel's own order of additions)
+        tot = tot + parts[:, j]
+    outs = []
+    for xs, np_ in ((parts, L.XSUM_PARTS), (tot, 1)):
+        q = L.DgAugSet()
+        q.x, q.xsum, q.xsum_parts = out.data_ptr(), xs.data_ptr(), np_
+        q.u_b, q.u_c, q.t_h, q.t_w, q.o_x, q.o_y = args
+        h0 = torch.empty(B, H, W, 2, device=DEV)
+        L.check(lib.dg_diffaug_blur_fwd((L.DgAugSet * 1)(q), 1, A.mask, B, H, W, 1, h0.data_ptr(), L.DG_F32, None))
+        outs.append(h0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().mean()) > 0
+    # refusals
+    f.HW = 4096
+    assert lib.dg_step_prologue_fetch(None, None, 0, None, 0, C.byref(f), None) == L.DG_EUNSUPPORTED
+    assert lib.dg_step_prologue_fetch(None, None, 0, None, 0, None, None) == L.DG_EINVAL
 
 
 @pytest.mark.parametrize("shape", [(3, 1, 8, 32), (2, 1, 1, 1), (5, 1, 7, 9)])
@@ -460,8 +558,10 @@ def test_final_gan_bwd_equals_the_separate_launches(L, dtype, metric, mode_g, r1
                                  b["dd4"].data_ptr(), None if mode_g else b["db"].data_ptr(),
                                  None if mode_g else b["dwf"].data_ptr(), None, None))
     torch.cuda.synchronize()
-    for k in ("dy", "up", "rs", "acc", "fb", "dd4", "dwf"):
+    for k in ("dy", "up", "rs", "acc", "fb", "dd4"):
         assert torch.equal(a[k], b[k]), k
+    # (round 6: eight waves split the samples instead of four - the weight gradient's partial sums meet in another order)
+    assert rel_l2(b["dwf"].cpu(), a["dwf"].cpu()) < 1e-6 or mode_g
     assert float(a["dd4"].float().abs().mean()) > 0 and (mode_g or float(a["dwf"].abs().mean()) > 0)
     assert rel_l2(b["db"].cpu(), a["db"].cpu()) < 1e-5 or mode_g
     if not mode_g:
@@ -493,6 +593,95 @@ def test_final_gan_bwd_equals_the_separate_launches(L, dtype, metric, mode_g, r1
     assert lib.dg_final_gan_bwd(0, 1, 1.0, None, y_fake, B, 1.0, 1, b["dy"].data_ptr(), None, None, b["acc"].data_ptr(), None,
                                 d4.data_ptr(), dt, wf.data_ptr(), scale, n, C, b["dd4"].data_ptr(), None, None,
                                 None, None) == L.DG_EINVAL
+
+
+@pytest.mark.parametrize("with_ema,co", [(False, 128), (True, 64), (True, 256)])
+@pytest.mark.parametrize("sdt", [torch.bfloat16, torch.float32])
+def test_one_launch_optimizer_is_the_four_launches(L, with_ema, co, sdt):
+    """dg_adam_fused (round 6) against the launches it replaces - dg_batch_wsum, dg_wgrad_reduce, dg_adam_ema_step_dev,
+    dg_transpose_shadow_multi - on a parameter buffer with a fat conv segment (split-K partial tiles), a bias with more partial
+    rows than the wide path's threshold, a plain run and a segment that takes an extra batch term (the final conv's R1 term):
+    master, exp_avg_sq, EMA, gradient, shadow and transposed shadow bit for bit (the sums are taken in the same order), the
+    extra-term segment to rounding; the reference arithmetic: torch.optim.Adam at beta1 = 0 + ema_inplace,
+    trainers/dcgan_amp.py:30-35,116-125."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(77)
+    ci = 48 if co != 64 else 32
+    n_conv, n_b, n_plain, n_ws = 16 * ci * co, 96, 320, 2048
+    offs = [0, n_conv, n_conv + 128, n_conv + 128 + n_plain]
+    n = offs[3] + n_ws
+    sp_conv, sp_b, nb = 5, 100, 6
+
+    def fresh():
+        gg = torch.Generator().manual_seed(5)
+        d = dict(p=torch.randn(n, generator=gg), v=torch.rand(n, generator=gg) * 1e-2, grad=torch.randn(n, generator=gg) * 0.1,
+                 ema=torch.randn(n, generator=gg))
+        d = {k: t.to(DEV) for k, t in d.items()}
+        d["shadow"] = torch.zeros(n, dtype=sdt, device=DEV)
+        d["coci"] = torch.zeros(n_conv, dtype=sdt, device=DEV)
+        return d
+    part_conv = (torch.randn(sp_conv, n_conv, generator=g) * 0.1).to(DEV)
+    part_b = (torch.randn(sp_b, n_b, generator=g) * 0.1).to(DEV)
+    src = torch.randn(nb, n_ws, generator=g).to(DEV, torch.bfloat16)
+    coef = torch.randn(nb, generator=g).to(DEV)
+    step = torch.full((1,), 3, dtype=torch.int64, device=DEV)
+    lr, b2, eps, decay, gscale = 2e-3, 0.99, 1e-8, 0.998, 0.5
+    code = L.dtype_code(sdt)
+    # the four launches
+    a = fresh()
+    L.check(lib.dg_batch_wsum(src.data_ptr(), L.DG_BF16, coef.data_ptr(), 0.25, nb, n_ws, a["grad"].data_ptr() + 4 * offs[3], None))
+    items = (L.DgWgradReduce * 2)()
+    items[0].ws, items[0].dw, items[0].numel, items[0].splits, items[0].accumulate = part_conv.data_ptr(), a["grad"].data_ptr(), n_conv, sp_conv, 1
+    items[1].ws, items[1].dw, items[1].numel, items[1].splits, items[1].accumulate = part_b.data_ptr(), a["grad"].data_ptr() + 4 * offs[1], n_b, sp_b, 0
+    L.check(lib.dg_wgrad_reduce(items, 2, None))
+    L.check(lib.dg_adam_ema_step_dev(a["p"].data_ptr(), a["grad"].data_ptr(), None, a["v"].data_ptr(),
+                                     a["ema"].data_ptr() if with_ema else None, a["shadow"].data_ptr(), code, n, gscale, lr, 0.0,
+                                     b2, eps, step.data_ptr(), decay, None))
+    desc = torch.tensor([0, a["coci"].data_ptr(), ci, co, 0], dtype=torch.int64).to(DEV)
+    L.check(lib.dg_transpose_shadow_multi(a["p"].data_ptr(), desc.data_ptr(), 1, 16 * ((ci + 31) // 32) * ((co + 31) // 32), code, None))
+    # one launch
+    b = fresh()
+    segs = (L.DgOptSeg * 4)()
+    segs[0].off, segs[0].numel, segs[0].part, segs[0].splits, segs[0].accumulate = 0, n_conv, part_conv.data_ptr(), sp_conv, 1
+    segs[0].kind, segs[0].ci, segs[0].co, segs[0].shadow_t = 1, ci, co, b["coci"].data_ptr()
+    segs[1].off, segs[1].numel, segs[1].part, segs[1].splits, segs[1].accumulate = offs[1], n_b, part_b.data_ptr(), sp_b, 0
+    segs[2].off, segs[2].numel, segs[2].accumulate = offs[1] + n_b, offs[3] - offs[1] - n_b, 1      # the plain run (+ padding)
+    segs[3].off, segs[3].numel, segs[3].accumulate = offs[3], n_ws, 1
+    segs[3].ws_src, segs[3].ws_bf16, segs[3].ws_coef, segs[3].ws_n, segs[3].ws_stride, segs[3].ws_scale = src.data_ptr(), 1, coef.data_ptr(), nb, n_ws, 0.25
+    for _ in range(1):
+        L.check(lib.dg_adam_fused(b["p"].data_ptr(), b["grad"].data_ptr(), b["v"].data_ptr(), b["ema"].data_ptr() if with_ema else None,
+                                  b["shadow"].data_ptr(), code, segs, 4, gscale, lr, b2, eps, step.data_ptr(), decay, None))
+    torch.cuda.synchronize()
+    lo = offs[3]
+    assert torch.equal(a["grad"][:lo], b["grad"][:lo])       # the sums: same additions in the same order
+    for k in ("p", "v", "grad", "ema", "shadow"):
+        # (Adam's arithmetic may be contracted into fused multiply-adds differently in the two kernels: last-bit differences)
+        tol = 1e-2 if (k == "shadow" and sdt == torch.bfloat16) else 1e-6
+        assert rel_l2(b[k][:lo].float().cpu(), a[k][:lo].float().cpu()) < tol, k
+        assert rel_l2(b[k][lo:].float().cpu(), a[k][lo:].float().cpu()) < max(tol, 1e-5), k
+    assert torch.equal(b["shadow"], b["p"].to(sdt))          # the shadows ARE the updated master, rounded
+    assert torch.equal(b["coci"].view(16, co, ci), b["p"][:n_conv].view(16, ci, co).to(sdt).permute(0, 2, 1).contiguous())
+    # against the formulas (fp64)
+    f = fresh()
+    gsum = f["grad"].double().cpu()
+    gsum[:n_conv] += part_conv.double().cpu().sum(0)
+    gsum[offs[1]:offs[1] + n_b] = part_b.double().cpu().sum(0)
+    gsum[lo:] += 0.25 * (coef.double().cpu()[:, None] * src.double().cpu()).sum(0)
+    gg = gsum * gscale
+    v = b2 * f["v"].double().cpu() + (1 - b2) * gg * gg
+    pnew = f["p"].double().cpu() - lr * gg / (v.sqrt() / math.sqrt(1 - b2 ** 4) + eps)
+    assert rel_l2(b["grad"].double().cpu(), gsum) < 1e-6 and rel_l2(b["v"].double().cpu(), v) < 1e-6
+    assert rel_l2(b["p"].double().cpu(), pnew) < 1e-6
+    if with_ema:
+        assert rel_l2(b["ema"].double().cpu(), decay * f["ema"].double().cpu() + (1 - decay) * pnew) < 1e-6
+    else:
+        assert torch.equal(b["ema"], f["ema"])
+    # argument errors
+    segs[0].co = 40
+    assert lib.dg_adam_fused(b["p"].data_ptr(), b["grad"].data_ptr(), b["v"].data_ptr(), None, b["shadow"].data_ptr(), code, segs, 4,
+                             gscale, lr, b2, eps, step.data_ptr(), decay, None) == L.DG_EINVAL
+    assert lib.dg_adam_fused(b["p"].data_ptr(), b["grad"].data_ptr(), b["v"].data_ptr(), None, b["shadow"].data_ptr(), code, segs, 0,
+                             gscale, lr, b2, eps, step.data_ptr(), decay, None) == L.DG_EINVAL
 
 
 def test_transpose_shadow_multi_tail_carries_the_counters(L):
