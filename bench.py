@@ -586,6 +586,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Everything the timed region needs from the host is made BEFORE the warm-up: the per-step HIP events (one after every
+    # step on the launch stream - the replayed graph / the eager launches of a step run on torch's current stream, so
+    # consecutive events bracket exactly one step) and the garbage collection (no collector pass inside the timed region: one
+    # run showed a single 12.6 ms step among 2.9 ms ones, a host-side stall).  Round 6: with the collection (50-100 ms of host
+    # time) BETWEEN warm-up and timed region the GPU sat idle long enough to drop its clocks, and the first ~15 timed steps
+    # ran 3-15 % above the steady state whatever the warm-up length (profiles/r06_timed_region_ramp.txt) - 2 % of a 20-step
+    # window.  Now the warm-up's last replay has barely finished when the bracket's synchronize returns.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    import gc
+    gc.collect()
+    gc.disable()
     last = None
     for i in range(args.warmup):
         last = tr.step(i)
@@ -594,16 +605,6 @@ def main():
             progress(f"warm-up step {i}: {tr.launch_mode()}")
     if last is not None:
         _ = list(last.values())
-    # per-step device times: one HIP event after every step on the launch stream (the replayed graph / the eager
-    # launches of a step run on torch's current stream, so consecutive events bracket exactly one step)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # no Python garbage-collection pass inside the timed region (one run of this script showed a single 12.6 ms step
-    # among 2.9 ms ones: a host-side stall, not device time).  All of this BEFORE the bracket's barrier + synchronize: the
-    # collection takes tens of milliseconds, and a GPU left idle that long starts the timed steps at a lower clock (round 6:
-    # the first steps of a 20-step window ran 5-15 % above the soak's median).
-    import gc
-    gc.collect()
-    gc.disable()
     progress("timed region")
     sync()
     t0 = time.perf_counter()
@@ -640,7 +641,8 @@ def main():
                                   "Adam+EMA, random-init weights",
                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
            "step_ms_device": {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90), "min": round(per[0], 4),
-                              "max": round(per[-1], 4), "first_steps": [round(marks[i].elapsed_time(marks[i + 1]), 4) for i in range(min(5, args.steps))],
+                              "max": round(per[-1], 4), "first_steps": [round(marks[i].elapsed_time(marks[i + 1]), 4)
+                                              for i in range(min(int(os.environ.get("DUSTY_BENCH_FIRST_STEPS", "5")), args.steps))],
                               "note": "HIP events between consecutive steps, rank 0"},
            "launch_mode": tr.launch_mode(),
            "scalars_last_step": {k: round(v, 5) for k, v in scal.items()}}

@@ -324,12 +324,18 @@ def step_prologue(tensors, draws, fetch=None):
 
 class AccArena:
     """Small fp32 accumulators that must start at zero (per-sample sums, logits, the logged scalars), carved from ONE
-    buffer that one kernel zero-fills at the start of a training step - instead of one ~5 us zero-fill node per
+    buffer per DEVICE that one kernel zero-fills at the start of a training step - instead of one ~5 us zero-fill node per
     accumulator (11 per step).  `take(n)` hands out a slice that has been zero since the last `begin()` and is handed
-    out once; None when the arena is not in use or exhausted (the caller then uses the self-zeroing entry point)."""
+    out once; None when the arena is not in use or exhausted (the caller then uses the self-zeroing entry point).
+    Round 6: one arena (+ fixed-point shadow) per device, allocated once and kept for the life of the process: a captured
+    hipGraph holds raw pointers into it, and the library's per-device registration (dg_det_arena) points at it - a second
+    trainer on another device gets that device's own arena instead of re-allocating (and silently un-registering) the first
+    one's (round-5 review, item 7).  Trainers that share a device share its arena: their steps are ordered on the device, and
+    every step opens its epoch with a zero-fill."""
     SIZE = 8192
-    buf, pos, epoch = None, 0, 0               # epoch: counts begin() calls (a slice is only meaningful within its epoch)
+    buf, pos, epoch = None, 0, 0               # the arena of the device `begin` was last called for; epoch counts begin() calls
     shadow = None                              # fixed-point shadow words of the slots (deterministic cross-block sums)
+    _by_dev = {}                               # device index -> (buf, shadow)
 
     @staticmethod
     def _same(dev, want):
@@ -338,20 +344,31 @@ class AccArena:
         return dev.type == want.type and (want.index is None or dev.index == want.index)
 
     @classmethod
+    def _for_device(cls, device):
+        import torch
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ent = cls._by_dev.get(idx)
+        if ent is None:
+            dev = torch.device("cuda", idx)
+            buf = torch.empty(cls.SIZE, dtype=torch.float32, device=dev)
+            shadow = None
+            # bit-reproducible sums into the arena's slots (csrc/common.h dg_acc_add): a shadow of 128 bytes per float, zero at
+            # rest, registered with the library for this device; DUSTY_GAN_DETERMINISTIC=0 keeps the float atomics
+            if os.environ.get("DUSTY_GAN_DETERMINISTIC", "1") != "0":
+                shadow = torch.zeros(cls.SIZE * 32, dtype=torch.int32, device=dev)   # DG_DET_STRIDE = 128 bytes per slot
+                torch.cuda.synchronize(dev)
+                with torch.cuda.device(dev):
+                    check(lib().dg_det_arena(ptr(buf), cls.SIZE, ptr(shadow)), "dg_det_arena")
+            ent = cls._by_dev[idx] = (buf, shadow)
+        return ent
+
+    @classmethod
     def begin(cls, device, also=(), draws=(), fetch=None):
         """open a new epoch: the arena - and the fp32 buffers in `also` (the step's gradient buffers) - zero-filled by
         one launch, which also runs the DgDraw jobs in `draws` (the step's parameter draws) and, with `fetch` (a DgFetch),
         fetch_reals of the step's batch"""
-        import torch
-        if cls.buf is None or not cls._same(cls.buf.device, device):
-            cls.buf = torch.empty(cls.SIZE, dtype=torch.float32, device=device)
-            # bit-reproducible sums into the arena's slots (csrc/common.h dg_acc_add): a shadow of 128 bytes per float, zero at
-            # rest, registered with the library for this device; DUSTY_GAN_DETERMINISTIC=0 keeps the float atomics
-            if os.environ.get("DUSTY_GAN_DETERMINISTIC", "1") != "0":
-                cls.shadow = torch.zeros(cls.SIZE * 32, dtype=torch.int32, device=device)   # DG_DET_STRIDE = 128 bytes per slot
-                torch.cuda.synchronize(cls.buf.device)
-                with torch.cuda.device(cls.buf.device):
-                    check(lib().dg_det_arena(ptr(cls.buf), cls.SIZE, ptr(cls.shadow)), "dg_det_arena")
+        cls.buf, cls.shadow = cls._for_device(device)
         if draws or fetch is not None:
             step_prologue([cls.buf] + list(also), list(draws), fetch)
         else:

@@ -93,11 +93,20 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
   const int blk = (int)blockIdx.x - sg.first_block;
   const float t = (float)(*stepp + 1ull);
   const float inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, t));
-  // Adam (beta1 = 0) + EMA + every store of four consecutive parameters at flat float4 index i4, given their gradient sum
-  auto update4 = [&](long i4, f32x4_opt g, float (&pn)[4]) {
-    const float4 v4 = ((const float4*)v)[i4];
-    const float4 p4 = ((const float4*)p)[i4];
-    const float4 e4 = ema ? ((const float4*)ema)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // Adam (beta1 = 0) + EMA + every store of four consecutive parameters at flat float4 index i4, given their gradient sum.
+  // The parameter-state loads are issued by `state_load` BEFORE the partial rows are summed (they do not depend on the sum:
+  // more bytes in flight, a shorter dependent chain per workgroup).
+  struct State { float4 v4, p4, e4; f32x4_opt g0; };
+  auto state_load = [&](long i4, bool acc) {
+    State st;
+    st.v4 = ((const float4*)v)[i4];
+    st.p4 = ((const float4*)p)[i4];
+    st.e4 = ema ? ((const float4*)ema)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    st.g0 = acc ? ((const f32x4_opt*)grad)[i4] : f32x4_opt{0.f, 0.f, 0.f, 0.f};
+    return st;
+  };
+  auto update4 = [&](long i4, f32x4_opt g, const State& st, float (&pn)[4]) {
+    const float4 v4 = st.v4, p4 = st.p4, e4 = st.e4;
     ((f32x4_opt*)grad)[i4] = g;
     const float gg[4] = {g[0] * gscale, g[1] * gscale, g[2] * gscale, g[3] * gscale};
     float vv[4] = {v4.x, v4.y, v4.z, v4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
@@ -151,9 +160,10 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
 #pragma unroll
       for (int j = 1; j < 16; ++j) g += s_part[j][el];
       const long i4 = sg.off / 4 + e4;
-      if (sg.accumulate) g += ((const f32x4_opt*)grad)[i4];
+      const State st = state_load(i4, sg.accumulate != 0);
+      g += st.g0;
       float pn[4];
-      update4(i4, g, pn);
+      update4(i4, g, st, pn);
     }
     return;
   }
@@ -161,9 +171,10 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     const long e4 = (long)blk * 256 + threadIdx.x;
     if (4 * e4 >= sg.numel) return;
     const long i4 = sg.off / 4 + e4;
+    const State st = state_load(i4, sg.accumulate != 0);
     f32x4_opt g = {0.f, 0.f, 0.f, 0.f};
     if (sg.part) g = part_sum(e4, 0, 1);
-    if (sg.accumulate) g += ((const f32x4_opt*)grad)[i4];
+    g += st.g0;
     if (sg.ws_src) {                               // + ws_scale * sum_b coef[b] * src[b][4 e4 .. 4 e4 + 3]
       f32x4_opt w = {0.f, 0.f, 0.f, 0.f};
       for (int b0 = 0; b0 < sg.ws_n; b0 += 8) {
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
       g += sg.ws_scale * w;
     }
     float pn[4];
-    update4(i4, g, pn);
+    update4(i4, g, st, pn);
     return;
   }
   // kind 1: a tile of 1024 elements = R rows (ci) x CW columns (co) of one tap, CW = min(Co, 128), R = 1024 / CW: CONTIGUOUS
@@ -204,11 +215,12 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
   const int tx = threadIdx.x % (CW / 4), ty = threadIdx.x / (CW / 4);
   const long e4 = (((long)tap * Ci + ci0 + ty) * Co + co0) / 4 + tx;
   const long i4 = sg.off / 4 + e4;
+  const State st = state_load(i4, sg.accumulate != 0);
   f32x4_opt g = {0.f, 0.f, 0.f, 0.f};
   if (sg.part) g = part_sum(e4, 0, 1);
-  if (sg.accumulate) g += ((const f32x4_opt*)grad)[i4];
+  g += st.g0;
   float pn[4];
-  update4(i4, g, pn);
+  update4(i4, g, st, pn);
   float* tl = (float*)tile;                        // [R][CW + 1]
 #pragma unroll
   for (int q = 0; q < 4; ++q) tl[ty * (CW + 1) + 4 * tx + q] = pn[q];

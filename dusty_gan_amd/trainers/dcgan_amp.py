@@ -189,7 +189,7 @@ class FlatAdam:
         return (FlatAdam.fused_enabled and shadow_dtype == torch.bfloat16 and self.betas[0] == 0.0 and E.PROFILE is None
                 and self.store.shadow is not None and self.store.shadow is not self.store.flat)
 
-    def _fused_plan(self, st, off, extra):
+    def _fused_plan(self, st, off, extra, sole=False):
         """the DgOptSeg list of dg_adam_fused for flat[off:] from the store's segments and the split-K workspace's pending items
         (each must be THE one gradient term of a whole segment), or None (the caller then reduces first and runs the plain
         optimizer).  extra: {segment: (src_ptr, is_bf16, coef_ptr, n, stride, scale)} - a dg_batch_wsum term folded in."""
@@ -222,6 +222,9 @@ class FlatAdam:
             q = flat(sg.off, sg.off + sg.numel)
             if it is not None:
                 q.part, q.splits, q.accumulate = it[0], it[3], it[4]
+                if sole and fat:
+                    q.accumulate = 0   # (the launch's partial tiles are the segment's ONLY gradient term: the zero-filled
+                                       #  gradient buffer need not be read back - x + 0 is x, the bits do not change)
             if fat:
                 q.kind, q.ci, q.co, q.shadow_t = 1, sg.shape[2], sg.shape[3], L.ptr(st.coci[name])
             if ex is not None:
@@ -233,14 +236,19 @@ class FlatAdam:
             segs.append(flat(run, st.n))
         if by_dw or not segs or len(segs) > L.OPT_MAX_SEG:
             return None
+        # the longest sums first (a thread of a 64-row piece makes eight dependent batches of loads, one of a 4-row piece one:
+        # with the deep pieces' workgroups at the END of the grid the launch would finish on a handful of CUs - dg_wgrad_reduce's rule)
+        segs.sort(key=lambda q: -q.splits)
         return (L.DgOptSeg * len(segs))(*segs), len(segs), ws
 
     def step(self, gscale=1.0, ema_store=None, ema_decay=0.0, shadow_dtype=torch.float32, fused_proj=None, between=None,
-             extra=None):
+             extra=None, sole=False):
         """fused_proj = (dp0, zT, op_dtype, nb, Np, K, wscale): the first segment of the store is Proj.weight [Np][K] and
         its gradient is NOT in st.grad - the kernel forms wscale * dp0^T zT itself (dg_adam_proj_fused).  Returns
         False (and does nothing) if that kernel refuses the shape, so the caller can fall back.
-        extra: gradient terms the caller left to the optimizer launch (`will_fuse`): {segment: dg_batch_wsum operands}."""
+        extra: gradient terms the caller left to the optimizer launch (`will_fuse`): {segment: dg_batch_wsum operands}.
+        sole: the caller vouches that a fat conv segment's pending partial tiles are its only gradient term this step (one
+        micro-batch, no path-length terms) and that the gradient buffer was zero-filled at the step's start."""
         st = self.store
         off = 0
         assert not (fused_proj is not None and extra), "extra terms are applied before the call can still fall back"
@@ -248,7 +256,7 @@ class FlatAdam:
             if self.betas[0] != 0.0:
                 return False
             off = fused_proj[4] * fused_proj[5]
-        plan = self._fused_plan(st, off, extra) if self.will_fuse(shadow_dtype) else None
+        plan = self._fused_plan(st, off, extra, sole) if self.will_fuse(shadow_dtype) else None
         if plan is None:
             if extra:   # (the terms left to the fused launch, as launches of their own)
                 for name, (src, is_bf16, coef, n, stride, scale) in extra.items():
@@ -463,6 +471,8 @@ class Trainer:
         self._cap, self._cap_cur, self._cap_pool, self._gather = None, None, None, None
         self._force_seg = os.environ.get("DUSTY_GAN_FORCE_SEG", "0") == "1"  # one process runs the multi-rank schedule
         self._multi = D_.through_backend()  # exchanges go through torch.distributed (utils/dist.py)
+        if self._multi:
+            D_.side_group()   # (collective: every rank's constructor) the gloo group the capture decision is taken over
         self._works, self._comm_events = {}, None
         self._fuse_proj_ok = os.environ.get("DUSTY_GAN_FUSE_PROJ", "1") != "0"
         # Collectives INSIDE the captured step (nccl = RCCL only): the process group enqueues a captured collective on its
@@ -862,7 +872,7 @@ class Trainer:
             gscale = 1.0 / self.world
         else:
             gscale = self._allreduce(Dst)
-        self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype, extra=extra_D)  # :238
+        self.optim_D.step(gscale=gscale, shadow_dtype=self.dtype, extra=extra_D, sole=self.n_acc == 1)  # :238
         self._dev_scal = scal
         return scal
 
@@ -976,7 +986,7 @@ class Trainer:
         # Adam + EMA fused (:312, :316); single-GPU bf16 runs also fold Proj.weight's gradient GEMM into the kernel
         tail_wait = (lambda: self._comm_wait("G.tail")) if (gather_proj and not pl_on and fused is not None) else None
         ok = self.optim_G.step(gscale=gscale, ema_store=_backbone(self.G_ema).store, ema_decay=self.ema_decay,
-                               shadow_dtype=self.dtype, fused_proj=fused, between=tail_wait)
+                               shadow_dtype=self.dtype, fused_proj=fused, between=tail_wait, sole=self.n_acc == 1 and not pl_on)
         if not ok:  # shape the fused kernel does not take: materialise the gradient and run the plain optimizer
             if tail_wait is not None:
                 tail_wait()

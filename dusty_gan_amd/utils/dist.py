@@ -56,13 +56,37 @@ def broadcast_int(value, device, src=0):
     return int(t.item())
 
 
+_SIDE = {"group": None, "made": False}
+
+
+def side_group():
+    """A gloo process group beside an nccl default group, for decisions that must not depend on the communicator they are
+    ABOUT (round-5 advice: `all_agree` ran its all-reduce on the RCCL communicator right after an aborted capture whose
+    recorded nodes included RCCL collectives).  Collective: every rank calls it at the same point (the Trainer's
+    constructor); None without a process group, with one rank, or when the default group already is gloo."""
+    if not _SIDE["made"]:
+        _SIDE["made"] = True
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != "gloo":
+            try:
+                _SIDE["group"] = dist.new_group(backend="gloo")
+            except Exception:  # noqa: BLE001  (no gloo in this build: the default group has to do)
+                _SIDE["group"] = None
+    return _SIDE["group"]
+
+
 def all_agree(ok, device=None):
     """True iff `ok` is true on EVERY rank (a blocking MIN all-reduce of one flag; the flag itself without a process
     group).  The ranks use it to take one decision about something each of them tried alone - whether the step's
     collectives could be captured inside its hipGraph: a rank that fell back to segments while its peers replay captured
-    collectives would be the only one issuing host-side calls."""
+    collectives would be the only one issuing host-side calls.  Runs over the gloo side group when there is one (a CPU
+    tensor over sockets: nothing the failed capture touched)."""
     if world_size() == 1:
         return bool(ok)
+    side = side_group()
+    if side is not None:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=side)
+        return bool(int(t.item()))
     dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)

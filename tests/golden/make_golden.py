@@ -545,16 +545,24 @@ def make_covmmd_golden():
 
 
 def make_full_golden(name="full_dusty2", arch="dusty2", seed=20261, B=2, shape=(64, 1024), in_ch=512, ch_base=64,
-                     ch_max=512):
+                     ch_max=512, autocast=False):
     """One step of the REFERENCE's modules at the benchmark's full width (BASELINE configs 2-4: 64x1024, 512 latent,
     channels 64..512; dusty2 = the superset of the three archs), B = 2.  Parameters and inputs come from torch's CPU
     generator (tests/golden_util.full_inputs - regenerated identically on the checking side) and are LOADED into the
     reference's modules; the Gumbel noise is injected through the reference's own `GumbelSigmoid.fixed_noise` attribute;
     DiffAugment's draws are captured by replay as in make_step_golden.  Stored:
     digests (golden_util.digest) of every output, logit, augmented image, R1 gradient, parameter gradient and updated
-    parameter, plus the scalars."""
+    parameter, plus the scalars.
+    autocast=True (`make_golden.py autocast` -> full_dusty2_autocast.npz): the SAME step - same parameters, inputs, noise and
+    (asserted by the replay) the same DiffAugment draws - with the reference trainer's `enable_amp` regions
+    (trainers/dcgan_amp.py:194-211, :228-232, :253-264) under torch.autocast("cpu", dtype=torch.bfloat16): what bfloat16
+    autocast costs the REFERENCE ITSELF, tensor by tensor - the yardstick the timed mode's tolerances are held to
+    (tests/test_oracle_golden.py, tests/test_gpu_configs.py).  No GradScaler: bfloat16 needs none, and the
+    reference's scale / unscale pair is an identity on the values."""
+    import contextlib
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from tests.golden_util import digest, full_inputs
+    amp = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
     H, W = shape
     Gp, Dp, pol, mask_b, z, u = full_inputs(arch, in_ch, ch_base, ch_max, shape, B, seed)
     cfg = make_cfg(arch, in_ch, ch_base, ch_max, list(shape), True)
@@ -576,7 +584,7 @@ def make_full_golden(name="full_dusty2", arch="dusty2", seed=20261, B=2, shape=(
     data = {"meta/arch": np.array(arch), "meta/shape": np.array(shape), "meta/in_ch": np.array(in_ch),
             "meta/ch_base": np.array(ch_base), "meta/ch_max": np.array(ch_max), "meta/B": np.array(B),
             "meta/seed": np.array(seed), "meta/lr": np.array(lr), "meta/ema_decay": np.array(decay),
-            "meta/torch": np.array(torch.__version__)}
+            "meta/torch": np.array(torch.__version__), "meta/autocast": np.array("bfloat16" if autocast else "off")}
 
     def put(key, t):
         data[f"{key}/stats"], data[f"{key}/sample"] = digest(t)
@@ -596,24 +604,26 @@ def make_full_golden(name="full_dusty2", arch="dusty2", seed=20261, B=2, shape=(
     G.gumbel_pixel.fixed_noise = ln(u[0], u[1])
     G.gumbel_image.fixed_noise = ln(u[2], u[3])
     G.train()
-    synth = G(latent=z)
-    for k, v in synth.items():
-        put(f"synth/{k}", v)
-    x_real_aug, rp0 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
-    x_real_aug = x_real_aug.detach().requires_grad_()
-    x_fake_aug, rp1 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
-    x_fake_aug = x_fake_aug.detach()
-    put("x_real_aug", x_real_aug)
-    put("x_fake_aug", x_fake_aug)
-    y_real, y_fake = D(x_real_aug), D(x_fake_aug)
-    data["y_real"], data["y_fake"] = y_real.detach().numpy().copy(), y_fake.detach().numpy().copy()
-    sc = {"loss/D/output/real": y_real.mean().item(), "loss/D/output/fake": y_fake.mean().item()}
-    loss_gan = crit(y_real, y_fake, "D")
+    with amp():                                                           # trainers/dcgan_amp.py:194-211
+        synth = G(latent=z)
+        for k, v in synth.items():
+            put(f"synth/{k}", v)
+        x_real_aug, rp0 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
+        x_real_aug = x_real_aug.detach().requires_grad_()
+        x_fake_aug, rp1 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
+        x_fake_aug = x_fake_aug.detach()
+        put("x_real_aug", x_real_aug)
+        put("x_fake_aug", x_fake_aug)
+        y_real, y_fake = D(x_real_aug), D(x_fake_aug)
+        data["y_real"], data["y_fake"] = y_real.detach().float().numpy().copy(), y_fake.detach().float().numpy().copy()
+        sc = {"loss/D/output/real": y_real.mean().item(), "loss/D/output/fake": y_fake.mean().item()}
+        loss_gan = crit(y_real, y_fake, "D")
     sc["loss/D/adversarial"] = loss_gan.item()
-    (grads,) = torch.autograd.grad(outputs=y_real.sum(), inputs=[x_real_aug], create_graph=True, only_inputs=True)
-    r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
-    sc["loss/D/gradient_penalty"] = r1.item()
-    loss_D = loss_gan + 0.5 * r1 + 0.0 * y_real.squeeze()[0]
+    (grads,) = torch.autograd.grad(outputs=y_real.sum(), inputs=[x_real_aug], create_graph=True, only_inputs=True)   # :216-224
+    with amp():                                                           # :228-232
+        r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
+        sc["loss/D/gradient_penalty"] = r1.item()
+        loss_D = loss_gan + 0.5 * r1 + 0.0 * y_real.squeeze()[0]
     put("r1_grads", grads)
     optD.zero_grad(set_to_none=True)
     loss_D.backward()
@@ -623,11 +633,12 @@ def make_full_golden(name="full_dusty2", arch="dusty2", seed=20261, B=2, shape=(
     for p in D.parameters():
         p.requires_grad = False
     optG.zero_grad(set_to_none=True)
-    _, rp2 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
-    x_fake_aug2, rp3 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
-    y_fake2 = D(x_fake_aug2)
-    data["y_fake2"] = y_fake2.detach().numpy().copy()
-    loss_gan_g = crit(None, y_fake2, "G")
+    with amp():                                                           # :253-264
+        _, rp2 = run_and_capture(lambda: A(x_real), lambda: capture_aug(B, H, W, A.policy))
+        x_fake_aug2, rp3 = run_and_capture(lambda: A(synth["depth"]), lambda: capture_aug(B, H, W, A.policy))
+        y_fake2 = D(x_fake_aug2)
+        data["y_fake2"] = y_fake2.detach().float().numpy().copy()
+        loss_gan_g = crit(None, y_fake2, "G")
     sc["loss/G/adversarial"] = loss_gan_g.item()
     loss_gan_g.backward()
     for k, p in G.named_parameters():
@@ -680,6 +691,10 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["full"]:
         torch.set_num_threads(8)
         make_full_golden()
+        sys.exit(0)
+    if sys.argv[1:] == ["autocast"]:
+        torch.set_num_threads(8)
+        make_full_golden(name="full_dusty2_autocast", autocast=True)
         sys.exit(0)
     if sys.argv[1:] == ["lidar"]:
         make_lidar_golden()

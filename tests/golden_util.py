@@ -84,9 +84,15 @@ def full_inputs(arch, in_ch, ch_base, ch_max, shape, B, seed):
     return G, D, pol, mask, z, u
 
 
-def check_digest(npz, key, t, tol, what=""):
+def sample_dev(npz, key, t):
+    """relative L2 distance of tensor `t`'s strided sample from the one stored under `key` (what `check_digest` bounds)"""
+    _, sample = digest(t)
+    return rel_l2(sample, npz[f"{key}/sample"])
+
+
+def check_digest(npz, key, t, tol, what="", cos=None):
     """hold tensor `t` to the digest stored under `key`: l2 norm and sum |x| within `tol` relative, the sum within `tol` of
-    sum |x|, the strided sample within `tol` relative L2"""
+    sum |x|, the strided sample within `tol` relative L2 (and, with `cos`, at least that cosine to it)"""
     stats, sample = digest(t)
     ref_stats, ref_sample = npz[f"{key}/stats"], npz[f"{key}/sample"]
     scale = max(float(ref_stats[1]), 1e-30)
@@ -95,6 +101,10 @@ def check_digest(npz, key, t, tol, what=""):
     assert abs(stats[2] - ref_stats[2]) <= tol * max(float(ref_stats[2]), 1e-30), (what, key, "norm", stats[2], ref_stats[2])
     err = rel_l2(sample, ref_sample)
     assert err <= tol, (what, key, "sample", err)
+    if cos is not None:
+        a, b = np.asarray(sample, dtype=np.float64).ravel(), np.asarray(ref_sample, dtype=np.float64).ravel()
+        c = float((a * b).sum() / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+        assert c >= cos, (what, key, "cosine", c)
 
 
 def full_case(npz):

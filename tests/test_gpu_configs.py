@@ -135,12 +135,58 @@ def test_timed_mode_gradients_tight_against_emulating_oracle(trace, arch):
     _check(res[0], tr, state, **BF16_EMU)
 
 
+def test_timed_mode_within_the_reference_autocast_yardstick():
+    """The bf16 mode bench.py times, held to numbers the REFERENCE produced (round-5 review, item 4): the full-width step of
+    tests/golden/full_dusty2.npz run by the engine in bf16, every output and gradient compared with the reference's fp32
+    digests - its distance may not exceed 1.5 x the distance of the reference's OWN bfloat16-autocast run of the same step
+    (tests/golden/full_dusty2_autocast.npz: `make_golden.py autocast`, the reference's modules under torch.autocast("cpu",
+    bfloat16) in the trainer's enable_amp regions, trainers/dcgan_amp.py:194-211,228-232,253-264), tensor by tensor.
+    One-number tensors (head bias gradients: sums that cancel to 1e-3 of their absolute sum) are held to 1.0 instead."""
+    from tests.golden_util import sample_dev
+    g, ga = load("full_dusty2"), load("full_dusty2_autocast")
+    if str(g["meta/torch"]) != torch.__version__:
+        pytest.skip(f"fixture made with torch {g['meta/torch']}: the regenerated inputs need the same CPU generator")
+    ref_dev = {k[:-7]: rel_l2(ga[k], g[k]) for k in g.files if k.endswith("/sample") and k in ga.files}
+    G, D, pol, mask, rand = full_case(g)
+    shape = tuple(int(v) for v in g["meta/shape"])
+    tr = make_trainer(str(g["meta/arch"]), True, shape, int(g["meta/in_ch"]), int(g["meta/ch_base"]),
+                      int(g["meta/ch_max"]), int(g["meta/B"]), amp=True)
+    assert tr.dtype == torch.bfloat16
+    tr.G.load_state_dict(G)
+    tr.G_ema.load_state_dict(G)
+    sync_D(tr, D)
+    x_real, m_real = tr.fetch_reals({"depth": pol, "mask": mask})
+    tr.optimize_D(reals=[(x_real, m_real)], rands=[rand])
+    synth = {k: v.detach().cpu().clone() for k, v in tr._mb[0]["synth"].items()}
+    gD = grads_by_name(tr.optim_D)
+    scal = tr.optimize_G().cpu().tolist()
+    gG = grads_by_name(tr.optim_G)
+    report = {}
+    for key, t in ([(f"synth/{k}", synth[k]) for k in ("depth_orig", "confidence")]
+                   + [(f"grad_D/{k}", v) for k, v in gD.items()] + [(f"grad_G/{k}", v) for k, v in gG.items()]):
+        dev = sample_dev(g, key, t.cpu())
+        if t.numel() <= 4:
+            assert dev <= 1.0, (key, dev)
+            continue
+        report[key] = (dev, ref_dev[key])
+        assert dev <= 1.5 * ref_dev[key], (key, dev, ref_dev[key])
+    _, msample = digest(synth["mask"])
+    assert (msample != g["synth/mask/sample"]).mean() <= 5e-3          # hard Gumbel thresholds: a logit within bf16 of zero may flip
+    for k, v in zip(KEYS, scal):
+        d_ref = abs(float(ga[f"scalar/{k}"]) - float(g[f"scalar/{k}"]))
+        assert abs(v - float(g[f"scalar/{k}"])) <= 1.5 * d_ref + 2e-3 * max(1.0, abs(float(g[f"scalar/{k}"]))), (k, v, d_ref)
+    worst = max(report.items(), key=lambda kv: kv[1][0] / kv[1][1])
+    print("bf16 engine vs reference autocast (distance from the reference's fp32 digests), worst ratio:", worst[0],
+          "%.3e / %.3e" % worst[1])
+
+
 @pytest.mark.parametrize("x3,pairs", [(False, False), (True, True), (True, False)], ids=["fp32", "fp32x3", "fp32x3-register-split"])
 def test_hip_path_matches_reference_at_full_width(monkeypatch, x3, pairs):
     """The HIP fp32 path against what the REFERENCE's own modules computed at 64x1024 / 512 channels (dusty2, B = 2, one
     step): digests from tests/golden/full_dusty2.npz, inputs regenerated from its seed.  Outputs, logits, losses 1e-4;
-    gradients 2e-2 on the digests (a unit within fp32 rounding of zero takes the other slope in the two
-    implementations - tests/test_gpu_step.py::test_step_fp32_vs_oracle_full_width_64x1024); updated parameters 1e-3.
+    gradients 5e-3 and cosine >= 0.99999 on the digests (a unit within fp32 rounding of zero takes the other slope in the
+    two implementations - tests/test_gpu_step.py::test_step_fp32_vs_oracle_full_width_64x1024: measured worst 1.5e-3 /
+    0.999998); updated parameters 1e-3.
     fp32x3: the same bounds with the fat layers' contractions on the bf16 matrix instructions (operands split into bf16
     hi + lo, DG_FORCE_FP32X3 on every launch of this trainer's engines) - the fast parity mode of `bench.py --precision fp32x3`:
     with the fat feature maps STORED as split-bf16 pairs (DG_BF16X2, round 5: the bf16 ping-pong conv and LDS-DMA weight
@@ -180,12 +226,34 @@ def test_hip_path_matches_reference_at_full_width(monkeypatch, x3, pairs):
             assert (sample != g["synth/mask/sample"]).mean() <= 1e-3
         else:
             check_digest(g, f"synth/{k}", v, 1e-4)
-    for k, v in gD.items():
-        check_digest(g, f"grad_D/{k}", v, 2e-2, "grad_D")
-    for k, v in gG.items():
-        # (fp32x3: a head bias gradient is ONE number, the sum of 131 072 signed per-pixel gradients that cancel to ~1e-3 of
-        #  their absolute sum; the split products' 2^-16 relative error shows there first - 3.7e-2 measured, held to 6e-2)
-        check_digest(g, f"grad_G/{k}", v, 6e-2 if (x3 and v.numel() <= 4) else 2e-2, "grad_G")
+    # gradients against the REFERENCE's digests (round 6; the 2e-2 of rounds 3-5 would have passed a 1 % defect in one layer):
+    #   fp32            5e-3 and cosine >= 0.99999 (measured worst 1.5e-3 / 0.999998)
+    #   fp32x3          weights 1.3e-2 / 0.9999 (measured worst 1.01e-2, 16 mantissa bits per operand); bias gradients - sums over 10^4..10^5 signed terms, where the split products'
+    #                   2^-16 relative error shows first - 1.5e-2 / 0.9999 (measured 1.07e-2 on Proj's bias); a head bias
+    #                   gradient is ONE number, the sum of 131 072 per-pixel gradients that cancel to ~1e-3 of their absolute
+    #                   sum: 3.7e-2 measured, held to 1.25 x that
+    from tests.golden_util import sample_dev
+    measured, bad = {}, []
+    for pre, grads in (("grad_D", gD), ("grad_G", gG)):
+        for k, v in grads.items():
+            key = f"{pre}/{k}"
+            measured[key] = sample_dev(g, key, v)
+            one, bias = v.numel() <= 4, v.dim() == 1
+            if x3 and one:
+                tol, cos = 4.6e-2, None
+            elif x3 and bias:
+                tol, cos = 1.5e-2, 0.9999
+            elif x3:
+                tol, cos = 1.3e-2, 0.9999    # (measured worst 1.01e-2: Up2's weight gradient)
+            else:
+                tol, cos = 5e-3, (None if one else 0.99999)
+            try:
+                check_digest(g, key, v, tol, pre, cos=cos)
+            except AssertionError as e:   # (all of them in one report)
+                bad.append((key, measured[key], tol, str(e)[:120]))
+    assert not bad, bad
+    print("gradient distances from the reference digests, worst five:",
+          sorted(measured.items(), key=lambda kv: -kv[1])[:5])
     for tag, net in (("G", tr.G), ("D", tr.D), ("G_ema", tr.G_ema)):
         for k, v in net.state_dict().items():
             if k == "drop_const" or k.endswith("kernel"):
