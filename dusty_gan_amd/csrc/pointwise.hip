@@ -133,6 +133,77 @@ __global__ __launch_bounds__(256) void blur_fwd4_kernel(const float* __restrict_
   }
 }
 
+// BlurVH's adjoint for NR consecutive rows ys .. ys + NR - 1 of one pixel quad (columns x0 .. x0 + 3): the NR + 2 source rows
+// and the 2 NR ring neighbours of a thread are loaded TOGETHER, unconditionally (rows clamped into the image; what a clamped
+// row contributes is never used) - row after row, each row's loads waited for before the next row's were issued: four to six
+// dependent memory round trips per workgroup (round 6: blur_bwd4_kernel 8.9 us, 6.8 without its sums).  Same expressions in
+// the same order as the per-row code: bit-identical results.  Rows outside [0, H) come back as garbage the caller skips.
+template <typename T, int NR>
+__device__ __forceinline__ void blur_adj_rows(const T* __restrict__ d, long base, int ys, int x0, int H, int W, int ring,
+                                              float (&g)[NR][4]) {
+  float rows[NR + 2][8];
+  float el[NR], er[NR];
+  auto clampy = [&](int yy) { return yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy); };
+#pragma unroll
+  for (int r = 0; r < NR + 2; ++r) {
+    const T* p = d + (base + (long)clampy(ys - 1 + r) * W + x0) * 2;
+    if constexpr (sizeof(T) == 2) {
+      Vec16<bf16>::load((const bf16*)p, rows[r]);
+    } else {
+      const float4 a = *(const float4*)p, b2 = *(const float4*)(p + 4);
+      rows[r][0] = a.x; rows[r][1] = a.y; rows[r][2] = a.z; rows[r][3] = a.w;
+      rows[r][4] = b2.x; rows[r][5] = b2.y; rows[r][6] = b2.z; rows[r][7] = b2.w;
+    }
+  }
+  // channel 1 of the pixels left and right of the quad (circular columns: wrapped; reflect columns: clamped - then unused
+  // at the border): two 2- or 4-byte loads per row, unconditional like the rows'
+  const int xl = ring ? (x0 == 0 ? W - 1 : x0 - 1) : (x0 == 0 ? 0 : x0 - 1);
+  const int xr = ring ? (x0 + 3 == W - 1 ? 0 : x0 + 4) : (x0 + 4 > W - 1 ? W - 1 : x0 + 4);
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const long rowb = base + (long)clampy(ys + j) * W;
+    el[j] = (float)d[(rowb + xl) * 2 + 1];
+    er[j] = (float)d[(rowb + xr) * 2 + 1];
+  }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int y = ys + j;
+    const float (&m)[8] = rows[j + 1];
+    const float (&tu)[8] = rows[j];
+    const float (&td)[8] = rows[j + 2];
+    float v[4], h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = 0.5f * m[2 * k];
+    if (y > 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += 0.25f * tu[2 * k]; }
+    if (y < H - 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += 0.25f * td[2 * k]; }
+    if (y == 1) {                                  // row 0 read x[1] as its reflected upper neighbour (row 0 IS tu here)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += 0.25f * tu[2 * k]; }
+    if (y == H - 2) {                              // row H-1 read x[H-2] as its reflected lower neighbour (row H-1 IS td here)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += 0.25f * td[2 * k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = x0 + k;
+      h[k] = 0.5f * m[2 * k + 1];
+      const bool hasl = k > 0, hasr = k < 3;
+      if (ring) {
+        h[k] += 0.25f * (hasl ? m[2 * k - 1] : el[j]) + 0.25f * (hasr ? m[2 * k + 3] : er[j]);
+      } else {
+        if (xx > 0) h[k] += 0.25f * (hasl ? m[2 * k - 1] : el[j]);
+        if (xx < W - 1) h[k] += 0.25f * (hasr ? m[2 * k + 3] : er[j]);
+        if (xx == 1) h[k] += 0.25f * m[1];         // column 0 read x[1] as its reflected left neighbour (pixel 0 = this quad's first)
+        if (xx == W - 2) h[k] += 0.25f * m[7];     // column W-1 read x[W-2] (pixel W-1 = this quad's last)
+      }
+      g[j][k] = v[k] + h[k];
+    }
+  }
+}
+
 // ssq != nullptr (R1): dx = oscale * g and ssq[b] += sum of g^2 over the sample, g = the adjoint's result - the R1
 // penalty's per-sample |g|^2 and its tangent v = (gp / B) g in the pass that makes g.  A block owns `rows_pb` consecutive
 // rows of one sample (one atomic per block).
@@ -157,6 +228,28 @@ __global__ __launch_bounds__(256) void blur_bwd4_kernel(const T* __restrict__ d,
     w_r0 = (win.policy & 16) ? win.o_x[b] - win.cut_h / 2 : 0;
     w_c0 = (win.policy & 16) ? win.o_y[b] - win.cut_w / 2 : 0;
   }
+  if (rows_pb == 4 && y0 + 4 <= H) {               // the band's loads batched (blur_adj_rows)
+    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+      const int x0 = q4 * 4;
+      float g[4][4];
+      blur_adj_rows<T, 4>(d, base, y0, x0, H, W, ring, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = y0 + j;
+        const float g0 = g[j][0], g1 = g[j][1], g2 = g[j][2], g3 = g[j][3];
+        *(float4*)(dx + base + (long)y * W + x0) = make_float4(oscale * g0, oscale * g1, oscale * g2, oscale * g3);
+        if (!use_win) {
+          ssacc += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
+        } else if (y + w_th >= 0 && y + w_th < H) {
+          const bool cutrow = (win.policy & 16) && y >= w_r0 && y < w_r0 + win.cut_h;
+          const float gq[4] = {g0, g1, g2, g3};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (!(cutrow && x0 + k >= w_c0 && x0 + k < w_c0 + win.cut_w)) ssacc += gq[k];
+        }
+      }
+    }
+  } else
   for (int y = y0; y < y1; ++y)
   for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
   const int x0 = q4 * 4;
@@ -243,57 +336,15 @@ __global__ __launch_bounds__(256) void blur_r1_tangent_kernel(const T* __restric
   const long base = (long)b * H * W;
   const int y0 = blockIdx.x * R1T_ROWS;
   float ssacc = 0.f;
-  for (int r = 0; r < R1T_ROWS + 2; ++r) {
-    const int y = y0 - 1 + r;
-    if (y < 0 || y >= H) continue;                // (block-uniform: the rows beyond the image are never read below)
-    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
-      const int x0 = q4 * 4;
-      auto row8 = [&](int yy, float (&v)[8]) {    // (ch0, ch1) of pixels x0 .. x0+3 of row yy
-        const T* p = d + (base + (long)yy * W + x0) * 2;
-        if constexpr (sizeof(T) == 2) {
-          Vec16<bf16>::load((const bf16*)p, v);
-        } else {
-          const float4 a = *(const float4*)p, b2 = *(const float4*)(p + 4);
-          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b2.x; v[5] = b2.y; v[6] = b2.z; v[7] = b2.w;
-        }
-      };
-      auto D1 = [&](int yy, int xq) { return (float)d[(base + (long)yy * W + xq) * 2 + 1]; };
-      float m[8], tu[8], td[8];
-      row8(y, m);
-      row8(y > 0 ? y - 1 : y, tu);
-      row8(y < H - 1 ? y + 1 : y, td);
-      float el = 0.f, er = 0.f;
-      if (ring) { el = D1(y, x0 == 0 ? W - 1 : x0 - 1); er = D1(y, x0 + 3 == W - 1 ? 0 : x0 + 4); }
-      float v[4], h[4];
+  for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+    const int x0 = q4 * 4;
+    float g[R1T_ROWS + 2][4];
+    blur_adj_rows<T, R1T_ROWS + 2>(d, base, y0 - 1, x0, H, W, ring, g);   // rows y0 - 1 .. y0 + R1T_ROWS, their loads batched
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = 0.5f * m[2 * k];
-      if (y > 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += 0.25f * tu[2 * k]; }
-      if (y < H - 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += 0.25f * td[2 * k]; }
-      if (y == 1) { float t[8]; row8(0, t);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
-      if (y == H - 2) { float t[8]; row8(H - 1, t);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += 0.25f * t[2 * k]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int xx = x0 + k;
-        h[k] = 0.5f * m[2 * k + 1];
-        const bool hasl = k > 0, hasr = k < 3;
-        if (ring) {
-          h[k] += 0.25f * (hasl ? m[2 * k - 1] : el) + 0.25f * (hasr ? m[2 * k + 3] : er);
-        } else {
-          if (xx > 0) h[k] += 0.25f * (hasl ? m[2 * k - 1] : D1(y, xx - 1));
-          if (xx < W - 1) h[k] += 0.25f * (hasr ? m[2 * k + 3] : D1(y, xx + 1));
-          if (xx == 1) h[k] += 0.25f * D1(y, 0);
-          if (xx == W - 2) h[k] += 0.25f * D1(y, W - 1);
-        }
-      }
-      const float g0 = v[0] + h[0], g1 = v[1] + h[1], g2 = v[2] + h[2], g3 = v[3] + h[3];
+    for (int r = 0; r < R1T_ROWS + 2; ++r) {
+      const int y = y0 - 1 + r;
+      if (y < 0 || y >= H) continue;              // (block-uniform: the rows beyond the image are never read below)
+      const float g0 = g[r][0], g1 = g[r][1], g2 = g[r][2], g3 = g[r][3];
       *(float4*)(s_g + r * W + x0) = make_float4(oscale * g0, oscale * g1, oscale * g2, oscale * g3);
       if (r >= 1 && r <= R1T_ROWS) ssacc += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
     }
@@ -1143,24 +1194,33 @@ __global__ __launch_bounds__(256) void diffaug_blur_fwd_kernel(AugSrc s0, AugSrc
     mean = sx / (float)HW + br;
   }
   // stage: LDS row r holds the source row of augmented row ya = y0 - 1 + r (rows outside the image are never read below; a
-  // row whose source row falls outside the image is all zeros after the translation: any valid row is staged, `ok` says so)
+  // row the translation moved out of the image is staged as zeros), with brightness and contrast applied where the pixel is
+  // STAGED (once per source pixel, not once per tap that reads it): the same two expressions as diffaug_fwd_kernel.
+  // The six rows' loads of a thread are issued TOGETHER (a first version staged row after row: hipcc kept each row's
+  // load -> arithmetic -> LDS store a loop of its own, six dependent memory round trips per workgroup - 12 of the launch's 17 us).
+  const float* srcr[DAB_ROWS + 2];
+  bool okr[DAB_ROWS + 2], inr[DAB_ROWS + 2];
 #pragma unroll
   for (int r = 0; r < DAB_ROWS + 2; ++r) {
-    const int ya = y0 - 1 + r;
-    if (ya < 0 || ya >= H) continue;
-    const int sy = ya + th;
-    const bool okr = sy >= 0 && sy < H;
-    const float* src = x + (long)b * HW + (long)(okr ? sy : 0) * W;
-    // brightness and contrast where the pixel is STAGED (once per source pixel, not once per tap that reads it): the same
-    // two expressions as diffaug_fwd_kernel; a row the translation moved out of the image is staged as zeros
-    for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
-      const float4 p = *(const float4*)(src + q4 * 4);
-      float v[4] = {p.x, p.y, p.z, p.w};
+    const int ya = y0 - 1 + r, sy = ya + th;
+    inr[r] = ya >= 0 && ya < H;
+    okr[r] = sy >= 0 && sy < H;
+    srcr[r] = x + (long)b * HW + (long)(okr[r] ? sy : 0) * W;
+  }
+  for (int q4 = threadIdx.x; q4 < W4; q4 += 256) {
+    float4 pq[DAB_ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < DAB_ROWS + 2; ++r) pq[r] = *(const float4*)(srcr[r] + q4 * 4);   // (unconditional: srcr is always a valid
+                                                                                            //  row - a predicated load costs a vmcnt(0))
+#pragma unroll
+    for (int r = 0; r < DAB_ROWS + 2; ++r) {
+      if (!inr[r]) continue;
+      float v[4] = {pq[r].x, pq[r].y, pq[r].z, pq[r].w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float t = v[q] + br;
         t = mean + cc * (t - mean);
-        v[q] = okr ? t : 0.f;
+        v[q] = okr[r] ? t : 0.f;
       }
       *(float4*)(s_rows + r * W + q4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
