@@ -261,7 +261,7 @@ def bench_config_key(args, arch):
             "pl": args.pl, "augment": not args.no_augment}
 
 
-PMC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_FILE = "profiles/r06_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, args, arch):

@@ -186,6 +186,14 @@ __device__ __forceinline__ float dg_wave_sum(float v) {
 // memory-side) before the ticket is taken, so the last ticket holder reads every contribution.  Range +-2^31, resolution
 // 2.3e-10 per contribution; a non-finite or larger partial reaches the float as it is (a NaN stays a NaN).  Anything outside
 // the arena, or with no arena registered, falls back to the float atomic.
+// What the parity modes rely on (round-5 advice): the window.  Each CONTRIBUTION is range-checked, the running total is not -
+// it wraps beyond +-2^31, so a slot's contributors must stay below that in sum: the step's slots hold per-sample image sums
+// (<= H W = 2.6e5 at 128x2048), logits (O(1)), R1's per-sample |g|^2 (O(1)) and the augment adjoint's window sums: eight
+// orders of magnitude of head-room.  The resolution is ABSOLUTE (2^-32 per contribution): a sum whose true value is far below
+// 1e-6 - R1's |g|^2 late in a collapsed training run - keeps fewer significant bits here than a float atomic would; the
+// logged penalty then reads a few 1e-10 off, its gradient is untouched (the tangent is formed from g itself, not from ssq).
+// Ordering: the integer add is a memory-side atomic; `s_waitcnt vmcnt(0)` returns when it has been performed, and the ticket is
+// a second memory-side atomic on the same line issued behind it - the last ticket holder's exchange follows every add.
 // One 128-byte line per slot (round 6): device-scope atomics execute memory-side and adds to ONE line serialise - with 16 bytes
 // per slot the 32 per-sample sums of a batch shared four lines, and every image-sized kernel that sums per sample paid 4-5 us
 // for its 512-1536 adds (scripts/bench_pointwise.py: head_post_fwd 10.6 us with sums, 6.9 without).

@@ -84,7 +84,9 @@ typedef struct DgConv {
                               * partial row of N floats per workgroup at dbias_part + row * N - summed inside the workgroup in a
                               * fixed order - and add nothing to dbias; the caller sums the rows with
                               * dg_wgrad_reduce(ws = dbias_part, dw = dbias, numel = N, splits = dbias_rows).  Kernels that do
-                              * not take it ignore it and add onto dbias with atomics as before. */
+                              * not take it ignore it and add onto dbias with atomics as before.  The rows are NOT folded:
+                              * row element n is the sum for output channel n, so the form needs bias_mod == N - the kernels that take
+                              * rows refuse (DG_EUNSUPPORTED) a dbias launch with bias_mod < N, with or without dbias_part. */
   void* mask_out;            /* optional, DG_EPI_LRELU: also store bit = (out element > 0) for every element written.  The
                               * ping-pong conv and the thin matrix-core MODE_S2 kernel write it from their epilogues, behind any
                               * other kernel the library adds one packing launch: the bits are there when dg_conv returns OK */

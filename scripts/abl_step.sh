@@ -1,5 +1,5 @@
 #!/bin/bash
-# In-step ablations of the ping-pong conv: the replayed training step (bench.py under rocprofv3 --kernel-trace) with the
+# In-step ablations of the ping-pong conv: the replayed training step (bench.py --soak-steps 0 --no-clock under rocprofv3 --kernel-trace) with the
 # diagnostic library built for each DG_PP_DIAG bit set (1 no DMA, 2 no MFMA, 4 no epilogue, 16 no fragment reads, 64 no
 # mask loads, 128 no output stores).  Unlike scripts/abl_conv.sh (one layer repeated on hot buffers) the kernels here
 # run in the step's own order on cold operands.   usage: scripts/abl_step.sh [bits ...]

@@ -1,9 +1,9 @@
 #!/bin/bash
-# per-kernel time table of bench.py in a given mode (rocprofv3 --kernel-trace --stats); usage: scripts/kernel_stats_mode.sh <outdir> [bench args]
+# per-kernel time table of bench.py --soak-steps 0 --no-clock in a given mode (rocprofv3 --kernel-trace --stats); usage: scripts/kernel_stats_mode.sh <outdir> [bench args]
 out=${1:-gpurun_out/ks}; shift
 root=$(pwd); mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/kt -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 10 --warmup 4 "$@" > $root/$out/bench.json 2> $root/$out/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/kt -- python3 $root/bench.py --soak-steps 0 --no-clock --no-other-configs --no-cpu-baseline --no-roofline --steps 10 --warmup 4 "$@" > $root/$out/bench.json 2> $root/$out/kt.log
 cd $root
 f=$(find $out/kt -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -18,7 +18,7 @@ from bench import bench_config_key, kernel_source_sha, parse  # noqa: E402
 FAMILIES = {  # bench.py family name -> substrings of the kernel symbols it covers
     "conv_mfma_kernel": ("conv_pp_kernel", "persist11conv_kernel", "conv_mfma_kernel"),
     "wgrad_mfma_kernel": ("wgrad_dma_kernel", "wgrad_group_kernel"),
-    "adam_ema_kernel": ("adam_ema_kernel", "adam_proj_fused_kernel", "wgrad_mfma_kernelIDF16bLi128ELi128ELb1"),
+    "adam_ema_kernel": ("adam_ema_kernel", "adam_fused_kernel", "adam_proj_fused_kernel", "wgrad_mfma_kernelIDF16bLi128ELi128ELb1"),
 }
 
 

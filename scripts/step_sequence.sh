@@ -5,7 +5,7 @@ out=${1:-gpurun_out/seq}
 root=$(pwd)
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $root/$out/kt -- python3 $root/bench.py --no-other-configs --no-cpu-baseline --no-roofline --steps 8 --warmup 4 $BENCH_ARGS > $root/$out/bench.json 2> $root/$out/kt.log
+rocprofv3 --kernel-trace --output-format csv -d $root/$out/kt -- python3 $root/bench.py --soak-steps 0 --no-clock --no-other-configs --no-cpu-baseline --no-roofline --steps 8 --warmup 4 $BENCH_ARGS > $root/$out/bench.json 2> $root/$out/kt.log
 cd $root
 f=$(find $out/kt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
