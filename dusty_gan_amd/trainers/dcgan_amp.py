@@ -694,7 +694,9 @@ class Trainer:
             gc.collect()
             self._gc_was_on = gc.isenabled()
             gc.disable()
-        g = torch.cuda.CUDAGraph()
+        # DUSTY_GAN_KEEP_GRAPH=1 (tests): keep the hipGraph_t behind the executable graph so that `graph_kernel_nodes()` can count
+        # its nodes - the launch count of the replayed step is a tested property (tests/test_gpu_timed_path.py)
+        g = torch.cuda.CUDAGraph(keep_graph=True) if os.environ.get("DUSTY_GAN_KEEP_GRAPH", "0") == "1" else torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while this thread captures
         ctx = torch.cuda.graph(g, pool=self._cap_pool, capture_error_mode="thread_local" if self._multi else "global")
         ctx.__enter__()
@@ -1287,6 +1289,34 @@ class Trainer:
         # shadows (built lazily, only when G_ema is evaluated) are stale now
         _backbone(self.G_ema).store._seen_version = -1
         return self._ring_slot() if self._g_out is None else self._g_out.clone()
+
+    def graph_kernel_nodes(self):
+        """kernel nodes of the captured step, summed over its hipGraph segments - i.e. the launches one replayed step makes;
+        None unless the step has been captured with DUSTY_GAN_KEEP_GRAPH=1 (hipGraphGetNodes / hipGraphNodeGetType on the
+        kept hipGraph_t; HIP runtime through ctypes: host-side introspection, nothing on the compute path)"""
+        if self._graph is None:
+            return None
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        total = 0
+        for item in self._graph:
+            if not isinstance(item, torch.cuda.CUDAGraph):
+                continue
+            try:
+                raw = item.raw_cuda_graph()
+            except Exception:  # noqa: BLE001  (captured without keep_graph)
+                return None
+            n = C.c_size_t(0)
+            if hip.hipGraphGetNodes(C.c_void_p(raw), None, C.byref(n)) != 0:
+                return None
+            nodes = (C.c_void_p * n.value)()
+            if hip.hipGraphGetNodes(C.c_void_p(raw), nodes, C.byref(n)) != 0:
+                return None
+            for nd in nodes:
+                t = C.c_int(-1)
+                if hip.hipGraphNodeGetType(C.c_void_p(nd), C.byref(t)) == 0 and t.value == 0:   # hipGraphNodeTypeKernel
+                    total += 1
+        return total
 
     def _step_graph_retry(self, batch, pooled):
         """second capture attempt of `_step_graph` (segments) on the batch the first one drew"""

@@ -28,13 +28,20 @@ STEP_BEGIN = ("step_prologue_kernel", "dg_zero_multi")   # the launch that opens
 def load(path, counter):
     tot, n, names = collections.Counter(), collections.Counter(), collections.defaultdict(set)
     with open(path, newline="") as f:
-        for r in csv.DictReader(f):
-            if r["Counter_Name"] != counter:
-                continue
+        rows = [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    prev_begin = False
+    if True:
+        for r in rows:
             tot["_all"] += float(r["Counter_Value"])
             n["_all"] += 1
-            if any(sb in r["Kernel_Name"] for sb in STEP_BEGIN):
+            # a step opens with ONE run of step-begin launches (eager steps on a host batch issue fetch_reals as a second
+            # prologue launch right behind the zero-fill / draws one: round 6)
+            begin = any(sb in r["Kernel_Name"] for sb in STEP_BEGIN)
+            if begin and not prev_begin:
                 n["_steps"] += 1
+            prev_begin = begin
             for fam, subs in FAMILIES.items():
                 if any(s in r["Kernel_Name"] for s in subs):
                     tot[fam] += float(r["Counter_Value"])
