@@ -22,6 +22,14 @@
 
 #include <type_traits>
 
+// (experiment knobs, `make variant VSRC=wgrad_mfma_dma VFLAGS=-DDG_WG_BM_MAX=64 ...`: the largest tile of a group launch's layers)
+#ifndef DG_WG_BM_MAX
+#define DG_WG_BM_MAX 128
+#endif
+#ifndef DG_WG_BN_MAX
+#define DG_WG_BN_MAX 128
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -560,7 +568,7 @@ int dg_wgrad_mfma_dma_group_launch(const WgradP* items, int n, int pairs, int ro
       target = (long)(rounds * 512.0 * fl[i] / fsum + 0.5);
       if (target < 64) target = 64;
     }
-    const int bm = p->Ci % 128 == 0 ? 128 : 64, bn = p->Co % 128 == 0 ? 128 : 64;
+    const int bm = (p->Ci % 128 == 0 && DG_WG_BM_MAX >= 128) ? 128 : 64, bn = (p->Co % 128 == 0 && DG_WG_BN_MAX >= 128) ? 128 : 64;
     const DmaGeo ge = bm == 128 ? (bn == 128 ? dma_geo<128, 128>(p, 1, pairs, true, target) : dma_geo<128, 64>(p, 1, pairs, true, target))
                                 : (bn == 128 ? dma_geo<64, 128>(p, 1, pairs, true, target) : dma_geo<64, 64>(p, 1, pairs, true, target));
     if (plans) {
