@@ -150,6 +150,14 @@ def test_two_ranks_over_rccl_match_single_process():
     assert torch.equal(outs[0]["G"], outs[1]["G"]) and torch.equal(outs[0]["D"], outs[1]["D"])
 
 
+def _det():
+    """deterministic sums (engine.DETERMINISTIC): runs that execute the same additions agree on the logged scalars like they
+    agree on the parameters - bit for bit, 1e-6 for the one float rounding a different launch form may add (round 6; the 3e-2 of
+    rounds 3-5 was the noise allowance of float atomics)"""
+    from dusty_gan_amd import engine as E
+    return E.DETERMINISTIC
+
+
 def rccl_graph_worker(rank, world, init_file, out_dir, mode):
     from tests.test_gpu_step import make_trainer
     os.environ["DUSTY_GAN_GRAPH_COMM"] = "1" if mode == "in_graph" else "0"
@@ -255,7 +263,7 @@ def test_forced_segments_single_process_match_one_graph(monkeypatch, x3):
             assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb))
     for x, y in zip(sa, sb):
         for k in x:
-            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+            assert abs(x[k] - y[k]) <= (1e-6 if _det() else 3e-2) * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
 def test_aborted_capture_leaves_no_pending_partials(monkeypatch):
@@ -308,7 +316,7 @@ def test_aborted_capture_leaves_no_pending_partials(monkeypatch):
             assert rel_l2(fa, fb) < 2e-3, (net, rel_l2(fa, fb), seen)
     for x, y in zip(sa, sb):
         for k in x:
-            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+            assert abs(x[k] - y[k]) <= (1e-6 if _det() else 3e-2) * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
 def rccl_worker(rank, world, init_file, out_dir, in_graph=True):
@@ -389,7 +397,7 @@ def test_single_rank_rccl_runs_the_multi_rank_schedule(monkeypatch, in_graph):
     print(f"single-rank RCCL schedule, in_graph={in_graph}: {a['mode']}, {a['ms']:.3f} ms per step")
     for x, y in zip(a["scal"], sb):
         for k in x:
-            assert abs(x[k] - y[k]) < 3e-2 * max(1.0, abs(y[k])), (k, x[k], y[k])
+            assert abs(x[k] - y[k]) <= (1e-6 if _det() else 3e-2) * max(1.0, abs(y[k])), (k, x[k], y[k])
     for net, key in (("G", "G"), ("D", "D"), ("G_ema", "E")):
         fb = getattr(b, net).store.flat.cpu()
         from dusty_gan_amd import engine as E
