@@ -48,6 +48,7 @@ class DgConv(C.Structure):
         ("dbias_part", C.c_void_p),
         ("mask_out", C.c_void_p),
         ("mask_in", C.c_void_p),
+        ("tanh_sum_parts", C.c_void_p),
     ]
 
 
@@ -115,7 +116,8 @@ class DgWgradReduce(C.Structure):
 
 class DgConvPlan(C.Structure):
     _fields_ = [("family", C.c_int), ("bm", C.c_int), ("bn", C.c_int), ("tiles", C.c_int), ("workgroups", C.c_int),
-                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int), ("mask_bits", C.c_int), ("dbias_rows", C.c_int)]
+                ("tiles_per_wg", C.c_int), ("thin_mfma", C.c_int), ("mask_bits", C.c_int), ("dbias_rows", C.c_int),
+                ("sum_parts", C.c_int)]
 
 
 _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64

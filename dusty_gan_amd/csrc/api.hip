@@ -14,6 +14,7 @@ int dg_conv_thin_supported(const ConvP* p);
 int dg_proj_stream_supported(const ConvP* p);
 int dg_proj_stream_launch(const ConvP* p, hipStream_t stream, DgConvPlan* plan);
 int dg_conv_thin_mfma_variant(const ConvP* p);
+int dg_conv_up_mfma_sum_parts(const ConvP* p);
 int dg_conv_s2_mfma_blocks(const ConvP* p);
 int dg_wgrad_thin_mfma_variant(const WgradP* p);
 int dg_wgrad_thin_ws_splits(const WgradP* p);
@@ -45,7 +46,7 @@ static int conv_dispatch0(const DgConv* p, int force_flags, int wg_cap, hipStrea
   if (p->dbias && p->bias_mod <= 0) return DG_EINVAL;
   const bool mfma_ok = !p->nscale && dg_conv_mfma_supported(p);
   const bool thin_ok = dg_conv_thin_supported(p);
-  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; plan->mask_bits = 0; plan->dbias_rows = 0; }
+  if (plan) { plan->family = 0; plan->bm = plan->bn = 0; plan->tiles = plan->workgroups = plan->tiles_per_wg = 0; plan->thin_mfma = 0; plan->mask_bits = 0; plan->dbias_rows = 0; plan->sum_parts = 0; }
   // Proj forward (bf16, K = 512, B <= 32): the weight-streaming kernel (proj_stream.hip); force 10 asks for it, 2 for the
   // general MFMA kernel it replaces
   if ((force == 0 || force == 10) && dg_proj_stream_supported(p)) return dg_proj_stream_launch(p, s, plan);
@@ -58,6 +59,7 @@ static int conv_dispatch0(const DgConv* p, int force_flags, int wg_cap, hipStrea
     if (plan) {
       plan->family = 3; plan->thin_mfma = dg_conv_thin_mfma_variant(p); plan->mask_bits = plan->thin_mfma == 1 ? 3 : 0;
       plan->dbias_rows = plan->thin_mfma == 1 ? dg_conv_s2_mfma_blocks(p) : 0;
+      plan->sum_parts = plan->thin_mfma == 2 ? dg_conv_up_mfma_sum_parts(p) : 0;
       return DG_OK;
     }
     return dg_conv_thin_launch(p, s);

@@ -238,6 +238,19 @@ __device__ __forceinline__ int dg_acc_add_last(float* dst, float v, unsigned con
   return 0;
 }
 
+// tanh for the depth head (Generator.forward, models/gans/dcgan_eqlr.py:71) in ~17 VALU instructions: libm's tanhf made
+// head_post_fwd4_kernel VALU-bound (8.4 M pixels x ~45 instructions = the whole 11 us of the launch, round 6).
+//   |x| >= 0.25: (1 - e) / (1 + e) with e = exp(-2 |x|) in (0, 0.61]: no cancellation, ~2 ulp
+//   |x| <  0.25: the odd Taylor polynomial through x^9 (next term < 9e-9 relative at 0.25)
+__device__ __forceinline__ float dg_tanh(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-2.f * ax);
+  const float big = (1.f - e) * __frcp_rn(1.f + e);
+  const float x2 = x * x;
+  const float small = ax + ax * x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f)));
+  return copysignf(ax < 0.25f ? small : big, x);
+}
+
 // Block-wide sum (blockDim.x a multiple of 64, <= 1024); result valid in thread 0.
 __device__ __forceinline__ float dg_block_sum(float v, float* red /* >= 16 floats of LDS */) {
   v = dg_wave_sum(v);

@@ -951,6 +951,8 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
     e_sc[h] = p.nscale ? p.scale * p.nscale[n] : p.scale;
     e_bias[h] = p.bias ? p.bias[n % p.bias_mod] : 0.f;
   }
+  const bool tsum = p.tanh_sum_parts != nullptr;                     // (DgConv.tanh_sum_parts: launcher-checked N == 1, fp32 out)
+  float lsum = 0.f;
   int cls = -1;
   tw_bf16x8 fa[18], fal[X2 ? 18 : 1];
   // the caller's fragments (kept current with its shadows) or the ones thin_up_prep_kernel has just built
@@ -997,7 +999,8 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
       const int q = 2 * kg + h;
       if (q >= 2 * N) continue;
       const int py = q / N, n = q % N;
-      const float v0 = acc[2 * h] * e_sc[h] + e_bias[h], v1 = acc[2 * h + 1] * e_sc[h] + e_bias[h];
+      float v0 = acc[2 * h] * e_sc[h] + e_bias[h], v1 = acc[2 * h + 1] * e_sc[h] + e_bias[h];
+      if (tsum) { v0 = dg_tanh(v0); v1 = dg_tanh(v1); lsum += v0 + v1; }   // the depth head: tanh + the image's sum (N == 1)
       const long o = (long)b * p.out_sb + ((long)(2 * m + py) * (2 * Wc) + 2 * x) * p.out_sp + (long)n * p.out_sn;
       if (p.out_dtype == DG_F32 && p.out_sp == 1) {
         *(float2*)((float*)p.out + o) = make_float2(v0, v1);
@@ -1008,6 +1011,10 @@ __global__ __launch_bounds__(256) void thin_up_mfma_kernel(ConvP p, int tiles_x,
     }
     if (more) put_row(m + 2, st);                                    // slot (m + 3) & 3 = the slot of row m - 2: not read this step
     __syncthreads();                                                 // row m + 2 visible; row m - 1's slot free for row m + 3
+  }
+  if (tsum) {                                                        // this workgroup's share of sample b's image sum: stored, not
+    const float t = dg_block_sum(lsum, (float*)s_in);                // added (a fixed order at the reader: bit-reproducible)
+    if (tid == 0) p.tanh_sum_parts[logical] = t;
   }
 }
 
@@ -1022,8 +1029,15 @@ int dg_conv_up_mfma_supported(const ConvP* p) {
   return 1;
 }
 
+// partial sums per sample the kernel stores for DgConv.tanh_sum_parts (its workgroups per sample), 0 where it does not take it
+int dg_conv_up_mfma_sum_parts(const ConvP* p) {
+  if (!dg_conv_up_mfma_supported(p) || p->N != 1 || p->out_dtype != DG_F32 || p->out_sp != 1) return 0;
+  return (p->Wc / TU_PX) * ((p->Hc + TU_RS - 1) / TU_RS);
+}
+
 int dg_conv_up_mfma_launch(const ConvP* p, hipStream_t s) {
   if (!dg_conv_up_mfma_supported(p)) return DG_EUNSUPPORTED;
+  if (p->tanh_sum_parts && !dg_conv_up_mfma_sum_parts(p)) return DG_EINVAL;
   if (p->up_frag && ((size_t)p->up_frag & 15)) return DG_EINVAL;
   const bool x2 = p->in_dtype == DG_BF16X2;
   if (x2) thin_up_prep_x2_kernel<<<dim3(UP_FRAG_BLOCKS, 3, 2), 256, 0, s>>>(*p);

@@ -551,19 +551,6 @@ __global__ void batch_wsum_scalar_kernel(const T* __restrict__ src, const float*
 // dsum != nullptr: dsum[b] += sum of depth[b] - the per-sample sum DiffAugment's contrast needs of its input, produced where
 // the image is produced.  A block then owns `chunk` consecutive pixels of ONE sample (HW % chunk == 0) and issues one atomic:
 // with one block per 256 pixels the 8192 atomics on 32 addresses cost 80 us (round 1 met the same in head_post_bwd).
-// tanh for the depth head (Generator.forward, models/gans/dcgan_eqlr.py:71) in ~17 VALU instructions: libm's tanhf made
-// head_post_fwd4_kernel VALU-bound (8.4 M pixels x ~45 instructions = the whole 11 us of the launch, round 6).
-//   |x| >= 0.25: (1 - e) / (1 + e) with e = exp(-2 |x|) in (0, 0.61]: no cancellation, ~2 ulp
-//   |x| <  0.25: the odd Taylor polynomial through x^9 (next term < 9e-9 relative at 0.25)
-__device__ __forceinline__ float dg_tanh(float x) {
-  const float ax = fabsf(x);
-  const float e = __expf(-2.f * ax);
-  const float big = (1.f - e) * __frcp_rn(1.f + e);
-  const float x2 = x * x;
-  const float small = ax + ax * x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f)));
-  return copysignf(ax < 0.25f ? small : big, x);
-}
-
 template <int arch>
 __device__ __forceinline__ float head_post_px(float* __restrict__ gout, const float* __restrict__ noise_pixel,
                                               const float* __restrict__ noise_image, int training,
@@ -2087,7 +2074,7 @@ int dg_diffaug_blur_fwd(const DgAugSet* sets, int nsets, int policy, int B, int 
     src[k].x = q.x;
     src[k].xsum = q.xsum;
     src[k].parts = q.xsum_parts;
-    if (q.xsum_parts < 0 || q.xsum_parts > 64) return DG_EINVAL;
+    if (q.xsum_parts < 0 || q.xsum_parts > 256) return DG_EINVAL;
   }
   if (H % DAB_ROWS != 0) return DG_EUNSUPPORTED;                     // bands of DAB_ROWS output rows
   const dim3 grid(H / DAB_ROWS, nsets * B);

@@ -607,8 +607,11 @@ class Ops:
 
     def conv(self, mode, adj, ring, B, Hc, Wc, K, N, x, x_strides, out, out_strides, w_ptr, scale, epi,
              bias=None, bias_mod=0, aux=None, dbias=None, rowscale=None, in_dt=None, out_dt=None, nscale=None,
-             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None, up_frag=None, defer_db=False):
-        """defer_db: the bias-gradient rows of a deterministic launch (DETERMINISTIC, kernels with DgConvPlan.dbias_rows) wait in
+             x_off=0, out_off=0, aux_off=0, w_strides=None, w_dt=None, up_frag=None, defer_db=False, tanh_sums=None):
+        """tanh_sums (a float32 buffer of >= B * 256 elements): ask the launch for DgConv.tanh_sum_parts - tanh on the output and
+        the per-workgroup sums of it; returns DgConvPlan.sum_parts (> 0: done, the partial sums per sample; 0: the kernel that
+        takes this launch does not do it, nothing of it happened).
+        defer_db: the bias-gradient rows of a deterministic launch (DETERMINISTIC, kernels with DgConvPlan.dbias_rows) wait in
         WGRAD_WS for the caller's flush like a deferred weight gradient's partials; otherwise they are summed at once."""
         x2_out = None
         if mode == L.MODE_GEMM and (is_x2(x) or is_x2(out) or is_x2(aux)):
@@ -653,6 +656,14 @@ class Ops:
         p.in_dtype, p.out_dtype, p.w_dtype = in_dt, out_dt, (self.dt if w_dt is None else w_dt)
         p.nscale = L.ptr(nscale)
         p.up_frag = up_frag
+        sum_parts = 0
+        if tanh_sums is not None:
+            p.tanh_sum_parts = L.ptr(tanh_sums)
+            pl = L.DgConvPlan()
+            L.check(self.lib.dg_conv_plan(C.byref(p), self._f, self.wg_cap, C.byref(pl)), "dg_conv_plan")
+            sum_parts = pl.sum_parts if B * pl.sum_parts <= tanh_sums.numel() else 0
+            if not sum_parts:
+                p.tanh_sum_parts = None
         if epi == L.EPI_LRELU and out_dt == L.DG_BF16:
             p.mask_out = MaskBits.slice_ptr(out, out_off, N, out_strides)
         elif epi == L.EPI_MASK and aux is not None and out_dt == L.DG_BF16:
@@ -681,7 +692,7 @@ class Ops:
             self._db_rows_done(p, db_rows, dbias, N, defer_db)
             if x2_out is not None:
                 x2_pack(out, x2_out, out_off, B * N)
-            return
+            return sum_parts
         # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
         choice = self.lib.dg_conv_kernel_choice(C.byref(p)) if self.force == 0 else self.force
         wes = 2 if p.w_dtype == L.DG_BF16 else 4
@@ -700,6 +711,7 @@ class Ops:
         self._db_rows_done(p, db_rows, dbias, N, defer_db)
         if x2_out is not None:
             x2_pack(out, x2_out, out_off, B * N)
+        return sum_parts
 
     def _db_rows_done(self, p, rows, dbias, N, defer_db):
         """the launch left `rows` partial bias-gradient rows in the workspace: queue their sum onto dbias"""
@@ -882,6 +894,7 @@ def x2_eligible(cfg):
 
 class GEngine:
     """Generator forward / backward on one ParamStore (models/gans/dcgan_eqlr.py:49-72 + models/dusty.py)."""
+    head_tanh_fused = os.environ.get("DUSTY_GAN_HEAD_TANH", "1") != "0"   # (A/B switch, tests: the separate head_post launch)
 
     def __init__(self, cfg: NetCfg, dtype, x3=False, x2=False):
         self.cfg, self.dtype = cfg, dtype
@@ -918,6 +931,7 @@ class GEngine:
         self.hp_ws = torch.zeros(B * 1024, dtype=torch.float32, device=device)  # dg_head_post_bwd's per-sample bias staging
         self.mask = torch.empty(B, max(c.nheads - 1, 1), c.H, c.W, dtype=torch.float32, device=device)
         self.depth = torch.empty(B, 1, c.H, c.W, dtype=torch.float32, device=device)
+        self.dsum_parts = torch.empty(B * 256, dtype=torch.float32, device=device)   # DgConv.tanh_sum_parts (baseline generator)
         self.zT = torch.empty(B * c.nz, dtype=T, device=device)
         self.noise_pixel = None
         self.noise_image = None
@@ -960,10 +974,18 @@ class GEngine:
         # (weight (tap, n = head, k = ci) in the fp32 master [tap][ci][co]: strides (ci co, 1, co))
         frag = (st.up_frag("head_w", (chs[3] * c.nheads, 1, c.nheads), c.nheads, hc, 0)
                 if (c.ring and chs[3] == 64 and c.nheads <= 3) else None)
-        o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.gout,
-               (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR,
-               bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale, up_frag=frag)
         arch = ARCH_ID[c.arch]
+        # the baseline generator's head (one channel, then torch.tanh, dcgan_eqlr.py:69-72): the thin matrix-core kernel applies
+        # the tanh itself and stores the image's per-sample sums as partials (DgConv.tanh_sum_parts, round 6) - no head
+        # post-processing launch; `depth` then IS gout
+        parts = o.conv(L.MODE_UP, 0, c.ring, B, hc, wc, chs[3], c.nheads, self.a[3], (hc * wc * chs[3], chs[3], 1), self.gout,
+                       (c.nheads * self.HW, 1, self.HW), L.ptr(st.coci["head_w"]), 1.0, L.EPI_LINEAR,
+                       bias=st.fptr("head_b"), bias_mod=c.nheads, out_dt=L.DG_F32, nscale=self.nscale, up_frag=frag,
+                       tanh_sums=self.dsum_parts if (arch == 0 and GEngine.head_tanh_fused) else None)
+        if parts:
+            out = OrderedDict()
+            out["depth"] = L.tag_sums(self.gout.view(B, 1, c.H, c.W), self.dsum_parts, parts=parts)
+            return out
         if arch:
             if noise is None or "pixel" not in noise:
                 raise ValueError("dusty generator needs logistic noise (engine.sample_noise or injected)")

@@ -93,6 +93,13 @@ typedef struct DgConv {
   const void* mask_in;       /* optional, DG_EPI_MASK: the bits of `aux` (written through mask_out by the launch that produced
                               * aux); kernels that take bits (DgConvPlan.mask_bits & 2) read 1/16 of the bytes, the others use aux,
                               * which stays mandatory */
+  float* tanh_sum_parts;     /* optional (round 6), the thin matrix-core MODE_UP kernel only (DgConvPlan.sum_parts > 0: N == 1,
+                              * DG_EPI_LINEAR, fp32 output - the depth head, models/gans/dcgan_eqlr.py:29-46): the launch writes
+                              * tanh(out) instead of out (Generator.forward's torch.tanh, :71) and every workgroup STORES the sum
+                              * of what it wrote at tanh_sum_parts[its index]; sample b's workgroups are the sum_parts indices
+                              * from b * sum_parts: the per-sample sums DiffAugment's contrast needs (DgAugSet.xsum_parts), made
+                              * where the image is made - no head post-processing launch for the baseline generator.  Kernels
+                              * that do not take it (sum_parts == 0) ignore it: the caller then runs dg_head_post_fwd[_sum]. */
 } DgConv;
 #define DG_UP_FRAG_BYTES (3 * 18 * 1024)
 #define DG_DBIAS_SLOTS 32
@@ -158,6 +165,7 @@ typedef struct DgConvPlan {
   int thin_mfma;     /* family 3: 1 = thin_s2_mfma, 2 = thin_up_mfma (matrix cores), 0 = the VALU kernels */
   int mask_bits;     /* 1: the kernel writes DgConv.mask_out itself (else a packing launch follows it), 2: it reads mask_in */
   int dbias_rows;    /* > 0: the kernel takes DgConv.dbias_part and writes this many partial rows of N floats; 0: it does not */
+  int sum_parts;     /* > 0: the kernel takes DgConv.tanh_sum_parts and stores this many partial sums per sample; 0: it does not */
 } DgConvPlan;
 int dg_conv_ex(const DgConv* p, int force, int wg_cap, void* stream);
 int dg_conv_plan(const DgConv* p, int force, int wg_cap, DgConvPlan* plan);

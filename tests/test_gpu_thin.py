@@ -361,6 +361,52 @@ def test_thin_up_fragments_kept_with_the_shadows(L, case, Hc):
                                                (L.DgUpFrag * 1)(d), 1, None) == L.DG_EINVAL
 
 
+@pytest.mark.parametrize("Hc,Wc,B", [(8, 64, 3), (32, 512, 2), (20, 128, 2)])
+def test_depth_head_applies_tanh_and_stores_the_image_sums(L, Hc, Wc, B):
+    """DgConv.tanh_sum_parts (round 6): the thin matrix-core MODE_UP kernel as the baseline generator's depth head writes
+    tanh(out) (Generator.forward, models/gans/dcgan_eqlr.py:69-72) and every workgroup stores the sum of what it wrote - against
+    the same launch without the field followed by tanh: the image within fp32 rounding of the 17-instruction tanh (1.3e-7
+    absolute), the per-sample sums of DgConvPlan.sum_parts partials in index order equal to the image's sums; two launches
+    agree bit for bit; a two-channel head (N = 2) does not take the field (sum_parts = 0, plain output)."""
+    from dusty_gan_amd.engine import Ops
+    g = torch.Generator().manual_seed(Hc + Wc)
+    K = 64
+    o = Ops(torch.bfloat16)
+    o.force = 3
+    x = torch.randn(B, Hc, Wc, K, generator=g).to(DEV, torch.bfloat16)
+    for N in (1, 2):
+        w = (torch.randn(16, N, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(DEV)
+        nscale = torch.full((N,), 0.25, device=DEV)
+        HW = 4 * Hc * Wc
+
+        def run(parts_buf):
+            out = torch.full((B, N, 2 * Hc, 2 * Wc), 7.0, device=DEV)
+            n = o.conv(L.MODE_UP, 0, True, B, Hc, Wc, K, N, x, (Hc * Wc * K, K, 1), out, (N * HW, 1, HW), w.data_ptr(), 1.0,
+                       L.EPI_LINEAR, bias=bias.data_ptr(), bias_mod=N, out_dt=L.DG_F32, nscale=nscale, tanh_sums=parts_buf)
+            torch.cuda.synchronize()
+            return out, n
+        plain, n0 = run(None)
+        assert n0 == 0 and float(plain.abs().mean()) > 0.05
+        buf = torch.full((B * 256,), float("nan"), device=DEV)
+        got, parts = run(buf)
+        if N == 2:
+            assert parts == 0 and torch.equal(got, plain) and bool(torch.isnan(buf).all())
+            continue
+        assert parts == (Wc // 64) * ((Hc + 7) // 8)
+        want = torch.tanh(plain.double())
+        assert float((got.double() - want).abs().max()) < 4e-7
+        sums = torch.zeros(B, device=DEV)
+        for j in range(parts):                       # the reader's order of additions (dg_diffaug_blur_fwd)
+            sums = sums + buf[:B * parts].view(B, parts)[:, j]
+        ref = got.double().sum(dim=[1, 2, 3])
+        assert float((sums.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        assert bool(torch.isnan(buf[B * parts:]).all())
+        buf2 = torch.zeros(B * 256, device=DEV)
+        got2, _ = run(buf2)
+        assert torch.equal(got, got2) and torch.equal(buf[:B * parts], buf2[:B * parts])
+
+
 def test_param_store_rebuilds_up_fragments_with_every_refresh(L):
     """engine.ParamStore.up_frag: registered once, rebuilt by every refresh_transposed (the launch behind each optimizer
     step) - after a weight change the fragments equal those of a freshly registered store."""

@@ -170,9 +170,9 @@ def test_graph_replay_matches_eager_at_bench_size(monkeypatch):
             assert abs(x[k] - y[k]) <= tol * max(1.0, abs(y[k])), (k, x[k], y[k])
 
 
-def test_replayed_step_makes_at_most_49_launches(monkeypatch):
+def test_replayed_step_makes_at_most_48_launches(monkeypatch):
     """The launch count of the step bench.py times (config 2: 64x1024, B = 32, bf16, R1 + DiffAugment on), counted as kernel
-    nodes of the captured hipGraph: 49 (round 5: 54; round 4: 58) - fetch_reals rides on the step's first launch
+    nodes of the captured hipGraph: 48 (round 5: 54; round 4: 58) - the depth head applies its tanh and sums itself (DgConv.tanh_sum_parts), fetch_reals rides on the step's first launch
     (dg_step_prologue_fetch), R1's turn-around at the image is one launch (dg_blur_r1_tangent), each network's optimizer is one
     launch that sums its own partial tiles (dg_adam_fused) plus the small shadow / counter launch behind it.  A workspace that
     grows during capture, a fallback to an unfused form, a stray zero-fill - each shows up here as a number."""
@@ -185,7 +185,7 @@ def test_replayed_step_makes_at_most_49_launches(monkeypatch):
     assert tr._graph is not None
     n = tr.graph_kernel_nodes()
     assert n is not None, "hipGraphGetNodes did not answer"
-    assert 40 <= n <= 49, n
+    assert 40 <= n <= 48, n
 
 
 @pytest.mark.parametrize("arch,amp", [("none", True), ("dusty2", True), ("dusty2", False)], ids=["none", "dusty2", "dusty2-fp32x3"])
