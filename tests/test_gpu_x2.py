@@ -385,12 +385,13 @@ def test_split_storage_training_tracks_fp32_over_30_steps(monkeypatch):
     """The fp32x3 mode's TRAINING with split storage, through `Trainer.step` (the captured hipGraph from the third step on, the
     weight-shadow twins rebuilt behind every optimizer step, device RNG): 30 steps of a 64x1024 net (128 latent, 64..256
     channels, dusty2, R1 + DiffAugment, B = 8) against the exact fp32 mode from the same seeds.  GAN training amplifies the 2^-16
-    operand rounding about tenfold every two steps (measured: 1e-5 at step 2, 2e-3 at step 4, 2e-2 at step 6), so the runs are
-    held step by step while that is meaningful - steps 1-5, i.e. two eager steps, the capture and the first two replays: the
-    first 1e-4, steps 2-4 within 2e-2 of max(1, |fp32|) on every logged scalar (measured <= 4e-3 in round 5; 1.1e-2 on the R1
-    penalty of step 3 after round 6 changed the order of several per-sample sums - the amplification is chaotic), step 5 within 5e-2 (2.3e-2,
-    the register-split form is as far away) - and as curves afterwards, like the bf16 mode's 50-step
-    test (tests/test_gpu_large_batch.py): window means within 0.1 (measured 0.004-0.054 over several boxes at this batch of 8).
+    operand rounding chaotically: Adam's first steps move every parameter by about +-lr whatever its gradient's size, so a gradient
+    entry near zero that lands on the other side flips a whole update (scripts/probes/x2_step_gap.py, three seeds, worst logged
+    scalar against max(1, |fp32|): step 1 2e-6..3e-5, step 2 1.3e-3..1.4e-2, step 3 5.7e-3..1.1e-2, step 4 7e-3..1.4e-2, step 5
+    6e-3..2.2e-2, step 8 5e-3..4.6e-2).  So the first step is held to 1e-4 and steps 2-5 - the second eager step, the capture
+    and the first two replays - to 5e-2 on every logged scalar, which is what the bug below missed by a factor of five; after
+    that the runs are compared as curves, like the bf16 mode's 50-step test (tests/test_gpu_large_batch.py): window means
+    within 0.1 (measured 0.004-0.054 over several boxes at this batch of 8).
     (This test found the one bug of the form's bring-up that no single-step test could: the twins were re-allocated on every
     refresh, harmless in eager steps, but inside the capture the D phase had already been recorded with the old twins'
     addresses - replays trained the discriminator's fat layers on stale weights: 0.25 off at the second replay.)"""
@@ -407,7 +408,7 @@ def test_split_storage_training_tracks_fp32_over_30_steps(monkeypatch):
     a, b = run(False), run(True)
     for i in range(5):
         for k in a[0]:
-            tol = 1e-4 if i == 0 else (2e-2 if i < 4 else 5e-2)   # (round 6: 1.13e-2 at step 3 once, see the docstring)
+            tol = 1e-4 if i == 0 else 5e-2
             assert abs(a[i][k] - b[i][k]) <= tol * max(1.0, abs(a[i][k])), (i, k, a[i][k], b[i][k])
     worst = {}
     for lo, hi in ((0, 10), (10, 20), (20, 30)):
