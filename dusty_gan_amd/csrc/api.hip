@@ -18,6 +18,8 @@ int dg_conv_up_mfma_sum_parts(const ConvP* p);
 int dg_conv_s2_mfma_blocks(const ConvP* p);
 int dg_wgrad_thin_mfma_variant(const WgradP* p);
 int dg_wgrad_thin_ws_splits(const WgradP* p);
+int dg_wgrad_mfma_ws_splits(const WgradP* p, int accumulate);
+int dg_wgrad_direct_ws_splits(const WgradP* p);
 int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream);
 int dg_wgrad_mfma_launch(const WgradP* p, int accumulate, hipStream_t stream, int x3);
 int dg_wgrad_thin_launch(const WgradP* p, hipStream_t stream);
@@ -120,11 +122,18 @@ static int wgrad_dispatch(const DgWgrad* p, int accumulate, int force_flags, hip
   // the thin matrix-core kernels (Down1, Head) also have the workspace form: one partial tile per block
   const bool thin_runs = thin_ok && (force == 3 || (force == 0 && !mfma_ok));
   const int thin_splits = thin_runs ? dg_wgrad_thin_ws_splits(p) : 0;
+  // ... and so have the register-staged MFMA kernel (the fp32 modes' fat layers) and the direct kernel (narrow nets) wherever
+  // they split K over workgroups (round 6: their fp32 atomics summed in arrival order)
+  const bool mfma_runs = mfma_ok && (force == 0 || force == 2 || force == 6);
+  const bool direct_runs = !mfma_runs && !thin_runs && (force == 0 || force == 1) && !p->g_mod;
+  const int other_splits = mfma_runs ? dg_wgrad_mfma_ws_splits(p, accumulate) : (direct_runs ? dg_wgrad_direct_ws_splits(p) : 0);
   if (plan) {
+    const long numel = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
     if (thin_splits) { plan->splits = thin_splits; plan->ws_floats = (long)thin_splits * 16 * p->Ci * p->Co; }
+    else if (other_splits) { plan->splits = other_splits; plan->ws_floats = other_splits * numel; }
     return plan->variant ? DG_OK : DG_EUNSUPPORTED;
   }
-  if (p->ws && !thin_splits) return DG_EUNSUPPORTED;   // (the LDS-DMA kernel and those two: nobody else)
+  if (p->ws && !thin_splits && !other_splits) return DG_EUNSUPPORTED;
   // ... and the gradient-sample map exists there and in the thin matrix-core kernel of Down1 (checked by its launcher)
   const bool thin_map = p->g_mod && thin_ok && !mfma_ok && (force == 0 || force == 3);
   if (p->g_mod && !thin_map) return DG_EUNSUPPORTED;

@@ -238,6 +238,54 @@ __device__ __forceinline__ int dg_acc_add_last(float* dst, float v, unsigned con
   return 0;
 }
 
+// ---- two-word fixed point (round 6): float sums that do not depend on the order of their terms, without the one-word form's
+// absolute resolution.  v = hi 2^-20 + lo 2^-60 with hi = rint(v 2^20) and lo = the residual, which float arithmetic forms exactly
+// (|v| < 16: Sterbenz; above, v is a multiple of 2^-20 already and the residual is zero): every float down to 2^-36 in magnitude
+// enters the sum EXACTLY, smaller ones rounded to 2^-60; range +-4e12 per term (larger or non-finite: the caller's float path),
+// +-8.8e12 for the total.  Integer adds are associative, so the total is one pair of integers whatever the arrival order; it is
+// rounded to float once.  Used by the bias-gradient sums of the kernels outside the timed path (conv_direct, conv_mfma).
+__device__ __forceinline__ bool dg_fix2(float v, long long& hi, long long& lo) {
+  if (!(fabsf(v) < 4.0e12f)) return false;
+  const float t = rintf(v * 1048576.f);
+  hi = (long long)t;
+  const float r = __fmaf_rn(-t, 1.f / 1048576.f, v);
+  lo = __double2ll_rn((double)r * 1152921504606846976.0);
+  return true;
+}
+__device__ __forceinline__ float dg_fix2_value(long long hi, long long lo) {
+  return (float)((double)hi * (1.0 / 1048576.0) + (double)lo * (1.0 / 1152921504606846976.0));
+}
+// ... across the workgroups of one launch, through the caller's staging scratch (DgConv.dbias_ws: zero on entry, left zero): word
+// pair i belongs to bias channel i, the LAST u64 of the scratch is the ticket.  Every workgroup adds its channel sums
+// (dg_dbias_ws_add), then ALL its threads call dg_dbias_ws_finish once: the adds are acknowledged (memory-side atomics), a ticket
+// is drawn, and the workgroup that draws the last one adds the totals onto dbias - one float add per channel and launch.
+#define DG_DBIAS_WS_WORDS (DG_DBIAS_SLOTS * DG_DBIAS_SLOT_FLOATS / 2)
+__device__ __forceinline__ bool dg_dbias_ws_ok(const float* ws, int bias_mod) {
+  return ws != nullptr && 2 * bias_mod + 2 <= DG_DBIAS_WS_WORDS;
+}
+__device__ __forceinline__ void dg_dbias_ws_add(float* ws, int ch, long long hi, long long lo) {
+  unsigned long long* w = (unsigned long long*)ws;
+  if (hi) atomicAdd(&w[2 * ch], (unsigned long long)hi);
+  if (lo) atomicAdd(&w[2 * ch + 1], (unsigned long long)lo);
+}
+__device__ __forceinline__ void dg_dbias_ws_finish(float* ws, int bias_mod, float* dbias) {
+  unsigned long long* w = (unsigned long long*)ws;
+  __shared__ unsigned s_dbias_ticket;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned nthr = blockDim.x * blockDim.y * blockDim.z;
+  const unsigned t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  if (t == 0) s_dbias_ticket = atomicAdd((unsigned*)&w[DG_DBIAS_WS_WORDS - 1], 1u);
+  __syncthreads();
+  if (s_dbias_ticket != nblk - 1) return;
+  for (int i = (int)t; i < bias_mod; i += (int)nthr) {
+    const long long hi = (long long)atomicExch(&w[2 * i], 0ull), lo = (long long)atomicExch(&w[2 * i + 1], 0ull);
+    if (hi | lo) atomicAdd(&dbias[i], dg_fix2_value(hi, lo));
+  }
+  if (t == 0) atomicExch((unsigned*)&w[DG_DBIAS_WS_WORDS - 1], 0u);
+}
+
 // tanh for the depth head (Generator.forward, models/gans/dcgan_eqlr.py:71) in ~17 VALU instructions: libm's tanhf made
 // head_post_fwd4_kernel VALU-bound (8.4 M pixels x ~45 instructions = the whole 11 us of the launch, round 6).
 //   |x| >= 0.25: (1 - e) / (1 + e) with e = exp(-2 |x|) in (0, 0.61]: no cancellation, ~2 ulp

@@ -11,10 +11,12 @@
 // One thread computes NV consecutive output channels of one output pixel.
 template <int NV>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p) {
-  __shared__ float s_db[512];
+  // bias-gradient sums: two-word fixed point (common.h dg_fix2) in LDS and, through DgConv.dbias_ws, across the workgroups -
+  // integer adds, the same bits whatever the order (round 6: float atomics at both levels summed in arrival order)
+  __shared__ unsigned long long s_db[512][2];
   const bool want_db = p.dbias != nullptr;
   if (want_db) {
-    for (int i = threadIdx.x; i < p.bias_mod; i += blockDim.x) s_db[i] = 0.f;
+    for (int i = threadIdx.x; i < p.bias_mod; i += blockDim.x) s_db[i][0] = s_db[i][1] = 0ull;
     __syncthreads();
   }
   const int NG = (p.N + NV - 1) / NV;
@@ -71,16 +73,25 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p) {
         const float auxv = p.epi == EPI_MASK ? dg_ld(p.aux, o, p.out_dtype) : 0.f;
         const float r = dg_epilogue(acc[v], p.nscale ? p.scale * p.nscale[n] : p.scale, p.epi, bias, auxv);
         dg_st(p.out, o, p.out_dtype, r);
-        if (want_db) atomicAdd(&s_db[n % p.bias_mod], r * rs);
+        if (want_db) {
+          long long hi, lo;
+          if (dg_fix2(r * rs, hi, lo)) {
+            if (hi) atomicAdd(&s_db[n % p.bias_mod][0], (unsigned long long)hi);
+            if (lo) atomicAdd(&s_db[n % p.bias_mod][1], (unsigned long long)lo);
+          } else atomicAdd(&p.dbias[n % p.bias_mod], r * rs);
+        }
       }
     }
   }
   if (want_db) {
     __syncthreads();
+    const bool ws = dg_dbias_ws_ok(p.dbias_ws, p.bias_mod);
     for (int i = threadIdx.x; i < p.bias_mod; i += blockDim.x) {
-      const float v = s_db[i];
-      if (v != 0.f) atomicAdd(&p.dbias[i], v);
+      const long long hi = (long long)s_db[i][0], lo = (long long)s_db[i][1];
+      if (ws) dg_dbias_ws_add(p.dbias_ws, i, hi, lo);
+      else if (hi | lo) atomicAdd(&p.dbias[i], dg_fix2_value(hi, lo));
     }
+    if (ws) dg_dbias_ws_finish(p.dbias_ws, p.bias_mod, p.dbias);
   }
 }
 
@@ -124,7 +135,9 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradP p) {
     }
     tot += (p.rowscale ? p.rowscale[b] : 1.f) * acc;
   }
-  atomicAdd(&p.dw[idx], tot * p.scale);
+  // workspace form (DgWgrad.ws): slab y stores its partial at ws[y][idx], dg_wgrad_reduce sums the slabs in index order
+  if (p.ws) p.ws[(long)blockIdx.y * total + idx] = tot * p.scale;
+  else atomicAdd(&p.dw[idx], tot * p.scale);
 }
 
 int dg_conv_direct_launch(const ConvP* p, hipStream_t stream) {
@@ -149,15 +162,28 @@ int dg_conv_direct_launch(const ConvP* p, hipStream_t stream) {
   return DG_OK;
 }
 
-int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream) {
-  const int ntap = p->wmode == 2 ? 1 : 16;
-  const long total = (long)ntap * p->Ci * p->Co;
+// enough slabs to fill the chip, never more than the rows there are
+static long direct_slabs(const WgradP* p) {
+  const long total = (long)(p->wmode == 2 ? 1 : 16) * p->Ci * p->Co;
   const long rows = (long)p->B * p->Hc;
-  // enough slabs to fill the chip, never more than the rows there are
   long slabs = (256L * 16 * 256) / (total > 0 ? total : 1);
   if (slabs < 1) slabs = 1;
   if (slabs > rows) slabs = rows;
   if (slabs > 4096) slabs = 4096;
+  return slabs;
+}
+
+// > 1: the direct kernel's launch has that many slabs and takes DgWgrad.ws (slabs x numel floats) instead of atomics
+int dg_wgrad_direct_ws_splits(const WgradP* p) {
+  const long s = direct_slabs(p);
+  return s > 1 ? (int)s : 0;
+}
+
+int dg_wgrad_direct_launch(const WgradP* p, hipStream_t stream) {
+  const int ntap = p->wmode == 2 ? 1 : 16;
+  const long total = (long)ntap * p->Ci * p->Co;
+  const long slabs = direct_slabs(p);
+  if (p->ws && slabs <= 1) return DG_EUNSUPPORTED;
   dim3 grid((unsigned)((total + 255) / 256), (unsigned)slabs);
   wgrad_direct_kernel<<<grid, 256, 0, stream>>>(*p);
   HIP_CHECK_RET(hipGetLastError());

@@ -251,9 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n,
   constexpr int CPT = PROWS * OCH / 256;       // 16-byte chunks per thread per pass
   static_assert(PROWS * ORS + BN * 4 <= NS * STAGE, "epilogue staging does not fit the pipeline's LDS");
   unsigned char* s_out = lds;
-  float* s_db = (float*)(lds + PROWS * ORS);
+  // bias-gradient column sums: one row per wave (each wave writes every channel of the tile once), summed in wave order, then
+  // across the workgroups as two-word fixed point through DgConv.dbias_ws (common.h) - the same bits whatever the arrival
+  // order (round 6: an LDS float atomic per wave and a global one per workgroup)
+  __shared__ float s_dbw[4][BN];
   const bool want_db = p.dbias != nullptr;
-  if (tid < BN) s_db[tid] = 0.f;
   T* out = (T*)p.out;
   float csum[EPC];
 #pragma unroll
@@ -330,13 +332,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p, int tiles_n,
     for (int e = 0; e < EPC; ++e) {
       float v = csum[e];
       for (int d = OCH; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-      if (lane < OCH) atomicAdd(&s_db[part * EPC + e], v);
+      if (lane < OCH) s_dbw[tid >> 6][part * EPC + e] = v;
     }
     __syncthreads();
+    const bool ws = dg_dbias_ws_ok(p.dbias_ws, p.bias_mod);
     if (tid < BN && nb0 + tid < p.N) {
       const float rs = p.rowscale ? p.rowscale[b] : 1.f;
-      atomicAdd(&p.dbias[(nb0 + tid) % p.bias_mod], s_db[tid] * rs);
+      const float v = (((s_dbw[0][tid] + s_dbw[1][tid]) + s_dbw[2][tid]) + s_dbw[3][tid]) * rs;
+      const int ch = (nb0 + tid) % p.bias_mod;
+      long long hi, lo;
+      if (ws && dg_fix2(v, hi, lo)) dg_dbias_ws_add(p.dbias_ws, ch, hi, lo);
+      else atomicAdd(&p.dbias[ch], v);
     }
+    if (ws) dg_dbias_ws_finish(p.dbias_ws, p.bias_mod, p.dbias);
   }
 }
 

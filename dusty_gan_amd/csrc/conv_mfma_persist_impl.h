@@ -106,8 +106,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
   constexpr int RS = RB + 16;
   constexpr int CR = RB / 16;                  // 16-byte chunks per strip row
   constexpr int NDB0 = 512;
+  // bias-gradient rows in LDS: fp32 (the parity mode) keeps one per wave ROW, each written by one wave per channel in tile order -
+  // the workgroup's sums do not depend on which wave adds first (round 6); bf16 has no room for them beside its ring
+  constexpr int DBR = sizeof(T) == 4 ? WM : 1;
   // strip rows: 16 unless the ring + 16-row strips would not fit the 160 KiB of LDS
-  constexpr int SR = (NS * STAGE + NWV * 16 * RS + NDB0 * 4 > 160 * 1024) ? 8 : 16;
+  constexpr int SR = (NS * STAGE + NWV * 16 * RS + NDB0 * 4 * DBR > 160 * 1024) ? 8 : 16;
   constexpr int CPL = SR * CR / 64;            // chunks per lane per strip
   constexpr int STRIP = SR * RS;
   constexpr int NQ = 32 / SR;                  // strips per 32-row MFMA block
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
   static_assert(IA >= 1 && IB >= 1, "piece distribution");
   static_assert(NS >= 3 && NS <= 4 && KS >= 2 && KS % 2 == 0 && 2 * IPT + NST <= 63, "ring / vmcnt immediates");
   constexpr int NDB = 512;                     // bias-gradient accumulators (N <= 512 when dbias is wanted)
-  static_assert(NS * STAGE + NWV * STRIP + NDB * 4 <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + NWV * STRIP + NDB * 4];
+  static_assert(NS * STAGE + NWV * STRIP + NDB * 4 * DBR <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE + NWV * STRIP + NDB * 4 * DBR];
 
   // ---- this workgroup's chunk of the tile order
   // XCD-aware, bijective chunk assignment (blocks id and id+8 share an XCD): the chunks of one XCD are CONTIGUOUS in
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
   const unsigned sdb0 = lds0 + NS * STAGE + NWV * STRIP;
   const bool want_db = p.dbias != nullptr;
   if (want_db) {
-    for (int i = tid; i < NDB; i += 64 * NWV) s_db[i] = 0.f;
+    for (int i = tid; i < NDB * DBR; i += 64 * NWV) s_db[i] = 0.f;
     __syncthreads();
   }
   T* out = (T*)p.out;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
           float v = csum[e];
           for (int d = CR; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
           if (lane < CR) {
-            const unsigned a = sdb0 + (unsigned)(colb + part * EPC + e) * 4;
+            const unsigned a = sdb0 + (unsigned)((DBR > 1 ? wm * NDB : 0) + colb + part * EPC + e) * 4;
             asm volatile("ds_add_f32 %0, %1" ::"v"(a), "v"(v) : "memory");
           }
         }
@@ -448,7 +451,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_kernel(ConvP p, Geo g) {
   if (want_db) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int n = tid; n < p.N; n += 64 * NWV) atomicAdd(&p.dbias[n % p.bias_mod], s_db[n]);
+    for (int n = tid; n < p.N; n += 64 * NWV) {
+      float v = s_db[n];
+#pragma unroll
+      for (int r = 1; r < DBR; ++r) v += s_db[r * NDB + n];
+      // dbias_part: this workgroup's row of the caller's workspace (summed by dg_wgrad_reduce in a fixed order) - else atomics
+      if (p.dbias_part) p.dbias_part[(long)blockIdx.x * p.N + n] = v;
+      else atomicAdd(&p.dbias[n % p.bias_mod], v);
+    }
   }
 }
 
@@ -497,6 +507,7 @@ int launch(const ConvP* p, const Geo& g0, hipStream_t stream, int wg_cap, DgConv
   if (plan) {
     plan->family = 4; plan->bm = BM; plan->bn = BN; plan->tiles = g.ntiles; plan->workgroups = G;
     plan->tiles_per_wg = (g.ntiles + G - 1) / G;
+    plan->dbias_rows = (sizeof(T) == 4 && p->bias_mod == p->N) ? G : 0;   // fp32: one partial row per workgroup (DgConv.dbias_part)
     return DG_OK;
   }
   conv_kernel<T, BM, BN, WM, WN, SB, NS, MODE><<<(unsigned)G, 64 * WM * WN, 0, stream>>>(*p, g);

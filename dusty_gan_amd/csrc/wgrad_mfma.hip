@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
     }
     return;
   }
-  float* dw = p.dw + (long)tap * p.Ci * p.Co;
+  // workspace form (DgWgrad.ws, round 6): split z stores its partial tile plainly at ws[z][tap][ci][co]; dg_wgrad_reduce sums
+  // the splits in index order - bit-reproducible, where the atomics below sum in arrival order
+  float* dw = p.ws ? p.ws + ((long)blockIdx.z * gridDim.y + tap) * p.Ci * p.Co : p.dw + (long)tap * p.Ci * p.Co;
+  if (p.ws) accumulate = 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -313,18 +316,34 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradP p, int tiles_n, 
       }
 }
 
-template <typename T, int BM, int BN, bool X3 = false>
-static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
+// K split of a launch: none without `accumulate` (plain stores), else towards >= 2 workgroups per CU
+static long k_split(const WgradP* p, int BM, int BN, int accumulate) {
   const int tiles_m = (p->Ci + BM - 1) / BM, tiles_n = (p->Co + BN - 1) / BN;
   const int ntap = p->wmode == 2 ? 1 : 16;
   const long units = (long)p->B * p->Hc;
   long tiles = (long)tiles_m * tiles_n * ntap;
   long split = 1;
   if (accumulate) {
-    split = (512 + tiles - 1) / tiles;  // aim at >= 2 workgroups per CU
+    split = (512 + tiles - 1) / tiles;
     if (split > units) split = units;
     if (split < 1) split = 1;
   }
+  return split;
+}
+
+// > 1: the launch splits K that many ways and takes DgWgrad.ws (splits x numel floats) instead of adding with atomics
+int dg_wgrad_mfma_ws_splits(const WgradP* p, int accumulate) {
+  if (!dg_wgrad_mfma_supported(p) || p->a_dtype == DG_BF16X2) return 0;
+  const long s = k_split(p, p->Ci % 128 == 0 ? 128 : 64, p->Co % 128 == 0 ? 128 : 64, accumulate);
+  return s > 1 ? (int)s : 0;
+}
+
+template <typename T, int BM, int BN, bool X3 = false>
+static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
+  const int tiles_m = (p->Ci + BM - 1) / BM, tiles_n = (p->Co + BN - 1) / BN;
+  const int ntap = p->wmode == 2 ? 1 : 16;
+  const long split = k_split(p, BM, BN, accumulate);
+  if (p->ws && split <= 1) return DG_EUNSUPPORTED;   // (a workspace is only taken by a launch that splits: dg_wgrad_plan says so)
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ntap, (unsigned)split);
   wgrad_mfma_kernel<T, BM, BN, false, X3><<<grid, 256, 0, stream>>>(*p, tiles_n, accumulate);
   HIP_CHECK_RET(hipGetLastError());

@@ -74,13 +74,18 @@ typedef struct DgConv {
                               * dg_transpose_shadow_multi_frags; NULL: built by a launch in front of the kernel */
   float* dbias_ws;           /* optional scratch of DG_DBIAS_SLOTS x DG_DBIAS_SLOT_FLOATS floats, zero on entry and left zero:
                               * per-slot staging of the bias-gradient rows of the thin matrix-core MODE_S2 kernel (hundreds of
-                              * atomic rows on the same two lines serialise memory-side; other kernels ignore it) */
+                              * atomic rows on the same two lines serialise memory-side) and, since round 6, the
+                              * cross-workgroup staging of the direct and one-tile MFMA kernels' bias-gradient sums - two 64-bit
+                              * fixed-point words per channel + a ticket, bias_mod <= 8191 - which makes those sums independent
+                              * of the arrival order (without it they are float atomics); other kernels ignore it.  One launch
+                              * at a time per scratch: launches of one stream may share it */
   /* Saved leaky-relu masks, 1 bit per element (models/ops/common.py:99-106 under autograd saves the sign of the
    * pre-activation; the backward / R1 tangent passes only ever need that sign).  Bit e of a mask buffer belongs to the
    * element at offset e of the tensor it describes (bit e % 8 of byte e / 8): the mask of `out` is indexed like `out`, the
    * mask of `aux` like `aux`.  Needs out_sn == 1 and N, out_sp, out_sb multiples of 8 (16 for the matrix-core kernels). */
   float* dbias_part;         /* optional, with dbias (round 5, bit-reproducible bias gradients): kernels that take it
-                              * (DgConvPlan.dbias_rows > 0: the ping-pong conv, the thin matrix-core MODE_S2 kernel) store ONE
+                              * (DgConvPlan.dbias_rows > 0: the ping-pong conv, the thin matrix-core MODE_S2 kernel, the lock-step
+                              * persistent conv at fp32) store ONE
                               * partial row of N floats per workgroup at dbias_part + row * N - summed inside the workgroup in a
                               * fixed order - and add nothing to dbias; the caller sums the rows with
                               * dg_wgrad_reduce(ws = dbias_part, dw = dbias, numel = N, splits = dbias_rows).  Kernels that do
@@ -121,7 +126,10 @@ typedef struct DgWgrad {
   /* Optional (zero = off).  ws: caller-owned workspace for the split-K partial tiles of the MFMA LDS-DMA kernel: split s
    * stores its [16][Ci][Co] partial at ws + s * 16 Ci Co with plain stores and NOTHING is added to dw - the caller sums
    * the partials with dg_wgrad_reduce (sizes from dg_wgrad_plan).  Without it the partial tiles meet in dw through fp32
-   * atomics, which the memory side executes at ~1.3 TB/s against ~6 TB/s for stores (8x the bytes of dw per launch).
+   * atomics, which the memory side executes at ~1.3 TB/s against ~6 TB/s for stores (8x the bytes of dw per launch) - and in
+   * arrival order.  Since round 6 every kernel that splits the reduction over workgroups has the form (the thin kernels, the
+   * register-staged MFMA kernel of the fp32 modes, the direct kernel: numel = Ci Co for wmode 2); dg_wgrad_plan says which
+   * launch takes it (splits > 1), a workspace handed to a launch that does not is DG_EUNSUPPORTED.
    * g_mod: the gradient's sample index is b % g_mod, so ONE launch over 3B input samples (real | fake | R1 tangent) can
    * pair the tangent rows with the real batch's gradient chain again (trainers/dcgan_amp.py:229-235). */
   float* ws;

@@ -829,3 +829,66 @@ def test_philox_known_answer(L):
     z = torch.empty(n, device=DEV)
     L.check(lib.dg_philox_fill(123, 1, 0, 1, 0.0, 1.0, 0, 1, n, z.data_ptr(), None))
     assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,B,dtype,cforce,wforce,family,variant", [
+    (6, 4, 8, 16, 3, torch.float32, 1, 1, 1, 1),       # direct conv + direct weight gradient (narrow nets, golden cases)
+    (24, 20, 16, 32, 4, torch.float32, 1, 1, 1, 1),
+    (64, 128, 4, 128, 4, torch.float32, 2, 2, 2, 2),   # one tile per workgroup + register-staged MFMA weight gradient (fp32 modes)
+    (128, 64, 8, 64, 4, torch.bfloat16, None, 6, 0, 2),  # ... that weight-gradient kernel at bf16 (force 6: behind the LDS-DMA form)
+    (128, 256, 2, 64, 8, torch.float32, 4, 2, 4, 2),   # lock-step persistent conv at fp32: one bias-gradient row per workgroup
+], ids=["direct-6x4", "direct-24x20", "one-tile-fp32", "register-staged-bf16", "lock-step-fp32"])
+def test_kernels_off_the_timed_path_sum_in_a_fixed_order(L, Ci, Co, H, W, B, dtype, cforce, wforce, family, variant):
+    """Round 6: the kernels the fp32 modes and narrow nets run no longer add with float atomics in arrival order.
+    Weight gradients: the register-staged MFMA kernel and the direct kernel store one partial per K split / slab in the
+    split-K workspace (dg_wgrad_plan reports splits > 1 and ws_floats), summed by dg_wgrad_reduce in index order.  Bias
+    gradients: the direct kernel and the one-tile MFMA kernel sum as two-word fixed point (common.h dg_fix2: exact for every
+    float down to 2^-36) in LDS / across workgroups through DgConv.dbias_ws; the lock-step persistent kernel at fp32 keeps one
+    LDS row per wave row and leaves one partial row per workgroup (DgConvPlan.dbias_rows).  Checked: the plans say so, two
+    launches over the same data agree BIT FOR BIT (data spread over six orders of magnitude, so that another order of the
+    additions would show), and the bias-gradient sums match a float64 sum of the launch's own output (the values of the
+    weight gradients are test_down_fwd_bwd_wgrad's business: same kernels, same workspace path)."""
+    from dusty_gan_amd import engine as E
+    from dusty_gan_amd.engine import Ops
+    assert E.DETERMINISTIC
+    g = torch.Generator().manual_seed(Ci * 131 + Co)
+    mag = lambda *s: torch.randn(*s, generator=g) * torch.exp(3.0 * torch.randn(*s, generator=g))
+    e = mag(B, Co, H, W)
+    x = mag(B, Ci, 2 * H, 2 * W)
+    wt = torch.randn(Co, Ci, 4, 4, generator=g)
+    prev = torch.randn(B, Ci, 2 * H, 2 * W, generator=g)
+    rs = torch.rand(B, generator=g) + 0.5
+    if dtype == torch.bfloat16:
+        e, x, wt = e.bfloat16().float(), x.bfloat16().float(), wt.bfloat16().float()
+    _, bwd = pack_down(wt)
+    s = 1.0 / math.sqrt(Ci * 16)
+    # ---- bias-gradient sums of the backward-data pass
+    if cforce is not None:
+        E.TRACE = []
+        try:
+            outs = [run_conv(L, L.MODE_UP, 1, True, e, bwd, Ci, s, L.EPI_MASK, dtype, cforce, aux=prev, want_db=True, rowscale=rs)
+                    for _ in range(2)]
+        finally:
+            trace, E.TRACE = E.TRACE, None
+        assert {t[1] for t in trace if t[0] == "conv"} == {family}, trace
+        (dx1, db1), (dx2, db2) = outs
+        assert torch.equal(db1, db2), (db1 - db2).abs().max()
+        ref = (dx1.double() * rs.double().view(B, 1, 1, 1)).sum(dim=[0, 2, 3])
+        assert rel_l2(db1.double(), ref) < 2e-6, rel_l2(db1.double(), ref)
+    # ---- weight gradient
+    o = Ops(dtype)
+    o.force = wforce
+    xd, ed = nhwc(x).to(DEV, dtype), nhwc(e).to(DEV, dtype)
+    dw0 = torch.zeros(16, Ci, Co, device=DEV)
+    p = o._wgrad_params(0, True, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw0.data_ptr(), s, None,
+                        None, None, 0, 0, 0)
+    pl = o.wgrad_plan(p, 1)
+    assert pl.variant == variant and pl.splits > 1 and pl.ws_floats == pl.splits * 16 * Ci * Co, (pl.variant, pl.splits, pl.ws_floats)
+    dws = []
+    for _ in range(2):
+        dw = torch.zeros(16, Ci, Co, device=DEV)
+        o.wgrad(0, True, B, H, W, Ci, Co, xd, (4 * H * W * Ci, Ci, 1), ed, (H * W * Co, Co, 1), dw.data_ptr(), s, rowscale=rs.to(DEV))
+        torch.cuda.synchronize()
+        dws.append(dw.cpu())
+    assert torch.isfinite(dws[0]).all() and dws[0].abs().max() > 0
+    assert torch.equal(dws[0], dws[1]), (dws[0] - dws[1]).abs().max()
