@@ -143,7 +143,7 @@ struct AdamEpi {
   const unsigned long long* stepp;
 };
 
-int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream);
+int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream, int fp32x3);
 
 // DG_BF16X2 (include/dusty_gan_hip.h): element i = the bf16 pair (hi, lo) at bf16 index 2 i - i % 64 and 64 further
 __host__ __device__ __forceinline__ long dg_x2_index(long i) { return 2 * i - (i & 63); }

@@ -1031,13 +1031,18 @@ int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_
                        float eps, const unsigned long long* step_dev, float ema_decay, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   if (!p || !v || !dp0 || !zT || !step_dev) return DG_EINVAL;
-  if (op_dtype != DG_BF16 || Np <= 0 || nb < 2) return DG_EUNSUPPORTED;
+  // op_dtype: the operands' element type, DG_BF16 or (round 6) DG_F32, the latter optionally | DG_FORCE_FP32X3 - the fp32 rows
+  // split into bf16 pairs in registers (the fp32x3 mode's arithmetic); fp32 operands run on the matrix-core path only
+  const int x3 = (op_dtype & DG_FORCE_FP32X3) ? 1 : 0;
+  op_dtype &= ~DG_FORCE_FP32X3;
+  if ((op_dtype != DG_BF16 && op_dtype != DG_F32) || (x3 && op_dtype != DG_F32) || Np <= 0 || nb < 2) return DG_EUNSUPPORTED;
   const size_t lds = ((size_t)(nb / 2) * K + (size_t)APF_ROWS * (nb / 2)) * 4;
   const bool valu_ok = nb <= 64 && nb % 2 == 0 && K % 4 == 0 && K / 4 <= 256 && 256 % (K / 4) == 0 && lds <= 64 * 1024;
   // The MFMA gradient GEMM with the optimizer as its epilogue takes every batch size when Np and K are multiples of 128
   // and measured 6 % faster than the LDS-resident VALU kernel even at nb = 32 (scripts/bench_proj_adam.py: 311 vs
   // 331 us); the VALU kernel takes the shapes the GEMM does not tile.
   const bool mfma_ok = Np % 128 == 0 && K % 128 == 0;
+  if (op_dtype == DG_F32 && !mfma_ok) return DG_EUNSUPPORTED;
   if (!valu_ok || mfma_ok) {
     // (wgrad_mfma.hip; also the only fused path for nb > 64, i.e. the all-gathered global batch of a multi-GPU run);
     // shapes neither kernel takes -> DG_EUNSUPPORTED -> caller's unfused path
@@ -1045,10 +1050,10 @@ int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_
     w.wmode = 2; w.ring = 1; w.B = 1; w.Hc = 1; w.Wc = nb; w.Ci = (int)Np; w.Co = K;
     w.a = dp0; w.a_sb = 0; w.a_sp = Np; w.a_sc = 1;
     w.g = zT; w.g_sb = 0; w.g_sp = K; w.g_sc = 1;
-    w.dw = nullptr; w.scale = wscale; w.rowscale = nullptr; w.a_dtype = DG_BF16; w.g_dtype = DG_BF16;
+    w.dw = nullptr; w.scale = wscale; w.rowscale = nullptr; w.a_dtype = op_dtype; w.g_dtype = op_dtype;
     AdamEpi ad{p, v, ema, shadow, shadow && shadow_dtype == DG_BF16 ? 1 : 0, gscale, lr, beta2, eps, ema_decay, step_dev};
     if (Np > 0x7fffffffL) return DG_EUNSUPPORTED;
-    return dg_wgrad_mfma_adam_launch(&w, &ad, s);
+    return dg_wgrad_mfma_adam_launch(&w, &ad, s, x3);
   }
   const unsigned grid = (unsigned)((Np + APF_ROWS - 1) / APF_ROWS);
   if (shadow && shadow_dtype == DG_BF16)

@@ -352,13 +352,17 @@ static int launch_cfg(const WgradP* p, int accumulate, hipStream_t stream) {
 
 // Proj.weight's gradient GEMM with the optimizer folded into its epilogue (optim.hip dg_adam_proj_fused dispatches here
 // when the batch is too large for its LDS-resident VALU kernel, i.e. the all-gathered global batch of multi-GPU runs)
-int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream) {
-  if (p->wmode != 2 || p->a_dtype != DG_BF16 || p->g_dtype != DG_BF16 || p->a_sc != 1 || p->g_sc != 1)
+int dg_wgrad_mfma_adam_launch(const WgradP* p, const AdamEpi* ad, hipStream_t stream, int fp32x3) {
+  if (p->wmode != 2 || p->a_dtype != p->g_dtype || (p->a_dtype != DG_BF16 && p->a_dtype != DG_F32) || p->a_sc != 1 || p->g_sc != 1)
     return DG_EUNSUPPORTED;
   if (p->Ci % 128 != 0 || p->Co % 128 != 0 || p->rowscale) return DG_EUNSUPPORTED;
   const int tiles_m = p->Ci / 128, tiles_n = p->Co / 128;
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, 1);  // no K split: every tile sees the whole batch
-  wgrad_mfma_kernel<bf16, 128, 128, true><<<grid, 256, 0, stream>>>(*p, tiles_n, 0, *ad);
+  // fp32 operands (round 6: the parity-class modes' Proj.weight, which ran gradient GEMM + reduce + plain optimizer): on the
+  // fp32 matrix instructions, or - fp32x3 - split into bf16 hi / lo in registers like every other GEMM of that mode
+  if (p->a_dtype == DG_BF16) wgrad_mfma_kernel<bf16, 128, 128, true><<<grid, 256, 0, stream>>>(*p, tiles_n, 0, *ad);
+  else if (fp32x3) wgrad_mfma_kernel<float, 128, 128, true, true><<<grid, 256, 0, stream>>>(*p, tiles_n, 0, *ad);
+  else wgrad_mfma_kernel<float, 128, 128, true, false><<<grid, 256, 0, stream>>>(*p, tiles_n, 0, *ad);
   HIP_CHECK_RET(hipGetLastError());
   return DG_OK;
 }

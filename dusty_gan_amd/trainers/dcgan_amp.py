@@ -275,7 +275,8 @@ class FlatAdam:
         ema_ptr = L.ptr(ema_store.flat) if ema_store is not None else None
         if fused_proj is not None:
             dp0, zT, op_dt, nb, Np, K, wscale = fused_proj
-            rc = lib.dg_adam_proj_fused(L.ptr(st.flat), L.ptr(st.v), ema_ptr, L.ptr(st.shadow), sdt, L.ptr(dp0), L.ptr(zT),
+            rc = lib.dg_adam_proj_fused(L.ptr(st.flat), L.ptr(st.v), ema_ptr,
+                                        None if st.shadow is st.flat else L.ptr(st.shadow), sdt, L.ptr(dp0), L.ptr(zT),
                                         op_dt, nb, Np, K, wscale, gscale, self.lr, self.betas[1], self.eps,
                                         L.ptr(self._step_dev), ema_decay, L.stream_ptr())
             if rc == L.DG_EUNSUPPORTED:
@@ -475,6 +476,7 @@ class Trainer:
             D_.side_group()   # (collective: every rank's constructor) the gloo group the capture decision is taken over
         self._works, self._comm_events = {}, None
         self._fuse_proj_ok = os.environ.get("DUSTY_GAN_FUSE_PROJ", "1") != "0"
+        self._fuse_proj_fp32 = os.environ.get("DUSTY_GAN_FUSE_PROJ_FP32", "1") != "0"   # (A/B of the round-6 fp32 forms)
         # Collectives INSIDE the captured step (nccl = RCCL only): the process group enqueues a captured collective on its
         # own stream behind an event of the capture stream, and work.wait() joins it back - fork / join edges of ONE hipGraph,
         # no host call and no stream hand-off between graph segments at replay.  "1": try it first and fall back to the
@@ -891,7 +893,8 @@ class Trainer:
         else:
             self.optim_G.zero_grad(skip=("proj_w",) if self.n_acc == 1 else ())
         gather_proj = (self.world > 1 or self._force_seg) and self.n_acc == 1 and next(iter(Gst.seg)) == "proj_w"
-        fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype == torch.bfloat16
+        fuse_proj = (not gather_proj and self.world == 1 and self.n_acc == 1 and self.dtype in (torch.bfloat16, torch.float32)
+                     and (self.dtype == torch.bfloat16 or self._fuse_proj_fp32)
                      and next(iter(Gst.seg)) == "proj_w" and Gst.seg["proj_w"].off == 0 and self._fuse_proj_ok
                      and self.optim_G.betas[0] == 0.0 and E.PROFILE is None)
         fuse_gathered = (gather_proj and self.dtype == torch.bfloat16 and Gst.seg["proj_w"].off == 0
@@ -983,7 +986,17 @@ class Trainer:
                 c = geng.cfg
                 Np = c.h0 * c.w0 * c.ch[3]
                 dp0, zT, nloc = self._proj_operands(geng, B)
-                fused = (dp0, zT, L.dtype_code(self.dtype), nloc, Np, c.nz, 1.0 / math.sqrt(Np))
+                op_dt = L.dtype_code(self.dtype)
+                if self.dtype == torch.float32:
+                    # the parity-class modes (round 6): fp32 rows - split-bf16 pairs (fp32x3 with split storage) through an fp32
+                    # copy, as the unfused GEMM takes them - on the fp32 matrix instructions or, fp32x3, as bf16 pairs in registers
+                    if E.is_x2(dp0):
+                        dp0 = E.x2_unpack(dp0, geng.ops._f32_copy("wa", dp0))
+                    if E.is_x2(zT):
+                        zT = E.x2_unpack(zT, geng.ops._f32_copy("wg", zT))
+                    if geng.ops.x3:
+                        op_dt |= L.DG_FORCE_FP32X3
+                fused = (dp0, zT, op_dt, nloc, Np, c.nz, 1.0 / math.sqrt(Np))
                 self.optim_G.regen_grad = lambda: geng.proj_wgrad(Gst, dp0, zT, nloc, False)
         # Adam + EMA fused (:312, :316); single-GPU bf16 runs also fold Proj.weight's gradient GEMM into the kernel
         tail_wait = (lambda: self._comm_wait("G.tail")) if (gather_proj and not pl_on and fused is not None) else None

@@ -601,8 +601,11 @@ int dg_adam_fused(float* p, float* grad, float* v, float* ema, void* shadow, int
  * and zT [nb][K]: the 268 MB gradient is never written.  Two kernels behind it: an LDS-resident VALU kernel for the
  * per-GPU batch (nb even, <= 64, operands fit 64 KB of LDS) and, for larger nb (the all-gathered global batch of a
  * data-parallel run), the MFMA gradient GEMM with the optimizer as its epilogue (Np % 128 == 0, K % 128 == 0).
- * DG_EUNSUPPORTED for anything else (op_dtype not bf16, other shapes) - the caller then uses dg_wgrad +
- * dg_adam_ema_step_dev. */
+ * Round 6: op_dtype DG_F32 (fp32 operands on the fp32 matrix instructions: the exact-fp32 mode) and DG_F32 | DG_FORCE_FP32X3
+ * (fp32 operands split into bf16 pairs in registers: the fp32x3 mode) take the matrix-core path too - those modes ran the
+ * gradient GEMM, its reduce and the plain optimizer over the 268 MB gradient.  shadow may be NULL (fp32 modes: the master IS
+ * what the forward pass reads).  DG_EUNSUPPORTED for anything else (other element types, other shapes) - the caller then uses
+ * dg_wgrad + dg_adam_ema_step_dev. */
 int dg_adam_proj_fused(float* p, float* v, float* ema, void* shadow, int shadow_dtype, const void* dp0, const void* zT,
                        int op_dtype, int nb, long Np, int K, float wscale, float gscale, float lr, float beta2,
                        float eps, const unsigned long long* step_dev, float ema_decay, void* stream);

@@ -800,14 +800,51 @@ def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
     torch.cuda.synchronize()
     assert rel_l2(pd.cpu(), pc) < 1e-5 and rel_l2(vd.cpu(), vc) < 1e-4 and rel_l2(ed.cpu(), ec) < 1e-5
     assert torch.equal(sh.cpu(), pd.cpu().bfloat16())
-    # shapes the kernel refuses (the trainer then forms the gradient with dg_wgrad)
+    # operand types / shapes the kernel refuses (the trainer then forms the gradient with dg_wgrad)
     assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_BF16, dpd.data_ptr(), zd.data_ptr(),
-                                  L.DG_F32, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay,
+                                  L.DG_BF16X2, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay,
+                                  None) == L.DG_EUNSUPPORTED
+    assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_BF16, dpd.data_ptr(), zd.data_ptr(),
+                                  L.DG_BF16 | L.DG_FORCE_FP32X3, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay,
                                   None) == L.DG_EUNSUPPORTED
     if nb > 64:  # neither the LDS-resident kernel (batch) nor the MFMA epilogue (Np % 128) takes this one
         assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_BF16, dpd.data_ptr(),
                                       zd.data_ptr(), L.DG_BF16, nb, Np - 64, K, wscale, gscale, lr, b2, eps,
                                       stepd.data_ptr(), decay, None) == L.DG_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32", "fp32x3"])
+@pytest.mark.parametrize("nb,Np,K", [(8, 256, 128), (32, 1024, 512), (100, 128, 256), (8, 131072, 512)])
+def test_adam_proj_fused_takes_fp32_operands(L, nb, Np, K, x3):
+    """Round 6: the parity-class modes' Proj.weight runs the same fused launch - fp32 operand rows on the fp32 matrix
+    instructions (op_dtype DG_F32) or split into bf16 pairs in registers (DG_F32 | DG_FORCE_FP32X3; operands with 16 mantissa
+    bits, as the mode's split storage holds them, are then exact) - with no shadow (the master is what the forward reads).
+    Against the oracle's Adam on the float64 gradient; shapes off the 128 grid are refused."""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(nb * 7 + K)
+    dp0 = torch.randn(nb, Np, generator=g)
+    z = torch.randn(nb, K, generator=g)
+    if x3:   # hi + lo of a split-bf16 pair: 16 mantissa bits
+        dp0 = dp0.bfloat16().float() + (dp0 - dp0.bfloat16().float()).bfloat16().float()
+        z = z.bfloat16().float() + (z - z.bfloat16().float()).bfloat16().float()
+    wscale, gscale, lr, b2, eps, decay, step = 1.0 / math.sqrt(Np), 0.5, 0.002, 0.99, 1e-8, 0.9, 3
+    grad = ((dp0.double().t() @ z.double()) * wscale).float()
+    p, v, ema = (torch.randn(Np * K, generator=g) for _ in range(3))
+    v.abs_()
+    pc, mc, vc, ec = p.clone(), torch.zeros_like(p), v.clone(), ema.clone()
+    O.adam_update(pc, grad.reshape(-1) * gscale, mc, vc, step + 1, lr, 0.0, b2)
+    ec = decay * ec + (1 - decay) * pc
+    pd, vd, ed = (t.to(DEV) for t in (p, v, ema))
+    dpd, zd = dp0.to(DEV).contiguous(), z.to(DEV).contiguous()
+    stepd = torch.full((1,), step, dtype=torch.int64, device=DEV)
+    op = L.DG_F32 | (L.DG_FORCE_FP32X3 if x3 else 0)
+    L.check(lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), ed.data_ptr(), None, L.DG_F32, dpd.data_ptr(), zd.data_ptr(),
+                                   op, nb, Np, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay, None), "dg_adam_proj_fused")
+    torch.cuda.synchronize()
+    # (fp32x3 drops the lo x lo products: 2^-16 relative per product, far below what Adam's normalised step passes on)
+    assert rel_l2(pd.cpu(), pc) < 1e-5 and rel_l2(vd.cpu(), vc) < 1e-4 and rel_l2(ed.cpu(), ec) < 1e-5
+    assert lib.dg_adam_proj_fused(pd.data_ptr(), vd.data_ptr(), None, None, L.DG_F32, dpd.data_ptr(), zd.data_ptr(), op, nb,
+                                  Np - 64, K, wscale, gscale, lr, b2, eps, stepd.data_ptr(), decay, None) == L.DG_EUNSUPPORTED
 
 
 def test_philox_known_answer(L):
