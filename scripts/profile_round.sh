@@ -17,6 +17,10 @@ cd $root
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_bench_bf16_b32.csv
 python3 scripts/pmc_traffic.py $out/${tag}_pmc_traffic.json $(find $out/fetch -name "*counter_collection.csv" | head -1) $(find $out/write -name "*counter_collection.csv" | head -1)
 python3 scripts/pmc_summary.py $out/${tag}_pmc_sq.json $(find $out/sq -name "*counter_collection.csv" | head -1) > $out/${tag}_pmc_sq_summary.txt
+# bench.py's `roofline.traffic` reads the committed PMC file (bench.PMC_FILE): put this collection there first, so that the
+# bench lines below carry it (same kernel sources -> the hash matches); the caller copies the same file into profiles/
+pmc_file=$(python3 -c "import re; print(re.search(r'^PMC_FILE = \"([^\"]+)\"', open('bench.py').read(), re.M).group(1))")
+cp $out/${tag}_pmc_traffic.json $pmc_file
 # bench lines: the driver's default, then the other configurations of SURVEY.md §8d
 python3 bench.py > $out/${tag}_bench_config2.json 2> /dev/null
 python3 bench.py --arch dusty1 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_config3_dusty1.json 2> /dev/null
