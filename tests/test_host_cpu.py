@@ -412,3 +412,39 @@ def test_counter_queues_are_per_owner():
     assert t.data_ptr() not in L.Counters.pending and not L.Counters.ride      # the process-wide default queue: untouched
     assert b.pending[t.data_ptr()][1] == 1 and a.ride and not b.ride
     a.pending.clear(); b.pending.clear()
+
+
+def test_two_word_fixed_point_split_is_exact():
+    """csrc/common.h dg_fix2 (round 6: order-independent bias-gradient sums of the kernels off the timed path), restated in
+    numpy: v = hi 2^-20 + lo 2^-60 with hi = rint(v 2^20) and lo = rint((v - hi 2^-20) 2^60).  Claims checked on a wide random
+    sample of floats (magnitudes 2^-40 ... 2^41 (all below the 4e12 cut-off), both signs, plus edge values): (1) the residual v - hi 2^-20 that the kernel
+    forms with ONE float fma is exactly representable in float32 (so the float op loses nothing); (2) for |v| >= 2^-36 the
+    pair reproduces v exactly, below that to 2^-60; (3) integer sums of the pairs do not depend on the order of the terms and
+    equal the exact sum of the values to 2^-60 per term (checked against Python integers / Fraction)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(7)
+    mant = rng.uniform(1.0, 2.0, 20000).astype(np.float32)
+    expo = rng.integers(-40, 41, 20000)
+    v = (np.ldexp(mant, expo) * rng.choice([-1.0, 1.0], 20000)).astype(np.float32)
+    v = np.concatenate([v, np.float32([0.0, 1.0, -1.0, 0.5 / 1048576, 0.50001 / 1048576, 1.5 / 1048576, 15.999999, 16.0,
+                                       2.0 ** -36, 2.0 ** -37, 3.9e12, 1e-30])])
+    assert np.all(np.abs(v) < 4.0e12)
+    t = np.rint(v * np.float32(1048576.0)).astype(np.float32)          # exact scaling by a power of two, integer-valued
+    hi = t.astype(np.int64)
+    r64 = v.astype(np.float64) - t.astype(np.float64) / 1048576.0       # what fma(-t, 2^-20, v) computes before rounding
+    assert np.array_equal(r64.astype(np.float32).astype(np.float64), r64), "the residual is not a float: the fma would round"
+    assert np.all(np.abs(r64) <= 2.0 ** -21)
+    lo = np.rint(r64 * 2.0 ** 60).astype(np.int64)
+    back = [Fraction(int(h), 2 ** 20) + Fraction(int(l), 2 ** 60) for h, l in zip(hi, lo)]
+    exact = [Fraction(float(x)) for x in v]
+    for x, b, e in zip(v, back, exact):
+        if abs(float(x)) >= 2.0 ** -36:
+            assert b == e, float(x)
+        else:
+            assert abs(b - e) <= Fraction(1, 2 ** 61), float(x)
+    # order independence + value of the sum (what the last workgroup converts: one rounding of the exact integer pair)
+    idx = rng.permutation(len(v))
+    assert int(hi.sum()) == int(hi[idx].sum()) and sum(int(x) for x in lo) == sum(int(x) for x in lo[idx])
+    big = np.abs(v) >= 2.0 ** -36
+    tot = Fraction(sum(int(x) for x in hi[big]), 2 ** 20) + Fraction(sum(int(x) for x in lo[big]), 2 ** 60)
+    assert tot == sum((Fraction(float(x)) for x in v[big]), Fraction(0))
