@@ -592,7 +592,9 @@ def main():
     # run showed a single 12.6 ms step among 2.9 ms ones, a host-side stall).  Round 6: with the collection (50-100 ms of host
     # time) BETWEEN warm-up and timed region the GPU sat idle long enough to drop its clocks, and the first ~15 timed steps
     # ran 3-15 % above the steady state whatever the warm-up length (profiles/r06_timed_region_ramp.txt) - 2 % of a 20-step
-    # window.  Now the warm-up's last replay has barely finished when the bracket's synchronize returns.
+    # window.  Now the warm-up's last replay has barely finished when the bracket's synchronize returns - and the warm-up's
+    # capture step no longer collects either (with the collector already off the trainer's capture guard has nothing to do:
+    # that collection was 66 of the capture step's 76 ms, two replays in front of the driver's 20-step window).
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     import gc
     gc.collect()

@@ -692,10 +692,15 @@ class Trainer:
         # of EARLIER trainers - their hipGraphs, tensors of their private pools - and destroying a graph or freeing pool memory
         # from inside a capturing thread aborts the process (round 5: torch 2.10's graph context no longer collects on entry,
         # and the suite died in whichever test the allocation counters happened to trigger it).  Collect now, outside.
-        if self._cap_cur is None and not getattr(self, "_gc_was_on", None):
-            gc.collect()
+        # A caller that already runs with the collector off (bench.py, from in front of its warm-up) has taken it out of the
+        # picture: nothing can start a collection inside the capture, and the ~70 ms of a full collection here would idle the
+        # GPU long enough to send its clock down right in front of the first replays (round 6: the capture step took 76 ms of
+        # host time, 66 of them in gc.collect; scripts/probes/capture_idle.py).
+        if self._cap_cur is None and getattr(self, "_gc_was_on", None) is None:
             self._gc_was_on = gc.isenabled()
-            gc.disable()
+            if self._gc_was_on:
+                gc.collect()
+                gc.disable()
         # DUSTY_GAN_KEEP_GRAPH=1 (tests): keep the hipGraph_t behind the executable graph so that `graph_kernel_nodes()` can count
         # its nodes - the launch count of the replayed step is a tested property (tests/test_gpu_timed_path.py)
         g = torch.cuda.CUDAGraph(keep_graph=True) if os.environ.get("DUSTY_GAN_KEEP_GRAPH", "0") == "1" else torch.cuda.CUDAGraph()

@@ -360,6 +360,45 @@ def test_r1_turnaround_in_one_launch(L, H, W, ring, dtype):
     assert lib.dg_blur_r1_tangent(d.data_ptr(), dt, out.data_ptr(), 1.0, None, None, B, B, H, W, ring, None) == L.DG_EINVAL
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-3, 3e-5], ids=["unit", "1e-3", "3e-5"])
+def test_r1_sums_in_the_arena_keep_their_documented_window(L, mag):
+    """The accumulator arena's sums are 32.32 FIXED POINT (csrc/common.h dg_acc_add): order-independent, with an ABSOLUTE
+    resolution of 2^-32 per contribution (round-5 advice: say what that means for small magnitudes, and test it).  R1's per-sample
+    |g|^2 through dg_blur_r1_tangent with its sums in the arena, for gradient maps of magnitude 1, 1e-3 and 3e-5 (|g|^2 per
+    sample ~ 2e4, 2e-2, 2e-5): two launches agree bit for bit at every magnitude, and the sums are within
+    contributors x 2^-33 (the rounding of each contribution) + 1e-6 relative (the float partials) of a float64 reference - i.e.
+    exact to float precision at ordinary magnitudes and ~1e-4 relative at |g|^2 ~ 2e-5, the regime of a collapsed run, where
+    only the LOGGED penalty reads it (the tangent is formed from g itself, asserted here: scaled inputs give the scaled map)."""
+    lib = L.lib()
+    B, H, W = 4, 64, 256
+    g = torch.Generator().manual_seed(17)
+    d1 = torch.randn(B, H, W, 2, generator=g)
+    d = (d1 * mag).to(DEV)
+    outs, sums = [], []
+    for _ in range(2):
+        L.AccArena.begin(DEV)
+        ssq, macc = L.AccArena.take(B, DEV), L.AccArena.take(1, DEV)
+        out = torch.empty(B, H, W, 2, device=DEV)
+        L.check(lib.dg_blur_r1_tangent(d.data_ptr(), L.DG_F32, out.data_ptr(), 0.5, ssq.data_ptr(), macc.data_ptr(), B, B, H, W, 1, None))
+        torch.cuda.synchronize()
+        outs.append(out.cpu()); sums.append((ssq.cpu().clone(), macc.cpu().clone()))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(sums[0][0], sums[1][0]) and torch.equal(sums[0][1], sums[1][1])
+    vg = torch.empty(B, 1, H, W, device=DEV)
+    L.check(lib.dg_blur_bwd(d.data_ptr(), L.DG_F32, vg.data_ptr(), B, H, W, 1, None))
+    want = (vg.double() ** 2).sum(dim=[1, 2, 3]).cpu()
+    err = (sums[0][0].double() - want).abs()
+    bound = 1024 * 2.0 ** -33 + 1e-6 * want
+    assert (err <= bound).all(), (mag, err.tolist(), want.tolist())
+    assert abs(float(sums[0][1]) - float(want.mean())) <= 1024 * 2.0 ** -33 + 1e-6 * float(want.mean())
+    if mag != 1.0:   # the tangent map does not go through the sums: it scales with its input
+        L.AccArena.begin(DEV)
+        s1, m1 = L.AccArena.take(B, DEV), L.AccArena.take(1, DEV)
+        o1 = torch.empty(B, H, W, 2, device=DEV)
+        L.check(lib.dg_blur_r1_tangent(d1.to(DEV).data_ptr(), L.DG_F32, o1.data_ptr(), 0.5, s1.data_ptr(), m1.data_ptr(), B, B, H, W, 1, None))
+        torch.cuda.synchronize()
+        assert rel_l2(outs[0], o1.cpu() * mag) < 1e-6
+
+
 def test_fetch_reals_from_the_device_resident_pool(L):
     """dg_fetch_reals_pool_sum picks batch (*counter % pool) on the device: == dg_fetch_reals_sum of that batch"""
     lib = L.lib()
