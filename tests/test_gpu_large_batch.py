@@ -38,6 +38,9 @@ def _slice(r, s):
             "aug": [{k: v[s] for k, v in rp.items()} for rp in r["aug"]]}
 
 
+G_PLAN_TOL = 5e-2   # relative L2, with cosine >= 0.999 (measured: see the test)
+
+
 def _pair(arch, shape, B, mb):
     torch.manual_seed(2024)
     big = make_trainer(arch, True, shape, 512, 64, 512, B, amp=True)
@@ -85,15 +88,24 @@ def test_large_batch_plan_equals_accumulated_micro_batches(arch, shape, B):
     for k in gb:
         if float(gb[k].abs().max()) > 0:
             assert rel_l2(ga[k], gb[k]) < 2e-2 and _cos(ga[k], gb[k]) > 0.9995, ("D", k, rel_l2(ga[k], gb[k]))
+    # (iii) the generator's gradients through the SAME updated discriminator: the two D steps differ by rounding, and Adam's
+    # first step turns a sign flip of a rounding-noise gradient into +-lr - through discriminators of their own the two G
+    # phases sat 8e-2 apart (rounds 3-5's bound, blind to a few-% defect of the B = 64 plan).  The accumulated run takes the
+    # big run's updated D, so what is compared is the plan alone: measured 1.6e-2 / cosine 0.99987 (128x2048) and 3.8e-2 / 0.9993
+    # (64x1024, on the head's bias; bit-reproducible runs, so these are THE numbers) - the bf16 rounding flips of per-sample
+    # activations between two accumulation orders, carried through ten layers; bound 5e-2 / 0.999.
+    acc.D.load_state_dict(big.D.state_dict())
     ws.hwm = ws.early_flushes = ws.refused = 0
     big.optimize_G()
     g_stats = (ws.hwm, ws.early_flushes, ws.refused)
     acc.optimize_G()
     gb, ga = grads_by_name(big.optim_G), grads_by_name(acc.optim_G)
+    worst = max((rel_l2(ga[k], gb[k]), k) for k in gb if float(gb[k].abs().max()) > 0)
+    wcos = min((_cos(ga[k], gb[k]), k) for k in gb if float(gb[k].abs().max()) > 0)
+    print(f"G gradients, B = {B} plan against {B // mb} x {mb} accumulated through the same D: worst {worst}, cosine {wcos}")
     for k in gb:
         if float(gb[k].abs().max()) > 0:
-            # (G's gradients pass through the UPDATED discriminators, which differ by the rounding of the D step)
-            assert rel_l2(ga[k], gb[k]) < 8e-2 and _cos(ga[k], gb[k]) > 0.995, ("G", k, rel_l2(ga[k], gb[k]))
+            assert rel_l2(ga[k], gb[k]) < G_PLAN_TOL and _cos(ga[k], gb[k]) > 0.999, ("G", k, rel_l2(ga[k], gb[k]), _cos(ga[k], gb[k]))
     # (iv) the split-K workspace in the B = 64 step (one micro-batch): below capacity in either phase, no reduce forced early,
     # nothing pushed to atomics.  (The 16-micro-batch run defers every micro-batch's partials to one reduce per phase and is
     # MEANT to fill the buffer and reduce early; its gradients were just compared.)
