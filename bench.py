@@ -486,6 +486,14 @@ def _supervise_attempts(args, rank, world, stall, cap, first, child_cmd, store, 
                 time.sleep(0.25)
         history.append({"attempt": a, "mode": name, "outcome": outcome, "seconds": round(time.time() - t0, 1)})
         if outcome == "ok":
+            # Every rank says that it has SEEN the attempt succeed, and rank 0 - whose process may host the store when no
+            # launcher does - leaves only when all have (bounded): returning at once took the store away under a peer's last
+            # poll about once in thirty runs of tests/test_bench_supervisor.py ("Failed to recv ... Connection was likely
+            # closed" -> that supervisor exited 1 behind a good record).  After its `seen` a rank makes no store call.
+            try:
+                store.set(f"{key}/seen/{rank}", "1")
+            except Exception:  # noqa: BLE001  (the record is rank 0's business; nothing left to coordinate)
+                pass
             if rank == 0:
                 line = None
                 with open(out_path) as fh:
@@ -498,6 +506,12 @@ def _supervise_attempts(args, rank, world, stall, cap, first, child_cmd, store, 
                 rec = json.loads(line)
                 rec.setdefault("distributed", {})["launch_attempts"] = history
                 print(json.dumps(rec), flush=True)
+                t2, seen = time.time(), [f"{key}/seen/{r}" for r in range(world)]
+                try:
+                    while not store.check(seen) and time.time() - t2 < 10.0:
+                        time.sleep(0.05)
+                except Exception:  # noqa: BLE001
+                    pass
             return 0
         print(f"bench.py supervisor (rank {rank}): attempt {a} [{name}] failed: {outcome}", file=sys.stderr, flush=True)
     return 1
