@@ -813,6 +813,52 @@ def test_adam_proj_fused_matches_gemm_plus_adam(L, nb, Np, K):
                                       stepd.data_ptr(), decay, None) == L.DG_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,B,force", [(24, 20, 16, 32, 4, 1), (64, 128, 4, 128, 4, 2)], ids=["direct", "one-tile"])
+def test_bias_gradient_staging_scratch_protocol(L, Ci, Co, H, W, B, force):
+    """DgConv.dbias_ws as the direct / one-tile MFMA kernels use it (round 6): (1) the scratch is zero again when the launch
+    has finished - word pairs and ticket - so the next launch of the stream can share it; (2) WITHOUT the scratch (a C-ABI caller
+    that passes NULL) the same launch adds with float atomics and gives the same sums to rounding."""
+    import ctypes as C
+    from dusty_gan_amd import engine as E
+    g = torch.Generator().manual_seed(5 + Ci)
+    e = torch.randn(B, Co, H, W, generator=g)
+    wt = torch.randn(Co, Ci, 4, 4, generator=g)
+    prev = torch.randn(B, Ci, 2 * H, 2 * W, generator=g)
+    rs = torch.rand(B, generator=g) + 0.5
+    _, bwd = pack_down(wt)
+    s = 1.0 / math.sqrt(Ci * 16)
+    _, db = run_conv(L, L.MODE_UP, 1, True, e, bwd, Ci, s, L.EPI_MASK, torch.float32, force, aux=prev, want_db=True, rowscale=rs)
+    torch.cuda.synchronize()
+    assert E.Ops._dbias_ws, "no staging scratch was handed to the launch"
+    for ws in E.Ops._dbias_ws.values():
+        assert int(ws.view(torch.int32).ne(0).sum()) == 0, "the staging scratch was not left zero"
+
+    class NoScratch:                       # the library with DgConv.dbias_ws forced to NULL in front of every conv entry point
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            f = getattr(self._lib, name)
+            if name not in ("dg_conv", "dg_conv_ex", "dg_conv_plan"):
+                return f
+
+            def call(pref, *a):
+                pref._obj.dbias_ws = None
+                return f(pref, *a)
+            return call
+    init = E.Ops.__init__
+
+    def init_nows(self, dtype, x3=False):
+        init(self, dtype, x3=x3)
+        self.lib = NoScratch(self.lib)
+    try:
+        E.Ops.__init__ = init_nows
+        _, db2 = run_conv(L, L.MODE_UP, 1, True, e, bwd, Ci, s, L.EPI_MASK, torch.float32, force, aux=prev, want_db=True, rowscale=rs)
+    finally:
+        E.Ops.__init__ = init
+    assert rel_l2(db2, db) < 1e-6, rel_l2(db2, db)
+
+
 @pytest.mark.parametrize("x3", [False, True], ids=["fp32", "fp32x3"])
 @pytest.mark.parametrize("nb,Np,K", [(8, 256, 128), (32, 1024, 512), (100, 128, 256), (8, 131072, 512)])
 def test_adam_proj_fused_takes_fp32_operands(L, nb, Np, K, x3):
